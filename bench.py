@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Benchmark of the dex-ct hot path on MI355X.
+
+A step = one pass of the hot path over BASELINE.json's metric configuration (configs[2]):
+512^3 synthetic water/bone phantom, 1000 views x 800 channels, dual 80/140 kVp spectra, i.e.
+  plan -> Siddon traversal + polychromatic detection of BOTH spectra (one fused traversal)
+       -> Gauss-Newton decomposition (50 iterations, as main.py:153) + air mask
+       -> (N > 1) all-gather of the four sinograms over RCCL.
+Detector rows: BASELINE.json does not name a row count and a single row touches one slice of the
+512^3 volume, so the workload is the stacked fan N_rows = Nz = 512; the
+single-row case is reported under "single_row".  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: projection angles are sharded; weak scaling - every rank projects `--views` angles of an
+N x views scan of the same phantom.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=512, help='phantom is n^3')
+    ap.add_argument('--views', type=int, default=1000, help='views per GPU')
+    ap.add_argument('--channels', type=int, default=800)
+    ap.add_argument('--rows', type=int, default=0, help='detector rows (0: n)')
+    ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--gn-precision', default=None, choices=[None, 'f64', 'mixed'])
+    ap.add_argument('--kernel', type=int, default=0, help='0 choose, 1 ray-parallel, 2 row-parallel')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--skip-single-row', action='store_true')
+    return ap.parse_args()
+
+
+def segment_count(co, geom, view_cs, chan_cs, n_views_total, view_begin, view_end):
+    """Exact number of Siddon segments per (view, channel) of this rank's shard, from the CPU oracle."""
+    plan = co.plan(geom, view_cs, chan_cs, view_begin, view_end)
+    return int(co.count_segments(geom, plan)), plan
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import _shard, forward_project as fp, matdecomp as md, synthetic
+
+    dev = torch.device('cuda', local_rank)
+    n, rows = args.n, (args.rows or args.n)
+    total_views = args.views * world
+    det = os.path.join(ROOT, 'dex-ct-sim_amd', 'input', 'detector', 'eta_eid_mv.bin')
+    ct = dx.FanBeamGeometry(N_channels=args.channels, N_proj=total_views, gamma_fan=0.8230337, SID=60.0, SDD=100.0,
+                            eid=True, detector_file=det, N_rows=rows)
+    ph = synthetic.make_phantom(n, n, extent=51.2, seed=1234)
+    specs = [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
+    vb, ve = _shard.split(total_views, rank, world)
+    pj = fp.Projector(ct, ph, view_range=(vb, ve), kernel=args.kernel)
+    E, mu_d, w_d, air = pj.upload_tables(specs)
+    n_e_spec = [int((w_d[k] != 0).sum().item()) for k in range(2)]
+    _, i0, mus = md.decomposition_tables(ct, specs[0], specs[1])
+    i0_d = torch.tensor(i0, dtype=torch.float64, device=dev)
+    mus_d = torch.tensor(mus, dtype=torch.float64, device=dev)
+    lib = pj.lib
+    import ctypes as C
+    from dex_ct_sim_amd import _native
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+
+    nV = pj.n_local_views
+    n_rays = nV * rows * args.channels
+    counts = torch.empty((2, nV, rows, args.channels), dtype=torch.float32, device=dev)
+    a_out = torch.empty((nV, rows, args.channels, 2), dtype=torch.float64, device=dev)
+    gmax = torch.empty((), dtype=torch.float64, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    precision = args.gn_precision or md.DEFAULT_PRECISION
+
+    def step(timed):
+        st = stream_ptr()
+        _native.check(lib.dexct_fan_plan(C.byref(pj.geom), ptr(pj.view_cs), ptr(pj.chan_cs), vb, ve, ptr(pj.plan), st),
+                      'plan')
+        if timed:
+            ev[0].record()
+        pj.project_tables(mu_d, w_d, out=counts)
+        if timed:
+            ev[1].record()
+        _native.check(lib.dexct_reduce_max(ptr(counts[0]), 0, counts[0].numel(), ptr(gmax), st), 'max')
+        gm = _shard.global_max(gmax)
+        if timed:
+            ev[2].record()
+        md.gn_device(counts[0], counts[1], i0_d, mus_d, args.iters, precision, out=a_out)
+        if timed:
+            ev[3].record()
+        thresh = 0.95 * float(gm.item())
+        _native.check(lib.dexct_gn_apply_mask(ptr(counts[0]), 0, counts[0].numel(), thresh, ptr(a_out), st), 'mask')
+        if world > 1:
+            gathered = _shard.gather_views(counts, total_views, view_dim=1)
+            mats = _shard.gather_views(a_out.to(torch.float32), total_views, view_dim=0)
+            return gathered, mats
+        return counts, a_out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t_sid, t_gn = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        torch.cuda.synchronize()
+        t_sid.append(ev[0].elapsed_time(ev[1]))
+        t_gn.append(ev[2].elapsed_time(ev[3]))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor(elapsed, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    integrals_per_step = world * n_rays * sum(n_e_spec)
+    value = integrals_per_step / (elapsed / args.steps)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    sid_ms, gn_ms = float(np.mean(t_sid)), float(np.mean(t_gn))
+    out = {
+        'metric': 'Siddon ray-energy integrals/sec', 'value': value, 'unit': 'ray-energy integrals/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 traversal+detection, '
+        + ('f64' if precision == 'f64' else 'f32 bulk + f64 polish') + ' Newton', 'data': 'synthetic',
+        'config': {'workload': f'{n}^3 water/bone phantom, {args.views} views/GPU x {args.channels} channels x '
+                               f'{rows} rows (stacked fan), dual 140/80 kVp Kramers spectra ({n_e_spec[0]}+{n_e_spec[1]} '
+                               f'energy bins), fused dual-spectrum Siddon + {args.iters}-iteration Gauss-Newton',
+                   'rays_per_gpu': n_rays, 'parallelism': f'views sharded x{world}'},
+        'kernel_ms': {'siddon_project': sid_ms, 'gn_decompose': gn_ms},
+        'siddon_only_integrals_per_s': n_rays * sum(n_e_spec) / (sid_ms * 1e-3),
+        'siddon_rays_per_s': n_rays / (sid_ms * 1e-3),
+        'gn_pixel_solves_per_s': n_rays / (gn_ms * 1e-3),
+    }
+
+    # ---- roofline of the traversal kernel: algorithmic bytes = exact segment count x 1 B + outputs
+    from oracle import c_oracle as co
+    geom = co.make_geom(ct.N_proj, ct.N_channels, rows, ph.z_index, n, n, n, ph.dx, ph.dy, ph.dz, ct.SID, ct.SDD)
+    seg_vc, _ = segment_count(co, geom, ct.view_cs(), ct.chan_cs(), total_views, vb, ve)
+    alg_bytes = seg_vc * rows * 1 + 4 * 2 * n_rays
+    achieved = alg_bytes / (sid_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get('siddon_hbm_bytes_per_launch')
+    out['roofline'] = {'kernel': 'rows_kernel' if pj.vol_zf is not None and args.kernel != 1 else 'rays_kernel',
+                       'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                       'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                       'algorithmic_bytes_per_launch': alg_bytes, 'segments_per_launch': seg_vc * rows,
+                       'avg_launch_ms': sid_ms}
+    gn_flops = n_rays * args.iters * i0.shape[1] * (28 + 1)      # 28 flops + 1 exp per energy-iteration
+    out['roofline_gn'] = {'kernel': 'gn_kernel', 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
+                          'achieved': gn_flops / (gn_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
+                          'unit': 'TFLOP/s', 'frac': gn_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          'avg_launch_ms': gn_ms, 'note': 'exp counted as 1 flop; not HBM bound (16 B/pixel)'}
+
+    # ---- single-row (the reference's own 2-D case), ray-parallel kernel
+    if not args.skip_single_row:
+        ct1 = dx.FanBeamGeometry(N_channels=args.channels, N_proj=args.views, gamma_fan=0.8230337, SID=60.0,
+                                 SDD=100.0, eid=True, detector_file=det, N_rows=1)
+        ph1 = synthetic.make_phantom(n, 1, extent=51.2, seed=1234)
+        pj1 = fp.Projector(ct1, ph1, kernel=1)
+        c1 = torch.empty((2, args.views, 1, args.channels), dtype=torch.float32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pj1.project_tables(mu_d, w_d, out=c1)
+        e0.record()
+        for _ in range(10):
+            pj1.project_tables(mu_d, w_d, out=c1)
+        e1.record()
+        torch.cuda.synchronize()
+        ms1 = e0.elapsed_time(e1) / 10
+        out['single_row'] = {'rays': args.views * args.channels, 'siddon_ms': ms1,
+                             'integrals_per_s': args.views * args.channels * sum(n_e_spec) / (ms1 * 1e-3)}
+
+    # ---- CPU baseline: the oracle (float64 textbook Siddon + detection, then float64 Newton) on a bounded
+    # sample of the same workload, all host cores
+    if not args.no_cpu_baseline:
+        threads = co.max_threads()
+        sample_rows, sample_views = 8, 2
+        gs = co.make_geom(ct.N_proj, ct.N_channels, sample_rows, n // 2 - sample_rows // 2, n, n, n, ph.dx, ph.dy,
+                          ph.dz, ct.SID, ct.SDD)
+        mu64, w64 = mu_d.double().cpu().numpy(), w_d.double().cpu().numpy()
+        t0 = time.perf_counter()
+        cs = co.project_classic(gs, ct.view_cs(), ct.chan_cs(), 0, sample_views, ph.volume, mu64, w64,
+                                n_threads=threads)
+        dt = time.perf_counter() - t0
+        # scale the sample to about cpu_seconds of work
+        sample_views = int(max(2, min(args.views, sample_views * args.cpu_seconds * 0.5 / max(dt, 1e-3))))
+        t0 = time.perf_counter()
+        cs = co.project_classic(gs, ct.view_cs(), ct.chan_cs(), 0, sample_views, ph.volume, mu64, w64,
+                                n_threads=threads)
+        t_proj = time.perf_counter() - t0
+        n_sample = sample_views * sample_rows * args.channels
+        t0 = time.perf_counter()
+        co.gn_decompose(cs[0].ravel(), cs[1].ravel(), i0, mus, args.iters, n_threads=threads)
+        t_gn_cpu = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': n_sample * sum(n_e_spec) / (t_proj + t_gn_cpu), 'unit': 'ray-energy integrals/s',
+                               'cores': threads, 'kind': 'port',
+                               'sample': f'{sample_views} views x {sample_rows} rows x {args.channels} channels of the same '
+                                         f'scan (oracle: float64 Siddon 1985 + detection {t_proj:.1f} s, float64 Newton '
+                                         f'{t_gn_cpu:.1f} s, OpenMP over rays / pixels)',
+                               'siddon_only_integrals_per_s': n_sample * sum(n_e_spec) / t_proj,
+                               'gn_pixel_solves_per_s': n_sample / t_gn_cpu}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,70 @@
+"""ctypes binding of libdexct_hip.so (include/dexct.h).  No fallback: if the library is missing or
+does not export the ABI the import of the compute modules fails loudly."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libdexct_hip.so')
+ABI_VERSION = 1
+
+# every entry point include/dexct.h declares
+SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
+           'dexct_siddon_project', 'dexct_siddon_trace', 'dexct_gn_decompose', 'dexct_gn_apply_mask',
+           'dexct_reduce_max']
+
+
+class FanGeom(C.Structure):
+    """dexct_fan_geom"""
+    _fields_ = [('n_views', C.c_int32), ('n_channels', C.c_int32), ('n_rows', C.c_int32), ('z_first', C.c_int32),
+                ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32), ('pad_', C.c_int32),
+                ('dx', C.c_double), ('dy', C.c_double), ('dz', C.c_double), ('sid', C.c_double), ('sdd', C.c_double)]
+
+
+PLAN_BYTES = 40   # sizeof(dexct_ray_plan)
+
+
+class DexctError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it is absent (build with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DexctError(f'{LIB_PATH} not found: the HIP extension is not built '
+                         f'(run `python -c "import __graft_entry__ as g; g.build()"` or `make -C dex-ct-sim_amd/csrc`). '
+                         f'There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise DexctError(f'{LIB_PATH} does not export {name}')
+    lib.dexct_strerror.restype = C.c_char_p
+    lib.dexct_strerror.argtypes = [C.c_int]
+    if lib.dexct_abi_version() != ABI_VERSION:
+        raise DexctError(f'ABI version mismatch: library {lib.dexct_abi_version()}, binding {ABI_VERSION}')
+    vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    lib.dexct_volume_layouts.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.dexct_fan_plan.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp]
+    lib.dexct_siddon_project.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp,
+                                         vp, i32, vp]
+    lib.dexct_siddon_trace.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.dexct_gn_decompose.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.dexct_gn_apply_mask.argtypes = [vp, i32, i64, f64, vp, vp]
+    lib.dexct_reduce_max.argtypes = [vp, i32, i64, vp, vp]
+    for name in SYMBOLS[3:]:
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        lib = load()
+        msg = lib.dexct_strerror(code).decode()
+        extra = f' (hipError {lib.dexct_last_hip_error()})' if code == -3 else ''
+        raise DexctError(f'{what}: {msg}{extra}')

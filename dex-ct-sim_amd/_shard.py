@@ -1,0 +1,52 @@
+"""Multi-GPU sharding of the hot path: projection angles split contiguously over the ranks.
+
+Every ray and every detector pixel is independent, so the only exchange is assembling the
+sinogram: one all-gather (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests), plus
+one scalar all-reduce(max) for the air mask of get_basismat_sinos (matdecomp.py:195-196 uses the
+GLOBAL maximum of sinogram 1).  The phantom and the tables are replicated.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def split(n, rank, world_size):
+    """Contiguous block of rank: the first n % world ranks get one extra item."""
+    base, rem = divmod(n, world_size)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def my_views(n_views):
+    r, w = world()
+    return split(n_views, r, w)
+
+
+def gather_views(local, n_views, view_dim=0):
+    """All-gather view shards (possibly of unequal size) into the full tensor on every rank."""
+    r, w = world()
+    if w == 1:
+        return local
+    local = local.movedim(view_dim, 0).contiguous()
+    sizes = [split(n_views, k, w) for k in range(w)]
+    n_max = max(e - b for b, e in sizes)
+    pad = n_max - local.shape[0]
+    if pad:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], dim=0)
+    out = local.new_empty((w * n_max,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, local)
+    parts = [out[k * n_max:k * n_max + (e - b)] for k, (b, e) in enumerate(sizes)]
+    return torch.cat(parts, dim=0).movedim(0, view_dim)
+
+
+def global_max(value):
+    """max over ranks of a 0-d tensor (device or CPU)."""
+    r, w = world()
+    if w > 1:
+        dist.all_reduce(value, op=dist.ReduceOp.MAX)
+    return value

@@ -1,0 +1,168 @@
+// Volume layouts and per-(view, channel) traversal plans.
+//
+// The plan is the float64 part of the projector: source / detector placement of the fan-beam
+// geometry (input/params.txt:18-27 of the reference), dominant in-plane axis, slope and
+// intercept of the minor coordinate, quantised once to 40-bit fixed point.  Everything the
+// traversal kernels do afterwards is integer or float32 arithmetic on these numbers, which is
+// what makes voxel-index sequences reproducible bit for bit (oracle/dexct_oracle.c orc_plan_one
+// restates the same operations in the same order; build with -ffp-contract=off).
+#include "common.h"
+
+namespace dexct {
+
+thread_local int g_last_hip_error = 0;
+
+__global__ __launch_bounds__(256) void fan_plan_kernel(dexct_fan_geom g, const double* __restrict__ view_cs,
+                                                       const double* __restrict__ chan_cs, int view_begin,
+                                                       int n_local_views, dexct_ray_plan* __restrict__ plan) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (c >= g.n_channels || v >= n_local_views) return;
+  const int view = view_begin + v;
+  const double cb = view_cs[2 * view], sb = view_cs[2 * view + 1];
+  const double cg = chan_cs[2 * c], sg = chan_cs[2 * c + 1];
+  const double sx = g.sid * cb, sy = g.sid * sb;
+  const double ex = -(cb * cg - sb * sg), ey = -(sb * cg + cb * sg);
+  const double sxv = sx / g.dx + 0.5 * g.nx, syv = sy / g.dy + 0.5 * g.ny;
+  const double exv = ex / g.dx, eyv = ey / g.dy;
+  const int axis = fabs(exv) >= fabs(eyv) ? 0 : 1;
+  double su, sv_, eu, ev;
+  int nu, nv;
+  if (axis == 0) { su = sxv; sv_ = syv; eu = exv; ev = eyv; nu = g.nx; nv = g.ny; }
+  else           { su = syv; sv_ = sxv; eu = eyv; ev = exv; nu = g.ny; nv = g.nx; }
+  const double kOne = 1099511627776.0;  // 2^40
+  const double slope = ev / eu;
+  const double v0 = sv_ - su * slope;
+  const long long SV = llrint(slope * kOne);
+  const long long V0 = llrint(v0 * kOne);
+  const double sq = (double)SV / kOne;
+  const double v0q = (double)V0 / kOne;
+  double ulo = 0.0, uhi = (double)nu;
+  bool miss = false;
+  if (SV > 0) {
+    ulo = fmax(ulo, (0.0 - v0q) / sq);
+    uhi = fmin(uhi, ((double)nv - v0q) / sq);
+  } else if (SV < 0) {
+    ulo = fmax(ulo, ((double)nv - v0q) / sq);
+    uhi = fmin(uhi, (0.0 - v0q) / sq);
+  } else if (v0q < 0.0 || v0q >= (double)nv) {
+    miss = true;
+  }
+  if (!(uhi > ulo)) miss = true;
+  double inv = 16777216.0;
+  if (SV != 0) inv = fmin(kOne / fabs((double)SV), 16777216.0);
+  dexct_ray_plan p;
+  p.V0 = V0;
+  p.SV = SV;
+  p.kf = (float)(inv * (1.0 / 4294967296.0));
+  p.len_per_u = (float)(1.0 / fabs(eu));
+  p.flags = (uint32_t)axis | (SV > 0 ? 2u : 0u);
+  if (miss) {
+    p.i_first = 0;
+    p.n_slabs = 0;
+    p.chord_u = 0.0f;
+  } else {
+    int i0 = (int)floor(ulo), i1 = (int)ceil(uhi) - 1;
+    if (i0 < 0) i0 = 0;
+    if (i1 > nu - 1) i1 = nu - 1;
+    p.i_first = i0;
+    p.n_slabs = i1 - i0 + 1;
+    p.chord_u = (float)(uhi - ulo);
+  }
+  plan[(size_t)v * g.n_channels + c] = p;
+}
+
+// [nz][ny][nx] -> [nz][nx][ny] through a 64x64 LDS tile (coalesced on both sides), and
+// optionally -> [ny][nx][nz] (z fastest).
+__global__ __launch_bounds__(256) void transpose_xy_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                           int nx, int ny) {
+  __shared__ uint8_t tile[64][65];
+  const size_t slice = (size_t)blockIdx.z * nx * ny;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int r = ty; r < 64; r += 4) {
+    int x = x0 + tx, y = y0 + r;
+    if (x < nx && y < ny) tile[r][tx] = src[slice + (size_t)y * nx + x];
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    int y = y0 + tx, x = x0 + r;
+    if (x < nx && y < ny) dst[slice + (size_t)x * ny + y] = tile[tx][r];
+  }
+}
+
+// [nz][ny*nx] -> [ny*nx][nz]: a 2-D transpose with rows = z, columns = in-plane index.
+__global__ __launch_bounds__(256) void transpose_z_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                          size_t nxy, int nz) {
+  __shared__ uint8_t tile[64][65];
+  const size_t p0 = (size_t)blockIdx.x * 64;
+  const int z0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    size_t p = p0 + tx;
+    int z = z0 + r;
+    if (p < nxy && z < nz) tile[r][tx] = src[(size_t)z * nxy + p];
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    size_t p = p0 + r;
+    int z = z0 + tx;
+    if (p < nxy && z < nz) dst[p * nz + z] = tile[tx][r];
+  }
+}
+
+}  // namespace dexct
+
+using namespace dexct;
+
+extern "C" {
+
+const char* dexct_strerror(int code) {
+  switch (code) {
+    case DEXCT_OK: return "ok";
+    case DEXCT_EINVAL: return "invalid argument";
+    case DEXCT_ERANGE: return "size out of supported range";
+    case DEXCT_EHIP: return "HIP runtime error (see dexct_last_hip_error)";
+    default: return "unknown dexct error";
+  }
+}
+
+int dexct_abi_version(void) { return DEXCT_ABI_VERSION; }
+
+int dexct_last_hip_error(void) { return g_last_hip_error; }
+
+int dexct_volume_layouts(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, uint8_t* vol_xy, uint8_t* vol_zf,
+                         void* stream) {
+  if (!vol || nx <= 0 || ny <= 0 || nz <= 0 || (!vol_xy && !vol_zf)) return DEXCT_EINVAL;
+  if (nz > 65535 || (ny + 63) / 64 > 65535) return DEXCT_ERANGE;
+  hipStream_t st = as_stream(stream);
+  if (vol_xy) {
+    dim3 grid((nx + 63) / 64, (ny + 63) / 64, nz);
+    hipLaunchKernelGGL(transpose_xy_kernel, grid, dim3(256), 0, st, vol, vol_xy, nx, ny);
+    DEXCT_LAUNCH_CHECK();
+  }
+  if (vol_zf) {
+    size_t nxy = (size_t)nx * ny;
+    dim3 grid((unsigned)((nxy + 63) / 64), (nz + 63) / 64, 1);
+    hipLaunchKernelGGL(transpose_z_kernel, grid, dim3(256), 0, st, vol, vol_zf, nxy, nz);
+    DEXCT_LAUNCH_CHECK();
+  }
+  return DEXCT_OK;
+}
+
+int dexct_fan_plan(const dexct_fan_geom* geom, const double* view_cs, const double* chan_cs, int32_t view_begin,
+                   int32_t view_end, dexct_ray_plan* plan, void* stream) {
+  if (!geom || !view_cs || !chan_cs || !plan) return DEXCT_EINVAL;
+  if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
+  if (geom->n_channels <= 0 || geom->nx <= 0 || geom->ny <= 0) return DEXCT_EINVAL;
+  if (geom->nx > 8192 || geom->ny > 8192) return DEXCT_ERANGE;  // fixed-point range: 13 + 40 bits
+  const int nv = view_end - view_begin;
+  if (nv > 65535) return DEXCT_ERANGE;
+  dim3 grid((geom->n_channels + 255) / 256, nv, 1);
+  hipLaunchKernelGGL(fan_plan_kernel, grid, dim3(256), 0, as_stream(stream), *geom, view_cs, chan_cs, view_begin,
+                     nv, plan);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+}  // extern "C"

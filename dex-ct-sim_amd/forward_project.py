@@ -1,0 +1,164 @@
+"""Forward projection: drop-in for the reference's ``xtomosim.forward_project.get_sino``.
+
+``get_sino(ct, phantom, spec) -> (sino_raw, sino_log)`` is called at main.py:120 of the reference;
+its source (x-tomo-sim) is not in the reference checkout, so the contract is reconstructed from the
+callers: two ``[N_proj, N_channels]`` arrays, ``sino_raw`` in detected counts (matdecomp.py:30,179)
+and ``sino_log`` the log-normalised sinogram fed to reconstruction (main.py:134).  Detection uses
+the weighting that the reference's decomposition assumes (matdecomp.py:146-150):
+``counts = sum_E I0(E) eta(E) [E if EID] dE exp(-sum_m mu_m(E) L_m)``, noise-free.
+
+All work runs in the HIP library (dexct_fan_plan, dexct_volume_layouts, dexct_siddon_project).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native, _shard
+from ._device import device, ptr, stream_ptr, to_dev
+
+
+def effective_weights(ct, spec):
+    """I0 * detector response * dE on the spectrum's own grid (matdecomp.py:142,146-150)."""
+    return spec.I0 * ct.detector_response(spec.E) * spec.bin_widths()
+
+
+def merged_tables(ct, phantom, specs):
+    """One energy grid for a fused multi-spectrum traversal.
+
+    Each spectrum keeps its own quadrature: on the merged grid its weight is non-zero only at its
+    own energies (no interpolation), bins that no spectrum weights are dropped.
+    Returns E [nE], mu [M, nE] (float64, 1/cm), w [S, nE] (float64).
+    """
+    E = np.unique(np.concatenate([s.E for s in specs]))
+    w = np.zeros((len(specs), E.size))
+    for k, s in enumerate(specs):
+        w[k, np.searchsorted(E, s.E)] = effective_weights(ct, s)
+    keep = np.any(w != 0.0, axis=0)
+    E, w = E[keep], w[:, keep]
+    return E, phantom.mu_table(E), w
+
+
+class Projector:
+    """Device-resident state of one (scanner, phantom) pair: volume layouts and ray plans.
+
+    ``view_range`` restricts the instance to a contiguous shard of projection angles (one per
+    rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel.
+    """
+
+    def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
+        self.lib = _native.load()
+        self.dev = dev or device()
+        self.ct, self.phantom = ct, phantom
+        self.kernel = kernel
+        vb, ve = view_range if view_range is not None else (0, ct.N_proj)
+        if not (0 <= vb < ve <= ct.N_proj):
+            raise ValueError(f'bad view range {view_range}')
+        self.view_begin, self.view_end = int(vb), int(ve)
+        z_first = phantom.z_index
+        if z_first < 0 or z_first + ct.N_rows > phantom.Nz:
+            raise ValueError(f'rows {ct.N_rows} from slice {z_first} do not fit Nz={phantom.Nz}')
+        half_diag = 0.5 * np.hypot(phantom.Nx * phantom.dx, phantom.Ny * phantom.dy)
+        if ct.SID <= half_diag or ct.SDD - ct.SID < 0:
+            raise ValueError('source must lie outside the phantom grid (SID > half diagonal) and SDD >= SID')
+        self.geom = _native.FanGeom(ct.N_proj, ct.N_channels, ct.N_rows, z_first, phantom.Nx, phantom.Ny,
+                                    phantom.Nz, 0, phantom.dx, phantom.dy, phantom.dz, ct.SID, ct.SDD)
+        st = stream_ptr()
+        self.view_cs = to_dev(ct.view_cs(), torch.float64, self.dev)
+        self.chan_cs = to_dev(ct.chan_cs(), torch.float64, self.dev)
+        n_local = self.view_end - self.view_begin
+        self.plan = torch.empty(n_local * ct.N_channels * _native.PLAN_BYTES, dtype=torch.uint8, device=self.dev)
+        _native.check(self.lib.dexct_fan_plan(C.byref(self.geom), ptr(self.view_cs), ptr(self.chan_cs),
+                                              self.view_begin, self.view_end, ptr(self.plan), st), 'dexct_fan_plan')
+        self.vol_yx = to_dev(phantom.volume, torch.uint8, self.dev)
+        self.vol_xy = torch.empty_like(self.vol_yx)
+        want_zf = kernel == 2 or (kernel == 0 and ct.N_rows >= 64)
+        self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
+        _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, phantom.Nz,
+                                                    ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
+
+    @property
+    def n_local_views(self):
+        return self.view_end - self.view_begin
+
+    def upload_tables(self, specs):
+        E, mu, w = merged_tables(self.ct, self.phantom, specs)
+        return (E, to_dev(mu, torch.float32, self.dev), to_dev(w, torch.float32, self.dev), w.sum(axis=1))
+
+    def project_tables(self, mu_d, w_d, want_pathlen=False, out=None):
+        """Device-side call: mu_d [M, nE], w_d [S, nE] float32 tensors -> counts [S, nV, rows, ch]."""
+        S, nE = w_d.shape
+        M = mu_d.shape[0]
+        ct = self.ct
+        counts = out if out is not None else torch.empty((S, self.n_local_views, ct.N_rows, ct.N_channels),
+                                                         dtype=torch.float32, device=self.dev)
+        pathlen = None
+        if want_pathlen:
+            pathlen = torch.empty((self.n_local_views, ct.N_rows, ct.N_channels, M), dtype=torch.float32,
+                                  device=self.dev)
+        _native.check(self.lib.dexct_siddon_project(
+            C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy),
+            ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), self.kernel, stream_ptr()),
+            'dexct_siddon_project')
+        return (counts, pathlen) if want_pathlen else counts
+
+    def project(self, specs, want_pathlen=False):
+        _, mu_d, w_d, air = self.upload_tables(specs)
+        return self.project_tables(mu_d, w_d, want_pathlen), air
+
+    def trace(self, rays_vrc, max_seg=None):
+        """Voxel-index sequence and float32 piece lengths of selected rays (views relative to the shard)."""
+        rays = to_dev(np.asarray(rays_vrc, dtype=np.int32).reshape(-1, 3), torch.int32, self.dev)
+        n = rays.shape[0]
+        max_seg = max_seg or 2 * max(self.phantom.Nx, self.phantom.Ny) + 4
+        vox = torch.zeros((n, max_seg), dtype=torch.int32, device=self.dev)
+        ln = torch.zeros((n, max_seg), dtype=torch.float32, device=self.dev)
+        ns = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        _native.check(self.lib.dexct_siddon_trace(C.byref(self.geom), ptr(self.plan), ptr(rays), n, max_seg,
+                                                  ptr(vox), ptr(ln), ptr(ns), stream_ptr()), 'dexct_siddon_trace')
+        return vox.cpu().numpy(), ln.cpu().numpy(), ns.cpu().numpy()
+
+    def plan_host(self):
+        """The plan table as a NumPy structured array (for parity tests)."""
+        dt = np.dtype([('V0', '<i8'), ('SV', '<i8'), ('i_first', '<i4'), ('n_slabs', '<i4'), ('kf', '<f4'),
+                       ('len_per_u', '<f4'), ('chord_u', '<f4'), ('flags', '<u4')])
+        return self.plan.cpu().numpy().view(dt)
+
+
+_cache = {}
+
+
+def _projector(ct, phantom, view_range):
+    key = (id(ct), id(phantom), view_range, ct.N_proj, ct.N_channels, ct.N_rows, phantom.z_index)
+    pj = _cache.get(key)
+    if pj is None or pj.ct is not ct or pj.phantom is not phantom:
+        _cache.clear()                      # keep one (scanner, phantom) pair resident
+        pj = _cache[key] = Projector(ct, phantom, view_range)
+    return pj
+
+
+def get_sinos(ct, phantom, specs):
+    """Several spectra from ONE traversal (path lengths are energy independent).
+
+    Returns a list of (sino_raw, sino_log) float32 NumPy pairs, shaped [N_proj, N_channels]
+    (or [N_proj, N_rows, N_channels] for N_rows > 1).  Under torch.distributed the projection angles
+    are sharded over the ranks and every rank returns the full gathered sinograms.
+    """
+    vb, ve = _shard.my_views(ct.N_proj)
+    pj = _projector(ct, phantom, (vb, ve))
+    counts, air = pj.project(specs)
+    counts = _shard.gather_views(counts, ct.N_proj, view_dim=1)
+    raw = counts.cpu().numpy()
+    if ct.N_rows == 1:
+        raw = raw[:, :, 0, :]
+    out = []
+    for k in range(len(specs)):
+        with np.errstate(divide='ignore'):
+            log = np.log(np.float32(air[k]) / raw[k])
+        out.append((raw[k], log.astype(np.float32)))
+    return out
+
+
+def get_sino(ct, phantom, spec):
+    """Drop-in for the reference call ``sino_raw, sino_log = get_sino(ct, phantom, spec)`` (main.py:120)."""
+    return get_sinos(ct, phantom, [spec])[0]

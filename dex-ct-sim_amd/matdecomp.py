@@ -1,0 +1,137 @@
+"""Dual-energy basis-material decomposition on the GPU: drop-in for the reference's matdecomp.py.
+
+Same public names and argument meaning as /root/reference/matdecomp.py:
+``mat1, matcomp1, density1, mat2, matcomp2, density2`` (:11-17, imported by plots.py:18),
+``optimize_sino`` / ``optimize_sino_cpu`` (:20-127), ``do_matdecomp_gn`` (:130-164),
+``get_basismat_sinos`` (:167-207).  The Newton iterations run in the HIP kernel behind
+``dexct_gn_decompose``; this module only builds the energy tables the way the reference does
+and moves arrays.  There is no NumPy or CuPy compute path here.
+
+Error behaviour: the reference raises ``numpy.linalg.LinAlgError`` when a pixel's 2x2 Hessian is
+exactly singular (matdecomp.py:125); the kernel never traps and leaves inf/NaN in such a pixel
+(masked air pixels are set to 0 afterwards exactly as in the reference, :204-205).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _native, _shard, xcompy as xc
+from ._device import device, ptr, stream_ptr, to_dev
+
+# Basis materials, as data (matdecomp.py:11-17).
+mat1 = 'ICRU tissue'
+matcomp1 = 'H(10.2)C(14.3)N(3.4)O(70.8)Na(0.2)P(0.3)S(0.3)Cl(0.2)K(0.3)'
+density1 = 1.06  # [g/cm3]
+mat2 = 'ICRU bone'
+matcomp2 = 'H(3.4)C(15.5)N(4.2)O(43.5)Na(0.1)Mg(0.2)P(10.3)S(0.3)Ca(22.5)'
+density2 = 1.92  # [g/cm3]
+
+# 'f64': float64 throughout (the reference's arithmetic).  'mixed': float32 bulk iterations, then
+# N_POLISH float64 iterations (same total count).  Override with DEXCT_GN_PRECISION.
+DEFAULT_PRECISION = os.environ.get('DEXCT_GN_PRECISION', 'f64')
+N_POLISH = 4
+
+
+def _as_device_counts(x, dev):
+    """Counts as a contiguous device tensor, float64 if given float64, else float32."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(dev)
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.to(torch.float64)
+        return t.contiguous()
+    a = np.asarray(x)
+    dt = torch.float32 if a.dtype == np.float32 else torch.float64
+    return to_dev(a.astype(np.float32 if dt == torch.float32 else np.float64, copy=False), dt, dev)
+
+
+def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None):
+    """g1, g2: device tensors of equal shape; i0, mus: [2, nE] float64 (host or device).
+    Returns a device tensor of shape g1.shape + (2,) float64."""
+    lib = _native.load()
+    dev = g1.device
+    precision = precision or DEFAULT_PRECISION
+    if precision not in ('f64', 'mixed'):
+        raise ValueError(f'precision {precision!r}')
+    if g1.shape != g2.shape or g1.dtype != g2.dtype:
+        raise ValueError('the two sinograms must agree in shape and dtype')
+    i0_d = to_dev(i0, torch.float64, dev)
+    mus_d = to_dev(mus, torch.float64, dev)
+    if i0_d.shape != mus_d.shape or i0_d.shape[0] != 2:
+        raise ValueError('i0 and mus must both be [2, nE]')
+    a = out if out is not None else torch.empty(tuple(g1.shape) + (2,), dtype=torch.float64, device=dev)
+    _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), int(g1.dtype == torch.float64), g1.numel(), ptr(i0_d),
+                                         ptr(mus_d), i0_d.shape[1], int(n_iters), int(precision == 'mixed'),
+                                         int(n_polish), ptr(a), stream_ptr()), 'dexct_gn_decompose')
+    return a
+
+
+def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None):
+    """Newton iterations for every pixel (signature of matdecomp.py:20 / :87).
+
+    Sino_gg [2, nViews, nBins] counts; i0 [2, nBins, nEnergies] (must not vary over bins, which is
+    all do_matdecomp_gn ever builds, :151) or [2, nEnergies]; mus [2, nEnergies].
+    Returns Sino_aa [nViews, nBins, 2] float64 NumPy.  ``ee`` is unused, as in the reference.
+    """
+    i0 = np.asarray(i0, dtype=np.float64)
+    if i0.ndim == 3:
+        if not np.all(i0 == i0[:, :1, :]):
+            raise NotImplementedError('channel-dependent effective spectra are not supported by the HIP kernel')
+        i0 = i0[:, 0, :]
+    dev = device()
+    g = _as_device_counts(np.asarray(Sino_gg), dev)
+    a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision)
+    return a.cpu().numpy()
+
+
+optimize_sino_cpu = optimize_sino   # the reference's NumPy twin (:87); same engine here
+
+
+def decomposition_tables(ct, spec1, spec2):
+    """Union energy grid and effective spectra exactly as matdecomp.py:140-150 builds them."""
+    ee = np.array(sorted(set(np.append(spec1.E, spec2.E))))
+    dE = np.append([ee[0]], ee[1:] - ee[:-1])          # 1st energy bin is 0 to E[0]
+    detresponse = np.interp(ee, ct.det_E, ct.det_eta_E)
+    if ct.eid:
+        detresponse = detresponse * ee
+    i0 = np.stack([np.interp(ee, spec1.E, spec1.I0) * detresponse * dE,
+                   np.interp(ee, spec2.E, spec2.I0) * detresponse * dE])
+    mus = np.stack([xc.mixatten(matcomp1, ee), xc.mixatten(matcomp2, ee)])   # mass attenuation (:158)
+    return ee, i0, mus
+
+
+def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None):
+    """[N_proj, N_channels, 2] density line integrals (matdecomp.py:130-164)."""
+    _, i0, mus = decomposition_tables(ct, spec1, spec2)
+    dev = device()
+    g1 = _as_device_counts(sino1, dev)
+    g2 = _as_device_counts(sino2, dev).to(g1.dtype)
+    a = gn_device(g1, g2, i0, mus, n_iters, precision)
+    return a if isinstance(sino1, torch.Tensor) else a.cpu().numpy()
+
+
+def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None):
+    """Basis-material sinograms (matdecomp.py:167-207): air mask from sinogram 1
+    (``>= mask_thresh * max``), Newton decomposition, masked pixels set to exactly 0.
+
+    NumPy in -> NumPy float64 out (two views of one buffer, like the reference); device tensors
+    in -> device tensors out.  Under torch.distributed the inputs are each rank's own view shard
+    and the mask threshold uses the all-reduced global maximum.
+    """
+    lib = _native.load()
+    dev = device()
+    _, i0, mus = decomposition_tables(ct, spec1, spec2)
+    g1 = _as_device_counts(sino_raw_1, dev)
+    g2 = _as_device_counts(sino_raw_2, dev).to(g1.dtype)
+    is64 = int(g1.dtype == torch.float64)
+    gmax = torch.empty((), dtype=torch.float64, device=dev)
+    _native.check(lib.dexct_reduce_max(ptr(g1), is64, g1.numel(), ptr(gmax), stream_ptr()), 'dexct_reduce_max')
+    gmax = _shard.global_max(gmax)
+    a = gn_device(g1, g2, i0, mus, n_iters, precision)
+    thresh = float(mask_thresh) * float(gmax.item())
+    _native.check(lib.dexct_gn_apply_mask(ptr(g1), is64, g1.numel(), thresh, ptr(a), stream_ptr()),
+                  'dexct_gn_apply_mask')
+    if isinstance(sino_raw_1, torch.Tensor):
+        return a[..., 0], a[..., 1]
+    a = a.cpu().numpy()
+    return a[..., 0], a[..., 1]

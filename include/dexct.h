@@ -1,0 +1,138 @@
+/*
+ * dexct.h - C ABI of the MI355X-native dual-energy CT hot path.
+ *
+ * The reference (gjadick/dex-ct-sim) has no FFI: its boundary for this path is two Python
+ * functions, get_sino(ct, phantom, spec) (main.py:120, source in the un-vendored x-tomo-sim
+ * submodule) and get_basismat_sinos(ct, sino1, sino2, spec1, spec2, n_iters, mask_thresh)
+ * (matdecomp.py:167-207).  The Python shims with exactly those signatures live in
+ * dex-ct-sim_amd/ and call the entry points below through ctypes; INTEGRATION.md shows the
+ * binding.  Everything here is plain C: device pointers are passed as void* / typed pointers
+ * obtained from any HIP allocator (the shims use torch-ROCm tensors as containers), the
+ * stream is a hipStream_t passed as void*, the caller owns every buffer, no entry point
+ * allocates, synchronises or throws.  Return value: 0 on success, a negative DEXCT_E* code
+ * otherwise (dexct_strerror gives text).
+ */
+#ifndef DEXCT_H
+#define DEXCT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEXCT_ABI_VERSION 1
+
+#define DEXCT_OK 0
+#define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
+#define DEXCT_ERANGE (-2)   /* a size exceeds what the kernels support (see DEXCT_MAX_*) */
+#define DEXCT_EHIP (-3)     /* a HIP runtime call failed; dexct_last_hip_error() has the code */
+
+#define DEXCT_MAX_MATERIALS 64 /* material ids 0..63 in the uint8 volume */
+#define DEXCT_MAX_SPECTRA 4    /* spectra detected per traversal */
+#define DEXCT_FIX_FRAC 40      /* fractional bits of the fixed-point minor-axis coordinate */
+
+/* Fan-beam scan of a voxel grid (the reference's "fan_beam" scanner_geometry,
+ * input/params.txt:18-27, with detector rows stacked along z: row r images slice z_first + r,
+ * which at n_rows == 1 is the reference's z_index, params.txt:16). */
+typedef struct dexct_fan_geom {
+  int32_t n_views;    /* N_projections */
+  int32_t n_channels; /* N_channels    */
+  int32_t n_rows;     /* detector rows = z-slices imaged (1 in the reference) */
+  int32_t z_first;    /* slice index of row 0 */
+  int32_t nx, ny, nz; /* phantom grid */
+  int32_t pad_;
+  double dx, dy, dz;  /* voxel size [cm] */
+  double sid, sdd;    /* source-isocentre / source-detector distance [cm] */
+} dexct_fan_geom;
+
+/* Per (view, channel) traversal plan, produced on the device by dexct_fan_plan.
+ * All rows of a stacked fan share it.  The minor in-plane coordinate v is carried as a
+ * signed fixed-point number with DEXCT_FIX_FRAC fractional bits: v(i) = (V0 + i*SV) / 2^40
+ * at the entry face of dominant-axis slab i, so voxel indices are exact integer arithmetic
+ * and identical on any device or host. */
+typedef struct dexct_ray_plan {
+  int64_t V0;        /* fixed-point v at u = 0 */
+  int64_t SV;        /* fixed-point dv/du, |SV| <= 2^40 */
+  int32_t i_first;   /* first dominant-axis slab the ray touches */
+  int32_t n_slabs;   /* number of slabs (0 = ray misses the grid) */
+  float kf;          /* 2^-32 * min(1/|dv/du|, 2^24): fraction -> crossing parameter */
+  float len_per_u;   /* path length [cm] per unit of u */
+  float chord_u;     /* length of the ray inside the grid, in units of u */
+  uint32_t flags;    /* bit0: dominant axis (0: u=x, v=y; 1: u=y, v=x); bit1: SV > 0 */
+} dexct_ray_plan;
+
+const char* dexct_strerror(int code);
+int dexct_abi_version(void);
+int dexct_last_hip_error(void);
+
+/* Volume layouts.  The phantom arrives as uint8 material ids, C order [nz][ny][nx] (x fastest).
+ * dexct_volume_layouts writes the two layouts the traversal kernels read:
+ *   vol_yx  [nz][ny][nx]   (a straight copy; minor axis x contiguous; used by y-dominant rays)
+ *   vol_xy  [nz][nx][ny]   (in-plane transpose; minor axis y contiguous; x-dominant rays)
+ *   vol_zf  [ny][nx][nz]   (z fastest; used by the row-parallel kernel)          (may be NULL)
+ * Each destination holds nx*ny*nz bytes. */
+int dexct_volume_layouts(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, uint8_t* vol_xy,
+                         uint8_t* vol_zf, void* stream);
+
+/* Plans for views [view_begin, view_end): plan[(view - view_begin) * n_channels + channel].
+ * view_cs[2*view + {0,1}] = cos, sin of the source angle; chan_cs[2*channel + {0,1}] = cos, sin of
+ * the fan angle of the channel (float64, computed once on the host so that every
+ * implementation starts from the same numbers). */
+int dexct_fan_plan(const dexct_fan_geom* geom, const double* view_cs, const double* chan_cs,
+                   int32_t view_begin, int32_t view_end, dexct_ray_plan* plan, void* stream);
+
+/* Siddon forward projection + polychromatic detection: replaces get_sino (main.py:120).
+ *   mu[m*n_energies + e]      linear attenuation [1/cm] of material id m at energy bin e
+ *   weights[s*n_energies + e] effective spectrum of spectrum s (I0 * detector response * dE,
+ *                             the weighting of matdecomp.py:146-150)
+ *   counts[((s*n_local_views + view - view_begin)*n_rows + row)*n_channels + channel]  (float32)
+ *   pathlen (optional, may be NULL): [ray][n_materials] float32 path length [cm] per material,
+ *                             ray = ((view - view_begin)*n_rows + row)*n_channels + channel
+ * vol_yx / vol_xy / vol_zf as written by dexct_volume_layouts (vol_zf may be NULL: then the
+ * ray-parallel kernel is used for every shape).
+ * kernel: 0 = choose, 1 = ray-parallel (one thread per ray), 2 = row-parallel (one workgroup
+ * per (view, channel), lanes over detector rows). */
+int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
+                         int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
+                         const uint8_t* vol_zf, int32_t n_materials, int32_t n_energies,
+                         int32_t n_spectra, const float* mu, const float* weights, float* counts,
+                         float* pathlen, int32_t kernel, void* stream);
+
+/* Trace of single rays for parity tests: voxel-index sequence and segment lengths.
+ * For each of n_rays rays (view, row, channel given in ray_vrc[3*r + {0,1,2}], view relative to
+ * the plan's view_begin) writes up to max_seg segments: seg_voxel[r*max_seg + k] = linear voxel
+ * index (z*ny + y)*nx + x, seg_len[r*max_seg + k] = length in units of u (float32, exactly the
+ * numbers the projection kernels accumulate), n_seg[r] = number of segments produced. */
+int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const int32_t* ray_vrc,
+                       int32_t n_rays, int32_t max_seg, int32_t* seg_voxel, float* seg_len,
+                       int32_t* n_seg, void* stream);
+
+/* Per-pixel Newton (Gauss-Newton) basis-material decomposition: replaces optimize_sino_cpu
+ * (matdecomp.py:87-127) for channel-independent effective spectra (the only case
+ * do_matdecomp_gn produces, matdecomp.py:151).
+ *   g1, g2     measured counts of the two spectra, n_pix values each; g_is_f64 selects
+ *              float64 (1) or float32 (0) input
+ *   i0[k*n_energies + e]   effective spectra (float64), k = 0, 1
+ *   mus[m*n_energies + e]  basis mass attenuation (float64), m = 0, 1
+ *   out_a[2*p + m]         density line integrals (float64), initialised to 1e-6 inside
+ *   precision: 0 = float64 throughout (reference arithmetic);
+ *              1 = float32 bulk iterations followed by float64 polish iterations
+ *   n_polish   number of trailing float64 iterations when precision == 1 */
+int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
+                       const double* mus, int32_t n_energies, int32_t n_iters, int32_t precision,
+                       int32_t n_polish, double* out_a, void* stream);
+
+/* Air mask of get_basismat_sinos (matdecomp.py:194-205): out_a[2p], out_a[2p+1] = 0 wherever
+ * g1[p] >= thresh_value (thresh_value = mask_thresh * global max, computed by the caller so that a
+ * sharded run can all-reduce the max first). */
+int dexct_gn_apply_mask(const void* g1, int32_t g_is_f64, int64_t n_pix, double thresh_value,
+                        double* out_a, void* stream);
+
+/* max(g1) over n_pix values into *out_max (device float64 scalar). */
+int dexct_reduce_max(const void* g1, int32_t g_is_f64, int64_t n_pix, double* out_max, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEXCT_H */

@@ -1,0 +1,49 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+INPUT = os.path.join(ROOT, 'dex-ct-sim_amd', 'input')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs an MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return np.load(os.path.join(GOLDEN, 'gn_reference.npz'))
+
+
+@pytest.fixture(scope='session')
+def hip():
+    """The HIP library and a device; fails (not skips) if either is missing on a GPU run."""
+    import torch
+    from dex_ct_sim_amd import _native
+    lib = _native.load()
+    assert torch.cuda.is_available(), 'gpu-marked test started without a HIP device'
+    return lib
+
+
+def small_scan(n=48, nz=1, n_views=60, n_channels=96, n_rows=1, z_index=0, materials=None, seed=1234):
+    """A small fan-beam scan of a synthetic phantom, reference geometry scaled down."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import synthetic
+    ct = dx.FanBeamGeometry(N_channels=n_channels, N_proj=n_views, gamma_fan=0.8230337, SID=60.0, SDD=100.0,
+                            eid=True, detector_file=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'), N_rows=n_rows)
+    ph = synthetic.make_phantom(n, nz, seed=seed, z_index=z_index)
+    if materials is not None:
+        ph.materials = materials
+    return ct, ph
+
+
+def oracle_geom(ct, ph):
+    from oracle import c_oracle as co
+    return co.make_geom(ct.N_proj, ct.N_channels, ct.N_rows, ph.z_index, ph.Nx, ph.Ny, ph.Nz, ph.dx, ph.dy, ph.dz,
+                        ct.SID, ct.SDD)

@@ -1,0 +1,115 @@
+"""HIP Gauss-Newton decomposition against golden vectors from the real reference and the oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+TOL_F64 = 1e-9      # float64 kernel vs reference: rounding-level (relative to max(|a|, 1))
+TOL_NS = 1e-5       # north-star tolerance, used for the mixed-precision mode
+
+
+def err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))
+
+
+def run(g, i0, mus, n_iters, precision):
+    from dex_ct_sim_amd import matdecomp as md
+    return md.optimize_sino(g, None, i0, mus, n_iters, precision=precision)
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2])
+@pytest.mark.parametrize('n_iters', [1, 2, 50])
+def test_f64_trajectory_matches_reference(hip, golden, ci, n_iters):
+    g = golden
+    a = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], n_iters, 'f64')
+    assert a.shape == (4, 32, 2) and a.dtype == np.float64
+    assert err(a, g[f'gn{ci}_a_iters{n_iters}']) < TOL_F64
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2])
+def test_mixed_precision_final_matches_reference(hip, golden, ci):
+    g = golden
+    a = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], 50, 'mixed')
+    assert err(a, g[f'gn{ci}_a_iters50']) < TOL_NS
+
+
+def test_reference_layout_i0_accepted_and_bowtie_rejected(hip, golden):
+    g = golden
+    i0_tiled = np.repeat(g['gn0_i0'][:, None, :], 32, axis=1)
+    a = run(g['gn0_g'], i0_tiled, g['gn0_mus'], 5, 'f64')
+    assert err(a, g['gn0_a_iters5']) < TOL_F64
+    with pytest.raises(NotImplementedError):
+        run(g['opt_g'], g['opt_i0'], g['opt_mus'], 3, 'f64')
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2])
+def test_get_basismat_sinos_matches_reference(hip, golden, ci):
+    from dex_ct_sim_amd import matdecomp as md, xcompy
+    g = golden
+    ct = types.SimpleNamespace(det_E=g[f'gn{ci}_det_E'], det_eta_E=g[f'gn{ci}_det_eta'], eid=bool(g[f'gn{ci}_eid']))
+    s1 = types.SimpleNamespace(E=g[f'gn{ci}_spec1_E'], I0=g[f'gn{ci}_spec1_I0'])
+    s2 = types.SimpleNamespace(E=g[f'gn{ci}_spec2_E'], I0=g[f'gn{ci}_spec2_I0'])
+    ee, i0, mus = md.decomposition_tables(ct, s1, s2)
+    assert np.array_equal(ee, g[f'gn{ci}_ee']) and np.array_equal(i0, g[f'gn{ci}_i0'])
+    assert np.array_equal(mus, g[f'gn{ci}_mus'])
+    for key, kw in (('50', dict(n_iters=50)), ('default', {}), ('thresh50', dict(n_iters=50, mask_thresh=0.5))):
+        m1, m2 = md.get_basismat_sinos(ct, g[f'gn{ci}_g'][0].copy(), g[f'gn{ci}_g'][1].copy(), s1, s2, **kw)
+        r1, r2 = g[f'gn{ci}_mat1_{key}'], g[f'gn{ci}_mat2_{key}']
+        assert m1.dtype == np.float64 and m1.shape == r1.shape
+        assert np.array_equal(m1 == 0, r1 == 0) and np.array_equal(m2 == 0, r2 == 0)
+        assert err(m1, r1) < TOL_F64 and err(m2, r2) < TOL_F64
+
+
+def test_float32_sinograms_and_device_tensors(hip, golden):
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    g32 = g['gn0_g'].astype(np.float32)
+    ref = co.gn_decompose(g32[0].astype(np.float64), g32[1].astype(np.float64), g['gn0_i0'], g['gn0_mus'], 50)
+    a = run(g32, g['gn0_i0'], g['gn0_mus'], 50, 'f64')
+    assert err(a, ref) < TOL_F64
+    d = md.gn_device(torch.tensor(g32[0], device='cuda'), torch.tensor(g32[1], device='cuda'), g['gn0_i0'],
+                     g['gn0_mus'], 50)
+    assert d.is_cuda and err(d.cpu().numpy(), ref) < TOL_F64
+
+
+def test_large_random_against_c_oracle(hip, golden):
+    """20k pixels of noisy dual-energy data: float64 kernel vs the C oracle; mixed mode within 1e-5."""
+    g = golden
+    rng = np.random.default_rng(3)
+    i0, mus = g['gn0_i0'], g['gn0_mus']
+    a_true = np.stack([rng.uniform(0, 40, 20000), rng.uniform(0, 8, 20000)], -1)
+    ex = np.exp(-a_true @ mus)
+    cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)])
+    cnt *= 1 + 0.003 * rng.standard_normal(cnt.shape)
+    ref = co.gn_decompose(cnt[0], cnt[1], i0, mus, 50, n_threads=8)
+    ok = np.isfinite(ref).all(-1)
+    assert ok.mean() > 0.99
+    a = run(cnt.reshape(2, 100, 200), i0, mus, 50, 'f64').reshape(-1, 2)
+    assert err(a[ok], ref[ok]) < TOL_F64
+    m = run(cnt.reshape(2, 100, 200), i0, mus, 50, 'mixed').reshape(-1, 2)
+    assert err(m[ok], ref[ok]) < TOL_NS
+
+
+def test_round_trip_projection_to_thickness(hip):
+    """forward project a water/bone phantom with both spectra on the GPU, decompose on the GPU:
+    the recovered density line integrals reproduce the measured counts (self-consistency of the
+    two halves of the hot path) and are finite on every non-air ray."""
+    import dex_ct_sim_amd as dx
+    from conftest import small_scan
+    from dex_ct_sim_amd import matdecomp as md, synthetic
+    ct, ph = small_scan(n=64, n_views=40, n_channels=100)
+    s1, s2 = synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)
+    (r1, _), (r2, _) = dx.get_sinos(ct, ph, [s1, s2])
+    m1, m2 = md.get_basismat_sinos(ct, r1.astype(np.float64), r2.astype(np.float64), s1, s2, n_iters=50)
+    ee, i0, mus = md.decomposition_tables(ct, s1, s2)
+    keep = r1 < 0.95 * r1.max()
+    assert np.isfinite(m1[keep]).all() and np.isfinite(m2[keep]).all()
+    assert (m1[~keep] == 0).all() and (m2[~keep] == 0).all()
+    ex = np.exp(-(m1[..., None] * mus[0] + m2[..., None] * mus[1]))
+    back = np.stack([(i0[k] * ex).sum(-1) for k in range(2)])
+    assert np.max(np.abs(back[0][keep] - r1[keep]) / r1[keep]) < 1e-6
+    assert np.max(np.abs(back[1][keep] - r2[keep]) / r2[keep]) < 1e-6

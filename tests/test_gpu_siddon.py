@@ -1,0 +1,172 @@
+"""HIP Siddon projector against the oracle (all calls go through the C ABI via the host shims).
+
+bit-exact: plan table, voxel-index sequences, float32 piece lengths, per-material path lengths
+           (vs the DDA form of the oracle, which mirrors the kernel arithmetic and is itself pinned
+           against the float64 textbook Siddon in test_siddon_oracle.py)
+1e-5 rel : sinogram counts vs the float64 textbook Siddon + float64 detection (north-star tolerance)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_geom, small_scan
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+
+
+def projector(ct, ph, **kw):
+    from dex_ct_sim_amd import forward_project as fp
+    return fp.Projector(ct, ph, **kw)
+
+
+def spectra():
+    from dex_ct_sim_amd import synthetic
+    return [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
+
+
+@pytest.mark.parametrize('n,nv,nc', [(48, 60, 96), (50, 72, 97), (64, 8, 300)])
+def test_plan_bit_exact(hip, n, nv, nc):
+    ct, ph = small_scan(n=n, n_views=nv, n_channels=nc)
+    pj = projector(ct, ph)
+    ref = co.plan(oracle_geom(ct, ph), ct.view_cs(), ct.chan_cs(), 0, nv)
+    got = pj.plan_host()
+    for f in ref.dtype.names:
+        assert np.array_equal(got[f], ref[f]), f
+
+
+def test_plan_nonsquare_anisotropic(hip):
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd.system import AIR, BONE, WATER
+    rng = np.random.default_rng(5)
+    vol = rng.integers(0, 3, (2, 40, 56), dtype=np.uint8)
+    ph = dx.VoxelPhantom.from_array('aniso', vol, [AIR, WATER, BONE], dx=0.5, dy=0.7, dz=1.0)
+    ct = dx.FanBeamGeometry(N_channels=70, N_proj=50, gamma_fan=0.7, SID=60.0, SDD=100.0, N_rows=2)
+    pj = projector(ct, ph)
+    g = oracle_geom(ct, ph)
+    ref = co.plan(g, ct.view_cs(), ct.chan_cs(), 0, 50)
+    got = pj.plan_host()
+    for f in ref.dtype.names:
+        assert np.array_equal(got[f], ref[f]), f
+    E = np.array([40.0, 60.0, 80.0])
+    mu, w = ph.mu_table(E), np.array([[1e4, 2e4, 1e4]])
+    for kernel in (1, 2):
+        pj = projector(ct, ph, kernel=kernel)
+        c, pl = pj.project_tables(torch.tensor(mu, dtype=torch.float32, device='cuda'),
+                                  torch.tensor(w, dtype=torch.float32, device='cuda'), want_pathlen=True)
+        _, rpl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, 50, ph.volume, mu, w, True)
+        assert np.array_equal(pl.cpu().numpy(), rpl)
+        cls = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, 50, ph.volume, mu, w)
+        assert np.max(np.abs(c.cpu().numpy() - cls) / cls) < REL_TOL
+
+
+@pytest.mark.parametrize('n,nv,nc', [(64, 90, 128), (50, 72, 97)])
+def test_voxel_index_sequence_bit_exact(hip, n, nv, nc):
+    """Every ray of the scan, incl. the axis-aligned views: the sequence of voxel indices and the
+    float32 piece lengths are identical to the oracle's."""
+    ct, ph = small_scan(n=n, n_views=nv, n_channels=nc)
+    pj = projector(ct, ph)
+    g = oracle_geom(ct, ph)
+    plan = co.plan(g, ct.view_cs(), ct.chan_cs(), 0, nv)
+    rays = np.array([(v, 0, c) for v in range(nv) for c in range(nc)], dtype=np.int32)
+    vox, ln, ns = pj.trace(rays)
+    for k, (v, _, c) in enumerate(rays):
+        rv, rl = co.dda_ray(g, plan[v * nc + c], 0)
+        assert ns[k] == len(rv)
+        assert np.array_equal(vox[k, :ns[k]], rv)
+        assert np.array_equal(ln[k, :ns[k]], rl)
+
+
+@pytest.mark.parametrize('kernel', [1, 2])
+@pytest.mark.parametrize('n_mat', [3, 7])
+def test_pathlen_bit_exact_and_counts(hip, kernel, n_mat):
+    """Register accumulators (<= 4 materials) and LDS accumulators (more), both kernels."""
+    from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
+    ct, ph = small_scan(n=48, nz=70, n_views=24, n_channels=80, n_rows=66, z_index=2)
+    if n_mat > 3:
+        rng = np.random.default_rng(11)
+        ph.volume = np.where(ph.volume > 0, rng.integers(1, n_mat, ph.volume.shape, dtype=np.uint8), 0).astype(np.uint8)
+        ph.materials = [AIR, WATER, BONE] + [Material(f'm{i}', 1.0 + 0.1 * i, 'H(11.2)O(88.8)') for i in range(3, n_mat)]
+    g = oracle_geom(ct, ph)
+    pj = projector(ct, ph, kernel=kernel)
+    sp = spectra()
+    (counts, pl), air = pj.project(sp, want_pathlen=True)
+    from dex_ct_sim_amd import forward_project as fp
+    E, mu, w = fp.merged_tables(ct, ph, sp)
+    _, rpl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w, True, n_threads=8)
+    assert np.array_equal(pl.cpu().numpy(), rpl)
+    cls = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w, n_threads=8)
+    rel = np.max(np.abs(counts.cpu().numpy() - cls) / cls)
+    assert rel < REL_TOL, rel
+
+
+def test_view_shard_equals_full(hip):
+    ct, ph = small_scan(n=40, n_views=30, n_channels=64)
+    sp = spectra()
+    full, _ = projector(ct, ph).project(sp)
+    a, _ = projector(ct, ph, view_range=(0, 13)).project(sp)
+    b, _ = projector(ct, ph, view_range=(13, 30)).project(sp)
+    assert torch.equal(torch.cat([a, b], dim=1), full)
+
+
+def test_wide_fan_misses_and_empty_volume(hip):
+    import dex_ct_sim_amd as dx
+    _, ph = small_scan(n=16, n_views=4, n_channels=32)
+    ct = dx.FanBeamGeometry(N_channels=32, N_proj=4, gamma_fan=2.4, SID=60.0, SDD=100.0)
+    sp = spectra()
+    counts, air = projector(ct, ph).project(sp)
+    c = counts.cpu().numpy()
+    plan = co.plan(oracle_geom(ct, ph), ct.view_cs(), ct.chan_cs(), 0, 4)
+    miss = (plan['n_slabs'] == 0).reshape(4, 32)
+    assert miss.any()
+    for s in range(2):       # rays that miss the grid see the unattenuated spectrum
+        assert np.allclose(c[s, :, 0, :][miss], air[s], rtol=2e-6)
+    ph.volume[:] = 0          # all air: attenuation by air only, still matches the oracle
+    counts, _ = projector(ct, ph).project(sp)
+    from dex_ct_sim_amd import forward_project as fp
+    E, mu, w = fp.merged_tables(ct, ph, sp)
+    cls = co.project_classic(oracle_geom(ct, ph), ct.view_cs(), ct.chan_cs(), 0, 4, ph.volume, mu, w)
+    assert np.max(np.abs(counts.cpu().numpy() - cls) / cls) < REL_TOL
+
+
+def test_full_size_properties(hip):
+    """256^2 x 64 slices, 360 views x 512 channels (BASELINE config 2 geometry, fewer slices):
+    size-independent properties instead of an oracle run: (a) total path length over materials equals
+    the analytic chord through the grid box, (b) both kernels agree bit for bit, (c) linearity: with one
+    energy bin, -log(counts/w) equals sum_m mu_m L_m."""
+    ct, ph = small_scan(n=256, nz=64, n_views=360, n_channels=512, n_rows=64)
+    mu = torch.tensor([[0.0002], [0.2], [0.5]], dtype=torch.float32, device='cuda')
+    w = torch.tensor([[1000.0]], dtype=torch.float32, device='cuda')
+    c1, p1 = projector(ct, ph, kernel=1).project_tables(mu, w, want_pathlen=True)
+    c2, p2 = projector(ct, ph, kernel=2).project_tables(mu, w, want_pathlen=True)
+    assert torch.equal(p1, p2)
+    assert torch.allclose(c1, c2, rtol=1e-6, atol=0)
+    tot = p1.sum(-1).double().cpu().numpy()[:, 0, :]
+    b, gm = ct.thetas[:, None], ct.gammas[None, :]
+    sx, sy = ct.SID * np.cos(b), ct.SID * np.sin(b)
+    ex, ey = -np.cos(b + gm), -np.sin(b + gm)
+    h = 0.5 * 256 * ph.dx
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ax0, ax1 = (-h - sx) / ex, (h - sx) / ex
+        ay0, ay1 = (-h - sy) / ey, (h - sy) / ey
+    t0 = np.maximum(np.minimum(ax0, ax1), np.minimum(ay0, ay1))
+    t1 = np.minimum(np.maximum(ax0, ax1), np.maximum(ay0, ay1))
+    chord = np.maximum(t1 - t0, 0.0)
+    assert np.max(np.abs(tot - chord)) < 2e-4
+    lin = (p1.double() * mu[:, 0].double()).sum(-1)
+    assert torch.max(torch.abs(-torch.log(c1[0].double() / 1000.0) - lin)) < 2e-5
+
+
+def test_get_sino_surface(hip):
+    """The reference call shape: two [N_proj, N_channels] arrays; log = ln(air / raw)."""
+    import dex_ct_sim_amd as dx
+    ct, ph = small_scan(n=32, n_views=20, n_channels=48)
+    sp = spectra()[0]
+    raw, log = dx.get_sino(ct, ph, sp)
+    assert raw.shape == (20, 48) and log.shape == (20, 48) and raw.dtype == np.float32
+    from dex_ct_sim_amd import forward_project as fp
+    air = fp.effective_weights(ct, sp).sum()
+    assert np.allclose(log, np.log(air / raw.astype(np.float64)), rtol=1e-5, atol=1e-6)
+    both = dx.get_sinos(ct, ph, spectra())
+    assert np.array_equal(both[0][0], raw)          # fused dual-spectrum traversal = single-spectrum result

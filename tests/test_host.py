@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference interface (no GPU, no HIP calls)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import INPUT, ROOT
+
+
+def test_import_names_and_aliases():
+    import dex_ct_sim_amd as dx
+    assert dx.ScannerGeometry is dx.FanBeamGeometry and dx.Phantom is dx.VoxelPhantom
+    assert dx.Spectrum is dx.xRaySpectrum
+    for n in ('read_parameter_file', 'get_sino', 'get_basismat_sinos'):
+        assert n in dx.__all__
+
+
+def test_spectrum_files_half_split():
+    import dex_ct_sim_amd as dx
+    for sid, n in (('80kV', 140), ('120kV', 140), ('140kV', 140), ('detunedMV', 100), ('6MV', 100)):
+        s = dx.xRaySpectrum(os.path.join(INPUT, 'spectrum', f'{sid}_1mGy_float32.bin'), sid)
+        assert s.E.shape == (n,) and s.I0.shape == (n,) and np.all(np.diff(s.E) > 0) and s.name == sid
+    s = dx.xRaySpectrum(os.path.join(INPUT, 'spectrum', '80kV_1mGy_float32.bin'), '80kV')
+    assert s.E[0] == 1.0 and s.E[-1] == 140.0 and s.I0[100:].sum() == 0.0
+    tot = s.I0.sum()
+    s.rescale_counts(0.5)
+    assert np.isclose(s.I0.sum(), 0.5 * tot)
+
+
+def test_geometry_matches_params_defaults():
+    import dex_ct_sim_amd as dx
+    ct = dx.FanBeamGeometry(N_channels=800, N_proj=1200, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=1.0,
+                            eid=True, detector_file=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'))
+    assert ct.det_E.shape == (6000,) and ct.det_E[0] == 1.0 and ct.det_E[-1] == 6000.0
+    assert np.isclose(ct.A_iso, 60.0 * 0.8230337 / 800 * 1.0)
+    assert ct.view_cs().shape == (1200, 2) and ct.chan_cs().shape == (800, 2)
+    assert np.isclose(ct.gammas.sum(), 0.0, atol=1e-12) and np.isclose(ct.thetas[-1], 2 * np.pi * 1199 / 1200)
+    r = ct.detector_response(np.array([50.0, 100.0]))
+    assert np.allclose(r, np.interp([50.0, 100.0], ct.det_E, ct.det_eta_E) * [50.0, 100.0])
+    pcd = dx.FanBeamGeometry(eid=False, detector_file=os.path.join(INPUT, 'detector', 'eta_pcd_Si_30mm.bin'))
+    assert pcd.det_E.shape == (5999,) and not pcd.eid
+
+
+def test_parameter_file_reference_keys(tmp_path):
+    """The reference's own params.txt keys (input/params.txt:1-37), with a phantom written here."""
+    import dex_ct_sim_amd as dx
+    vol = np.zeros((1, 16, 16), np.uint8)
+    vol[0, 4:12, 4:12] = 1
+    vol.tofile(tmp_path / 'ph.bin')
+    (tmp_path / 'mats.csv').write_text('id,name,density,composition\n0,air,0.0012,N(75.5)O(23.2)Ar(1.3)\n'
+                                       '1,water,1.0,H(11.2)O(88.8)\n')
+    p = {"RUN_ID": "t", "forward_project": True, "back_project": True, "phantom_type": "voxel",
+         "phantom_id": "box", "phantom_filename": str(tmp_path / 'ph.bin'), "matcomp_filename": str(tmp_path / 'mats.csv'),
+         "Nx": 16, "Ny": 16, "Nz": 1, "dx": 0.1, "dy": 0.1, "dz": 0.1, "z_index": 0, "scanner_geometry": "fan_beam",
+         "SID": 60.0, "SDD": 100.0, "N_channels": 800, "N_projections": 1200, "fan_angle_total": 0.8230337,
+         "rotation_angle_total": 6.283185, "detector_px_height": 1.0, "detector_mode": "eid",
+         "detector_filename": os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'), "spectrum_id": "NA",
+         "spectrum_filename": "NA", "N_photons_per_cm2_per_scan": "NA", "N_recon_matrix": 512, "FOV_recon": 50.0,
+         "ramp_filter_percent_Nyquist": 0.8}
+    f = tmp_path / 'params.txt'
+    f.write_text(json.dumps(p))
+    runs = dx.read_parameter_file(str(f))
+    assert len(runs) == 1
+    run_id, do_fp, do_bp, ct, ph, spec, N, FOV, ramp = runs[0]
+    assert (run_id, do_fp, do_bp, spec, N, FOV, ramp) == ('t', True, True, None, 512, 50.0, 0.8)
+    assert ct.N_channels == 800 and ct.N_proj == 1200 and ct.eid
+    assert ph.volume.shape == (1, 16, 16) and ph.n_materials == 2 and ph.materials[1].name == 'water'
+    assert ph.M_mono(60.0).shape == (16, 16)
+    f.write_text(json.dumps([p, dict(p, RUN_ID='u', detector_mode='pcd')]))     # a list of runs
+    runs = dx.read_parameter_file(str(f))
+    assert [r[0] for r in runs] == ['t', 'u'] and not runs[1][3].eid
+
+
+def test_mixatten_surface(golden):
+    from dex_ct_sim_amd import matdecomp as md, xcompy
+    E = golden['xc_E']
+    assert np.array_equal(xcompy.mixatten(md.matcomp1, E), golden['xc_tissue'])
+    assert np.array_equal(xcompy.mixatten(md.matcomp2, E), golden['xc_bone'])
+    assert xcompy.mixatten('H(11.2)O(88.8)', np.array([60.0])).shape == (1,)
+    assert md.density1 == golden['const_density'][0] and md.density2 == golden['const_density'][1]
+    xcompy.register_table('Xx(100)', [10.0, 100.0], [2.0, 0.2])
+    assert np.isclose(xcompy.mixatten('Xx(100)', np.array([10.0]))[0], 2.0)
+    with pytest.raises(KeyError):
+        xcompy.mixatten('Qq(100)', E)
+
+
+def test_merged_tables_keep_each_spectrum_quadrature():
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp, synthetic
+    ct = dx.FanBeamGeometry(64, 10, detector_file=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'))
+    ph = synthetic.make_phantom(16, 1)
+    s1 = dx.xRaySpectrum(os.path.join(INPUT, 'spectrum', 'detunedMV_1mGy_float32.bin'), 'mv')
+    s2 = synthetic.kramers_spectrum(80)
+    E, mu, w = fp.merged_tables(ct, ph, [s1, s2])
+    assert mu.shape == (3, E.size) and w.shape == (2, E.size)
+    assert np.isclose(w[0].sum(), fp.effective_weights(ct, s1).sum())
+    assert np.isclose(w[1].sum(), fp.effective_weights(ct, s2).sum())
+    assert np.all(w[0][np.isin(E, s1.E, invert=True)] == 0)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The built library exports exactly what include/dexct.h declares (no compute calls here)."""
+    from dex_ct_sim_amd import _native
+    hdr = open(os.path.join(ROOT, 'include', 'dexct.h')).read()
+    declared = sorted(set(re.findall(r'\b(dexct_[a-z_0-9]+)\s*\(', hdr)))
+    assert declared == sorted(_native.SYMBOLS)
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.dexct_abi_version.restype = ctypes.c_int
+    assert lib.dexct_abi_version() == 1
+    lib.dexct_strerror.restype = ctypes.c_char_p
+    assert lib.dexct_strerror(-2) == b'size out of supported range'
+    # struct layouts the binding mirrors
+    assert ctypes.sizeof(_native.FanGeom) == 72 and _native.PLAN_BYTES == 40
+
+
+def test_product_does_not_import_oracle():
+    """The shipped path never touches oracle/: grep the package sources."""
+    pkg = os.path.join(ROOT, 'dex-ct-sim_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt and 'oracle/' not in txt.replace(
+                    'oracle/dexct_oracle.c', ''), fn
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import _native, synthetic
+    ct = dx.FanBeamGeometry(32, 8)
+    with pytest.raises(_native.DexctError):
+        dx.get_sino(ct, synthetic.make_phantom(16, 1), synthetic.kramers_spectrum(80))

@@ -1,0 +1,53 @@
+"""Multi-rank path on CPU: gloo, world_size 2 (and 3 for ragged shards)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, n_views, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from dex_ct_sim_amd import _shard
+    full = torch.arange(2 * n_views * 3 * 5, dtype=torch.float32).reshape(2, n_views, 3, 5)
+    b, e = _shard.my_views(n_views)
+    got = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1)
+    mx = _shard.global_max(torch.tensor(float(rank + 1), dtype=torch.float64))
+    q.put((rank, (b, e), bool(torch.equal(got, full)), float(mx)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_views', [(2, 10), (2, 7), (3, 8)])
+def test_gather_views_and_global_max(world, n_views):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + world * 7 + n_views) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    covered = []
+    for rank, (b, e), ok, mx in res:
+        assert ok and mx == float(world)
+        covered += list(range(b, e))
+    assert covered == list(range(n_views))       # contiguous, disjoint, complete
+
+
+def test_split_is_balanced():
+    from dex_ct_sim_amd import _shard
+    for n in (1, 7, 1000, 2000):
+        for w in (1, 2, 3, 8):
+            parts = [_shard.split(n, r, w) for r in range(w)]
+            sizes = [e - b for b, e in parts]
+            assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
