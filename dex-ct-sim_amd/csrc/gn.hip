@@ -150,6 +150,20 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
     const int n_bulk = n_iters > n_polish ? n_iters - n_polish : 0;
     for (; it < n_bulk; ++it) newton_step_f32(lds_tab32, n_e, fg0, fg1, fa0, fa1);
     if (n_bulk > 0) { a0 = (double)fa0; a1 = (double)fa1; }
+    // float64 polish; a pixel whose float32 trajectory did not arrive (non-finite, or the polish
+    // steps are still moving it) is redone from the start in float64, i.e. in the reference's
+    // arithmetic.  Divergent, but rare on well-posed data.
+    double p0 = a0, p1 = a1;
+    for (; it < n_iters; ++it) {
+      p0 = a0; p1 = a1;
+      newton_step_f64(lds_tab, n_e, gd0, gd1, a0, a1);
+    }
+    const double moved = fmax(fabs(a0 - p0), fabs(a1 - p1));
+    const double size = fmax(fmax(fabs(a0), fabs(a1)), 1.0);
+    if (n_bulk > 0 && !(moved <= 1e-9 * size)) {
+      a0 = 1e-6; a1 = 1e-6;
+      for (it = 0; it < n_iters; ++it) newton_step_f64(lds_tab, n_e, gd0, gd1, a0, a1);
+    }
   }
   for (; it < n_iters; ++it) newton_step_f64(lds_tab, n_e, gd0, gd1, a0, a1);
   out_a[2 * p] = a0;

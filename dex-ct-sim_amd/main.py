@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's run sequence (main.py:74-178 of gjadick/dex-ct-sim):
+
+for every run in the parameter file, for every dual-energy spectrum pair:
+  1. per spectrum: load + dose-scale the spectrum (:64-69), forward project (:120), write
+     ``<spec>_<dose>uGy/sino_raw_float32.bin`` and ``sino_log_float32.bin`` (:121-122);
+  2. decompose the two raw sinograms into basis-material sinograms with 50 Newton iterations
+     (:153) and write ``matdecomp_<s1>_<s2>_<d1>uGy_<d2>uGy/mat{1,2}_sino_float32.bin`` (:154-155).
+Reconstruction (get_recon, :134,:168) is outside this engine's scope and is skipped.
+
+Differences from the reference script, all on purpose: inputs are command-line options instead of
+edited source lines (:80-82, :101-103); figures are off unless --show; both spectra of a pair are
+projected in ONE traversal (path lengths do not depend on energy); run with
+``python -m torch.distributed.run --nproc-per-node N main.py`` to shard the projection angles.
+"""
+import argparse
+import os
+import shutil
+import sys
+from time import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import dex_ct_sim_amd as dx  # noqa: E402
+from dex_ct_sim_amd.forward_project import get_sinos  # noqa: E402
+from dex_ct_sim_amd.matdecomp import get_basismat_sinos  # noqa: E402
+
+
+def load_spectrum(ct, spec_id, dose, input_dir):
+    """Spectrum at 1 mGy scaled to the target dose per view (main.py:64-69)."""
+    spec = dx.xRaySpectrum(os.path.join(input_dir, 'spectrum', f'{spec_id}_1mGy_float32.bin'), spec_id)
+    spec.rescale_counts(ct.A_iso * dose / ct.N_proj)
+    return spec
+
+
+def parse_pairs(items):
+    pairs = []
+    for it in items:
+        s1, s2, d1, d2 = it.split(':')
+        pairs.append((s1, s2, float(d1), float(d2)))
+    return pairs
+
+
+def show(title_a, a, title_b, b):
+    import matplotlib.pyplot as plt
+    fig, ax = plt.subplots(1, 2, figsize=[7, 3])
+    for axi, img, ttl in ((ax[0], a, title_a), (ax[1], b, title_b)):
+        m = axi.imshow(img, cmap='gray', aspect='auto')
+        axi.set_title(ttl)
+        fig.colorbar(m, ax=axi)
+    fig.tight_layout()
+    plt.show()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--params', default=os.path.join(HERE, 'input', 'params.txt'))
+    ap.add_argument('--out', default='./output/')
+    ap.add_argument('--input-dir', default=os.path.join(HERE, 'input'))
+    ap.add_argument('--pairs', nargs='+', default=['detunedMV:80kV:9:1'],
+                    help='spec1:spec2:dose1_mGy:dose2_mGy (reference default, main.py:101)')
+    ap.add_argument('--n-iters', type=int, default=50)
+    ap.add_argument('--show', action='store_true')
+    args = ap.parse_args(argv)
+
+    import torch.distributed as dist
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
+        dist.init_process_group('nccl')
+    rank = dist.get_rank() if dist.is_initialized() else 0
+
+    cwd = os.getcwd()
+    os.chdir(os.path.dirname(args.input_dir.rstrip('/')))      # './input/...' paths of the params file
+    all_params = dx.read_parameter_file(args.params)
+    os.chdir(cwd)
+    for params in all_params:
+        run_id, do_fp, do_bp = params[:3]
+        ct, phantom, _ = params[3:6]            # the spectrum entry is ignored, as in main.py:92
+        out_dir = os.path.join(args.out, run_id)
+        if rank == 0:
+            os.makedirs(out_dir, exist_ok=True)
+            shutil.copy(args.params, os.path.join(out_dir, 'params.txt'))
+        if do_bp and rank == 0:
+            print('back_project requested: reconstruction is outside this engine, skipping')
+        for s1, s2, d1, d2 in parse_pairs(args.pairs):
+            t0 = time()
+            specs = [load_spectrum(ct, s1, d1, args.input_dir), load_spectrum(ct, s2, d2, args.input_dir)]
+            print('Forward projecting!')
+            sinos = get_sinos(ct, phantom, specs)
+            for (spec_id, dose), (sino_raw, sino_log) in zip(((s1, d1), (s2, d2)), sinos):
+                sub_dir = os.path.join(out_dir, f'{spec_id}_{int(dose * 1000):04}uGy/')
+                if rank == 0:
+                    os.makedirs(sub_dir, exist_ok=True)
+                    print(f'\n*** {sub_dir} ***')
+                    sino_raw.astype(np.float32).tofile(sub_dir + 'sino_raw_float32.bin')
+                    sino_log.astype(np.float32).tofile(sub_dir + 'sino_log_float32.bin')
+                    if args.show:
+                        show('Raw line integrals', sino_raw, 'Log sinogram', sino_log)
+            sub_dir = os.path.join(out_dir, f'matdecomp_{s1}_{s2}_{int(d1 * 1000):04}uGy_{int(d2 * 1000):04}uGy/')
+            print('Decomposing into basis material sinograms!')
+            matsino1, matsino2 = get_basismat_sinos(ct, sinos[0][0], sinos[1][0], specs[0], specs[1],
+                                                    n_iters=args.n_iters)
+            if rank == 0:
+                os.makedirs(sub_dir, exist_ok=True)
+                print(f'\n*** {sub_dir} ***')
+                matsino1.astype(np.float32).tofile(sub_dir + 'mat1_sino_float32.bin')
+                matsino2.astype(np.float32).tofile(sub_dir + 'mat2_sino_float32.bin')
+                if args.show:
+                    show('Basis material 1', matsino1, 'Basis material 2', matsino2)
+                print(f'matdecomp finished for {s1}-{s2} : t={time() - t0:.2f}s')
+
+
+if __name__ == '__main__':
+    main()

@@ -115,12 +115,19 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     (``>= mask_thresh * max``), Newton decomposition, masked pixels set to exactly 0.
 
     NumPy in -> NumPy float64 out (two views of one buffer, like the reference); device tensors
-    in -> device tensors out.  Under torch.distributed the inputs are each rank's own view shard
-    and the mask threshold uses the all-reduced global maximum.
+    in -> device tensors out.  Under torch.distributed the inputs are either each rank's own view
+    shard or the full gathered sinograms (then each rank decomposes its own views and the result
+    is all-gathered); the mask threshold always uses the all-reduced global maximum.
     """
     lib = _native.load()
     dev = device()
     _, i0, mus = decomposition_tables(ct, spec1, spec2)
+    rank, world = _shard.world()
+    n_views = getattr(ct, 'N_proj', None)
+    full_in = world > 1 and n_views is not None and sino_raw_1.shape[0] == n_views
+    if full_in:                       # every rank holds the gathered sinograms: take this rank's views
+        vb, ve = _shard.split(n_views, rank, world)
+        sino_raw_1, sino_raw_2 = sino_raw_1[vb:ve], sino_raw_2[vb:ve]
     g1 = _as_device_counts(sino_raw_1, dev)
     g2 = _as_device_counts(sino_raw_2, dev).to(g1.dtype)
     is64 = int(g1.dtype == torch.float64)
@@ -131,6 +138,8 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     thresh = float(mask_thresh) * float(gmax.item())
     _native.check(lib.dexct_gn_apply_mask(ptr(g1), is64, g1.numel(), thresh, ptr(a), stream_ptr()),
                   'dexct_gn_apply_mask')
+    if full_in:
+        a = _shard.gather_views(a, n_views, view_dim=0)
     if isinstance(sino_raw_1, torch.Tensor):
         return a[..., 0], a[..., 1]
     a = a.cpu().numpy()
