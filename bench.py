@@ -174,9 +174,10 @@ def main():
     alg_bytes = seg_vc * rows * 1 + 4 * 2 * n_rays
     achieved = alg_bytes / (sid_ms * 1e-3) / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get('siddon_hbm_bytes_per_launch')
+    import glob
+    pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if pmc:      # newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_gpu.sh)
+        traffic = json.load(open(pmc[-1])).get('siddon_hbm_bytes_per_launch')
     out['roofline'] = {'kernel': 'rows_kernel' if pj.vol_zf is not None and args.kernel != 1 else 'rays_kernel',
                        'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

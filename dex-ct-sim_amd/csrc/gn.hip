@@ -8,10 +8,14 @@
 // term (:123), no damping, exactly as the reference.
 //
 // Mapping: one thread per pixel, all iterations in registers.  The 14 per-energy table values
-// (two attenuations + 2 x 6 products, with the reference's rounding of ssff / ssff2, :102,:105) are
-// built once per workgroup into LDS; all lanes read the same entry (broadcast, conflict free).
-// There is no dense contraction: the energy sum runs on the vector FP64 pipe (or FP32 for the
-// bulk iterations of precision mode 1), bounded by FMA + exp rate, not by HBM (16 B per pixel).
+// (two attenuations + 2 x 6 products, with the reference's rounding of ssff / ssff2, :102,:105)
+// are built once by gn_tables_kernel into a small workspace and read in the hot loop through the
+// scalar cache: the energy index is wave-uniform, so every table value is an SGPR operand of a
+// v_fma_f64 and costs neither LDS bandwidth nor VGPRs.  The only per-lane lookup is the 64-entry
+// 2^(j/64) table of the exponential, which sits in LDS.
+// There is no dense contraction: the kernel is bound by the FP64 vector rate (FMA + exp), not by
+// HBM (16 B read + 16 B written per pixel); per energy-iteration it issues 29 FP64 instructions
+// (2 exponent, 2 clip, 13 exp, 12 accumulate).
 #include "common.h"
 
 namespace dexct {
@@ -24,17 +28,34 @@ __device__ __forceinline__ T load_g(const void* p, int is_f64, int64_t i) {
   return is_f64 ? (T) reinterpret_cast<const double*>(p)[i] : (T) reinterpret_cast<const float*>(p)[i];
 }
 
-__device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, int n_e, double g0, double g1,
-                                                double& a0, double& a1) {
+// exp(x) for |x| <= 700: x = (64 k + j) ln2/64 + r, |r| <= ln2/128; exp = 2^k * 2^(j/64) * e^r with a
+// degree-5 polynomial for e^r - 1 (truncation 3e-17).  About 1 ulp.
+__device__ __forceinline__ double exp_tab64(double x, const double* __restrict__ lds_pow) {
+  const double n = rint(x * 0x1.71547652b82fep+6);
+  const int ni = (int)n;
+  double r = fma(n, -0x1.62e42fefa39efp-7, x);
+  r = fma(n, -0x1.abc9e3b39803fp-62, r);
+  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  q = fma(r, q, 1.0 / 6.0);
+  q = fma(r, q, 0.5);
+  q = fma(r, q, 1.0);
+  const double p = r * q;
+  const double tj = lds_pow[ni & 63];
+  return ldexp(fma(tj, p, tj), ni >> 6);
+}
+
+__device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
+                                                int n_e, double g0, double g1, double& a0, double& a1) {
   double nu[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
+#pragma unroll 2
   for (int e = 0; e < n_e; ++e) {
-    const double* t = tab + e * kTab;
-    double x = -(a0 * t[0] + a1 * t[1]);
+    const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
+    double x = -fma(a1, t[1], a0 * t[0]);
     x = fmin(fmax(x, -700.0), 700.0);
-    const double at = exp(x);
+    const double at = exp_tab64(x, lds_pow);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const double* tk = t + 2 + 6 * k;
+      const double* __restrict__ tk = t + 2 + 6 * k;
       nu[k] = fma(tk[0], at, nu[k]);
       G0[k] = fma(tk[1], at, G0[k]);
       G1[k] = fma(tk[2], at, G1[k]);
@@ -59,63 +80,67 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
   a1 -= (h00 * dF1 - h01 * dF0) / det;
 }
 
+// float32 table layout per energy: [mu0*log2e, mu1*log2e, then for c in {1, mu0, mu1, mu0^2, mu0mu1, mu1^2}:
+// (i0_0 * c, i0_1 * c)] - the two measurements of one product adjacent, so that each SGPR pair feeds one
+// v_pk_fma_f32 directly.
 __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, int n_e, float g0, float g1,
                                                 float& a0, float& a1) {
-  float nu[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
+  float acc[6][2];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) acc[c][0] = acc[c][1] = 0.0f;
+#pragma unroll 2
   for (int e = 0; e < n_e; ++e) {
-    const float* t = tab + e * kTab;
-    // tab holds mu * log2(e) in slots 0,1 for this path
-    float x = -(a0 * t[0] + a1 * t[1]);
+    const float* __restrict__ t = tab + e * kTab;
+    float x = -fmaf(a1, t[1], a0 * t[0]);
     x = fminf(fmaxf(x, -120.0f), 120.0f);
     const float at = __builtin_amdgcn_exp2f(x);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float* tk = t + 2 + 6 * k;
-      nu[k] = fmaf(tk[0], at, nu[k]);
-      G0[k] = fmaf(tk[1], at, G0[k]);
-      G1[k] = fmaf(tk[2], at, G1[k]);
-      H00[k] = fmaf(tk[3], at, H00[k]);
-      H01[k] = fmaf(tk[4], at, H01[k]);
-      H11[k] = fmaf(tk[5], at, H11[k]);
+    for (int c = 0; c < 6; ++c) {
+      acc[c][0] = fmaf(t[2 + 2 * c], at, acc[c][0]);
+      acc[c][1] = fmaf(t[3 + 2 * c], at, acc[c][1]);
     }
   }
   const float g[2] = {g0, g1};
   float dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const float c = g[k] / nu[k] - 1.0f, q = g[k] / (nu[k] * nu[k]);
-    dF0 += c * G0[k];
-    dF1 += c * G1[k];
-    h00 += q * (G0[k] * G0[k]) - c * H00[k];
-    h01 += q * (G0[k] * G1[k]) - c * H01[k];
-    h11 += q * (G1[k] * G1[k]) - c * H11[k];
+    const float nu = acc[0][k], G0 = acc[1][k], G1 = acc[2][k];
+    const float c = g[k] / nu - 1.0f, q = g[k] / (nu * nu);
+    dF0 += c * G0;
+    dF1 += c * G1;
+    h00 += q * (G0 * G0) - c * acc[3][k];
+    h01 += q * (G0 * G1) - c * acc[4][k];
+    h11 += q * (G1 * G1) - c * acc[5][k];
   }
   const float det = h00 * h11 - h01 * h01;
   a0 -= (h11 * dF0 - h01 * dF1) / det;
   a1 -= (h00 * dF1 - h01 * dF0) / det;
 }
 
-// MIXED: n_iters - n_polish iterations in float32, then n_polish in float64.
-template <bool MIXED>
-__global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
-                                                      int g_is_f64, int64_t n_pix, const double* __restrict__ i0,
-                                                      const double* __restrict__ mus, int n_e, int n_iters,
-                                                      int n_polish, double* __restrict__ out_a) {
-  extern __shared__ double lds_tab[];  // [n_e][14] f64, then (MIXED) [n_e][14] f32
-  float* lds_tab32 = reinterpret_cast<float*>(lds_tab + (size_t)n_e * kTab);
+// Workspace layout (doubles): [0] = scale of the float32 tables, [1..7] pad, then [n_e][14] float64,
+// then [n_e][14] float32.
+constexpr int kWsHeader = 8;
+
+__global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict__ i0, const double* __restrict__ mus,
+                                                        int n_e, double* __restrict__ ws) {
   // float32 tables are scaled by one power of two common to both measurements (the Newton step is
   // invariant under a common scaling of counts and spectra) so that sums stay near 1.
-  double scale = 1.0;
-  if (MIXED) {
+  __shared__ double s_scale;
+  if (threadIdx.x == 0) {
     double s0 = 0.0, s1 = 0.0;
-    for (int e = 0; e < n_e; ++e) { s0 += i0[e]; s1 += i0[n_e + e]; }   // wave-uniform scalar loads
+    for (int e = 0; e < n_e; ++e) { s0 += i0[e]; s1 += i0[n_e + e]; }
     int ex = 0;
     frexp(fmax(s0, s1), &ex);
-    scale = ldexp(1.0, -ex);
+    s_scale = ldexp(1.0, -ex);
+    ws[0] = s_scale;
   }
-  for (int e = threadIdx.x; e < n_e; e += kGnBlock) {
+  __syncthreads();
+  const double scale = s_scale;
+  double* tab = ws + kWsHeader;
+  float* tab32 = reinterpret_cast<float*>(tab + (size_t)n_e * kTab);
+  for (int e = threadIdx.x; e < n_e; e += blockDim.x) {
     const double m0 = mus[e], m1 = mus[n_e + e];
-    double* t = lds_tab + e * kTab;
+    double* t = tab + e * kTab;
     t[0] = m0;
     t[1] = m1;
     const double m00 = m0 * m0, m01 = m0 * m1, m11 = m1 * m1;
@@ -130,25 +155,38 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
       tk[4] = w * m01;
       tk[5] = w * m11;
     }
-    if (MIXED) {
-      float* f = lds_tab32 + e * kTab;
-      f[0] = (float)(m0 * 1.4426950408889634);
-      f[1] = (float)(m1 * 1.4426950408889634);
+    float* f = tab32 + e * kTab;
+    f[0] = (float)(m0 * 1.4426950408889634);
+    f[1] = (float)(m1 * 1.4426950408889634);
 #pragma unroll
-      for (int q = 2; q < kTab; ++q) f[q] = (float)(t[q] * scale);
+    for (int c = 0; c < 6; ++c) {
+      f[2 + 2 * c] = (float)(t[2 + c] * scale);
+      f[3 + 2 * c] = (float)(t[8 + c] * scale);
     }
   }
+}
+
+// MIXED: n_iters - n_polish iterations in float32, then n_polish in float64.
+template <bool MIXED>
+__global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
+                                                      int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
+                                                      int n_e, int n_iters, int n_polish, double* __restrict__ out_a) {
+  __shared__ double lds_pow[64];
+  if (threadIdx.x < 64) lds_pow[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
   __syncthreads();
+  const double* __restrict__ tab = ws + kWsHeader;
+  const float* __restrict__ tab32 = reinterpret_cast<const float*>(tab + (size_t)n_e * kTab);
   const int64_t p = (int64_t)blockIdx.x * kGnBlock + threadIdx.x;
   if (p >= n_pix) return;
   const double gd0 = load_g<double>(g1, g_is_f64, p), gd1 = load_g<double>(g2, g_is_f64, p);
   double a0 = 1e-6, a1 = 1e-6;
   int it = 0;
   if (MIXED) {
+    const double scale = ws[0];
     float fa0 = 1e-6f, fa1 = 1e-6f;
     const float fg0 = (float)(gd0 * scale), fg1 = (float)(gd1 * scale);
     const int n_bulk = n_iters > n_polish ? n_iters - n_polish : 0;
-    for (; it < n_bulk; ++it) newton_step_f32(lds_tab32, n_e, fg0, fg1, fa0, fa1);
+    for (; it < n_bulk; ++it) newton_step_f32(tab32, n_e, fg0, fg1, fa0, fa1);
     if (n_bulk > 0) { a0 = (double)fa0; a1 = (double)fa1; }
     // float64 polish; a pixel whose float32 trajectory did not arrive (non-finite, or the polish
     // steps are still moving it) is redone from the start in float64, i.e. in the reference's
@@ -156,16 +194,16 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
     double p0 = a0, p1 = a1;
     for (; it < n_iters; ++it) {
       p0 = a0; p1 = a1;
-      newton_step_f64(lds_tab, n_e, gd0, gd1, a0, a1);
+      newton_step_f64(tab, lds_pow, n_e, gd0, gd1, a0, a1);
     }
     const double moved = fmax(fabs(a0 - p0), fabs(a1 - p1));
     const double size = fmax(fmax(fabs(a0), fabs(a1)), 1.0);
     if (n_bulk > 0 && !(moved <= 1e-9 * size)) {
       a0 = 1e-6; a1 = 1e-6;
-      for (it = 0; it < n_iters; ++it) newton_step_f64(lds_tab, n_e, gd0, gd1, a0, a1);
+      for (it = 0; it < n_iters; ++it) newton_step_f64(tab, lds_pow, n_e, gd0, gd1, a0, a1);
     }
   }
-  for (; it < n_iters; ++it) newton_step_f64(lds_tab, n_e, gd0, gd1, a0, a1);
+  for (; it < n_iters; ++it) newton_step_f64(tab, lds_pow, n_e, gd0, gd1, a0, a1);
   out_a[2 * p] = a0;
   out_a[2 * p + 1] = a1;
 }
@@ -210,24 +248,31 @@ using namespace dexct;
 
 extern "C" {
 
+int64_t dexct_gn_workspace_bytes(int32_t n_energies) {
+  if (n_energies <= 0) return 0;
+  return (int64_t)sizeof(double) * kWsHeader + (int64_t)n_energies * kTab * (sizeof(double) + sizeof(float));
+}
+
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_iters, int32_t precision, int32_t n_polish,
-                       double* out_a, void* stream) {
-  if (!g1 || !g2 || !i0 || !mus || !out_a || n_pix <= 0 || n_energies <= 0 || n_iters < 0) return DEXCT_EINVAL;
+                       double* out_a, void* workspace, void* stream) {
+  if (!g1 || !g2 || !i0 || !mus || !out_a || !workspace || n_pix <= 0 || n_energies <= 0 || n_iters < 0)
+    return DEXCT_EINVAL;
   if (precision != 0 && precision != 1) return DEXCT_EINVAL;
   if (n_polish < 0) return DEXCT_EINVAL;
-  if (n_energies > 512) return DEXCT_ERANGE;
+  if (n_energies > 4096) return DEXCT_ERANGE;
   const int64_t nblk = (n_pix + kGnBlock - 1) / kGnBlock;
   if (nblk > 0x7FFFFFFFll) return DEXCT_ERANGE;
   hipStream_t st = as_stream(stream);
+  double* ws = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(gn_tables_kernel, dim3(1), dim3(256), 0, st, i0, mus, n_energies, ws);
+  DEXCT_LAUNCH_CHECK();
   if (precision == 0) {
-    const size_t lds = (size_t)n_energies * kTab * sizeof(double);
-    hipLaunchKernelGGL(gn_kernel<false>, dim3((unsigned)nblk), dim3(kGnBlock), lds, st, g1, g2, g_is_f64, n_pix, i0,
-                       mus, n_energies, n_iters, 0, out_a);
+    hipLaunchKernelGGL(gn_kernel<false>, dim3((unsigned)nblk), dim3(kGnBlock), 0, st, g1, g2, g_is_f64, n_pix,
+                       (const double*)ws, n_energies, n_iters, 0, out_a);
   } else {
-    const size_t lds = (size_t)n_energies * kTab * (sizeof(double) + sizeof(float));
-    hipLaunchKernelGGL(gn_kernel<true>, dim3((unsigned)nblk), dim3(kGnBlock), lds, st, g1, g2, g_is_f64, n_pix, i0,
-                       mus, n_energies, n_iters, n_polish, out_a);
+    hipLaunchKernelGGL(gn_kernel<true>, dim3((unsigned)nblk), dim3(kGnBlock), 0, st, g1, g2, g_is_f64, n_pix,
+                       (const double*)ws, n_energies, n_iters, n_polish, out_a);
   }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

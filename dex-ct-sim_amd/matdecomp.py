@@ -60,9 +60,11 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     if i0_d.shape != mus_d.shape or i0_d.shape[0] != 2:
         raise ValueError('i0 and mus must both be [2, nE]')
     a = out if out is not None else torch.empty(tuple(g1.shape) + (2,), dtype=torch.float64, device=dev)
+    n_e = i0_d.shape[1]
+    ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e), dtype=torch.uint8, device=dev)
     _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), int(g1.dtype == torch.float64), g1.numel(), ptr(i0_d),
-                                         ptr(mus_d), i0_d.shape[1], int(n_iters), int(precision == 'mixed'),
-                                         int(n_polish), ptr(a), stream_ptr()), 'dexct_gn_decompose')
+                                         ptr(mus_d), n_e, int(n_iters), int(precision == 'mixed'),
+                                         int(n_polish), ptr(a), ptr(ws), stream_ptr()), 'dexct_gn_decompose')
     return a
 
 

@@ -117,11 +117,15 @@ int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
  *   mus[m*n_energies + e]  basis mass attenuation (float64), m = 0, 1
  *   out_a[2*p + m]         density line integrals (float64), initialised to 1e-6 inside
  *   precision: 0 = float64 throughout (reference arithmetic);
- *              1 = float32 bulk iterations followed by float64 polish iterations
- *   n_polish   number of trailing float64 iterations when precision == 1 */
+ *              1 = float32 bulk iterations followed by float64 polish iterations; a pixel the
+ *                  polish is still moving is redone in float64 from the start
+ *   n_polish   number of trailing float64 iterations when precision == 1
+ *   workspace  device scratch of dexct_gn_workspace_bytes(n_energies) bytes (the product tables
+ *              the kernel reads through the scalar cache); owned by the caller, no hidden state */
+int64_t dexct_gn_workspace_bytes(int32_t n_energies);
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_iters, int32_t precision,
-                       int32_t n_polish, double* out_a, void* stream);
+                       int32_t n_polish, double* out_a, void* workspace, void* stream);
 
 /* Air mask of get_basismat_sinos (matdecomp.py:194-205): out_a[2p], out_a[2p+1] = 0 wherever
  * g1[p] >= thresh_value (thresh_value = mask_thresh * global max, computed by the caller so that a

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (written by tools/profile_gpu.sh) into
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_summary.md and profiles/<tag>_pmc_traffic.json.
+
+HBM traffic follows MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE come from separate
+--pmc passes, are reported in KiB, and FETCH_SIZE is calibrated on a kernel of known byte count with
+the same access shape: transpose_xy_kernel reads the uint8 volume once with 64-B wave loads, exactly
+the shape of the traversal kernels' loads (ratio printed below; 1.00 means no correction; wide 4-B+
+per-lane streams such as gn_kernel's input read 0.5 and are doubled).
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = os.path.join('gpurun_out', f'prof_{tag}')
+os.makedirs('profiles', exist_ok=True)
+stats = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
+shutil.copy(stats, os.path.join('profiles', f'{tag}_kernel_stats.csv'))
+rows = list(csv.DictReader(open(stats)))
+
+
+def pmc(which):
+    out = {}
+    files = glob.glob(os.path.join(src, f'pmc_{which}', '*', '*_counter_collection.csv'))
+    if not files:
+        return out
+    for r in csv.DictReader(open(files[0])):
+        out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+fetch, write = pmc('fetch'), pmc('write')
+bench = json.load(open(os.path.join(src, 'bench_stats.json')))
+lines = [f'# rocprofv3 summary `{tag}`', '',
+         f'command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {bench["steps"]} --warmup {bench["warmup"]}`'
+         ' (PMC passes: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` separately, 1 step)', '',
+         '| kernel | calls | avg ms | % of GPU time |', '|---|---|---|---|']
+for r in rows[:8]:
+    lines.append(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e6:.3f} | {r["Percentage"]} |')
+lines += ['', f'bench.py (same run) HIP-event averages: {bench["kernel_ms"]}', '']
+cal = [k for k in fetch if 'transpose_xy' in k]
+traffic = {}
+if cal:
+    # 512^3 = known bytes read by the in-plane transpose
+    n = bench['config']['rays_per_gpu']
+    lines.append('## HBM-side traffic (PMC)')
+    vol_bytes = None
+    for k in fetch:
+        if 'transpose_xy' in k:
+            vol_bytes = fetch[k]
+    lines.append(f'calibration: transpose_xy_kernel (reads the {bench["config"]["workload"].split(" ")[0]} uint8 volume '
+                 f'once, 64-B wave loads like the traversal kernels) FETCH_SIZE = {vol_bytes / 2**20:.2f} MiB')
+    lines += ['', '| kernel | FETCH_SIZE GB | WRITE_SIZE GB |', '|---|---|---|']
+    for k in fetch:
+        if 'dexct' in k:
+            lines.append(f'| `{k[:60]}` | {fetch[k] / 1e9:.3f} | {write.get(k, 0) / 1e9:.3f} |')
+    for k in fetch:
+        if 'rows_kernel' in k or ('rays_kernel' in k and 'siddon' not in traffic):
+            traffic['siddon_kernel'] = k
+            traffic['siddon_fetch_bytes'] = fetch[k]
+            traffic['siddon_write_bytes'] = write.get(k, 0.0)
+            traffic['siddon_hbm_bytes_per_launch'] = fetch[k] + write.get(k, 0.0)
+        if 'gn_kernel' in k:
+            traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
+            traffic['gn_write_bytes'] = write.get(k, 0.0)
+    traffic['transpose_xy_fetch_bytes'] = vol_bytes
+json.dump(traffic, open(os.path.join('profiles', f'{tag}_pmc_traffic.json'), 'w'), indent=1)
+json.dump(bench, open(os.path.join('profiles', f'{tag}_bench.json'), 'w'), indent=1)
+open(os.path.join('profiles', f'{tag}_summary.md'), 'w').write('\n'.join(lines) + '\n')
+print('\n'.join(lines))
