@@ -3,20 +3,33 @@
 // Replaces get_sino (reference call site main.py:120; algorithm: Siddon 1985 as named in
 // README.md:27-28,41).  The exact radiological path is computed in a slab-stepping form:
 // along the dominant in-plane axis u a ray crosses one slab per step and at most one plane of
-// the minor axis v inside it, so every slab contributes two pieces (voxel (i, ja) with length t
-// and voxel (i, jb) with length 1 - t, in units of u).  v is a 40-bit fixed-point number stepped
+// the minor axis v inside it, so every slab contributes two pieces: voxel (i, ja) with length t
+// and voxel (i, jb) with length 1 - t, in units of u.  v is a 40-bit fixed-point number stepped
 // by integer addition, so voxel indices are exact; t is one float32 multiply on the top 32
-// fraction bits.  Path lengths are accumulated per MATERIAL (energy independent), then one
-// pass over the energy bins applies the attenuation table and the detector weighting for every
-// spectrum (weights = I0 * eta * [E] * dE, the forward model of matdecomp.py:146-150).
+// fraction bits.
 //
-// Two traversal kernels:
-//   rays_kernel  one thread per ray, lanes over adjacent channels (coalesced on the layout whose
-//                minor axis is contiguous); any number of rows, the kernel for 2-D scans.
-//   rows_kernel  one workgroup per (view, channel): all rows of a stacked fan share the in-plane
-//                traversal, so the slab records are computed once per workgroup into LDS and every
-//                lane (= detector row = z-slice) only loads its voxel byte from the z-fastest
-//                layout (64 consecutive bytes per wave) and accumulates.
+// Path lengths are accumulated per MATERIAL (energy independent).  A slab's contribution to
+// material m, t*[ida == m] + (1 - t)*[idb == m], is rewritten as
+//        [idb == m]  +  t * ([ida == m] - [idb == m])
+// i.e. an INTEGER count of slabs (exact, order independent) plus a float32 correction that is
+// non-zero only where the v-plane crossing inside the slab separates two different materials.
+// L_m = ((float)count_m + corr_m) * len_per_u; material 0 comes from the chord.  The oracle
+// (oracle/dexct_oracle.c: orc_dda_pathlen) performs the same operations, so per-material path
+// lengths are compared bit for bit.  One pass over the energy bins then applies the attenuation
+// table and the detector weighting for every spectrum of the call (weights = I0 * eta * [E] * dE,
+// the forward model of matdecomp.py:146-150).
+//
+// Traversal kernels:
+//   rays_kernel   one thread per ray, lanes over adjacent channels (coalesced on the layout whose
+//                 minor axis is contiguous); any number of rows; the kernel for 2-D scans.
+//   rows_kernel   one workgroup per (view, channel): all rows of a stacked fan share the in-plane
+//                 traversal, so slab records are computed once per workgroup into LDS and every lane
+//                 (= detector row = z-slice) reads its voxel byte from the z-fastest layout.
+//   rows4_kernel  the same with 4 rows per lane: one dword load serves 4 rows and the integer counts
+//                 are kept as packed bytes (SWAR), ~1.3 VALU instructions per row and slab.  Slabs
+//                 without a crossing ("full") and with one are split into two LDS lists by a
+//                 workgroup prefix sum (legal because counts are order independent and corrections
+//                 only arise in crossing slabs, whose relative order is kept).  <= 4 materials.
 // Tables are wave-uniform and are read through the scalar cache (s_load), not LDS.
 #include "common.h"
 
@@ -27,7 +40,7 @@ constexpr float kLog2e = 1.44269504088896340736f;
 
 struct SlabPieces {
   int32_t ja, jb;
-  float la, lb;
+  float t;
 };
 
 // One slab of the fixed-point DDA (mirror: oracle/dexct_oracle.c dda_slab).
@@ -38,70 +51,8 @@ __device__ __forceinline__ SlabPieces dda_slab(long long Va, long long SV, uint3
   s.jb = (int32_t)(Vb >> DEXCT_FIX_FRAC);
   const uint32_t fr = (uint32_t)((unsigned long long)Va >> 8);
   const float d = (float)(fr ^ smask);
-  const float t = fminf(d * kf, 1.0f);
-  s.la = t;
-  s.lb = 1.0f - t;
+  s.t = fminf(d * kf, 1.0f);
   return s;
-}
-
-// counts[s] = sum_e w[s][e] * exp(-sum_m mu2[m][e] * L[m]) (v_exp_f32 on the log2(e)-scaled exponent).
-// mu2 and w are wave-uniform; NM is the number of materials held in registers.
-template <int NM>
-__device__ __forceinline__ void detect_store(const float (&L)[NM], int n_energies, int n_spectra,
-                                             const float* __restrict__ mu2, const float* __restrict__ w,
-                                             float* __restrict__ counts, size_t out_index, size_t spectrum_stride) {
-  float acc[DEXCT_MAX_SPECTRA][2];
-#pragma unroll
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) acc[s][0] = acc[s][1] = 0.0f;
-  int e = 0;
-  for (; e + 1 < n_energies; e += 2) {
-    float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      p0 = fmaf(mu2[m * n_energies + e], L[m], p0);
-      p1 = fmaf(mu2[m * n_energies + e + 1], L[m], p1);
-    }
-    const float t0 = __builtin_amdgcn_exp2f(-p0 * kLog2e), t1 = __builtin_amdgcn_exp2f(-p1 * kLog2e);
-#pragma unroll
-    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-      if (s < n_spectra) {
-        acc[s][0] = fmaf(w[s * n_energies + e], t0, acc[s][0]);
-        acc[s][1] = fmaf(w[s * n_energies + e + 1], t1, acc[s][1]);
-      }
-  }
-  if (e < n_energies) {
-    float p0 = 0.0f;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) p0 = fmaf(mu2[m * n_energies + e], L[m], p0);
-    const float t0 = __builtin_amdgcn_exp2f(-p0 * kLog2e);
-#pragma unroll
-    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-      if (s < n_spectra) acc[s][0] = fmaf(w[s * n_energies + e], t0, acc[s][0]);
-  }
-#pragma unroll
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-    if (s < n_spectra) counts[out_index + s * spectrum_stride] = acc[s][0] + acc[s][1];
-}
-
-// Same with the per-material lengths in LDS (column `tid` of lds_L[m*kBlock + tid]).
-__device__ __forceinline__ void detect_store_lds(const float* lds_L, int tid, int n_mat, int n_energies,
-                                                 int n_spectra, const float* __restrict__ mu2,
-                                                 const float* __restrict__ w, float* __restrict__ counts,
-                                                 size_t out_index, size_t spectrum_stride) {
-  float acc[DEXCT_MAX_SPECTRA];
-#pragma unroll
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) acc[s] = 0.0f;
-  for (int e = 0; e < n_energies; ++e) {
-    float p = 0.0f;
-    for (int m = 0; m < n_mat; ++m) p = fmaf(mu2[m * n_energies + e], lds_L[m * kBlock + tid], p);
-    const float t = __builtin_amdgcn_exp2f(-p * kLog2e);
-#pragma unroll
-    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-      if (s < n_spectra) acc[s] = fmaf(w[s * n_energies + e], t, acc[s]);
-  }
-#pragma unroll
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-    if (s < n_spectra) counts[out_index + s * spectrum_stride] = acc[s];
 }
 
 struct ProjArgs {
@@ -112,20 +63,181 @@ struct ProjArgs {
   const uint8_t* vol_zf;
   int n_local_views;
   int n_materials, n_energies, n_spectra;
-  const float* mu2;   // [M][nE] linear attenuation [1/cm]
+  const float* mu;    // [M][nE] linear attenuation [1/cm]
   const float* w;     // [S][nE]
   float* counts;      // [S][nV][rows][channels]
   float* pathlen;     // optional [ray][M]
 };
 
-// ---------------------------------------------------------------------------------------------
-// rays_kernel: one thread per ray.  NM > 0: materials 1..NM-1 accumulate in registers;
-// NM == 0: any number of materials, accumulators in LDS (one column per thread, conflict free).
+// counts[s] = sum_e w[s][e] * exp(-sum_m mu[m][e] * L[m]) (v_exp_f32 on the log2(e)-scaled exponent)
+// for R rays at once (R = 4 in rows4_kernel: one scalar table load serves 4 rays and the FMAs pair up
+// into v_pk_fma_f32).  mu and w are wave-uniform (scalar loads); NM materials in registers.
+template <int NM, int R>
+__device__ __forceinline__ void detect_store(const float (&L)[R][NM], const ProjArgs& a, const size_t (&ray)[R],
+                                             const bool (&valid)[R]) {
+  const int n_e = a.n_energies;
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  if (a.pathlen) {
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+      if (valid[q]) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) a.pathlen[ray[q] * NM + m] = L[q][m];
+      }
+  }
+  float acc[DEXCT_MAX_SPECTRA][R];
+#pragma unroll
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[s][q] = 0.0f;
+  const float* __restrict__ mu = a.mu;
+  const float* __restrict__ w = a.w;
+  for (int e = 0; e < n_e; ++e) {
+    float pe[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) pe[q] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const float mue = mu[m * n_e + e];
+#pragma unroll
+      for (int q = 0; q < R; ++q) pe[q] = fmaf(mue, L[q][m], pe[q]);
+    }
+    float te[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) te[q] = __builtin_amdgcn_exp2f(-pe[q] * kLog2e);
+#pragma unroll
+    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+      if (s < a.n_spectra) {
+        const float ws = w[s * n_e + e];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[s][q] = fmaf(ws, te[q], acc[s][q]);
+      }
+  }
+#pragma unroll
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+    if (s < a.n_spectra) {
+#pragma unroll
+      for (int q = 0; q < R; ++q)
+        if (valid[q]) a.counts[ray[q] + s * sstride] = acc[s][q];
+    }
+}
+
 template <int NM>
-__global__ __launch_bounds__(kBlock) void rays_kernel(ProjArgs a) {
-  extern __shared__ float lds_acc[];  // NM == 0: [n_materials][kBlock]
+__device__ __forceinline__ void detect_store1(const float (&L)[NM], const ProjArgs& a, size_t ray) {
+  float L1[1][NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) L1[0][m] = L[m];
+  const size_t rays[1] = {ray};
+  const bool valid[1] = {true};
+  detect_store<NM, 1>(L1, a, rays, valid);
+}
+
+// Any number of materials: per-material lengths in LDS column `tid` (stride `stride`).
+__device__ __forceinline__ void detect_store_lds(const float* lds_L, int tid, int stride, const ProjArgs& a,
+                                                 size_t ray) {
+  const int n_e = a.n_energies, n_mat = a.n_materials;
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  if (a.pathlen)
+    for (int m = 0; m < n_mat; ++m) a.pathlen[ray * n_mat + m] = lds_L[m * stride + tid];
+  float acc[DEXCT_MAX_SPECTRA];
+#pragma unroll
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) acc[s] = 0.0f;
+  const float* __restrict__ mu = a.mu;
+  const float* __restrict__ w = a.w;
+  for (int e = 0; e < n_e; ++e) {
+    float p = 0.0f;
+    for (int m = 0; m < n_mat; ++m) p = fmaf(mu[m * n_e + e], lds_L[m * stride + tid], p);
+    const float t = __builtin_amdgcn_exp2f(-p * kLog2e);
+#pragma unroll
+    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+      if (s < a.n_spectra) acc[s] = fmaf(w[s * n_e + e], t, acc[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+    if (s < a.n_spectra) a.counts[ray + s * sstride] = acc[s];
+}
+
+// Register accumulators of one ray for materials 1..NM-1.
+template <int NM>
+struct RegAcc {
+  int32_t cnt[NM > 1 ? NM : 2];
+  float corr[NM > 1 ? NM : 2];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int m = 0; m < (NM > 1 ? NM : 2); ++m) { cnt[m] = 0; corr[m] = 0.0f; }
+  }
+  __device__ __forceinline__ void slab(uint32_t ida, uint32_t idb, float t) {
+#pragma unroll
+    for (int m = 1; m < NM; ++m) cnt[m] += (idb == (uint32_t)m) ? 1 : 0;
+    if (ida != idb) {
+#pragma unroll
+      for (int m = 1; m < NM; ++m) {
+        corr[m] += (ida == (uint32_t)m) ? t : 0.0f;
+        corr[m] -= (idb == (uint32_t)m) ? t : 0.0f;
+      }
+    }
+  }
+  // the same without a branch (adding +0.0f leaves a sum unchanged): for lockstep lanes
+  __device__ __forceinline__ void slab_flat(uint32_t ida, uint32_t idb, float t) {
+    const float td = ida != idb ? t : 0.0f;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) {
+      cnt[m] += (idb == (uint32_t)m) ? 1 : 0;
+      corr[m] += (ida == (uint32_t)m) ? td : 0.0f;
+      corr[m] -= (idb == (uint32_t)m) ? td : 0.0f;
+    }
+  }
+  __device__ __forceinline__ void lengths(const dexct_ray_plan& p, float (&L)[NM]) const {
+    float others = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) {
+      L[m] = (float)cnt[m] + corr[m];
+      others += L[m];
+    }
+    L[0] = (p.chord_u - others) * p.len_per_u;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) L[m] *= p.len_per_u;
+  }
+};
+
+// LDS accumulators (any number of materials): cnt and corr columns of width `stride`, slot 0 is a sink.
+struct LdsAcc {
+  float* cnt;   // exact integers held as float32 (< 2^24 slabs)
+  float* corr;
+  int stride, tid, n_mat;
+  __device__ __forceinline__ void clear() {
+    for (int m = 0; m < n_mat; ++m) { cnt[m * stride + tid] = 0.0f; corr[m * stride + tid] = 0.0f; }
+  }
+  __device__ __forceinline__ void slab(uint32_t ida, uint32_t idb, float t) {
+    const uint32_t sa = ida < (uint32_t)n_mat ? ida : 0u, sb = idb < (uint32_t)n_mat ? idb : 0u;
+    __hip_atomic_fetch_add(&cnt[sb * stride + tid], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (sa != sb) {
+      __hip_atomic_fetch_add(&corr[sa * stride + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&corr[sb * stride + tid], -t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  // leaves the lengths [cm] in cnt[m]
+  __device__ __forceinline__ void lengths(const dexct_ray_plan& p) {
+    float others = 0.0f;
+    for (int m = 1; m < n_mat; ++m) {
+      const float l = cnt[m * stride + tid] + corr[m * stride + tid];
+      cnt[m * stride + tid] = l;
+      others += l;
+    }
+    cnt[tid] = (p.chord_u - others) * p.len_per_u;
+    for (int m = 1; m < n_mat; ++m) cnt[m * stride + tid] *= p.len_per_u;
+  }
+};
+
+constexpr int kLdsBlock = 128;   // block size of the LDS-accumulator instantiations (2 x M x 128 x 4 B)
+
+// ---------------------------------------------------------------------------------------------
+// rays_kernel: one thread per ray.  NM > 0: materials in registers; NM == 0: LDS accumulators.
+template <int NM, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a) {
+  extern __shared__ float lds_dyn[];
   const int tid = threadIdx.x;
-  const int c = blockIdx.x * kBlock + tid;
+  const int c = blockIdx.x * BLOCK + tid;
   const int r = blockIdx.y, v = blockIdx.z;
   const bool live = c < a.g.n_channels;
   dexct_ray_plan p;
@@ -135,13 +247,9 @@ __global__ __launch_bounds__(kBlock) void rays_kernel(ProjArgs a) {
   const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
   const int nv = axis == 0 ? a.g.ny : a.g.nx;
   const uint8_t* __restrict__ base = (axis == 0 ? a.vol_xy : a.vol_yx) + (size_t)(a.g.z_first + r) * a.g.nx * a.g.ny;
-  float acc[NM > 0 ? NM : 1];
-  if (NM > 0) {
-#pragma unroll
-    for (int m = 0; m < (NM > 0 ? NM : 1); ++m) acc[m] = 0.0f;
-  } else {
-    for (int m = 0; m < a.n_materials; ++m) lds_acc[m * kBlock + tid] = 0.0f;
-  }
+  RegAcc<(NM > 0 ? NM : 1)> ra;
+  LdsAcc la{lds_dyn, lds_dyn + a.n_materials * BLOCK, BLOCK, tid, a.n_materials};
+  if (NM > 0) ra.clear(); else la.clear();
   long long V = p.V0 + (long long)p.i_first * p.SV;
   uint32_t off = (uint32_t)p.i_first * (uint32_t)nv;
   for (int s = 0; s < p.n_slabs; ++s) {
@@ -149,67 +257,51 @@ __global__ __launch_bounds__(kBlock) void rays_kernel(ProjArgs a) {
     const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
     const uint32_t ida = ina ? base[off + (uint32_t)sp.ja] : 0u;
     const uint32_t idb = inb ? base[off + (uint32_t)sp.jb] : 0u;
-    if (NM > 0) {
-#pragma unroll
-      for (int m = 1; m < (NM > 0 ? NM : 1); ++m) {
-        acc[m] += (ida == (uint32_t)m) ? sp.la : 0.0f;
-        acc[m] += (idb == (uint32_t)m) ? sp.lb : 0.0f;
-      }
-    } else {
-      // slot 0 collects air / outside pieces and is never read
-      __hip_atomic_fetch_add(&lds_acc[ida * kBlock + tid], sp.la, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&lds_acc[idb * kBlock + tid], sp.lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+#ifdef DEXCT_RAYS_FLAT
+    if (NM > 0) ra.slab_flat(ida, idb, sp.t); else la.slab(ida, idb, sp.t);
+#else
+    if (NM > 0) ra.slab(ida, idb, sp.t); else la.slab(ida, idb, sp.t);
+#endif
     V += p.SV;
     off += (uint32_t)nv;
   }
   if (!live) return;
   const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
-  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   if (NM > 0) {
     float L[NM > 0 ? NM : 1];
-    float others = 0.0f;
-#pragma unroll
-    for (int m = 1; m < (NM > 0 ? NM : 1); ++m) others += acc[m];
-    L[0] = (p.chord_u - others) * p.len_per_u;
-#pragma unroll
-    for (int m = 1; m < (NM > 0 ? NM : 1); ++m) L[m] = acc[m] * p.len_per_u;
-    if (a.pathlen)
-      for (int m = 0; m < a.n_materials; ++m) a.pathlen[ray * a.n_materials + m] = m < NM ? L[m < NM ? m : 0] : 0.0f;
-    detect_store<(NM > 0 ? NM : 1)>(L, a.n_energies, a.n_spectra, a.mu2, a.w, a.counts, ray, sstride);
+    ra.lengths(p, L);
+    detect_store1<(NM > 0 ? NM : 1)>(L, a, ray);
   } else {
-    float others = 0.0f;
-    for (int m = 1; m < a.n_materials; ++m) others += lds_acc[m * kBlock + tid];
-    lds_acc[tid] = (p.chord_u - others) * p.len_per_u;
-    for (int m = 1; m < a.n_materials; ++m) lds_acc[m * kBlock + tid] *= p.len_per_u;
-    if (a.pathlen)
-      for (int m = 0; m < a.n_materials; ++m) a.pathlen[ray * a.n_materials + m] = lds_acc[m * kBlock + tid];
-    detect_store_lds(lds_acc, tid, a.n_materials, a.n_energies, a.n_spectra, a.mu2, a.w, a.counts, ray, sstride);
+    la.lengths(p);
+    detect_store_lds(la.cnt, tid, BLOCK, a, ray);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// rows_kernel: one workgroup per (view, channel, chunk of kBlock rows).
+// rows_kernel: one workgroup per (view, channel, chunk of BLOCK rows), one row per lane.
 struct SlabRec {
-  uint32_t offa, offb;  // byte offsets of the (x, y) columns in the z-fastest layout
-  float la, lb;         // 0 where the piece lies outside the grid
+  uint32_t offa, offb;  // byte offsets of the (x, y) columns in the z-fastest layout (0 where outside the grid)
+  float t;
+  uint32_t masks;       // bits 0-7: 0xFF if piece a lies inside the grid, bits 8-15: the same for piece b
 };
 
-template <int NM>
-__global__ __launch_bounds__(kBlock) void rows_kernel(ProjArgs a, int n_chunks) {
-  __shared__ SlabRec rec[kBlock];
-  extern __shared__ float lds_acc[];
+// XCD-aware remap: consecutive logical ids (adjacent channels of one view: rays that share voxel
+// columns) land on the same XCD and therefore in the same L2.
+__device__ __forceinline__ uint32_t xcd_logical_block() {
+  const uint32_t nblk = gridDim.x, b = blockIdx.x, per = nblk >> 3;
+  return (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
+}
+
+template <int NM, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rows_kernel(ProjArgs a, int n_chunks) {
+  __shared__ SlabRec rec[BLOCK];
+  extern __shared__ float lds_dyn[];
   const int tid = threadIdx.x;
-  // XCD-aware remap: consecutive logical ids (adjacent channels of one view: rays that share
-  // voxel columns) land on the same XCD and therefore in the same L2.
-  const uint32_t nblk = gridDim.x;
-  const uint32_t b = blockIdx.x;
-  const uint32_t per = nblk >> 3;
-  const uint32_t logical = (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
+  const uint32_t logical = xcd_logical_block();
   const int chunk = logical % n_chunks;
   const uint32_t vc = logical / n_chunks;
   const int c = vc % a.g.n_channels, v = vc / a.g.n_channels;
-  const int r = chunk * kBlock + tid;
+  const int r = chunk * BLOCK + tid;
   const bool live = r < a.g.n_rows;
   const int z = a.g.z_first + (live ? r : 0);
   const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];   // uniform
@@ -220,15 +312,11 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ProjArgs a, int n_chunks) 
   const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * (uint32_t)a.g.nz;
   const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * (uint32_t)a.g.nz;
   const uint8_t* __restrict__ col = a.vol_zf + z;
-  float acc[NM > 0 ? NM : 1];
-  if (NM > 0) {
-#pragma unroll
-    for (int m = 0; m < (NM > 0 ? NM : 1); ++m) acc[m] = 0.0f;
-  } else {
-    for (int m = 0; m < a.n_materials; ++m) lds_acc[m * kBlock + tid] = 0.0f;
-  }
-  for (int s0 = 0; s0 < p.n_slabs; s0 += kBlock) {
-    const int n_here = min(kBlock, p.n_slabs - s0);
+  RegAcc<(NM > 0 ? NM : 1)> ra;
+  LdsAcc la{lds_dyn, lds_dyn + a.n_materials * BLOCK, BLOCK, tid, a.n_materials};
+  if (NM > 0) ra.clear(); else la.clear();
+  for (int s0 = 0; s0 < p.n_slabs; s0 += BLOCK) {
+    const int n_here = min(BLOCK, p.n_slabs - s0);
     if (tid < n_here) {
       const int i = p.i_first + s0 + tid;
       const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
@@ -236,52 +324,197 @@ __global__ __launch_bounds__(kBlock) void rows_kernel(ProjArgs a, int n_chunks) 
       SlabRec q;
       q.offa = ina ? (uint32_t)i * su + (uint32_t)sp.ja * sv : 0u;
       q.offb = inb ? (uint32_t)i * su + (uint32_t)sp.jb * sv : 0u;
-      q.la = ina ? sp.la : 0.0f;
-      q.lb = inb ? sp.lb : 0.0f;
+      q.t = sp.t;
+      q.masks = (ina ? 0xFFu : 0u) | (inb ? 0xFF00u : 0u);
       rec[tid] = q;
     }
     __syncthreads();
 #pragma unroll 4
     for (int s = 0; s < n_here; ++s) {
       const SlabRec q = rec[s];
-      const uint32_t ida = col[q.offa];
-      const uint32_t idb = col[q.offb];
-      if (NM > 0) {
-#pragma unroll
-        for (int m = 1; m < (NM > 0 ? NM : 1); ++m) {
-          acc[m] += (ida == (uint32_t)m) ? q.la : 0.0f;
-          acc[m] += (idb == (uint32_t)m) ? q.lb : 0.0f;
-        }
-      } else {
-        __hip_atomic_fetch_add(&lds_acc[ida * kBlock + tid], q.la, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&lds_acc[idb * kBlock + tid], q.lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+      const uint32_t ida = col[q.offa] & q.masks;            // outside the grid -> id 0, no branch
+      const uint32_t idb = col[q.offb] & (q.masks >> 8);
+      if (NM > 0) ra.slab_flat(ida, idb, q.t); else la.slab(ida, idb, q.t);   // no branch: keeps the 8 loads of the unrolled body in flight
     }
     __syncthreads();
   }
   if (!live) return;
   const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
-  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   if (NM > 0) {
     float L[NM > 0 ? NM : 1];
-    float others = 0.0f;
-#pragma unroll
-    for (int m = 1; m < (NM > 0 ? NM : 1); ++m) others += acc[m];
-    L[0] = (p.chord_u - others) * p.len_per_u;
-#pragma unroll
-    for (int m = 1; m < (NM > 0 ? NM : 1); ++m) L[m] = acc[m] * p.len_per_u;
-    if (a.pathlen)
-      for (int m = 0; m < a.n_materials; ++m) a.pathlen[ray * a.n_materials + m] = m < NM ? L[m < NM ? m : 0] : 0.0f;
-    detect_store<(NM > 0 ? NM : 1)>(L, a.n_energies, a.n_spectra, a.mu2, a.w, a.counts, ray, sstride);
+    ra.lengths(p, L);
+    detect_store1<(NM > 0 ? NM : 1)>(L, a, ray);
   } else {
-    float others = 0.0f;
-    for (int m = 1; m < a.n_materials; ++m) others += lds_acc[m * kBlock + tid];
-    lds_acc[tid] = (p.chord_u - others) * p.len_per_u;
-    for (int m = 1; m < a.n_materials; ++m) lds_acc[m * kBlock + tid] *= p.len_per_u;
-    if (a.pathlen)
-      for (int m = 0; m < a.n_materials; ++m) a.pathlen[ray * a.n_materials + m] = lds_acc[m * kBlock + tid];
-    detect_store_lds(lds_acc, tid, a.n_materials, a.n_energies, a.n_spectra, a.mu2, a.w, a.counts, ray, sstride);
+    la.lengths(p);
+    detect_store_lds(la.cnt, tid, BLOCK, a, ray);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows4_kernel: 4 rows per lane, packed-byte counts.  Requires nz % 4 == 0, z_first % 4 == 0,
+// 2 <= NM <= 4 and material ids < NM in the volume.
+constexpr int kSuper = 512;    // slabs staged per pass: 2 KB full list + 6 KB crossing list
+
+struct CrossRec {
+  uint32_t offa, offb;   // ~0u = piece outside the grid
+  float t;
+};
+
+template <int NM, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, int n_chunks) {
+  __shared__ uint32_t list_full[kSuper];
+  __shared__ CrossRec list_cross[kSuper];
+  __shared__ uint32_t wave_tot[2][BLOCK / 64];
+  __shared__ uint32_t n_lists[2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t logical = xcd_logical_block();
+  const int chunk = logical % n_chunks;
+  const uint32_t vc = logical / n_chunks;
+  const int c = vc % a.g.n_channels, v = vc / a.g.n_channels;
+  const int r0 = (chunk * BLOCK + tid) * 4;          // first of this lane's 4 rows
+  const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];   // uniform
+  const int axis = p.flags & 1u;
+  const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
+  const int nv = axis == 0 ? a.g.ny : a.g.nx;
+  const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * (uint32_t)a.g.nz;
+  const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * (uint32_t)a.g.nz;
+  // lanes past the last row read the last aligned dword of the column (harmless) and store nothing
+  const int zl = min(a.g.z_first + r0, a.g.nz - 4);
+  const uint8_t* __restrict__ col = a.vol_zf + zl;
+  // packed byte counters: bit0 plane, bit1 plane, both bits; wide per-row counters
+  uint32_t c0 = 0, c1 = 0, c01 = 0;
+  uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w01[4] = {0, 0, 0, 0};
+  float corr[4][4];   // [material][row]
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) corr[m][q] = 0.0f;
+  int pending = 0;    // slabs counted into the packed bytes since the last flush (<= 255)
+
+  auto flush = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      w0[q] += (c0 >> (8 * q)) & 0xFFu;
+      w1[q] += (c1 >> (8 * q)) & 0xFFu;
+      if (NM > 3) w01[q] += (c01 >> (8 * q)) & 0xFFu;
+    }
+    c0 = c1 = c01 = 0;
+    pending = 0;
+  };
+  auto count4 = [&](uint32_t x) {
+    const uint32_t b0 = x & 0x01010101u, b1 = (x >> 1) & 0x01010101u;
+    c0 += b0;
+    c1 += b1;
+    if (NM > 3) c01 += b0 & b1;
+  };
+
+  for (int s0 = 0; s0 < p.n_slabs; s0 += kSuper) {
+    const int n_super = min(kSuper, p.n_slabs - s0);
+    if (tid == 0) { n_lists[0] = 0; n_lists[1] = 0; }
+    __syncthreads();
+    // ---- geometry: classify slabs, compact into the two lists (order kept)
+    for (int s1 = 0; s1 < n_super; s1 += BLOCK) {
+      const int s = s1 + tid;
+      bool is_full = false, is_cross = false;
+      uint32_t offa = ~0u, offb = ~0u;
+      float t = 0.0f;
+      if (s < n_super) {
+        const int i = p.i_first + s0 + s;
+        const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
+        const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
+        if (ina) offa = (uint32_t)i * su + (uint32_t)sp.ja * sv;
+        if (inb) offb = (uint32_t)i * su + (uint32_t)sp.jb * sv;
+        t = sp.t;
+        is_full = ina && inb && sp.ja == sp.jb;      // both pieces in one voxel column: count only
+        is_cross = !is_full && (ina || inb);
+      }
+      const unsigned long long mf = __ballot(is_full), mc = __ballot(is_cross);
+      const uint32_t below = (lane == 0) ? 0u : (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
+      const uint32_t belowc = (lane == 0) ? 0u : (uint32_t)__popcll(mc & ((1ull << lane) - 1ull));
+      if (lane == 0) { wave_tot[0][wid] = (uint32_t)__popcll(mf); wave_tot[1][wid] = (uint32_t)__popcll(mc); }
+      __syncthreads();
+      uint32_t basef = n_lists[0], basec = n_lists[1];
+#pragma unroll
+      for (int k = 0; k < BLOCK / 64; ++k)
+        if (k < wid) { basef += wave_tot[0][k]; basec += wave_tot[1][k]; }
+      if (is_full) list_full[basef + below] = offb;
+      if (is_cross) list_cross[basec + belowc] = CrossRec{offa, offb, t};
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t tf = 0, tc = 0;
+#pragma unroll
+        for (int k = 0; k < BLOCK / 64; ++k) { tf += wave_tot[0][k]; tc += wave_tot[1][k]; }
+        n_lists[0] += tf;
+        n_lists[1] += tc;
+      }
+      __syncthreads();
+    }
+    const int n_full = (int)n_lists[0], n_cross = (int)n_lists[1];
+    // ---- full slabs: one dword (4 rows) per slab, integer counts only
+    int s = 0;
+    while (s < n_full) {
+      const int batch = min(n_full - s, 248 - pending);
+      int k = 0;
+      for (; k + 8 <= batch; k += 8) {
+        uint32_t x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const uint32_t*>(col + list_full[s + k + q]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) count4(x[q]);
+      }
+      for (; k < batch; ++k) count4(*reinterpret_cast<const uint32_t*>(col + list_full[s + k]));
+      s += batch;
+      pending += batch;
+      if (pending >= 248) flush();
+    }
+    // ---- crossing slabs: two columns; count the b voxel, correct where the two voxels differ
+    for (int k = 0; k < n_cross; ++k) {
+      const CrossRec q = list_cross[k];
+      const uint32_t xa = q.offa != ~0u ? *reinterpret_cast<const uint32_t*>(col + q.offa) : 0u;   // uniform
+      const uint32_t xb = q.offb != ~0u ? *reinterpret_cast<const uint32_t*>(col + q.offb) : 0u;
+      count4(xb);
+      if (++pending >= 248) flush();
+      if (xa != xb) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const uint32_t ia = (xa >> (8 * rr)) & 0xFFu, ib = (xb >> (8 * rr)) & 0xFFu;
+          if (ia != ib) {
+#pragma unroll
+            for (int m = 1; m < NM; ++m) {
+              corr[m][rr] += (ia == (uint32_t)m) ? q.t : 0.0f;
+              corr[m][rr] -= (ib == (uint32_t)m) ? q.t : 0.0f;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  flush();
+  float L[4][NM];
+  size_t rays[4];
+  bool valid[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = r0 + rr;
+    valid[rr] = r < a.g.n_rows;
+    rays[rr] = ((size_t)v * a.g.n_rows + (valid[rr] ? r : 0)) * a.g.n_channels + c;
+    // ids are 0..NM-1: bit-plane counts -> per-material counts
+    uint32_t n[4];
+    n[3] = NM > 3 ? w01[rr] : 0u;
+    n[1] = w0[rr] - n[3];
+    n[2] = w1[rr] - n[3];
+    float others = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) {
+      L[rr][m] = (float)(int32_t)n[m] + corr[m][rr];
+      others += L[rr][m];
+    }
+    L[rr][0] = (p.chord_u - others) * p.len_per_u;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
+  }
+  detect_store<NM, 4>(L, a, rays, valid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,7 +537,7 @@ __global__ __launch_bounds__(64) void trace_kernel(dexct_fan_geom g, const dexct
     const int i = p.i_first + s;
     const SlabPieces sp = dda_slab(V, p.SV, smask, p.kf);
     const int j[2] = {sp.ja, sp.jb};
-    const float l[2] = {sp.la, sp.lb};
+    const float l[2] = {sp.t, 1.0f - sp.t};
     for (int q = 0; q < 2; ++q) {
       if ((uint32_t)j[q] >= (uint32_t)nv || !(l[q] > 0.0f)) continue;
       const int x = axis == 0 ? i : j[q], y = axis == 0 ? j[q] : i;
@@ -321,22 +554,44 @@ __global__ __launch_bounds__(64) void trace_kernel(dexct_fan_geom g, const dexct
 
 template <int NM>
 static int launch_rays(const ProjArgs& a, hipStream_t st) {
-  dim3 grid((a.g.n_channels + kBlock - 1) / kBlock, a.g.n_rows, a.n_local_views);
-  size_t lds = NM > 0 ? 0 : (size_t)a.n_materials * kBlock * sizeof(float);
-  hipLaunchKernelGGL(rays_kernel<NM>, grid, dim3(kBlock), lds, st, a);
+  constexpr int B = NM > 0 ? kBlock : kLdsBlock;
+  dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
+  size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
+  hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
 
 template <int NM>
 static int launch_rows(const ProjArgs& a, hipStream_t st) {
-  const int n_chunks = (a.g.n_rows + kBlock - 1) / kBlock;
+  constexpr int B = NM > 0 ? kBlock : kLdsBlock;
+  const int n_chunks = (a.g.n_rows + B - 1) / B;
   const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  size_t lds = NM > 0 ? 0 : (size_t)a.n_materials * kBlock * sizeof(float);
-  hipLaunchKernelGGL(rows_kernel<NM>, dim3((unsigned)nblk), dim3(kBlock), lds, st, a, n_chunks);
+  size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
+  hipLaunchKernelGGL((rows_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), lds, st, a, n_chunks);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
+}
+
+template <int NM, int B>
+static int launch_rows4_b(const ProjArgs& a, hipStream_t st) {
+  const int rows_per_block = 4 * B;
+  const int n_chunks = (a.g.n_rows + rows_per_block - 1) / rows_per_block;
+  const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL((rows4_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), 0, st, a, n_chunks);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+template <int NM>
+static int launch_rows4(const ProjArgs& a, hipStream_t st) {
+  // one lane per 4 rows: pick the smallest block that covers the rows in one chunk (up to 256 lanes)
+  const int lanes = (a.g.n_rows + 3) / 4;
+  if (lanes <= 64) return launch_rows4_b<NM, 64>(a, st);
+  if (lanes <= 128) return launch_rows4_b<NM, 128>(a, st);
+  return launch_rows4_b<NM, 256>(a, st);
 }
 
 }  // namespace dexct
@@ -354,11 +609,13 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
   if (n_materials > DEXCT_MAX_MATERIALS || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
   if (geom->z_first < 0 || geom->z_first + geom->n_rows > geom->nz) return DEXCT_EINVAL;
-  if ((uint64_t)geom->nx * geom->ny * geom->nz > 0xFFFFFFFFull) return DEXCT_ERANGE;  // 32-bit voxel offsets
-  if (kernel == 0) kernel = (vol_zf && geom->n_rows >= 64) ? 2 : 1;
+  if ((uint64_t)geom->nx * geom->ny * geom->nz > 0xFFFFFFFEull) return DEXCT_ERANGE;  // 32-bit voxel offsets
+  const bool can4 = vol_zf && n_materials >= 2 && n_materials <= 4 && geom->nz % 4 == 0 && geom->z_first % 4 == 0;
+  if (kernel == 0) kernel = (vol_zf && geom->n_rows >= 64) ? (can4 ? 3 : 2) : 1;
   if (kernel == 1 && (!vol_yx || !vol_xy)) return DEXCT_EINVAL;
   if (kernel == 2 && !vol_zf) return DEXCT_EINVAL;
-  if (kernel != 1 && kernel != 2) return DEXCT_EINVAL;
+  if (kernel == 3 && !can4) return DEXCT_EINVAL;
+  if (kernel < 1 || kernel > 3) return DEXCT_EINVAL;
   if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
   ProjArgs a;
   a.g = *geom;
@@ -370,7 +627,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   a.n_materials = n_materials;
   a.n_energies = n_energies;
   a.n_spectra = n_spectra;
-  a.mu2 = mu;
+  a.mu = mu;
   a.w = weights;
   a.counts = counts;
   a.pathlen = pathlen;
@@ -384,12 +641,19 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
       default: return launch_rays<0>(a, st);
     }
   }
+  if (kernel == 2) {
+    switch (n_materials) {
+      case 1: return launch_rows<1>(a, st);
+      case 2: return launch_rows<2>(a, st);
+      case 3: return launch_rows<3>(a, st);
+      case 4: return launch_rows<4>(a, st);
+      default: return launch_rows<0>(a, st);
+    }
+  }
   switch (n_materials) {
-    case 1: return launch_rows<1>(a, st);
-    case 2: return launch_rows<2>(a, st);
-    case 3: return launch_rows<3>(a, st);
-    case 4: return launch_rows<4>(a, st);
-    default: return launch_rows<0>(a, st);
+    case 2: return launch_rows4<2>(a, st);
+    case 3: return launch_rows4<3>(a, st);
+    default: return launch_rows4<4>(a, st);
   }
 }
 

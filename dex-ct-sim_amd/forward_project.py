@@ -43,7 +43,8 @@ class Projector:
     """Device-resident state of one (scanner, phantom) pair: volume layouts and ray plans.
 
     ``view_range`` restricts the instance to a contiguous shard of projection angles (one per
-    rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel.
+    rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel (1 row per lane),
+    3 row-parallel with 4 rows per lane (<= 4 materials, Nz and z_index multiples of 4).
     """
 
     def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
@@ -70,9 +71,11 @@ class Projector:
         self.plan = torch.empty(n_local * ct.N_channels * _native.PLAN_BYTES, dtype=torch.uint8, device=self.dev)
         _native.check(self.lib.dexct_fan_plan(C.byref(self.geom), ptr(self.view_cs), ptr(self.chan_cs),
                                               self.view_begin, self.view_end, ptr(self.plan), st), 'dexct_fan_plan')
+        if int(phantom.volume.max()) >= phantom.n_materials:
+            raise ValueError('the volume holds a material id without a table entry')
         self.vol_yx = to_dev(phantom.volume, torch.uint8, self.dev)
         self.vol_xy = torch.empty_like(self.vol_yx)
-        want_zf = kernel == 2 or (kernel == 0 and ct.N_rows >= 64)
+        want_zf = kernel in (2, 3) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, phantom.Nz,
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')

@@ -28,7 +28,7 @@ extern "C" {
 #define DEXCT_ERANGE (-2)   /* a size exceeds what the kernels support (see DEXCT_MAX_*) */
 #define DEXCT_EHIP (-3)     /* a HIP runtime call failed; dexct_last_hip_error() has the code */
 
-#define DEXCT_MAX_MATERIALS 64 /* material ids 0..63 in the uint8 volume */
+#define DEXCT_MAX_MATERIALS 48 /* material ids 0..47 in the uint8 volume */
 #define DEXCT_MAX_SPECTRA 4    /* spectra detected per traversal */
 #define DEXCT_FIX_FRAC 40      /* fractional bits of the fixed-point minor-axis coordinate */
 
@@ -92,7 +92,10 @@ int dexct_fan_plan(const dexct_fan_geom* geom, const double* view_cs, const doub
  * vol_yx / vol_xy / vol_zf as written by dexct_volume_layouts (vol_zf may be NULL: then the
  * ray-parallel kernel is used for every shape).
  * kernel: 0 = choose, 1 = ray-parallel (one thread per ray), 2 = row-parallel (one workgroup
- * per (view, channel), lanes over detector rows). */
+ * per (view, channel), one detector row per lane), 3 = row-parallel with 4 rows per lane and packed
+ * integer counts (needs vol_zf, 2..4 materials, nz and z_first multiples of 4).
+ * Precondition: every voxel id is < n_materials (ids outside are ignored by kernels 1 and 2 and
+ * give unspecified - but memory-safe - results in kernel 3). */
 int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                          int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
                          const uint8_t* vol_zf, int32_t n_materials, int32_t n_energies,

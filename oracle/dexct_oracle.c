@@ -216,12 +216,17 @@ int orc_dda_ray(const dexct_fan_geom* g, const dexct_ray_plan* p, int z, int max
   return n;
 }
 
-/* Per-material path lengths [cm] (float32, accumulation order = slab order, piece a then b,
- * exactly as one GPU thread accumulates).  Material 0 is obtained from the chord. */
+/* Per-material path lengths [cm], in exactly the arithmetic of the GPU kernels.  A slab contributes
+ * t*[ida == m] + (1 - t)*[idb == m] = [idb == m] + t*([ida == m] - [idb == m]), so the kernels keep
+ *   count[m]  integer number of slabs whose b-voxel is material m                  (exact, any order)
+ *   corr[m]   float32 sum, in slab order, of +t / -t for slabs whose two voxels differ in material
+ * and L_m = ((float)count[m] + corr[m]) * len_per_u.  A piece outside the grid counts as id 0;
+ * material 0 (and any id >= n_mat) is never accumulated: L_0 comes from the chord. */
 void orc_dda_pathlen(const dexct_fan_geom* g, const dexct_ray_plan* p, const uint8_t* vol, int z, int n_mat,
                      float* L) {
-  float acc[256];
-  for (int m = 0; m < n_mat; ++m) acc[m] = 0.0f;
+  int32_t count[256];
+  float corr[256];
+  for (int m = 0; m < 256; ++m) { count[m] = 0; corr[m] = 0.0f; }
   int axis = p->flags & 1u;
   int nv = axis == 0 ? g->ny : g->nx;
   for (int s = 0; s < p->n_slabs; ++s) {
@@ -229,19 +234,30 @@ void orc_dda_pathlen(const dexct_fan_geom* g, const dexct_ray_plan* p, const uin
     int32_t j[2];
     float l[2];
     dda_slab(p, i, &j[0], &j[1], &l[0], &l[1]);
+    int id[2];
     for (int q = 0; q < 2; ++q) {
-      if (j[q] < 0 || j[q] >= nv) continue;
-      int x = axis == 0 ? i : j[q], y = axis == 0 ? j[q] : i;
-      int id = vol[((size_t)z * g->ny + y) * g->nx + x];
-      if (id > 0 && id < n_mat) acc[id] += l[q];
+      id[q] = 0;
+      if (j[q] >= 0 && j[q] < nv) {
+        int x = axis == 0 ? i : j[q], y = axis == 0 ? j[q] : i;
+        id[q] = vol[((size_t)z * g->ny + y) * g->nx + x];
+      }
+    }
+    if (j[1] >= 0 && j[1] < nv) count[id[1]] += 1;
+    else if (j[0] < 0 || j[0] >= nv) continue;          /* slab entirely outside */
+    if (id[0] != id[1]) {
+      corr[id[0]] += l[0];
+      corr[id[1]] -= l[0];
     }
   }
+  float acc[256];
   float others = 0.0f;
-  for (int m = 1; m < n_mat; ++m) others += acc[m];
+  for (int m = 1; m < n_mat; ++m) {
+    acc[m] = (float)count[m] + corr[m];
+    others += acc[m];
+  }
   acc[0] = p->chord_u - others;
   for (int m = 0; m < n_mat; ++m) L[m] = acc[m] * p->len_per_u;
 }
-
 
 /* Exact number of Siddon segments (pieces inside the grid with positive length) summed over a plan
  * table: the S_ray of the algorithmic-bytes figure in bench.py. */

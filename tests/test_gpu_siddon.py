@@ -26,6 +26,15 @@ def spectra():
     return [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
 
 
+def ph_many(ph, n_mat):
+    """Scramble the non-air voxels over n_mat - 1 materials (many material boundaries)."""
+    from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
+    rng = np.random.default_rng(11)
+    ph.volume = np.where(ph.volume > 0, rng.integers(1, n_mat, ph.volume.shape, dtype=np.uint8), 0).astype(np.uint8)
+    ph.materials = [AIR, WATER, BONE] + [Material(f'm{i}', 1.0 + 0.1 * i, 'H(11.2)O(88.8)') for i in range(3, n_mat)]
+    return ph
+
+
 @pytest.mark.parametrize('n,nv,nc', [(48, 60, 96), (50, 72, 97), (64, 8, 300)])
 def test_plan_bit_exact(hip, n, nv, nc):
     ct, ph = small_scan(n=n, n_views=nv, n_channels=nc)
@@ -51,7 +60,7 @@ def test_plan_nonsquare_anisotropic(hip):
         assert np.array_equal(got[f], ref[f]), f
     E = np.array([40.0, 60.0, 80.0])
     mu, w = ph.mu_table(E), np.array([[1e4, 2e4, 1e4]])
-    for kernel in (1, 2):
+    for kernel in (1, 2):          # nz = 2 is not a multiple of 4: the 4-rows-per-lane kernel must refuse
         pj = projector(ct, ph, kernel=kernel)
         c, pl = pj.project_tables(torch.tensor(mu, dtype=torch.float32, device='cuda'),
                                   torch.tensor(w, dtype=torch.float32, device='cuda'), want_pathlen=True)
@@ -59,6 +68,10 @@ def test_plan_nonsquare_anisotropic(hip):
         assert np.array_equal(pl.cpu().numpy(), rpl)
         cls = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, 50, ph.volume, mu, w)
         assert np.max(np.abs(c.cpu().numpy() - cls) / cls) < REL_TOL
+    from dex_ct_sim_amd._native import DexctError
+    with pytest.raises(DexctError):
+        projector(ct, ph, kernel=3).project_tables(torch.tensor(mu, dtype=torch.float32, device='cuda'),
+                                                   torch.tensor(w, dtype=torch.float32, device='cuda'))
 
 
 @pytest.mark.parametrize('n,nv,nc', [(64, 90, 128), (50, 72, 97)])
@@ -78,16 +91,23 @@ def test_voxel_index_sequence_bit_exact(hip, n, nv, nc):
         assert np.array_equal(ln[k, :ns[k]], rl)
 
 
-@pytest.mark.parametrize('kernel', [1, 2])
-@pytest.mark.parametrize('n_mat', [3, 7])
+@pytest.mark.parametrize('kernel', [1, 2, 3])
+@pytest.mark.parametrize('n_mat', [2, 3, 4, 7])
 def test_pathlen_bit_exact_and_counts(hip, kernel, n_mat):
-    """Register accumulators (<= 4 materials) and LDS accumulators (more), both kernels."""
+    """Register accumulators (<= 4 materials), LDS accumulators (more) and the packed-count
+    4-rows-per-lane kernel; 66 rows from slice 4 of 72 (ragged last lane)."""
+    from dex_ct_sim_amd._native import DexctError
     from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
-    ct, ph = small_scan(n=48, nz=70, n_views=24, n_channels=80, n_rows=66, z_index=2)
+    ct, ph = small_scan(n=48, nz=72, n_views=24, n_channels=80, n_rows=66, z_index=4)
+    if n_mat == 2:
+        ph.volume = np.minimum(ph.volume, 1).astype(np.uint8)
+        ph.materials = [AIR, WATER]
+    if kernel == 3 and n_mat > 4:
+        with pytest.raises(DexctError):
+            projector(ct, ph_many(ph, n_mat), kernel=3).project(spectra())
+        return
     if n_mat > 3:
-        rng = np.random.default_rng(11)
-        ph.volume = np.where(ph.volume > 0, rng.integers(1, n_mat, ph.volume.shape, dtype=np.uint8), 0).astype(np.uint8)
-        ph.materials = [AIR, WATER, BONE] + [Material(f'm{i}', 1.0 + 0.1 * i, 'H(11.2)O(88.8)') for i in range(3, n_mat)]
+        ph = ph_many(ph, n_mat)
     g = oracle_geom(ct, ph)
     pj = projector(ct, ph, kernel=kernel)
     sp = spectra()
@@ -133,15 +153,16 @@ def test_wide_fan_misses_and_empty_volume(hip):
 def test_full_size_properties(hip):
     """256^2 x 64 slices, 360 views x 512 channels (BASELINE config 2 geometry, fewer slices):
     size-independent properties instead of an oracle run: (a) total path length over materials equals
-    the analytic chord through the grid box, (b) both kernels agree bit for bit, (c) linearity: with one
+    the analytic chord through the grid box, (b) all three kernels agree bit for bit, (c) linearity: with one
     energy bin, -log(counts/w) equals sum_m mu_m L_m."""
     ct, ph = small_scan(n=256, nz=64, n_views=360, n_channels=512, n_rows=64)
     mu = torch.tensor([[0.0002], [0.2], [0.5]], dtype=torch.float32, device='cuda')
     w = torch.tensor([[1000.0]], dtype=torch.float32, device='cuda')
     c1, p1 = projector(ct, ph, kernel=1).project_tables(mu, w, want_pathlen=True)
     c2, p2 = projector(ct, ph, kernel=2).project_tables(mu, w, want_pathlen=True)
-    assert torch.equal(p1, p2)
-    assert torch.allclose(c1, c2, rtol=1e-6, atol=0)
+    c3, p3 = projector(ct, ph, kernel=3).project_tables(mu, w, want_pathlen=True)
+    assert torch.equal(p1, p2) and torch.equal(p1, p3)
+    assert torch.allclose(c1, c2, rtol=1e-6, atol=0) and torch.allclose(c1, c3, rtol=1e-6, atol=0)
     tot = p1.sum(-1).double().cpu().numpy()[:, 0, :]
     b, gm = ct.thetas[:, None], ct.gammas[None, :]
     sx, sy = ct.SID * np.cos(b), ct.SID * np.sin(b)
