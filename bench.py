@@ -91,8 +91,13 @@ def main():
 
     nV = pj.n_local_views
     n_rays = nV * rows * args.channels
-    counts = torch.empty((2, nV, rows, args.channels), dtype=torch.float32, device=dev)
-    a_out = torch.empty((nV, rows, args.channels, 2), dtype=torch.float64, device=dev)
+    native = pj.native_layout          # 1: [view][channel][row] (row-parallel kernels), 0: [view][row][channel]
+    nat_shape = (nV, args.channels, rows) if native == 1 else (nV, rows, args.channels)
+    counts_nat = torch.empty((2,) + nat_shape, dtype=torch.float32, device=dev)
+    a_nat = torch.empty(nat_shape + (2,), dtype=torch.float64, device=dev)
+    # results in the reference's order ([view][row][channel]) are part of the step
+    counts = torch.empty((2, nV, rows, args.channels), dtype=torch.float32, device=dev) if native == 1 else counts_nat
+    a_out = torch.empty((nV, rows, args.channels, 2), dtype=torch.float64, device=dev) if native == 1 else a_nat
     gmax = torch.empty((), dtype=torch.float64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     precision = args.gn_precision or md.DEFAULT_PRECISION
@@ -103,18 +108,24 @@ def main():
                       'plan')
         if timed:
             ev[0].record()
-        pj.project_tables(mu_d, w_d, out=counts)
+        pj.project_tables(mu_d, w_d, out=counts_nat, layout=None)
         if timed:
             ev[1].record()
-        _native.check(lib.dexct_reduce_max(ptr(counts[0]), 0, counts[0].numel(), ptr(gmax), st), 'max')
+        _native.check(lib.dexct_reduce_max(ptr(counts_nat[0]), 0, counts_nat[0].numel(), ptr(gmax), st), 'max')
         gm = _shard.global_max(gmax)
         if timed:
             ev[2].record()
-        md.gn_device(counts[0], counts[1], i0_d, mus_d, args.iters, precision, out=a_out)
+        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, precision, out=a_nat)
         if timed:
             ev[3].record()
         thresh = 0.95 * float(gm.item())
-        _native.check(lib.dexct_gn_apply_mask(ptr(counts[0]), 0, counts[0].numel(), thresh, ptr(a_out), st), 'mask')
+        _native.check(lib.dexct_gn_apply_mask(ptr(counts_nat[0]), 0, counts_nat[0].numel(), thresh, ptr(a_nat), st),
+                      'mask')
+        if native == 1:       # hand the results over in the reference's [view][row][channel] order
+            _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows, 4, st),
+                          'transpose counts')
+            _native.check(lib.dexct_transpose_batched(ptr(a_nat), ptr(a_out), nV, args.channels, rows, 16, st),
+                          'transpose mats')
         if world > 1:
             gathered = _shard.gather_views(counts, total_views, view_dim=1)
             mats = _shard.gather_views(a_out.to(torch.float32), total_views, view_dim=0)
@@ -178,7 +189,8 @@ def main():
     pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
     if pmc:      # newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_gpu.sh)
         traffic = json.load(open(pmc[-1])).get('siddon_hbm_bytes_per_launch')
-    out['roofline'] = {'kernel': 'rows_kernel' if pj.vol_zf is not None and args.kernel != 1 else 'rays_kernel',
+    kname = {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel'}[args.kernel or (3 if native == 1 else 1)]
+    out['roofline'] = {'kernel': kname,
                        'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                        'algorithmic_bytes_per_launch': alg_bytes, 'segments_per_launch': seg_vc * rows,

@@ -11,11 +11,11 @@
 // (two attenuations + 2 x 6 products, with the reference's rounding of ssff / ssff2, :102,:105)
 // are built once by gn_tables_kernel into a small workspace and read in the hot loop through the
 // scalar cache: the energy index is wave-uniform, so every table value is an SGPR operand of a
-// v_fma_f64 and costs neither LDS bandwidth nor VGPRs.  The only per-lane lookup is the 64-entry
-// 2^(j/64) table of the exponential, which sits in LDS.
+// v_fma_f64 and costs neither LDS bandwidth nor VGPRs.  The only per-lane lookup is the 2048-entry
+// 2^(j/2048) table of the exponential, which sits in LDS (16 KB).
 // There is no dense contraction: the kernel is bound by the FP64 vector rate (FMA + exp), not by
-// HBM (16 B read + 16 B written per pixel); per energy-iteration it issues 29 FP64 instructions
-// (2 exponent, 2 clip, 13 exp, 12 accumulate).
+// HBM (8 B read + 16 B written per pixel); per energy-iteration it issues 25 FP64 instructions
+// (2 exponent, 2 clip, 9 exp, 12 accumulate).
 #include "common.h"
 
 namespace dexct {
@@ -28,20 +28,23 @@ __device__ __forceinline__ T load_g(const void* p, int is_f64, int64_t i) {
   return is_f64 ? (T) reinterpret_cast<const double*>(p)[i] : (T) reinterpret_cast<const float*>(p)[i];
 }
 
-// exp(x) for |x| <= 700: x = (64 k + j) ln2/64 + r, |r| <= ln2/128; exp = 2^k * 2^(j/64) * e^r with a
-// degree-5 polynomial for e^r - 1 (truncation 3e-17).  About 1 ulp.
-__device__ __forceinline__ double exp_tab64(double x, const double* __restrict__ lds_pow) {
-  const double n = rint(x * 0x1.71547652b82fep+6);
-  const int ni = (int)n;
-  double r = fma(n, -0x1.62e42fefa39efp-7, x);
-  r = fma(n, -0x1.abc9e3b39803fp-62, r);
-  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-  q = fma(r, q, 1.0 / 6.0);
-  q = fma(r, q, 0.5);
+// exp(x) for |x| <= 700: x = (2048 k + j) ln2/2048 + r, |r| <= ln2/4096; exp = 2^k * 2^(j/2048) * e^r with
+// a cubic for e^r - 1 (truncation r^4/24 < 4e-17).  The integer n = 2048 k + j comes out of the low
+// mantissa bits of fma(x, 2048/ln2, 1.5 * 2^52) (round to nearest even, like rint).  About 1 ulp.
+constexpr int kPowBits = 11;
+constexpr int kPowN = 1 << kPowBits;
+__device__ __forceinline__ double exp_tab(double x, const double* __restrict__ lds_pow) {
+  const double kMagic = 6755399441055744.0;   // 1.5 * 2^52
+  const double tm = fma(x, 0x1.71547652b82fep+11, kMagic);
+  const int ni = __double2loint(tm);
+  const double n = tm - kMagic;
+  double r = fma(n, -0x1.62e42fefa39efp-12, x);
+  r = fma(n, -0x1.abc9e3b39803fp-67, r);
+  double q = fma(r, 1.0 / 6.0, 0.5);
   q = fma(r, q, 1.0);
   const double p = r * q;
-  const double tj = lds_pow[ni & 63];
-  return ldexp(fma(tj, p, tj), ni >> 6);
+  const double tj = lds_pow[ni & (kPowN - 1)];
+  return ldexp(fma(tj, p, tj), ni >> kPowBits);
 }
 
 __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
@@ -52,7 +55,7 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
     const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
     double x = -fma(a1, t[1], a0 * t[0]);
     x = fmin(fmax(x, -700.0), 700.0);
-    const double at = exp_tab64(x, lds_pow);
+    const double at = exp_tab(x, lds_pow);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const double* __restrict__ tk = t + 2 + 6 * k;
@@ -171,8 +174,8 @@ template <bool MIXED>
 __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                       int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                       int n_e, int n_iters, int n_polish, double* __restrict__ out_a) {
-  __shared__ double lds_pow[64];
-  if (threadIdx.x < 64) lds_pow[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+  __shared__ double lds_pow[kPowN];     // 2^(j/2048), 16 KB
+  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();
   const double* __restrict__ tab = ws + kWsHeader;
   const float* __restrict__ tab32 = reinterpret_cast<const float*>(tab + (size_t)n_e * kTab);

@@ -111,6 +111,39 @@ __global__ __launch_bounds__(256) void transpose_z_kernel(const uint8_t* __restr
   }
 }
 
+// [batch][rows][cols] -> [batch][cols][rows], 32x32 tiles through LDS (coalesced both ways).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                                int rows, int cols) {
+  __shared__ T tile[32][33];
+  const size_t base = (size_t)blockIdx.z * rows * cols;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < rows && c < cols) tile[k][tx] = src[base + (size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (r < rows && c < cols) dst[base + (size_t)c * rows + r] = tile[tx][k];
+  }
+}
+
+template <typename T>
+static int launch_transpose(const void* src, void* dst, int64_t batch, int rows, int cols, hipStream_t st) {
+  // gridDim.z is limited to 65535: walk the batch in slices
+  for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+    const int nb = (int)((batch - b0) < 65535 ? (batch - b0) : 65535);
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nb);
+    hipLaunchKernelGGL(transpose_batched_kernel<T>, grid, dim3(256), 0, st,
+                       reinterpret_cast<const T*>(src) + (size_t)b0 * rows * cols,
+                       reinterpret_cast<T*>(dst) + (size_t)b0 * rows * cols, rows, cols);
+    DEXCT_LAUNCH_CHECK();
+  }
+  return DEXCT_OK;
+}
+
 }  // namespace dexct
 
 using namespace dexct;
@@ -148,6 +181,19 @@ int dexct_volume_layouts(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz,
     DEXCT_LAUNCH_CHECK();
   }
   return DEXCT_OK;
+}
+
+int dexct_transpose_batched(const void* src, void* dst, int64_t batch, int32_t rows, int32_t cols, int32_t elem_bytes,
+                            void* stream) {
+  if (!src || !dst || batch <= 0 || rows <= 0 || cols <= 0) return DEXCT_EINVAL;
+  if ((rows + 31) / 32 > 65535) return DEXCT_ERANGE;
+  hipStream_t st = as_stream(stream);
+  switch (elem_bytes) {
+    case 4: return launch_transpose<float>(src, dst, batch, rows, cols, st);
+    case 8: return launch_transpose<double>(src, dst, batch, rows, cols, st);
+    case 16: return launch_transpose<double2>(src, dst, batch, rows, cols, st);
+    default: return DEXCT_EINVAL;
+  }
 }
 
 int dexct_fan_plan(const dexct_fan_geom* geom, const double* view_cs, const double* chan_cs, int32_t view_begin,

@@ -31,6 +31,8 @@
 //                 workgroup prefix sum (legal because counts are order independent and corrections
 //                 only arise in crossing slabs, whose relative order is kept).  <= 4 materials.
 // Tables are wave-uniform and are read through the scalar cache (s_load), not LDS.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dexct {
@@ -63,17 +65,31 @@ struct ProjArgs {
   const uint8_t* vol_zf;
   int n_local_views;
   int n_materials, n_energies, n_spectra;
-  const float* mu;    // [M][nE] linear attenuation [1/cm]
-  const float* w;     // [S][nE]
-  float* counts;      // [S][nV][rows][channels]
+  float* counts;      // [S][ray]
   float* pathlen;     // optional [ray][M]
+  int view_tile;      // views per locality tile of the row-parallel kernels
+  int layout;         // 0: ray = (v*rows + r)*channels + c   1: ray = (v*channels + c)*rows + r
 };
+
+// The attenuation and weight tables are passed as DIRECT __restrict__ kernel arguments (not inside
+// ProjArgs): only then does the compiler know they are read-only and wave-uniform and fetch them with
+// s_load through the scalar cache; as struct members they were fetched with 670 vector loads per wave.
+struct Tables {
+  const float* __restrict__ mu;   // [M][nE] linear attenuation [1/cm]
+  const float* __restrict__ w;    // [S][nE]
+};
+
+__device__ __forceinline__ size_t ray_index(const ProjArgs& a, int v, int r, int c) {
+  return a.layout == 0 ? ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c
+                       : ((size_t)v * a.g.n_channels + c) * a.g.n_rows + r;
+}
 
 // counts[s] = sum_e w[s][e] * exp(-sum_m mu[m][e] * L[m]) (v_exp_f32 on the log2(e)-scaled exponent)
 // for R rays at once (R = 4 in rows4_kernel: one scalar table load serves 4 rays and the FMAs pair up
 // into v_pk_fma_f32).  mu and w are wave-uniform (scalar loads); NM materials in registers.
 template <int NM, int R>
-__device__ __forceinline__ void detect_store(const float (&L)[R][NM], const ProjArgs& a, const size_t (&ray)[R],
+__device__ __forceinline__ void detect_store(const float (&L)[R][NM], const ProjArgs& a, const float* __restrict__ mu,
+                                             const float* __restrict__ w, const size_t (&ray)[R],
                                              const bool (&valid)[R]) {
   const int n_e = a.n_energies;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
@@ -85,13 +101,17 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
         for (int m = 0; m < NM; ++m) a.pathlen[ray[q] * NM + m] = L[q][m];
       }
   }
+  // exponent in base 2: scale the lengths once instead of every exponent
+  float L2[R][NM];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) L2[q][m] = L[q][m] * kLog2e;
   float acc[DEXCT_MAX_SPECTRA][R];
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
 #pragma unroll
     for (int q = 0; q < R; ++q) acc[s][q] = 0.0f;
-  const float* __restrict__ mu = a.mu;
-  const float* __restrict__ w = a.w;
   for (int e = 0; e < n_e; ++e) {
     float pe[R];
 #pragma unroll
@@ -100,11 +120,11 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
     for (int m = 0; m < NM; ++m) {
       const float mue = mu[m * n_e + e];
 #pragma unroll
-      for (int q = 0; q < R; ++q) pe[q] = fmaf(mue, L[q][m], pe[q]);
+      for (int q = 0; q < R; ++q) pe[q] = fmaf(mue, L2[q][m], pe[q]);
     }
     float te[R];
 #pragma unroll
-    for (int q = 0; q < R; ++q) te[q] = __builtin_amdgcn_exp2f(-pe[q] * kLog2e);
+    for (int q = 0; q < R; ++q) te[q] = __builtin_amdgcn_exp2f(-pe[q]);
 #pragma unroll
     for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
       if (s < a.n_spectra) {
@@ -113,27 +133,36 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
         for (int q = 0; q < R; ++q) acc[s][q] = fmaf(ws, te[q], acc[s][q]);
       }
   }
+  // 4 consecutive rays (layout 1, rows4_kernel): one 16-byte store per spectrum
+  const bool vec4 = R == 4 && a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[R - 1];
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
     if (s < a.n_spectra) {
+      if (vec4) {
+        *reinterpret_cast<float4*>(a.counts + ray[0] + s * sstride) =
+            make_float4(acc[s][0], acc[s][R > 1 ? 1 : 0], acc[s][R > 2 ? 2 : 0], acc[s][R > 3 ? 3 : 0]);
+      } else {
 #pragma unroll
-      for (int q = 0; q < R; ++q)
-        if (valid[q]) a.counts[ray[q] + s * sstride] = acc[s][q];
+        for (int q = 0; q < R; ++q)
+          if (valid[q]) a.counts[ray[q] + s * sstride] = acc[s][q];
+      }
     }
 }
 
 template <int NM>
-__device__ __forceinline__ void detect_store1(const float (&L)[NM], const ProjArgs& a, size_t ray) {
+__device__ __forceinline__ void detect_store1(const float (&L)[NM], const ProjArgs& a, const float* __restrict__ mu,
+                                              const float* __restrict__ w, size_t ray) {
   float L1[1][NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) L1[0][m] = L[m];
   const size_t rays[1] = {ray};
   const bool valid[1] = {true};
-  detect_store<NM, 1>(L1, a, rays, valid);
+  detect_store<NM, 1>(L1, a, mu, w, rays, valid);
 }
 
 // Any number of materials: per-material lengths in LDS column `tid` (stride `stride`).
 __device__ __forceinline__ void detect_store_lds(const float* lds_L, int tid, int stride, const ProjArgs& a,
+                                                 const float* __restrict__ mu, const float* __restrict__ w,
                                                  size_t ray) {
   const int n_e = a.n_energies, n_mat = a.n_materials;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
@@ -142,8 +171,6 @@ __device__ __forceinline__ void detect_store_lds(const float* lds_L, int tid, in
   float acc[DEXCT_MAX_SPECTRA];
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) acc[s] = 0.0f;
-  const float* __restrict__ mu = a.mu;
-  const float* __restrict__ w = a.w;
   for (int e = 0; e < n_e; ++e) {
     float p = 0.0f;
     for (int m = 0; m < n_mat; ++m) p = fmaf(mu[m * n_e + e], lds_L[m * stride + tid], p);
@@ -234,7 +261,8 @@ constexpr int kLdsBlock = 128;   // block size of the LDS-accumulator instantiat
 // ---------------------------------------------------------------------------------------------
 // rays_kernel: one thread per ray.  NM > 0: materials in registers; NM == 0: LDS accumulators.
 template <int NM, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a) {
+__global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a, const float* __restrict__ mu,
+                                                      const float* __restrict__ w) {
   extern __shared__ float lds_dyn[];
   const int tid = threadIdx.x;
   const int c = blockIdx.x * BLOCK + tid;
@@ -266,14 +294,14 @@ __global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a) {
     off += (uint32_t)nv;
   }
   if (!live) return;
-  const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
+  const size_t ray = ray_index(a, v, r, c);
   if (NM > 0) {
     float L[NM > 0 ? NM : 1];
     ra.lengths(p, L);
-    detect_store1<(NM > 0 ? NM : 1)>(L, a, ray);
+    detect_store1<(NM > 0 ? NM : 1)>(L, a, mu, w, ray);
   } else {
     la.lengths(p);
-    detect_store_lds(la.cnt, tid, BLOCK, a, ray);
+    detect_store_lds(la.cnt, tid, BLOCK, a, mu, w, ray);
   }
 }
 
@@ -285,22 +313,39 @@ struct SlabRec {
   uint32_t masks;       // bits 0-7: 0xFF if piece a lies inside the grid, bits 8-15: the same for piece b
 };
 
-// XCD-aware remap: consecutive logical ids (adjacent channels of one view: rays that share voxel
-// columns) land on the same XCD and therefore in the same L2.
-__device__ __forceinline__ uint32_t xcd_logical_block() {
+// Block -> (view, channel, row chunk).  Two levels of locality:
+//  * XCD: hardware deals consecutive block ids round-robin over the 8 XCDs, so a contiguous range of
+//    LOGICAL ids is given to each XCD (its L2 then sees neighbouring rays);
+//  * tile: logical ids walk groups of kViewTile consecutive views with the view index fastest, then the
+//    channel.  The ~400 workgroups an XCD runs at once are then (kViewTile views x ~50 channels): rays of
+//    neighbouring views through the same voxel columns are in flight together and hit in L2 instead of
+//    going to the Infinity Cache / HBM once per view.
+constexpr int kViewTileDefault = 8;
+
+struct BlockRay { int v, c, chunk; };
+
+__device__ __forceinline__ BlockRay block_to_ray(int n_views, int n_channels, int n_chunks, int kViewTile) {
   const uint32_t nblk = gridDim.x, b = blockIdx.x, per = nblk >> 3;
-  return (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
+  const uint32_t logical = (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
+  const uint32_t group_size = (uint32_t)kViewTile * n_channels * n_chunks;
+  const uint32_t g = logical / group_size, rem = logical - g * group_size;
+  const uint32_t views_here = min((uint32_t)kViewTile, (uint32_t)n_views - g * kViewTile);
+  BlockRay r;
+  r.chunk = rem % n_chunks;
+  const uint32_t q = rem / n_chunks;
+  r.v = g * kViewTile + q % views_here;
+  r.c = q / views_here;
+  return r;
 }
 
 template <int NM, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void rows_kernel(ProjArgs a, int n_chunks) {
+__global__ __launch_bounds__(BLOCK) void rows_kernel(ProjArgs a, const float* __restrict__ mu,
+                                                      const float* __restrict__ w, int n_chunks) {
   __shared__ SlabRec rec[BLOCK];
   extern __shared__ float lds_dyn[];
   const int tid = threadIdx.x;
-  const uint32_t logical = xcd_logical_block();
-  const int chunk = logical % n_chunks;
-  const uint32_t vc = logical / n_chunks;
-  const int c = vc % a.g.n_channels, v = vc / a.g.n_channels;
+  const BlockRay br = block_to_ray(a.n_local_views, a.g.n_channels, n_chunks, a.view_tile);
+  const int chunk = br.chunk, c = br.c, v = br.v;
   const int r = chunk * BLOCK + tid;
   const bool live = r < a.g.n_rows;
   const int z = a.g.z_first + (live ? r : 0);
@@ -339,38 +384,37 @@ __global__ __launch_bounds__(BLOCK) void rows_kernel(ProjArgs a, int n_chunks) {
     __syncthreads();
   }
   if (!live) return;
-  const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
+  const size_t ray = ray_index(a, v, r, c);
   if (NM > 0) {
     float L[NM > 0 ? NM : 1];
     ra.lengths(p, L);
-    detect_store1<(NM > 0 ? NM : 1)>(L, a, ray);
+    detect_store1<(NM > 0 ? NM : 1)>(L, a, mu, w, ray);
   } else {
     la.lengths(p);
-    detect_store_lds(la.cnt, tid, BLOCK, a, ray);
+    detect_store_lds(la.cnt, tid, BLOCK, a, mu, w, ray);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // rows4_kernel: 4 rows per lane, packed-byte counts.  Requires nz % 4 == 0, z_first % 4 == 0,
 // 2 <= NM <= 4 and material ids < NM in the volume.
-constexpr int kSuper = 512;    // slabs staged per pass: 2 KB full list + 6 KB crossing list
+constexpr int kSuper = 512;    // slabs staged per pass: 2 KB full list + 8 KB crossing list
 
 struct CrossRec {
-  uint32_t offa, offb;   // ~0u = piece outside the grid
+  uint32_t offa, offb;   // column offsets (0 where the piece lies outside the grid)
   float t;
+  uint32_t valid;        // bit0: piece a inside the grid, bit1: piece b
 };
 
 template <int NM, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, int n_chunks) {
+__global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* __restrict__ mu,
+                                                       const float* __restrict__ w, int n_chunks) {
   __shared__ uint32_t list_full[kSuper];
   __shared__ CrossRec list_cross[kSuper];
-  __shared__ uint32_t wave_tot[2][BLOCK / 64];
-  __shared__ uint32_t n_lists[2];
+  __shared__ uint32_t wave_tot[kSuper / BLOCK][BLOCK / 64][2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t logical = xcd_logical_block();
-  const int chunk = logical % n_chunks;
-  const uint32_t vc = logical / n_chunks;
-  const int c = vc % a.g.n_channels, v = vc / a.g.n_channels;
+  const BlockRay br = block_to_ray(a.n_local_views, a.g.n_channels, n_chunks, a.view_tile);
+  const int chunk = br.chunk, c = br.c, v = br.v;
   const int r0 = (chunk * BLOCK + tid) * 4;          // first of this lane's 4 rows
   const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];   // uniform
   const int axis = p.flags & 1u;
@@ -379,8 +423,9 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, int n_chunks) 
   const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * (uint32_t)a.g.nz;
   const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * (uint32_t)a.g.nz;
   // lanes past the last row read the last aligned dword of the column (harmless) and store nothing
-  const int zl = min(a.g.z_first + r0, a.g.nz - 4);
-  const uint8_t* __restrict__ col = a.vol_zf + zl;
+  const uint32_t zl = (uint32_t)min(a.g.z_first + r0, a.g.nz - 4);
+  const uint8_t* __restrict__ vol = a.vol_zf;      // uniform base + 32-bit per-lane offset (saddr form)
+  auto ld4 = [&](uint32_t off) { return *reinterpret_cast<const uint32_t*>(vol + (uint32_t)(off + zl)); };
   // packed byte counters: bit0 plane, bit1 plane, both bits; wide per-row counters
   uint32_t c0 = 0, c1 = 0, c01 = 0;
   uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w01[4] = {0, 0, 0, 0};
@@ -408,49 +453,55 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, int n_chunks) 
     if (NM > 3) c01 += b0 & b1;
   };
 
+  constexpr int kPasses = kSuper / BLOCK, kWaves = BLOCK / 64;
   for (int s0 = 0; s0 < p.n_slabs; s0 += kSuper) {
     const int n_super = min(kSuper, p.n_slabs - s0);
-    if (tid == 0) { n_lists[0] = 0; n_lists[1] = 0; }
-    __syncthreads();
-    // ---- geometry: classify slabs, compact into the two lists (order kept)
-    for (int s1 = 0; s1 < n_super; s1 += BLOCK) {
-      const int s = s1 + tid;
-      bool is_full = false, is_cross = false;
-      uint32_t offa = ~0u, offb = ~0u;
-      float t = 0.0f;
+    // ---- geometry: every thread classifies kPasses slabs (slab = q*BLOCK + tid), one ballot each; the
+    // per-wave totals meet in LDS once, then everybody derives its list positions (slab order is kept).
+    uint32_t offa[kPasses], offb[kPasses], below_f[kPasses], below_c[kPasses];
+    float tt[kPasses];
+    bool is_full[kPasses], is_cross[kPasses];
+#pragma unroll
+    for (int q = 0; q < kPasses; ++q) {
+      const int s = q * BLOCK + tid;
+      is_full[q] = is_cross[q] = false;
+      offa[q] = offb[q] = ~0u;
+      tt[q] = 0.0f;
       if (s < n_super) {
         const int i = p.i_first + s0 + s;
         const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
         const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
-        if (ina) offa = (uint32_t)i * su + (uint32_t)sp.ja * sv;
-        if (inb) offb = (uint32_t)i * su + (uint32_t)sp.jb * sv;
-        t = sp.t;
-        is_full = ina && inb && sp.ja == sp.jb;      // both pieces in one voxel column: count only
-        is_cross = !is_full && (ina || inb);
+        if (ina) offa[q] = (uint32_t)i * su + (uint32_t)sp.ja * sv;
+        if (inb) offb[q] = (uint32_t)i * su + (uint32_t)sp.jb * sv;
+        tt[q] = sp.t;
+        is_full[q] = ina && inb && sp.ja == sp.jb;      // both pieces in one voxel column: count only
+        is_cross[q] = !is_full[q] && (ina || inb);
       }
-      const unsigned long long mf = __ballot(is_full), mc = __ballot(is_cross);
-      const uint32_t below = (lane == 0) ? 0u : (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
-      const uint32_t belowc = (lane == 0) ? 0u : (uint32_t)__popcll(mc & ((1ull << lane) - 1ull));
-      if (lane == 0) { wave_tot[0][wid] = (uint32_t)__popcll(mf); wave_tot[1][wid] = (uint32_t)__popcll(mc); }
-      __syncthreads();
-      uint32_t basef = n_lists[0], basec = n_lists[1];
-#pragma unroll
-      for (int k = 0; k < BLOCK / 64; ++k)
-        if (k < wid) { basef += wave_tot[0][k]; basec += wave_tot[1][k]; }
-      if (is_full) list_full[basef + below] = offb;
-      if (is_cross) list_cross[basec + belowc] = CrossRec{offa, offb, t};
-      __syncthreads();
-      if (tid == 0) {
-        uint32_t tf = 0, tc = 0;
-#pragma unroll
-        for (int k = 0; k < BLOCK / 64; ++k) { tf += wave_tot[0][k]; tc += wave_tot[1][k]; }
-        n_lists[0] += tf;
-        n_lists[1] += tc;
-      }
-      __syncthreads();
+      const unsigned long long mf = __ballot(is_full[q]), mc = __ballot(is_cross[q]);
+      const unsigned long long lower = (1ull << lane) - 1ull;
+      below_f[q] = (uint32_t)__popcll(mf & lower);
+      below_c[q] = (uint32_t)__popcll(mc & lower);
+      if (lane == 0) { wave_tot[q][wid][0] = (uint32_t)__popcll(mf); wave_tot[q][wid][1] = (uint32_t)__popcll(mc); }
     }
-    const int n_full = (int)n_lists[0], n_cross = (int)n_lists[1];
-    // ---- full slabs: one dword (4 rows) per slab, integer counts only
+    __syncthreads();
+    uint32_t run_f = 0, run_c = 0;
+#pragma unroll
+    for (int q = 0; q < kPasses; ++q) {
+#pragma unroll
+      for (int k = 0; k < kWaves; ++k) {
+        if (k == wid) {
+          if (is_full[q]) list_full[run_f + below_f[q]] = offb[q];
+          if (is_cross[q])
+            list_cross[run_c + below_c[q]] = CrossRec{offa[q] == ~0u ? 0u : offa[q], offb[q] == ~0u ? 0u : offb[q], tt[q],
+                                                      (offa[q] != ~0u ? 1u : 0u) | (offb[q] != ~0u ? 2u : 0u)};
+        }
+        run_f += wave_tot[q][k][0];
+        run_c += wave_tot[q][k][1];
+      }
+    }
+    const int n_full = (int)run_f, n_cross = (int)run_c;
+    __syncthreads();
+    // ---- full slabs: one dword (4 rows) per slab, integer counts only; 8 loads in flight
     int s = 0;
     while (s < n_full) {
       const int batch = min(n_full - s, 248 - pending);
@@ -458,35 +509,61 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, int n_chunks) 
       for (; k + 8 <= batch; k += 8) {
         uint32_t x[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const uint32_t*>(col + list_full[s + k + q]);
+        for (int q = 0; q < 8; ++q) x[q] = ld4(list_full[s + k + q]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) count4(x[q]);
       }
-      for (; k < batch; ++k) count4(*reinterpret_cast<const uint32_t*>(col + list_full[s + k]));
+      for (; k < batch; ++k) count4(ld4(list_full[s + k]));
       s += batch;
       pending += batch;
       if (pending >= 248) flush();
     }
-    // ---- crossing slabs: two columns; count the b voxel, correct where the two voxels differ
-    for (int k = 0; k < n_cross; ++k) {
-      const CrossRec q = list_cross[k];
-      const uint32_t xa = q.offa != ~0u ? *reinterpret_cast<const uint32_t*>(col + q.offa) : 0u;   // uniform
-      const uint32_t xb = q.offb != ~0u ? *reinterpret_cast<const uint32_t*>(col + q.offb) : 0u;
-      count4(xb);
-      if (++pending >= 248) flush();
-      if (xa != xb) {
+    // ---- crossing slabs: two columns; count the b voxel, correct where the two voxels differ.
+    // Groups of 4 slabs: 8 loads in flight, no branch unless some row of some slab differs.
+    auto correct = [&](uint32_t xa, uint32_t xb, float t) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const uint32_t ia = (xa >> (8 * rr)) & 0xFFu, ib = (xb >> (8 * rr)) & 0xFFu;
-          if (ia != ib) {
+      for (int rr = 0; rr < 4; ++rr) {
+        const uint32_t ia = (xa >> (8 * rr)) & 0xFFu, ib = (xb >> (8 * rr)) & 0xFFu;
+        const float td = ia != ib ? t : 0.0f;
 #pragma unroll
-            for (int m = 1; m < NM; ++m) {
-              corr[m][rr] += (ia == (uint32_t)m) ? q.t : 0.0f;
-              corr[m][rr] -= (ib == (uint32_t)m) ? q.t : 0.0f;
-            }
-          }
+        for (int m = 1; m < NM; ++m) {
+          corr[m][rr] += (ia == (uint32_t)m) ? td : 0.0f;
+          corr[m][rr] -= (ib == (uint32_t)m) ? td : 0.0f;
         }
       }
+    };
+    int k = 0;
+    for (; k + 4 <= n_cross; k += 4) {
+      uint32_t xa[4], xb[4];
+      float t4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const CrossRec q = list_cross[k + j];
+        xa[j] = ld4(q.offa) & (0u - (q.valid & 1u));           // outside the grid -> ids 0
+        xb[j] = ld4(q.offb) & (0u - ((q.valid >> 1) & 1u));
+        t4[j] = q.t;
+      }
+      uint32_t any = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        count4(xb[j]);
+        any |= xa[j] ^ xb[j];
+      }
+      pending += 4;
+      if (pending >= 244) flush();
+      if (any) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (xa[j] != xb[j]) correct(xa[j], xb[j], t4[j]);
+      }
+    }
+    for (; k < n_cross; ++k) {
+      const CrossRec q = list_cross[k];
+      const uint32_t xa = ld4(q.offa) & (0u - (q.valid & 1u));
+      const uint32_t xb = ld4(q.offb) & (0u - ((q.valid >> 1) & 1u));
+      count4(xb);
+      if (++pending >= 244) flush();
+      if (xa != xb) correct(xa, xb, q.t);
     }
     __syncthreads();
   }
@@ -498,7 +575,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, int n_chunks) 
   for (int rr = 0; rr < 4; ++rr) {
     const int r = r0 + rr;
     valid[rr] = r < a.g.n_rows;
-    rays[rr] = ((size_t)v * a.g.n_rows + (valid[rr] ? r : 0)) * a.g.n_channels + c;
+    rays[rr] = ray_index(a, v, valid[rr] ? r : 0, c);
     // ids are 0..NM-1: bit-plane counts -> per-material counts
     uint32_t n[4];
     n[3] = NM > 3 ? w01[rr] : 0u;
@@ -514,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, int n_chunks) 
 #pragma unroll
     for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
   }
-  detect_store<NM, 4>(L, a, rays, valid);
+  detect_store<NM, 4>(L, a, mu, w, rays, valid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -553,45 +630,45 @@ __global__ __launch_bounds__(64) void trace_kernel(dexct_fan_geom g, const dexct
 }
 
 template <int NM>
-static int launch_rays(const ProjArgs& a, hipStream_t st) {
+static int launch_rays(const ProjArgs& a, const Tables& t, hipStream_t st) {
   constexpr int B = NM > 0 ? kBlock : kLdsBlock;
   dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
   size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
-  hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a);
+  hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
 
 template <int NM>
-static int launch_rows(const ProjArgs& a, hipStream_t st) {
+static int launch_rows(const ProjArgs& a, const Tables& t, hipStream_t st) {
   constexpr int B = NM > 0 ? kBlock : kLdsBlock;
   const int n_chunks = (a.g.n_rows + B - 1) / B;
   const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
-  hipLaunchKernelGGL((rows_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), lds, st, a, n_chunks);
+  hipLaunchKernelGGL((rows_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), lds, st, a, t.mu, t.w, n_chunks);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
 
 template <int NM, int B>
-static int launch_rows4_b(const ProjArgs& a, hipStream_t st) {
+static int launch_rows4_b(const ProjArgs& a, const Tables& t, hipStream_t st) {
   const int rows_per_block = 4 * B;
   const int n_chunks = (a.g.n_rows + rows_per_block - 1) / rows_per_block;
   const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  hipLaunchKernelGGL((rows4_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), 0, st, a, n_chunks);
+  hipLaunchKernelGGL((rows4_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), 0, st, a, t.mu, t.w, n_chunks);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
 
 template <int NM>
-static int launch_rows4(const ProjArgs& a, hipStream_t st) {
+static int launch_rows4(const ProjArgs& a, const Tables& t, hipStream_t st) {
   // one lane per 4 rows: pick the smallest block that covers the rows in one chunk (up to 256 lanes)
   const int lanes = (a.g.n_rows + 3) / 4;
-  if (lanes <= 64) return launch_rows4_b<NM, 64>(a, st);
-  if (lanes <= 128) return launch_rows4_b<NM, 128>(a, st);
-  return launch_rows4_b<NM, 256>(a, st);
+  if (lanes <= 64) return launch_rows4_b<NM, 64>(a, t, st);
+  if (lanes <= 128) return launch_rows4_b<NM, 128>(a, t, st);
+  return launch_rows4_b<NM, 256>(a, t, st);
 }
 
 }  // namespace dexct
@@ -603,7 +680,7 @@ extern "C" {
 int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin, int32_t view_end,
                          const uint8_t* vol_yx, const uint8_t* vol_xy, const uint8_t* vol_zf, int32_t n_materials,
                          int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights, float* counts,
-                         float* pathlen, int32_t kernel, void* stream) {
+                         float* pathlen, int32_t kernel, int32_t layout, void* stream) {
   if (!geom || !plan || !mu || !weights || !counts) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
@@ -616,6 +693,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   if (kernel == 2 && !vol_zf) return DEXCT_EINVAL;
   if (kernel == 3 && !can4) return DEXCT_EINVAL;
   if (kernel < 1 || kernel > 3) return DEXCT_EINVAL;
+  if (layout != 0 && layout != 1) return DEXCT_EINVAL;
   if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
   ProjArgs a;
   a.g = *geom;
@@ -627,33 +705,35 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   a.n_materials = n_materials;
   a.n_energies = n_energies;
   a.n_spectra = n_spectra;
-  a.mu = mu;
-  a.w = weights;
   a.counts = counts;
   a.pathlen = pathlen;
+  a.layout = layout;
+  const Tables t{mu, weights};
+  a.view_tile = kViewTileDefault;
+  if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.view_tile = t; }   // tuning knob
   hipStream_t st = as_stream(stream);
   if (kernel == 1) {
     switch (n_materials) {
-      case 1: return launch_rays<1>(a, st);
-      case 2: return launch_rays<2>(a, st);
-      case 3: return launch_rays<3>(a, st);
-      case 4: return launch_rays<4>(a, st);
-      default: return launch_rays<0>(a, st);
+      case 1: return launch_rays<1>(a, t, st);
+      case 2: return launch_rays<2>(a, t, st);
+      case 3: return launch_rays<3>(a, t, st);
+      case 4: return launch_rays<4>(a, t, st);
+      default: return launch_rays<0>(a, t, st);
     }
   }
   if (kernel == 2) {
     switch (n_materials) {
-      case 1: return launch_rows<1>(a, st);
-      case 2: return launch_rows<2>(a, st);
-      case 3: return launch_rows<3>(a, st);
-      case 4: return launch_rows<4>(a, st);
-      default: return launch_rows<0>(a, st);
+      case 1: return launch_rows<1>(a, t, st);
+      case 2: return launch_rows<2>(a, t, st);
+      case 3: return launch_rows<3>(a, t, st);
+      case 4: return launch_rows<4>(a, t, st);
+      default: return launch_rows<0>(a, t, st);
     }
   }
   switch (n_materials) {
-    case 2: return launch_rows4<2>(a, st);
-    case 3: return launch_rows4<3>(a, st);
-    default: return launch_rows4<4>(a, st);
+    case 2: return launch_rows4<2>(a, t, st);
+    case 3: return launch_rows4<3>(a, t, st);
+    default: return launch_rows4<4>(a, t, st);
   }
 }
 

@@ -88,26 +88,54 @@ class Projector:
         E, mu, w = merged_tables(self.ct, self.phantom, specs)
         return (E, to_dev(mu, torch.float32, self.dev), to_dev(w, torch.float32, self.dev), w.sum(axis=1))
 
-    def project_tables(self, mu_d, w_d, want_pathlen=False, out=None):
-        """Device-side call: mu_d [M, nE], w_d [S, nE] float32 tensors -> counts [S, nV, rows, ch]."""
+    @property
+    def native_layout(self):
+        """1 (row fastest) when a row-parallel kernel will run, else 0 (channel fastest)."""
+        if self.kernel in (2, 3):
+            return 1
+        return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
+
+    def project_tables(self, mu_d, w_d, want_pathlen=False, out=None, layout=0):
+        """Device-side call: mu_d [M, nE], w_d [S, nE] float32 tensors -> counts.
+
+        layout 0: counts [S, nV, rows, channels] (the reference's order); layout 1: [S, nV, channels, rows]
+        (what the row-parallel kernels produce natively); ``layout=None`` returns the native one.  When
+        the requested layout is not the kernel's own, the kernel writes its own layout and
+        dexct_transpose_batched converts (cheaper than scattered 4-byte stores)."""
         S, nE = w_d.shape
         M = mu_d.shape[0]
         ct = self.ct
-        counts = out if out is not None else torch.empty((S, self.n_local_views, ct.N_rows, ct.N_channels),
-                                                         dtype=torch.float32, device=self.dev)
+        nV, nR, nC = self.n_local_views, ct.N_rows, ct.N_channels
+        native = self.native_layout
+        want = native if layout is None else layout
+        shape = {0: (S, nV, nR, nC), 1: (S, nV, nC, nR)}
+        direct = want == native or nR == 1
+        run_layout = want if direct else native
+        if out is not None and direct:
+            counts = out
+        else:
+            counts = torch.empty(shape[run_layout], dtype=torch.float32, device=self.dev)
         pathlen = None
         if want_pathlen:
-            pathlen = torch.empty((self.n_local_views, ct.N_rows, ct.N_channels, M), dtype=torch.float32,
-                                  device=self.dev)
+            pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
+            pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
         _native.check(self.lib.dexct_siddon_project(
             C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy),
-            ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), self.kernel, stream_ptr()),
-            'dexct_siddon_project')
+            ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), self.kernel, run_layout,
+            stream_ptr()), 'dexct_siddon_project')
+        if not direct:
+            dst = out if out is not None else torch.empty(shape[want], dtype=torch.float32, device=self.dev)
+            r, c = (nC, nR) if run_layout == 1 else (nR, nC)
+            _native.check(self.lib.dexct_transpose_batched(ptr(counts), ptr(dst), S * nV, r, c, 4, stream_ptr()),
+                          'dexct_transpose_batched')
+            counts = dst
+            if pathlen is not None:
+                pathlen = pathlen.permute(0, 2, 1, 3).contiguous()      # test-only output
         return (counts, pathlen) if want_pathlen else counts
 
-    def project(self, specs, want_pathlen=False):
+    def project(self, specs, want_pathlen=False, layout=0):
         _, mu_d, w_d, air = self.upload_tables(specs)
-        return self.project_tables(mu_d, w_d, want_pathlen), air
+        return self.project_tables(mu_d, w_d, want_pathlen, layout=layout), air
 
     def trace(self, rays_vrc, max_seg=None):
         """Voxel-index sequence and float32 piece lengths of selected rays (views relative to the shard)."""

@@ -86,9 +86,13 @@ int dexct_fan_plan(const dexct_fan_geom* geom, const double* view_cs, const doub
  *   mu[m*n_energies + e]      linear attenuation [1/cm] of material id m at energy bin e
  *   weights[s*n_energies + e] effective spectrum of spectrum s (I0 * detector response * dE,
  *                             the weighting of matdecomp.py:146-150)
- *   counts[((s*n_local_views + view - view_begin)*n_rows + row)*n_channels + channel]  (float32)
- *   pathlen (optional, may be NULL): [ray][n_materials] float32 path length [cm] per material,
- *                             ray = ((view - view_begin)*n_rows + row)*n_channels + channel
+ *   counts[s*n_rays + ray]    (float32), n_rays = n_local_views*n_rows*n_channels
+ *   pathlen (optional, may be NULL): [ray][n_materials] float32 path length [cm] per material
+ *   layout 0: ray = ((view - view_begin)*n_rows + row)*n_channels + channel   (the reference's
+ *             [N_proj, N_channels] order per row; native to the ray-parallel kernel)
+ *   layout 1: ray = ((view - view_begin)*n_channels + channel)*n_rows + row   (row fastest; native to
+ *             the row-parallel kernels, which then store 16 B per lane; dexct_transpose_batched
+ *             converts between the two)
  * vol_yx / vol_xy / vol_zf as written by dexct_volume_layouts (vol_zf may be NULL: then the
  * ray-parallel kernel is used for every shape).
  * kernel: 0 = choose, 1 = ray-parallel (one thread per ray), 2 = row-parallel (one workgroup
@@ -100,7 +104,13 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
                          int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
                          const uint8_t* vol_zf, int32_t n_materials, int32_t n_energies,
                          int32_t n_spectra, const float* mu, const float* weights, float* counts,
-                         float* pathlen, int32_t kernel, void* stream);
+                         float* pathlen, int32_t kernel, int32_t layout, void* stream);
+
+/* dst[b][c][r] = src[b][r][c] for b < batch: [batch][rows][cols] -> [batch][cols][rows], elements of
+ * elem_bytes = 4, 8 or 16 bytes (float32 sinograms, float64, the (a0, a1) float64 pairs of the
+ * decomposition).  src and dst must not overlap. */
+int dexct_transpose_batched(const void* src, void* dst, int64_t batch, int32_t rows, int32_t cols,
+                            int32_t elem_bytes, void* stream);
 
 /* Trace of single rays for parity tests: voxel-index sequence and segment lengths.
  * For each of n_rays rays (view, row, channel given in ray_vrc[3*r + {0,1,2}], view relative to

@@ -59,11 +59,14 @@ if cal:
         if 'dexct' in k:
             lines.append(f'| `{k[:60]}` | {fetch[k] / 1e9:.3f} | {write.get(k, 0) / 1e9:.3f} |')
     for k in fetch:
-        if 'rows_kernel' in k or ('rays_kernel' in k and 'siddon' not in traffic):
+        if 'rows' in k and 'kernel' in k:
             traffic['siddon_kernel'] = k
-            traffic['siddon_fetch_bytes'] = fetch[k]
+            # 4-B-per-lane dword loads (rows4) are tallied at half, like gn_kernel's float32 input stream
+            corr = 2.0 if 'rows4' in k else 1.0
+            traffic['siddon_fetch_correction'] = corr
+            traffic['siddon_fetch_bytes'] = corr * fetch[k]
             traffic['siddon_write_bytes'] = write.get(k, 0.0)
-            traffic['siddon_hbm_bytes_per_launch'] = fetch[k] + write.get(k, 0.0)
+            traffic['siddon_hbm_bytes_per_launch'] = corr * fetch[k] + write.get(k, 0.0)
         if 'gn_kernel' in k:
             traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
             traffic['gn_write_bytes'] = write.get(k, 0.0)
