@@ -47,17 +47,23 @@ __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ l
   return ldexp(fma(tj, p, tj), ni >> kPowBits);
 }
 
-__device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
-                                                int n_e, double g0, double g1, double& a0, double& a1) {
-  double nu[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
+// Energies are sorted by gn_tables_kernel into three classes: both spectra have weight (nA), only spectrum 0
+// (nB), only spectrum 1 (nC); energies no spectrum weights are dropped.  A zero weight contributes exactly
+// 0 to every sum (the attenuation factor is finite thanks to the clip), so skipping those FMAs changes no
+// term of the reference's sums - only their order.
+template <int KSEL>   // 0: both measurements, 1: only k = 0, 2: only k = 1
+__device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
+                                                int e0, int e1, double a0, double a1, double (&nu)[2], double (&G0)[2],
+                                                double (&G1)[2], double (&H00)[2], double (&H01)[2], double (&H11)[2]) {
 #pragma unroll 2
-  for (int e = 0; e < n_e; ++e) {
+  for (int e = e0; e < e1; ++e) {
     const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
     double x = -fma(a1, t[1], a0 * t[0]);
     x = fmin(fmax(x, -700.0), 700.0);
     const double at = exp_tab(x, lds_pow);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
+      if ((KSEL == 1 && k == 1) || (KSEL == 2 && k == 0)) continue;
       const double* __restrict__ tk = t + 2 + 6 * k;
       nu[k] = fma(tk[0], at, nu[k]);
       G0[k] = fma(tk[1], at, G0[k]);
@@ -67,6 +73,16 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
       H11[k] = fma(tk[5], at, H11[k]);
     }
   }
+}
+
+struct EnergyClasses { int nA, nB, nC; };
+
+__device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
+                                                EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
+  double nu[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
+  energy_sums_f64<0>(tab, lds_pow, 0, ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<1>(tab, lds_pow, ec.nA, ec.nA + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<2>(tab, lds_pow, ec.nA + ec.nB, ec.nA + ec.nB + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
   const double g[2] = {g0, g1};
   double dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
 #pragma unroll
@@ -86,23 +102,31 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
 // float32 table layout per energy: [mu0*log2e, mu1*log2e, then for c in {1, mu0, mu1, mu0^2, mu0mu1, mu1^2}:
 // (i0_0 * c, i0_1 * c)] - the two measurements of one product adjacent, so that each SGPR pair feeds one
 // v_pk_fma_f32 directly.
-__device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, int n_e, float g0, float g1,
-                                                float& a0, float& a1) {
-  float acc[6][2];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) acc[c][0] = acc[c][1] = 0.0f;
+template <int KSEL>
+__device__ __forceinline__ void energy_sums_f32(const float* __restrict__ tab, int e0, int e1, float a0, float a1,
+                                                float (&acc)[6][2]) {
 #pragma unroll 2
-  for (int e = 0; e < n_e; ++e) {
+  for (int e = e0; e < e1; ++e) {
     const float* __restrict__ t = tab + e * kTab;
     float x = -fmaf(a1, t[1], a0 * t[0]);
     x = fminf(fmaxf(x, -120.0f), 120.0f);
     const float at = __builtin_amdgcn_exp2f(x);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      acc[c][0] = fmaf(t[2 + 2 * c], at, acc[c][0]);
-      acc[c][1] = fmaf(t[3 + 2 * c], at, acc[c][1]);
+      if (KSEL != 2) acc[c][0] = fmaf(t[2 + 2 * c], at, acc[c][0]);
+      if (KSEL != 1) acc[c][1] = fmaf(t[3 + 2 * c], at, acc[c][1]);
     }
   }
+}
+
+__device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, EnergyClasses ec, float g0, float g1,
+                                                float& a0, float& a1) {
+  float acc[6][2];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) acc[c][0] = acc[c][1] = 0.0f;
+  energy_sums_f32<0>(tab, 0, ec.nA, a0, a1, acc);
+  energy_sums_f32<1>(tab, ec.nA, ec.nA + ec.nB, a0, a1, acc);
+  energy_sums_f32<2>(tab, ec.nA + ec.nB, ec.nA + ec.nB + ec.nC, a0, a1, acc);
   const float g[2] = {g0, g1};
   float dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
 #pragma unroll
@@ -120,8 +144,8 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, i
   a1 -= (h00 * dF1 - h01 * dF0) / det;
 }
 
-// Workspace layout (doubles): [0] = scale of the float32 tables, [1..7] pad, then [n_e][14] float64,
-// then [n_e][14] float32.
+// Workspace layout (doubles): [0] = scale of the float32 tables, [1..3] = nA, nB, nC (energy classes),
+// [4..7] pad, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
 constexpr int kWsHeader = 8;
 
 __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict__ i0, const double* __restrict__ mus,
@@ -129,21 +153,39 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
   // float32 tables are scaled by one power of two common to both measurements (the Newton step is
   // invariant under a common scaling of counts and spectra) so that sums stay near 1.
   __shared__ double s_scale;
+  __shared__ int s_n[3];
+  double* tab = ws + kWsHeader;
+  float* tab32 = reinterpret_cast<float*>(tab + (size_t)n_e * kTab);
+  int* perm = reinterpret_cast<int*>(tab32 + (size_t)n_e * kTab);
   if (threadIdx.x == 0) {
     double s0 = 0.0, s1 = 0.0;
     for (int e = 0; e < n_e; ++e) { s0 += i0[e]; s1 += i0[n_e + e]; }
     int ex = 0;
     frexp(fmax(s0, s1), &ex);
     s_scale = ldexp(1.0, -ex);
+    // stable partition of the energies into the classes A (both), B (only 0), C (only 1)
+    int n = 0;
+    for (int cls = 0; cls < 3; ++cls) {
+      int cnt = 0;
+      for (int e = 0; e < n_e; ++e) {
+        const bool z0 = i0[e] == 0.0, z1 = i0[n_e + e] == 0.0;
+        const int c = (!z0 && !z1) ? 0 : (!z0 ? 1 : (!z1 ? 2 : 3));
+        if (c == cls) { perm[n++] = e; ++cnt; }
+      }
+      s_n[cls] = cnt;
+    }
     ws[0] = s_scale;
+    ws[1] = (double)s_n[0];
+    ws[2] = (double)s_n[1];
+    ws[3] = (double)s_n[2];
   }
   __syncthreads();
   const double scale = s_scale;
-  double* tab = ws + kWsHeader;
-  float* tab32 = reinterpret_cast<float*>(tab + (size_t)n_e * kTab);
-  for (int e = threadIdx.x; e < n_e; e += blockDim.x) {
+  const int n_used = s_n[0] + s_n[1] + s_n[2];
+  for (int j = threadIdx.x; j < n_used; j += blockDim.x) {
+    const int e = perm[j];
     const double m0 = mus[e], m1 = mus[n_e + e];
-    double* t = tab + e * kTab;
+    double* t = tab + j * kTab;
     t[0] = m0;
     t[1] = m1;
     const double m00 = m0 * m0, m01 = m0 * m1, m11 = m1 * m1;
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
       tk[4] = w * m01;
       tk[5] = w * m11;
     }
-    float* f = tab32 + e * kTab;
+    float* f = tab32 + j * kTab;
     f[0] = (float)(m0 * 1.4426950408889634);
     f[1] = (float)(m1 * 1.4426950408889634);
 #pragma unroll
@@ -179,6 +221,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   __syncthreads();
   const double* __restrict__ tab = ws + kWsHeader;
   const float* __restrict__ tab32 = reinterpret_cast<const float*>(tab + (size_t)n_e * kTab);
+  const EnergyClasses ec{(int)ws[1], (int)ws[2], (int)ws[3]};
   const int64_t p = (int64_t)blockIdx.x * kGnBlock + threadIdx.x;
   if (p >= n_pix) return;
   const double gd0 = load_g<double>(g1, g_is_f64, p), gd1 = load_g<double>(g2, g_is_f64, p);
@@ -189,7 +232,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
     float fa0 = 1e-6f, fa1 = 1e-6f;
     const float fg0 = (float)(gd0 * scale), fg1 = (float)(gd1 * scale);
     const int n_bulk = n_iters > n_polish ? n_iters - n_polish : 0;
-    for (; it < n_bulk; ++it) newton_step_f32(tab32, n_e, fg0, fg1, fa0, fa1);
+    for (; it < n_bulk; ++it) newton_step_f32(tab32, ec, fg0, fg1, fa0, fa1);
     if (n_bulk > 0) { a0 = (double)fa0; a1 = (double)fa1; }
     // float64 polish; a pixel whose float32 trajectory did not arrive (non-finite, or the polish
     // steps are still moving it) is redone from the start in float64, i.e. in the reference's
@@ -197,16 +240,16 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
     double p0 = a0, p1 = a1;
     for (; it < n_iters; ++it) {
       p0 = a0; p1 = a1;
-      newton_step_f64(tab, lds_pow, n_e, gd0, gd1, a0, a1);
+      newton_step_f64(tab, lds_pow, ec, gd0, gd1, a0, a1);
     }
     const double moved = fmax(fabs(a0 - p0), fabs(a1 - p1));
     const double size = fmax(fmax(fabs(a0), fabs(a1)), 1.0);
     if (n_bulk > 0 && !(moved <= 1e-9 * size)) {
       a0 = 1e-6; a1 = 1e-6;
-      for (it = 0; it < n_iters; ++it) newton_step_f64(tab, lds_pow, n_e, gd0, gd1, a0, a1);
+      for (it = 0; it < n_iters; ++it) newton_step_f64(tab, lds_pow, ec, gd0, gd1, a0, a1);
     }
   }
-  for (; it < n_iters; ++it) newton_step_f64(tab, lds_pow, n_e, gd0, gd1, a0, a1);
+  for (; it < n_iters; ++it) newton_step_f64(tab, lds_pow, ec, gd0, gd1, a0, a1);
   out_a[2 * p] = a0;
   out_a[2 * p + 1] = a1;
 }
@@ -253,7 +296,8 @@ extern "C" {
 
 int64_t dexct_gn_workspace_bytes(int32_t n_energies) {
   if (n_energies <= 0) return 0;
-  return (int64_t)sizeof(double) * kWsHeader + (int64_t)n_energies * kTab * (sizeof(double) + sizeof(float));
+  return (int64_t)sizeof(double) * kWsHeader + (int64_t)n_energies * kTab * (sizeof(double) + sizeof(float)) +
+         (int64_t)n_energies * sizeof(int) + 16;
 }
 
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
