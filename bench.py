@@ -5,7 +5,7 @@ A step = one pass of the hot path over BASELINE.json's metric configuration (con
 512^3 synthetic water/bone phantom, 1000 views x 800 channels, dual 80/140 kVp spectra, i.e.
   plan -> Siddon traversal + polychromatic detection of BOTH spectra (one fused traversal)
        -> Gauss-Newton decomposition (50 iterations, as main.py:153) + air mask
-       -> (N > 1) all-gather of the four sinograms over RCCL.
+       -> (N > 1) all-gather of the two raw sinograms over RCCL, overlapped with the decomposition.
 Detector rows: BASELINE.json does not name a row count and a single row touches one slice of the
 512^3 volume, so the workload is the stacked fan N_rows = Nz = 512; the
 single-row case is reported under "single_row".  Inputs are resident in HBM before the timed region.
@@ -62,9 +62,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # RCCL ("nccl") over xGMI; DEXCT_DIST_BACKEND=gloo only for rehearsing the N > 1 control flow on a
+        # single-GPU box (ranks then share one device and collectives are staged through the host)
+        backend = os.environ.get('DEXCT_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     import dex_ct_sim_amd as dx
     from dex_ct_sim_amd import _shard, forward_project as fp, matdecomp as md, synthetic
@@ -113,6 +120,14 @@ def main():
             ev[1].record()
         _native.check(lib.dexct_reduce_max(ptr(counts_nat[0]), 0, counts_nat[0].numel(), ptr(gmax), st), 'max')
         gm = _shard.global_max(gmax)
+        finish_gather = None
+        if world > 1:
+            # the one data-path collective: assemble the raw sinograms (reference order) on every rank; it is
+            # started here and overlaps the Newton kernel, which only needs the local shard
+            if native == 1:
+                _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
+                                                          4, st), 'transpose counts')
+            finish_gather = _shard.gather_views(counts, total_views, view_dim=1, async_op=True)
         if timed:
             ev[2].record()
         md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, precision, out=a_nat)
@@ -122,14 +137,15 @@ def main():
         _native.check(lib.dexct_gn_apply_mask(ptr(counts_nat[0]), 0, counts_nat[0].numel(), thresh, ptr(a_nat), st),
                       'mask')
         if native == 1:       # hand the results over in the reference's [view][row][channel] order
-            _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows, 4, st),
-                          'transpose counts')
+            if world == 1:
+                _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
+                                                          4, st), 'transpose counts')
             _native.check(lib.dexct_transpose_batched(ptr(a_nat), ptr(a_out), nV, args.channels, rows, 16, st),
                           'transpose mats')
         if world > 1:
-            gathered = _shard.gather_views(counts, total_views, view_dim=1)
-            mats = _shard.gather_views(a_out.to(torch.float32), total_views, view_dim=0)
-            return gathered, mats
+            # basis-material sinograms stay view-sharded (each rank owns its angles, as a view-sharded
+            # back-projection would consume them); only the raw sinogram is assembled, as the north star says
+            return finish_gather(), a_out
         return counts, a_out
 
     def barrier():
@@ -184,12 +200,14 @@ def main():
     seg_vc, _ = segment_count(co, geom, ct.view_cs(), ct.chan_cs(), total_views, vb, ve)
     alg_bytes = seg_vc * rows * 1 + 4 * 2 * n_rays
     achieved = alg_bytes / (sid_ms * 1e-3) / 1e9
+    kname = {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel'}[args.kernel or (3 if native == 1 else 1)]
     traffic = None
     import glob
     pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
     if pmc:      # newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_gpu.sh)
-        traffic = json.load(open(pmc[-1])).get('siddon_hbm_bytes_per_launch')
-    kname = {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel'}[args.kernel or (3 if native == 1 else 1)]
+        j = json.load(open(pmc[-1]))
+        if j.get('rays_per_gpu') == n_rays and kname in j.get('siddon_kernel', ''):   # same workload and kernel only
+            traffic = j.get('siddon_hbm_bytes_per_launch')
     out['roofline'] = {'kernel': kname,
                        'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

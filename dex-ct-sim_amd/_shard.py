@@ -27,26 +27,50 @@ def my_views(n_views):
     return split(n_views, r, w)
 
 
-def gather_views(local, n_views, view_dim=0):
-    """All-gather view shards (possibly of unequal size) into the full tensor on every rank."""
+def _needs_cpu_staging(t):
+    """gloo (CPU tests, single-GPU rehearsals) cannot move device tensors in every collective."""
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
+def gather_views(local, n_views, view_dim=0, async_op=False):
+    """All-gather view shards (possibly of unequal size) into the full tensor on every rank.
+
+    With ``async_op=True`` returns ``finish`` - call it to wait and get the tensor (lets the caller
+    overlap the collective with compute; on the nccl/RCCL backend the transfer runs on the process
+    group's own stream)."""
     r, w = world()
     if w == 1:
-        return local
+        return (lambda: local) if async_op else local
     local = local.movedim(view_dim, 0).contiguous()
     sizes = [split(n_views, k, w) for k in range(w)]
     n_max = max(e - b for b, e in sizes)
     pad = n_max - local.shape[0]
     if pad:
         local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], dim=0)
-    out = local.new_empty((w * n_max,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, local)
-    parts = [out[k * n_max:k * n_max + (e - b)] for k, (b, e) in enumerate(sizes)]
-    return torch.cat(parts, dim=0).movedim(0, view_dim)
+    dev = local.device
+    staged = _needs_cpu_staging(local)
+    src = local.cpu() if staged else local
+    out = src.new_empty((w * n_max,) + tuple(src.shape[1:]))
+    work = dist.all_gather_into_tensor(out, src, async_op=async_op)
+
+    def finish():
+        if async_op:
+            work.wait()
+        parts = [out[k * n_max:k * n_max + (e - b)] for k, (b, e) in enumerate(sizes)]
+        full = torch.cat(parts, dim=0) if pad or w * n_max != n_views else out
+        return full.to(dev).movedim(0, view_dim)
+
+    return finish if async_op else finish()
 
 
 def global_max(value):
     """max over ranks of a 0-d tensor (device or CPU)."""
     r, w = world()
     if w > 1:
-        dist.all_reduce(value, op=dist.ReduceOp.MAX)
+        if _needs_cpu_staging(value):
+            v = value.cpu()
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            value.copy_(v)
+        else:
+            dist.all_reduce(value, op=dist.ReduceOp.MAX)
     return value
