@@ -9,7 +9,7 @@ from .system import (FanBeamGeometry, Material, Phantom, ScannerGeometry, Spectr
                      read_parameter_file, xRaySpectrum)
 
 __all__ = ['FanBeamGeometry', 'ScannerGeometry', 'VoxelPhantom', 'Phantom', 'xRaySpectrum', 'Spectrum', 'Material',
-           'read_parameter_file', 'get_sino', 'get_sinos', 'get_basismat_sinos', 'do_matdecomp_gn']
+           'read_parameter_file', 'get_sino', 'get_sinos', 'get_recon', 'get_basismat_sinos', 'do_matdecomp_gn']
 
 
 def __getattr__(name):
@@ -17,6 +17,9 @@ def __getattr__(name):
     if name in ('get_sino', 'get_sinos', 'Projector'):
         from . import forward_project
         return getattr(forward_project, name)
+    if name == 'get_recon':
+        from . import back_project
+        return back_project.get_recon
     if name in ('get_basismat_sinos', 'do_matdecomp_gn', 'optimize_sino', 'optimize_sino_cpu'):
         from . import matdecomp
         return getattr(matdecomp, name)

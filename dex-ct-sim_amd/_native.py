@@ -10,7 +10,8 @@ ABI_VERSION = 1
 # every entry point include/dexct.h declares
 SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
            'dexct_siddon_project', 'dexct_siddon_trace', 'dexct_gn_decompose', 'dexct_gn_apply_mask',
-           'dexct_reduce_max', 'dexct_transpose_batched', 'dexct_gn_workspace_bytes']
+           'dexct_reduce_max', 'dexct_transpose_batched', 'dexct_fbp_filter', 'dexct_fbp_backproject',
+           'dexct_gn_workspace_bytes']
 
 
 class FanGeom(C.Structure):
@@ -53,6 +54,8 @@ def load():
     lib.dexct_siddon_project.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                                          vp, i32, i32, vp]
     lib.dexct_transpose_batched.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    lib.dexct_fbp_filter.argtypes = [vp, vp, vp, i64, i32, f64, vp, vp]
+    lib.dexct_fbp_backproject.argtypes = [vp, vp, i32, i32, i32, f64, f64, f64, i32, f64, vp, vp]
     lib.dexct_siddon_trace.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp, vp, vp]
     lib.dexct_gn_decompose.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.dexct_gn_workspace_bytes.argtypes = [i32]

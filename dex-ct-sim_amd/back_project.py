@@ -1,0 +1,73 @@
+"""Fan-beam filtered back-projection: drop-in for the reference's ``xtomosim.back_project.get_recon``.
+
+``recon_raw, recon_HU = get_recon(sino, ct, spec, N_matrix, FOV, ramp)`` is called at main.py:134 (log
+sinogram of one spectrum) and main.py:168 (basis-material sinograms, ``spec`` a filler there).  The
+reference source is in the un-vendored x-tomo-sim submodule; README.md:30-31 describes it as fan-beam
+FBP with a windowed ramp filter.  This build implements Kak & Slaney 3.4.1 for the equiangular fan of
+``FanBeamGeometry`` (see oracle/fbp_oracle.py for the formulas): ``ramp`` is the cutoff of the
+band-limited ramp as a fraction of the Nyquist frequency (``ramp_filter_percent_Nyquist``,
+input/params.txt:35), ``recon_raw`` is in 1/cm on an ``N_matrix`` x ``N_matrix`` grid over ``FOV`` cm,
+``recon_HU = 1000 (raw - mu_w) / mu_w`` with the spectrum- and detector-weighted water attenuation.
+The convolution and the back-projection run in the HIP library (dexct_fbp_filter, dexct_fbp_backproject).
+"""
+import numpy as np
+import torch
+
+from . import _native, xcompy
+from ._device import device, ptr, stream_ptr, to_dev
+from .forward_project import effective_weights
+
+WATER = 'H(11.2)O(88.8)'       # the composition plots.py:140 uses for HU
+
+
+def ramp_taps(n_channels, dgamma, ramp=1.0):
+    """Equiangular filter taps g(n dgamma), n = -(N-1)..(N-1), cutoff ``ramp`` x Nyquist (float64)."""
+    n = np.arange(-(n_channels - 1), n_channels, dtype=np.float64)
+    c = float(ramp)
+    h = (c * c / (2 * dgamma ** 2)) * np.sinc(c * n) - (c * c / (4 * dgamma ** 2)) * np.sinc(c * n / 2) ** 2
+    t = n * dgamma
+    with np.errstate(invalid='ignore', divide='ignore'):
+        ratio = np.where(n == 0, 1.0, t / np.sin(t))
+    return 0.5 * ratio ** 2 * h
+
+
+def water_mu(ct, spec):
+    """Effective water attenuation [1/cm] seen by (spectrum, detector): weighted mean over the spectrum."""
+    w = effective_weights(ct, spec)
+    return float(np.sum(w * xcompy.mixatten(WATER, spec.E)) / np.sum(w))
+
+
+def recon_device(sino_d, ct, N_matrix, FOV, ramp):
+    """sino_d: device float32 [N_proj, N_channels] or [N_proj, N_rows, N_channels] -> image tensor
+    [N_matrix, N_matrix] or [N_rows, N_matrix, N_matrix] (float32, 1/cm)."""
+    lib = _native.load()
+    dev = sino_d.device
+    three_d = sino_d.dim() == 3
+    s = sino_d if three_d else sino_d[:, None, :]
+    s = s.contiguous()
+    n_views, n_rows, n_ch = s.shape
+    if n_views != ct.N_proj or n_ch != ct.N_channels:
+        raise ValueError(f'sinogram {tuple(sino_d.shape)} does not match the scanner ({ct.N_proj} x {ct.N_channels})')
+    if abs(ct.theta_tot - 2 * np.pi) > 1e-4:
+        raise NotImplementedError('only full 2 pi rotations are reconstructed')
+    taps = to_dev(ramp_taps(n_ch, ct.dgamma, ramp), torch.float32, dev)
+    weight = to_dev(ct.SID * np.cos(ct.gammas), torch.float32, dev)
+    view_cs = to_dev(ct.view_cs(), torch.float64, dev)
+    q = torch.empty_like(s)
+    st = stream_ptr()
+    _native.check(lib.dexct_fbp_filter(ptr(s), ptr(taps), ptr(weight), n_views * n_rows, n_ch, ct.dgamma, ptr(q), st),
+                  'dexct_fbp_filter')
+    img = torch.empty((n_rows, N_matrix, N_matrix), dtype=torch.float32, device=dev)
+    _native.check(lib.dexct_fbp_backproject(ptr(q), ptr(view_cs), n_views, n_ch, n_rows, ct.SID, ct.dgamma,
+                                            ct.theta_tot / ct.N_proj, int(N_matrix), float(FOV), ptr(img), st),
+                  'dexct_fbp_backproject')
+    return img if three_d else img[0]
+
+
+def get_recon(sino, ct, spec, N_matrix, FOV, ramp):
+    """Drop-in for ``recon_raw, recon_HU = get_recon(sino, ct, spec, N_matrix, FOV, ramp)`` (main.py:134)."""
+    dev = device()
+    sino_d = to_dev(np.asarray(sino, dtype=np.float32), torch.float32, dev)
+    raw = recon_device(sino_d, ct, N_matrix, FOV, ramp).cpu().numpy()
+    mu_w = water_mu(ct, spec)
+    return raw, (1000.0 * (raw - mu_w) / mu_w).astype(np.float32)

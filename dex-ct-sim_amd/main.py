@@ -6,7 +6,8 @@ for every run in the parameter file, for every dual-energy spectrum pair:
      ``<spec>_<dose>uGy/sino_raw_float32.bin`` and ``sino_log_float32.bin`` (:121-122);
   2. decompose the two raw sinograms into basis-material sinograms with 50 Newton iterations
      (:153) and write ``matdecomp_<s1>_<s2>_<d1>uGy_<d2>uGy/mat{1,2}_sino_float32.bin`` (:154-155).
-Reconstruction (get_recon, :134,:168) is outside this engine's scope and is skipped.
+  3. when ``back_project`` is set: reconstruct every log sinogram (:134 -> recon_raw/recon_HU .bin, :135-136)
+     and both basis-material sinograms (:168 -> mat{1,2}_recon_float32.bin, :169).
 
 Differences from the reference script, all on purpose: inputs are command-line options instead of
 edited source lines (:80-82, :101-103); figures are off unless --show; both spectra of a pair are
@@ -25,6 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 import dex_ct_sim_amd as dx  # noqa: E402
+from dex_ct_sim_amd.back_project import get_recon  # noqa: E402
 from dex_ct_sim_amd.forward_project import get_sinos  # noqa: E402
 from dex_ct_sim_amd.matdecomp import get_basismat_sinos  # noqa: E402
 
@@ -82,8 +84,8 @@ def main(argv=None):
         if rank == 0:
             os.makedirs(out_dir, exist_ok=True)
             shutil.copy(args.params, os.path.join(out_dir, 'params.txt'))
-        if do_bp and rank == 0:
-            print('back_project requested: reconstruction is outside this engine, skipping')
+        if do_bp:
+            N_matrix, FOV, ramp = params[6:9]
         for s1, s2, d1, d2 in parse_pairs(args.pairs):
             t0 = time()
             specs = [load_spectrum(ct, s1, d1, args.input_dir), load_spectrum(ct, s2, d2, args.input_dir)]
@@ -98,6 +100,14 @@ def main(argv=None):
                     sino_log.astype(np.float32).tofile(sub_dir + 'sino_log_float32.bin')
                     if args.show:
                         show('Raw line integrals', sino_raw, 'Log sinogram', sino_log)
+                    if do_bp:
+                        print('Back projecting!')
+                        spec = specs[0] if spec_id == s1 else specs[1]
+                        recon_raw, recon_HU = get_recon(sino_log, ct, spec, N_matrix, FOV, ramp)
+                        recon_raw.astype(np.float32).tofile(sub_dir + 'recon_raw_float32.bin')
+                        recon_HU.astype(np.float32).tofile(sub_dir + 'recon_HU_float32.bin')
+                        if args.show:
+                            show('Raw reconstruction [1/cm]', recon_raw, 'Hounsfield Units', recon_HU)
             sub_dir = os.path.join(out_dir, f'matdecomp_{s1}_{s2}_{int(d1 * 1000):04}uGy_{int(d2 * 1000):04}uGy/')
             print('Decomposing into basis material sinograms!')
             matsino1, matsino2 = get_basismat_sinos(ct, sinos[0][0], sinos[1][0], specs[0], specs[1],
@@ -109,6 +119,11 @@ def main(argv=None):
                 matsino2.astype(np.float32).tofile(sub_dir + 'mat2_sino_float32.bin')
                 if args.show:
                     show('Basis material 1', matsino1, 'Basis material 2', matsino2)
+                if do_bp:
+                    print('Back projecting basis material sinograms!')
+                    for i, matsino in enumerate([matsino1, matsino2]):
+                        recon_raw, _ = get_recon(matsino, ct, specs[0], N_matrix, FOV, ramp)    # spec is filler (:168)
+                        recon_raw.astype(np.float32).tofile(sub_dir + f'mat{i + 1}_recon_float32.bin')
                 print(f'matdecomp finished for {s1}-{s2} : t={time() - t0:.2f}s')
 
 

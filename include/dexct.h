@@ -149,6 +149,18 @@ int dexct_gn_apply_mask(const void* g1, int32_t g_is_f64, int64_t n_pix, double 
 /* max(g1) over n_pix values into *out_max (device float64 scalar). */
 int dexct_reduce_max(const void* g1, int32_t g_is_f64, int64_t n_pix, double* out_max, void* stream);
 
+/* Fan-beam filtered back-projection: replaces get_recon (main.py:134,168; x-tomo-sim back_project.py,
+ * absent; README.md:30-31).  Two steps on the log sinogram [n_lines = views*rows][n_channels]:
+ *   dexct_fbp_filter:      q[line][n] = dgamma * sum_m sino[line][m] * weight[m] * taps[(n - m) + n_channels - 1]
+ *                          (weight[m] = SID cos(gamma_m); taps = 2*n_channels - 1 equiangular ramp taps)
+ *   dexct_fbp_backproject: image[row][iy][ix] = dbeta * sum_views q(view, row, gamma'(x, y)) / L^2, pixel
+ *                          driven, linear interpolation; q is [view][row][channel]; image float32 in 1/cm. */
+int dexct_fbp_filter(const float* sino, const float* taps, const float* weight, int64_t n_lines,
+                     int32_t n_channels, double dgamma, float* q, void* stream);
+int dexct_fbp_backproject(const float* q, const double* view_cs, int32_t n_views, int32_t n_channels,
+                          int32_t n_rows, double sid, double dgamma, double dbeta, int32_t n_matrix, double fov,
+                          float* image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

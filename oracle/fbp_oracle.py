@@ -1,0 +1,74 @@
+"""ORACLE (test infrastructure): equiangular fan-beam filtered back-projection in NumPy float64.
+
+PARITY UNPINNED: the reference's ``get_recon`` (main.py:134,168) lives in the un-vendored
+x-tomo-sim submodule (``xtomosim/back_project.py``, "fan-beam filtered back projection with a sinc
+window filter", README.md:30-31).  Restated here from the textbook it implements - Kak & Slaney,
+"Principles of Computerized Tomographic Imaging", section 3.4.1 (equiangular rays):
+
+    R'(beta, n dg) = R(beta, n dg) * D * cos(n dg)                         (weighting, D = SID)
+    Q(beta, n dg)  = dg * sum_m R'(beta, m dg) g((n - m) dg)               (filtering)
+    g(n dg)        = 1/2 (n dg / sin(n dg))^2 h(n dg)
+    h(t)           = 2 fc^2 sinc(2 fc t) - fc^2 sinc^2(fc t),  fc = ramp / (2 dg)   (band-limited ramp)
+    f(x, y)        = dbeta * sum_beta Q(beta, gamma'(x, y)) / L^2(x, y, beta)     (back-projection, 2 pi scan)
+
+with this build's geometry (source at SID (cos b, sin b), channel angle measured from the central
+ray, image pixel (ix, iy) at ((ix - N/2 + 1/2) FOV/N, (iy - N/2 + 1/2) FOV/N), linear interpolation
+between channels).  Pins: reconstruction of analytically projected discs (tests/test_fbp_oracle.py).
+"""
+import numpy as np
+
+
+def ramp_taps(n_channels, dgamma, ramp=1.0):
+    """g((n) dg) for n = -(N-1) .. (N-1): the equiangular filter with cutoff ramp * Nyquist."""
+    n = np.arange(-(n_channels - 1), n_channels, dtype=np.float64)
+    c = float(ramp)
+    h = (c * c / (2 * dgamma ** 2)) * np.sinc(c * n) - (c * c / (4 * dgamma ** 2)) * np.sinc(c * n / 2) ** 2
+    t = n * dgamma
+    with np.errstate(invalid='ignore', divide='ignore'):
+        ratio = np.where(n == 0, 1.0, t / np.sin(t))
+    return 0.5 * ratio ** 2 * h
+
+
+def filter_sino(sino, gammas, sid, ramp=1.0):
+    """sino [..., N_channels] line integrals -> Q [..., N_channels]."""
+    sino = np.asarray(sino, dtype=np.float64)
+    n = sino.shape[-1]
+    dg = float(gammas[1] - gammas[0])
+    g = ramp_taps(n, dg, ramp)
+    rp = sino * (sid * np.cos(gammas))
+    idx = np.arange(n)[:, None] - np.arange(n)[None, :] + (n - 1)      # taps[n - m]
+    return dg * np.einsum('...m,nm->...n', rp, g[idx])
+
+
+def back_project(q, thetas, gammas, sid, n_matrix, fov):
+    """q [N_proj, N_channels] -> image [n_matrix, n_matrix] (index [iy, ix]) in 1/cm."""
+    q = np.asarray(q, dtype=np.float64)
+    n_views, n_ch = q.shape
+    dg = float(gammas[1] - gammas[0])
+    dbeta = 2 * np.pi / n_views if n_views > 1 else 2 * np.pi
+    if n_views > 1:
+        dbeta = float(thetas[1] - thetas[0])
+    c = (np.arange(n_matrix) - n_matrix / 2 + 0.5) * (fov / n_matrix)
+    x, y = np.meshgrid(c, c)             # x varies along the last axis
+    img = np.zeros((n_matrix, n_matrix))
+    for i in range(n_views):
+        cb, sb = np.cos(thetas[i]), np.sin(thetas[i])
+        dx, dy = x - sid * cb, y - sid * sb
+        c0x, c0y = -cb, -sb
+        dot = c0x * dx + c0y * dy
+        cross = c0x * dy - c0y * dx
+        gam = np.arctan2(cross, dot)
+        pos = gam / dg + 0.5 * (n_ch - 1)
+        k = np.floor(pos).astype(np.int64)
+        w = pos - k
+        ok = (k >= 0) & (k < n_ch - 1)
+        kk = np.clip(k, 0, n_ch - 2)
+        val = (1 - w) * q[i, kk] + w * q[i, kk + 1]
+        img += np.where(ok, val / (dx * dx + dy * dy), 0.0)
+    return img * dbeta
+
+
+def get_recon(sino_log, thetas, gammas, sid, n_matrix, fov, ramp, mu_water=None):
+    raw = back_project(filter_sino(sino_log, gammas, sid, ramp), thetas, gammas, sid, n_matrix, fov)
+    hu = None if mu_water is None else 1000.0 * (raw - mu_water) / mu_water
+    return raw, hu

@@ -1,0 +1,58 @@
+"""Pins of the FBP oracle (parity unpinned: the reference's get_recon source is absent).  Analytic
+sinograms of discs must reconstruct to the disc densities."""
+import numpy as np
+
+from oracle import fbp_oracle as fo
+
+SID = 60.0
+
+
+def disc_sino(thetas, gammas, discs):
+    s = np.zeros((thetas.size, gammas.size))
+    for i, b in enumerate(thetas):
+        sx, sy = SID * np.cos(b), SID * np.sin(b)
+        ang = b + np.pi + gammas
+        ex, ey = np.cos(ang), np.sin(ang)
+        for x0, y0, R, mu in discs:
+            d = (x0 - sx) * ey - (y0 - sy) * ex
+            s[i] += mu * 2 * np.sqrt(np.maximum(R * R - d * d, 0))
+    return s
+
+
+def scan(n_views=360, n_ch=257):
+    dg = 0.8230337 / n_ch
+    return np.arange(n_views) * 2 * np.pi / n_views, (np.arange(n_ch) - (n_ch - 1) / 2) * dg
+
+
+def test_discs_reconstruct_to_their_density():
+    th, gam = scan()
+    s = disc_sino(th, gam, [(0, 0, 10.0, 0.2), (5.0, -3.0, 2.0, 0.3)])
+    raw, hu = fo.get_recon(s, th, gam, SID, 128, 40.0, 1.0, mu_water=0.2)
+    c = (np.arange(128) - 64 + 0.5) * (40 / 128)
+    x, y = np.meshgrid(c, c)
+    bg = (x ** 2 + y ** 2 < 8.0 ** 2) & ~((x - 5) ** 2 + (y + 3) ** 2 < 2.6 ** 2)
+    small = (x - 5) ** 2 + (y + 3) ** 2 < 1.5 ** 2
+    assert abs(raw[bg].mean() - 0.2) < 1e-4
+    assert abs(raw[small].mean() - 0.5) < 1e-3        # x = +5, y = -3: orientation [iy, ix] is right
+    assert abs(raw[x ** 2 + y ** 2 > 12 ** 2].mean()) < 1e-3
+    assert abs(hu[bg].mean()) < 0.5 and abs(hu[small].mean() - 1500) < 5
+
+
+def test_ramp_cutoff_smooths_but_keeps_mean():
+    th, gam = scan(180, 129)
+    s = disc_sino(th, gam, [(0, 0, 8.0, 0.25)])
+    full, _ = fo.get_recon(s, th, gam, SID, 64, 30.0, 1.0)
+    soft, _ = fo.get_recon(s, th, gam, SID, 64, 30.0, 0.5)
+    c = (np.arange(64) - 32 + 0.5) * (30 / 64)
+    x, y = np.meshgrid(c, c)
+    inner = x ** 2 + y ** 2 < 5.0 ** 2
+    assert abs(full[inner].mean() - 0.25) < 1e-3 and abs(soft[inner].mean() - 0.25) < 5e-3
+    # a lower cutoff blurs the disc edge (and rings inside: a hard band limit, not an apodisation)
+    assert np.abs(np.diff(soft[32])).max() < np.abs(np.diff(full[32])).max()
+
+
+def test_ramlak_taps():
+    g = fo.ramp_taps(5, 0.01, 1.0)          # n = -4..4: classic Ram-Lak times the equiangular factor
+    assert np.isclose(g[4], 0.5 / (4 * 0.01 ** 2))
+    assert np.allclose(g[[2, 6]], 0.0, atol=1e-9)                  # even offsets vanish
+    assert np.isclose(g[5], 0.5 * (0.01 / np.sin(0.01)) ** 2 * (-1 / (np.pi ** 2 * 0.01 ** 2)))
