@@ -148,36 +148,49 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, E
 // [4..7] pad, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
 constexpr int kWsHeader = 8;
 
+// One block per spectrum row ("bin": 1 for the channel-independent case, else one per detector channel).
+// i0 is [2][n_bins][n_e].  With several bins the energies are NOT sorted into classes (they may differ
+// per bin): class A then simply holds all n_e energies.
 __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict__ i0, const double* __restrict__ mus,
-                                                        int n_e, double* __restrict__ ws) {
+                                                        int n_e, int n_bins, double* __restrict__ ws) {
   // float32 tables are scaled by one power of two common to both measurements (the Newton step is
   // invariant under a common scaling of counts and spectra) so that sums stay near 1.
   __shared__ double s_scale;
   __shared__ int s_n[3];
-  double* tab = ws + kWsHeader;
-  float* tab32 = reinterpret_cast<float*>(tab + (size_t)n_e * kTab);
-  int* perm = reinterpret_cast<int*>(tab32 + (size_t)n_e * kTab);
+  const int bin = blockIdx.x;
+  const double* __restrict__ i00 = i0 + (size_t)bin * n_e;                       // k = 0
+  const double* __restrict__ i01 = i0 + ((size_t)n_bins + bin) * n_e;            // k = 1
+  double* tab = ws + kWsHeader + (size_t)bin * n_e * kTab;
+  float* tab32 = reinterpret_cast<float*>(ws + kWsHeader + (size_t)n_bins * n_e * kTab);   // only for n_bins == 1
+  int* perm = reinterpret_cast<int*>(tab32 + (size_t)n_e * kTab) + (size_t)bin * n_e;
   if (threadIdx.x == 0) {
     double s0 = 0.0, s1 = 0.0;
-    for (int e = 0; e < n_e; ++e) { s0 += i0[e]; s1 += i0[n_e + e]; }
+    for (int e = 0; e < n_e; ++e) { s0 += i00[e]; s1 += i01[e]; }
     int ex = 0;
     frexp(fmax(s0, s1), &ex);
     s_scale = ldexp(1.0, -ex);
-    // stable partition of the energies into the classes A (both), B (only 0), C (only 1)
     int n = 0;
-    for (int cls = 0; cls < 3; ++cls) {
-      int cnt = 0;
-      for (int e = 0; e < n_e; ++e) {
-        const bool z0 = i0[e] == 0.0, z1 = i0[n_e + e] == 0.0;
-        const int c = (!z0 && !z1) ? 0 : (!z0 ? 1 : (!z1 ? 2 : 3));
-        if (c == cls) { perm[n++] = e; ++cnt; }
+    if (n_bins == 1) {
+      // stable partition of the energies into the classes A (both), B (only 0), C (only 1)
+      for (int cls = 0; cls < 3; ++cls) {
+        int cnt = 0;
+        for (int e = 0; e < n_e; ++e) {
+          const bool z0 = i00[e] == 0.0, z1 = i01[e] == 0.0;
+          const int c = (!z0 && !z1) ? 0 : (!z0 ? 1 : (!z1 ? 2 : 3));
+          if (c == cls) { perm[n++] = e; ++cnt; }
+        }
+        s_n[cls] = cnt;
       }
-      s_n[cls] = cnt;
+    } else {
+      for (int e = 0; e < n_e; ++e) perm[e] = e;
+      s_n[0] = n_e; s_n[1] = 0; s_n[2] = 0;
     }
-    ws[0] = s_scale;
-    ws[1] = (double)s_n[0];
-    ws[2] = (double)s_n[1];
-    ws[3] = (double)s_n[2];
+    if (bin == 0) {
+      ws[0] = s_scale;
+      ws[1] = (double)s_n[0];
+      ws[2] = (double)s_n[1];
+      ws[3] = (double)s_n[2];
+    }
   }
   __syncthreads();
   const double scale = s_scale;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
     const double m00 = m0 * m0, m01 = m0 * m1, m11 = m1 * m1;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const double w = i0[k * n_e + e];
+      const double w = k == 0 ? i00[e] : i01[e];
       double* tk = t + 2 + 6 * k;
       tk[0] = w;
       tk[1] = w * m0;
@@ -200,30 +213,36 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
       tk[4] = w * m01;
       tk[5] = w * m11;
     }
-    float* f = tab32 + j * kTab;
-    f[0] = (float)(m0 * 1.4426950408889634);
-    f[1] = (float)(m1 * 1.4426950408889634);
+    if (n_bins == 1) {
+      float* f = tab32 + j * kTab;
+      f[0] = (float)(m0 * 1.4426950408889634);
+      f[1] = (float)(m1 * 1.4426950408889634);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      f[2 + 2 * c] = (float)(t[2 + c] * scale);
-      f[3 + 2 * c] = (float)(t[8 + c] * scale);
+      for (int c = 0; c < 6; ++c) {
+        f[2 + 2 * c] = (float)(t[2 + c] * scale);
+        f[3 + 2 * c] = (float)(t[8 + c] * scale);
+      }
     }
   }
 }
 
 // MIXED: n_iters - n_polish iterations in float32, then n_polish in float64.
-template <bool MIXED>
+// PER_BIN: pixel p uses the tables of bin (p / bin_div) % n_bins (channel-dependent spectra, the general
+// signature of optimize_sino_cpu); the table pointer is then per lane and the values arrive by vector loads.
+template <bool MIXED, bool PER_BIN>
 __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                       int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
-                                                      int n_e, int n_iters, int n_polish, double* __restrict__ out_a) {
+                                                      int n_e, int n_iters, int n_polish, int n_bins, int bin_div,
+                                                      double* __restrict__ out_a) {
   __shared__ double lds_pow[kPowN];     // 2^(j/2048), 16 KB
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();
-  const double* __restrict__ tab = ws + kWsHeader;
-  const float* __restrict__ tab32 = reinterpret_cast<const float*>(tab + (size_t)n_e * kTab);
+  const float* __restrict__ tab32 = reinterpret_cast<const float*>(ws + kWsHeader + (size_t)n_bins * n_e * kTab);
   const EnergyClasses ec{(int)ws[1], (int)ws[2], (int)ws[3]};
   const int64_t p = (int64_t)blockIdx.x * kGnBlock + threadIdx.x;
   if (p >= n_pix) return;
+  const double* __restrict__ tab = ws + kWsHeader;
+  if (PER_BIN) tab += (size_t)((p / bin_div) % n_bins) * n_e * kTab;
   const double gd0 = load_g<double>(g1, g_is_f64, p), gd1 = load_g<double>(g2, g_is_f64, p);
   double a0 = 1e-6, a1 = 1e-6;
   int it = 0;
@@ -294,32 +313,38 @@ using namespace dexct;
 
 extern "C" {
 
-int64_t dexct_gn_workspace_bytes(int32_t n_energies) {
-  if (n_energies <= 0) return 0;
-  return (int64_t)sizeof(double) * kWsHeader + (int64_t)n_energies * kTab * (sizeof(double) + sizeof(float)) +
-         (int64_t)n_energies * sizeof(int) + 16;
+int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins) {
+  if (n_energies <= 0 || n_bins <= 0) return 0;
+  return (int64_t)sizeof(double) * kWsHeader + (int64_t)n_bins * n_energies * kTab * sizeof(double) +
+         (int64_t)n_energies * kTab * sizeof(float) + (int64_t)n_bins * n_energies * sizeof(int) + 16;
 }
 
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
-                       const double* mus, int32_t n_energies, int32_t n_iters, int32_t precision, int32_t n_polish,
-                       double* out_a, void* workspace, void* stream) {
+                       const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,
+                       int32_t precision, int32_t n_polish, double* out_a, void* workspace, void* stream) {
   if (!g1 || !g2 || !i0 || !mus || !out_a || !workspace || n_pix <= 0 || n_energies <= 0 || n_iters < 0)
     return DEXCT_EINVAL;
+  if (n_bins < 1 || bin_div < 1 || n_bins > 65535) return DEXCT_EINVAL;
   if (precision != 0 && precision != 1) return DEXCT_EINVAL;
+  if (precision == 1 && n_bins > 1) return DEXCT_EINVAL;   // mixed precision only with one shared spectrum
   if (n_polish < 0) return DEXCT_EINVAL;
   if (n_energies > 4096) return DEXCT_ERANGE;
   const int64_t nblk = (n_pix + kGnBlock - 1) / kGnBlock;
   if (nblk > 0x7FFFFFFFll) return DEXCT_ERANGE;
   hipStream_t st = as_stream(stream);
   double* ws = reinterpret_cast<double*>(workspace);
-  hipLaunchKernelGGL(gn_tables_kernel, dim3(1), dim3(256), 0, st, i0, mus, n_energies, ws);
+  hipLaunchKernelGGL(gn_tables_kernel, dim3(n_bins), dim3(256), 0, st, i0, mus, n_energies, n_bins, ws);
   DEXCT_LAUNCH_CHECK();
-  if (precision == 0) {
-    hipLaunchKernelGGL(gn_kernel<false>, dim3((unsigned)nblk), dim3(kGnBlock), 0, st, g1, g2, g_is_f64, n_pix,
-                       (const double*)ws, n_energies, n_iters, 0, out_a);
+  const dim3 grid((unsigned)nblk), block(kGnBlock);
+  if (n_bins > 1) {
+    hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
+                       n_energies, n_iters, 0, n_bins, bin_div, out_a);
+  } else if (precision == 0) {
+    hipLaunchKernelGGL((gn_kernel<false, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
+                       n_energies, n_iters, 0, 1, 1, out_a);
   } else {
-    hipLaunchKernelGGL(gn_kernel<true>, dim3((unsigned)nblk), dim3(kGnBlock), 0, st, g1, g2, g_is_f64, n_pix,
-                       (const double*)ws, n_energies, n_iters, n_polish, out_a);
+    hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
+                       n_energies, n_iters, n_polish, 1, 1, out_a);
   }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

@@ -45,8 +45,9 @@ def _as_device_counts(x, dev):
     return to_dev(a.astype(np.float32 if dt == torch.float32 else np.float64, copy=False), dt, dev)
 
 
-def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None):
-    """g1, g2: device tensors of equal shape; i0, mus: [2, nE] float64 (host or device).
+def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1):
+    """g1, g2: device tensors of equal shape; mus: [2, nE] float64; i0: [2, nE] (one spectrum for all
+    pixels) or [2, nBins, nE] (pixel p uses row (p // bin_div) % nBins: the reference's general layout).
     Returns a device tensor of shape g1.shape + (2,) float64."""
     lib = _native.load()
     dev = g1.device
@@ -57,29 +58,35 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
         raise ValueError('the two sinograms must agree in shape and dtype')
     i0_d = to_dev(i0, torch.float64, dev)
     mus_d = to_dev(mus, torch.float64, dev)
-    if i0_d.shape != mus_d.shape or i0_d.shape[0] != 2:
-        raise ValueError('i0 and mus must both be [2, nE]')
+    if i0_d.dim() == 2:
+        i0_d = i0_d[:, None, :].contiguous()
+    if i0_d.dim() != 3 or i0_d.shape[0] != 2 or mus_d.shape != (2, i0_d.shape[2]):
+        raise ValueError('i0 must be [2, nE] or [2, nBins, nE] and mus [2, nE]')
+    n_bins, n_e = i0_d.shape[1], i0_d.shape[2]
+    if n_bins > 1 and precision == 'mixed':
+        precision = 'f64'               # mixed precision exists for the shared-spectrum fast path only
     a = out if out is not None else torch.empty(tuple(g1.shape) + (2,), dtype=torch.float64, device=dev)
-    n_e = i0_d.shape[1]
-    ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, n_bins), dtype=torch.uint8, device=dev)
     _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), int(g1.dtype == torch.float64), g1.numel(), ptr(i0_d),
-                                         ptr(mus_d), n_e, int(n_iters), int(precision == 'mixed'),
-                                         int(n_polish), ptr(a), ptr(ws), stream_ptr()), 'dexct_gn_decompose')
+                                         ptr(mus_d), n_e, n_bins, int(bin_div), int(n_iters),
+                                         int(precision == 'mixed'), int(n_polish), ptr(a), ptr(ws), stream_ptr()),
+                  'dexct_gn_decompose')
     return a
 
 
 def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None):
     """Newton iterations for every pixel (signature of matdecomp.py:20 / :87).
 
-    Sino_gg [2, nViews, nBins] counts; i0 [2, nBins, nEnergies] (must not vary over bins, which is
-    all do_matdecomp_gn ever builds, :151) or [2, nEnergies]; mus [2, nEnergies].
+    Sino_gg [2, nViews, nBins] counts; i0 [2, nBins, nEnergies] (channel-dependent spectra are handled by a
+    slower per-lane-table kernel; the tiled spectrum do_matdecomp_gn builds, :151, takes the fast path) or
+    [2, nEnergies]; mus [2, nEnergies].
     Returns Sino_aa [nViews, nBins, 2] float64 NumPy.  ``ee`` is unused, as in the reference.
     """
     i0 = np.asarray(i0, dtype=np.float64)
-    if i0.ndim == 3:
-        if not np.all(i0 == i0[:, :1, :]):
-            raise NotImplementedError('channel-dependent effective spectra are not supported by the HIP kernel')
-        i0 = i0[:, 0, :]
+    if i0.ndim == 3 and np.all(i0 == i0[:, :1, :]):
+        i0 = i0[:, 0, :]                 # one spectrum tiled over the channels (:151): the fast path
+    if i0.ndim == 3 and i0.shape[1] != np.asarray(Sino_gg).shape[2]:
+        raise ValueError('i0 has a different number of bins than the sinogram')
     dev = device()
     g = _as_device_counts(np.asarray(Sino_gg), dev)
     a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision)

@@ -122,23 +122,26 @@ int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
                        int32_t* n_seg, void* stream);
 
 /* Per-pixel Newton (Gauss-Newton) basis-material decomposition: replaces optimize_sino_cpu
- * (matdecomp.py:87-127) for channel-independent effective spectra (the only case
- * do_matdecomp_gn produces, matdecomp.py:151).
+ * (matdecomp.py:87-127).
  *   g1, g2     measured counts of the two spectra, n_pix values each; g_is_f64 selects
  *              float64 (1) or float32 (0) input
- *   i0[k*n_energies + e]   effective spectra (float64), k = 0, 1
+ *   i0[(k*n_bins + b)*n_energies + e]  effective spectra (float64), k = 0, 1 - the reference's
+ *              [nMeas, nBins, nEnergies] layout.  n_bins = 1: one spectrum for every pixel (all that
+ *              do_matdecomp_gn builds, matdecomp.py:151; the fast path: tables through the scalar cache);
+ *              n_bins > 1: pixel p uses row b = (p / bin_div) % n_bins (bin_div = 1 when the channel is
+ *              the fastest pixel index, = n_rows for the row-fastest layout 1)
  *   mus[m*n_energies + e]  basis mass attenuation (float64), m = 0, 1
  *   out_a[2*p + m]         density line integrals (float64), initialised to 1e-6 inside
  *   precision: 0 = float64 throughout (reference arithmetic);
  *              1 = float32 bulk iterations followed by float64 polish iterations; a pixel the
- *                  polish is still moving is redone in float64 from the start
+ *                  polish is still moving is redone in float64 from the start (n_bins == 1 only)
  *   n_polish   number of trailing float64 iterations when precision == 1
- *   workspace  device scratch of dexct_gn_workspace_bytes(n_energies) bytes (the product tables
+ *   workspace  device scratch of dexct_gn_workspace_bytes(n_energies, n_bins) bytes (the product tables
  *              the kernel reads through the scalar cache); owned by the caller, no hidden state */
-int64_t dexct_gn_workspace_bytes(int32_t n_energies);
+int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
-                       const double* mus, int32_t n_energies, int32_t n_iters, int32_t precision,
-                       int32_t n_polish, double* out_a, void* workspace, void* stream);
+                       const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,
+                       int32_t precision, int32_t n_polish, double* out_a, void* workspace, void* stream);
 
 /* Air mask of get_basismat_sinos (matdecomp.py:194-205): out_a[2p], out_a[2p+1] = 0 wherever
  * g1[p] >= thresh_value (thresh_value = mask_thresh * global max, computed by the caller so that a

@@ -47,13 +47,17 @@ def test_mixed_precision_final_matches_reference(hip, golden, ci):
         assert e.max() < TOL_NS
 
 
-def test_reference_layout_i0_accepted_and_bowtie_rejected(hip, golden):
+def test_reference_layout_i0_tiled_and_channel_dependent(hip, golden):
     g = golden
     i0_tiled = np.repeat(g['gn0_i0'][:, None, :], 32, axis=1)
     a = run(g['gn0_g'], i0_tiled, g['gn0_mus'], 5, 'f64')
     assert err(a, g['gn0_a_iters5']) < TOL_F64
-    with pytest.raises(NotImplementedError):
-        run(g['opt_g'], g['opt_i0'], g['opt_mus'], 3, 'f64')
+    # the general signature: a different effective spectrum per channel (bow-tie), reference goldens
+    for n_iters in (1, 3, 30):
+        a = run(g['opt_g'], g['opt_i0'], g['opt_mus'], n_iters, 'f64')
+        assert a.shape == (3, 16, 2)
+        assert err(a, g[f'opt_a_iters{n_iters}']) < TOL_F64
+    assert err(run(g['opt_g'], g['opt_i0'], g['opt_mus'], 30, 'mixed'), g['opt_a_iters30']) < TOL_F64   # falls back to f64
 
 
 @pytest.mark.parametrize('ci', [0, 1, 2])

@@ -148,3 +148,35 @@ def test_no_gpu_fails_loudly():
     ct = dx.FanBeamGeometry(32, 8)
     with pytest.raises(_native.DexctError):
         dx.get_sino(ct, synthetic.make_phantom(16, 1), synthetic.kramers_spectrum(80))
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Argument validation happens before any HIP call: error codes instead of exceptions/crashes."""
+    import ctypes as C
+    from dex_ct_sim_amd import _native
+    lib = _native.load()
+    g = _native.FanGeom(10, 16, 1, 0, 8, 8, 1, 0, 0.1, 0.1, 0.1, 60.0, 100.0)
+    one = C.c_void_p(8)      # non-null dummy pointer; never dereferenced on these paths
+    EINVAL, ERANGE = -1, -2
+    assert lib.dexct_fan_plan(None, one, one, 0, 10, one, None) == EINVAL
+    assert lib.dexct_fan_plan(C.byref(g), one, one, 5, 5, one, None) == EINVAL          # empty view range
+    assert lib.dexct_fan_plan(C.byref(g), one, one, 0, 11, one, None) == EINVAL         # beyond n_views
+    big = _native.FanGeom(10, 16, 1, 0, 9000, 8, 1, 0, 0.1, 0.1, 0.1, 60.0, 100.0)
+    assert lib.dexct_fan_plan(C.byref(big), one, one, 0, 10, one, None) == ERANGE       # fixed-point range
+    assert lib.dexct_volume_layouts(one, 8, 8, 1, None, None, None) == EINVAL           # nothing to write
+    args = [C.byref(g), one, 0, 10, one, one, None]
+    assert lib.dexct_siddon_project(*args, 0, 10, 2, one, one, one, None, 0, 0, None) == EINVAL   # no materials
+    assert lib.dexct_siddon_project(*args, 49, 10, 2, one, one, one, None, 0, 0, None) == ERANGE  # > DEXCT_MAX_MATERIALS
+    assert lib.dexct_siddon_project(*args, 3, 10, 5, one, one, one, None, 0, 0, None) == ERANGE   # > DEXCT_MAX_SPECTRA
+    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 3, 0, None) == EINVAL   # kernel 3 needs vol_zf
+    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 7, None) == EINVAL   # layout
+    assert lib.dexct_gn_decompose(one, one, 1, 0, one, one, 10, 1, 1, 5, 0, 0, one, one, None) == EINVAL    # no pixels
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 2, 0, one, one, None) == EINVAL    # precision
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 8, 1, 5, 1, 0, one, one, None) == EINVAL    # mixed + per-bin
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, one, one, None) == ERANGE  # energies
+    assert lib.dexct_gn_workspace_bytes(140, 1) > 140 * 14 * 12 and lib.dexct_gn_workspace_bytes(0, 1) == 0
+    assert lib.dexct_transpose_batched(one, one, 1, 4, 4, 3, None) == EINVAL            # element size
+    assert lib.dexct_fbp_filter(one, one, one, 1, 1, 0.01, one, None) == EINVAL
+    assert lib.dexct_fbp_backproject(one, one, 10, 16, 1, 60.0, 0.0, 0.1, 32, 20.0, one, None) == EINVAL
+    for code, text in ((0, b'ok'), (-1, b'invalid argument'), (-3, b'HIP runtime error (see dexct_last_hip_error)')):
+        assert lib.dexct_strerror(code) == text
