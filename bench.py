@@ -211,6 +211,11 @@ def main():
     out['roofline'] = {'kernel': kname,
                        'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                       'traffic_GBps': None if traffic is None else traffic / (sid_ms * 1e-3) / 1e9,
+                       'note': 'achieved = ALGORITHMIC bytes / launch time; the 128 MiB volume is resident in L2 + '
+                               'Infinity Cache, so it can exceed the HBM peak; traffic = PMC FETCH_SIZE + WRITE_SIZE '
+                               '(fabric side, calibrated as in profiles/*_summary.md).  True-HBM regime (1024^3 volume): '
+                               'profiles/r01d_1024_*',
                        'algorithmic_bytes_per_launch': alg_bytes, 'segments_per_launch': seg_vc * rows,
                        'avg_launch_ms': sid_ms}
     gn_flops = n_rays * args.iters * i0.shape[1] * (28 + 1)      # 28 flops + 1 exp per energy-iteration
