@@ -1,0 +1,65 @@
+// Quantum noise on the detected sinogram (the reference scales spectra to a dose per view,
+// main.py:64-69, and treats sino_raw as photon counts, matdecomp.py:30,179 - its own noise code sits in the
+// absent x-tomo-sim submodule).
+//
+// Model: per energy bin the detected photons are Poisson(lambda_e) and each carries the detector signal
+// gain_e (E for an energy-integrating detector, 1 for a counting one), so the signal has mean
+// sum_e gain_e lambda_e (= the noise-free count the projector writes) and variance sum_e gain_e^2 lambda_e
+// (written by the projector when asked).  The sum over ~10^2 bins of 10^3..10^6 photons is drawn as
+// mean + sqrt(variance) * z with z standard normal; results are clipped at a tiny positive number so
+// that the log sinogram stays finite.
+// RNG: Philox4x32-10, counter = (global view, row, channel, spectrum), key = seed: every sample depends only
+// on what it belongs to, so any view sharding and either memory layout reproduce the same sinogram.
+#include "common.h"
+
+namespace dexct {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_noise_kernel(float* __restrict__ counts, const float* __restrict__ variance,
+                                                        int n_spectra, int n_views, int n_rows, int n_channels,
+                                                        int layout, int view_offset, uint32_t seed_lo, uint32_t seed_hi) {
+  const size_t n_rays = (size_t)n_views * n_rows * n_channels;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rays * n_spectra) return;
+  const uint32_t s = (uint32_t)(i / n_rays);
+  size_t ray = i - (size_t)s * n_rays;
+  uint32_t v, r, c;
+  if (layout == 0) { c = ray % n_channels; ray /= n_channels; r = ray % n_rows; v = (uint32_t)(ray / n_rows); }
+  else             { r = ray % n_rows; ray /= n_rows; c = ray % n_channels; v = (uint32_t)(ray / n_channels); }
+  uint32_t ctr[4] = {v + (uint32_t)view_offset, r, c, s};
+  philox4x32_10(ctr, seed_lo, seed_hi);
+  // Box-Muller on two 32-bit uniforms in (0, 1]
+  const float u1 = ((float)ctr[0] + 1.0f) * 2.3283064365386963e-10f;
+  const float u2 = (float)ctr[1] * 2.3283064365386963e-10f;
+  const float z = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+  const float noisy = fmaf(sqrtf(fmaxf(variance[i], 0.0f)), z, counts[i]);
+  counts[i] = fmaxf(noisy, 1.0e-20f);
+}
+
+}  // namespace dexct
+
+using namespace dexct;
+
+extern "C" int dexct_add_noise(float* counts, const float* variance, int32_t n_spectra, int32_t n_views, int32_t n_rows,
+                               int32_t n_channels, int32_t layout, int32_t view_offset, uint64_t seed, void* stream) {
+  if (!counts || !variance || n_spectra < 1 || n_views < 1 || n_rows < 1 || n_channels < 1) return DEXCT_EINVAL;
+  if (layout != 0 && layout != 1) return DEXCT_EINVAL;
+  const size_t n = (size_t)n_spectra * n_views * n_rows * n_channels;
+  const size_t nblk = (n + 255) / 256;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), counts, variance, n_spectra,
+                     n_views, n_rows, n_channels, layout, view_offset, (uint32_t)seed, (uint32_t)(seed >> 32));
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}

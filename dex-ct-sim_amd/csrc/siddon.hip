@@ -67,6 +67,7 @@ struct ProjArgs {
   int n_materials, n_energies, n_spectra;
   float* counts;      // [S][ray]
   float* pathlen;     // optional [ray][M]
+  float* variance;    // optional [S][ray]: variance of the detected signal (compound Poisson), needs w2
   int view_tile;      // views per locality tile of the row-parallel kernels
   int layout;         // 0: ray = (v*rows + r)*channels + c   1: ray = (v*channels + c)*rows + r
 };
@@ -77,6 +78,7 @@ struct ProjArgs {
 struct Tables {
   const float* __restrict__ mu;   // [M][nE] linear attenuation [1/cm]
   const float* __restrict__ w;    // [S][nE]
+  const float* __restrict__ w2;   // [S][nE] w * signal per photon (variance weights), or null
 };
 
 __device__ __forceinline__ size_t ray_index(const ProjArgs& a, int v, int r, int c) {
@@ -89,8 +91,8 @@ __device__ __forceinline__ size_t ray_index(const ProjArgs& a, int v, int r, int
 // into v_pk_fma_f32).  mu and w are wave-uniform (scalar loads); NM materials in registers.
 template <int NM, int R>
 __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const ProjArgs& a, const float* __restrict__ mu,
-                                             const float* __restrict__ w, const size_t (&ray)[R],
-                                             const bool (&valid)[R]) {
+                                             const float* __restrict__ w, const float* __restrict__ w2,
+                                             const size_t (&ray)[R], const bool (&valid)[R]) {
   const int n_e = a.n_energies;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   if (a.pathlen) {
@@ -133,6 +135,39 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
         for (int q = 0; q < R; ++q) acc[s][q] = fmaf(ws, te[q], acc[s][q]);
       }
   }
+  if (a.variance) {
+    // second pass, only when noise is requested: var_s = sum_e w2[s][e] * exp(-P_e), w2 = w * (signal per photon)
+    float var[DEXCT_MAX_SPECTRA][R];
+#pragma unroll
+    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+#pragma unroll
+      for (int q = 0; q < R; ++q) var[s][q] = 0.0f;
+    for (int e = 0; e < n_e; ++e) {
+      float pe[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) pe[q] = 0.0f;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const float mue = mu[m * n_e + e];
+#pragma unroll
+        for (int q = 0; q < R; ++q) pe[q] = fmaf(mue, L2[q][m], pe[q]);
+      }
+#pragma unroll
+      for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+        if (s < a.n_spectra) {
+          const float ws = w2[s * n_e + e];
+#pragma unroll
+          for (int q = 0; q < R; ++q) var[s][q] = fmaf(ws, __builtin_amdgcn_exp2f(-pe[q]), var[s][q]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+      if (s < a.n_spectra) {
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+          if (valid[q]) a.variance[ray[q] + s * sstride] = var[s][q];
+      }
+  }
   // 4 consecutive rays (layout 1, rows4_kernel): one 16-byte store per spectrum
   const bool vec4 = R == 4 && a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[R - 1];
 #pragma unroll
@@ -151,37 +186,43 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
 
 template <int NM>
 __device__ __forceinline__ void detect_store1(const float (&L)[NM], const ProjArgs& a, const float* __restrict__ mu,
-                                              const float* __restrict__ w, size_t ray) {
+                                              const float* __restrict__ w, const float* __restrict__ w2, size_t ray) {
   float L1[1][NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) L1[0][m] = L[m];
   const size_t rays[1] = {ray};
   const bool valid[1] = {true};
-  detect_store<NM, 1>(L1, a, mu, w, rays, valid);
+  detect_store<NM, 1>(L1, a, mu, w, w2, rays, valid);
 }
 
 // Any number of materials: per-material lengths in LDS column `tid` (stride `stride`).
 __device__ __forceinline__ void detect_store_lds(const float* lds_L, int tid, int stride, const ProjArgs& a,
                                                  const float* __restrict__ mu, const float* __restrict__ w,
-                                                 size_t ray) {
+                                                 const float* __restrict__ w2, size_t ray) {
   const int n_e = a.n_energies, n_mat = a.n_materials;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   if (a.pathlen)
     for (int m = 0; m < n_mat; ++m) a.pathlen[ray * n_mat + m] = lds_L[m * stride + tid];
-  float acc[DEXCT_MAX_SPECTRA];
+  float acc[DEXCT_MAX_SPECTRA], var[DEXCT_MAX_SPECTRA];
 #pragma unroll
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) acc[s] = 0.0f;
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) acc[s] = var[s] = 0.0f;
   for (int e = 0; e < n_e; ++e) {
     float p = 0.0f;
     for (int m = 0; m < n_mat; ++m) p = fmaf(mu[m * n_e + e], lds_L[m * stride + tid], p);
     const float t = __builtin_amdgcn_exp2f(-p * kLog2e);
 #pragma unroll
     for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-      if (s < a.n_spectra) acc[s] = fmaf(w[s * n_e + e], t, acc[s]);
+      if (s < a.n_spectra) {
+        acc[s] = fmaf(w[s * n_e + e], t, acc[s]);
+        if (a.variance) var[s] = fmaf(w2[s * n_e + e], t, var[s]);
+      }
   }
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-    if (s < a.n_spectra) a.counts[ray + s * sstride] = acc[s];
+    if (s < a.n_spectra) {
+      a.counts[ray + s * sstride] = acc[s];
+      if (a.variance) a.variance[ray + s * sstride] = var[s];
+    }
 }
 
 // Register accumulators of one ray for materials 1..NM-1.
@@ -262,7 +303,7 @@ constexpr int kLdsBlock = 128;   // block size of the LDS-accumulator instantiat
 // rays_kernel: one thread per ray.  NM > 0: materials in registers; NM == 0: LDS accumulators.
 template <int NM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a, const float* __restrict__ mu,
-                                                      const float* __restrict__ w) {
+                                                      const float* __restrict__ w, const float* __restrict__ w2) {
   extern __shared__ float lds_dyn[];
   const int tid = threadIdx.x;
   const int c = blockIdx.x * BLOCK + tid;
@@ -298,10 +339,10 @@ __global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a, const float* __
   if (NM > 0) {
     float L[NM > 0 ? NM : 1];
     ra.lengths(p, L);
-    detect_store1<(NM > 0 ? NM : 1)>(L, a, mu, w, ray);
+    detect_store1<(NM > 0 ? NM : 1)>(L, a, mu, w, w2, ray);
   } else {
     la.lengths(p);
-    detect_store_lds(la.cnt, tid, BLOCK, a, mu, w, ray);
+    detect_store_lds(la.cnt, tid, BLOCK, a, mu, w, w2, ray);
   }
 }
 
@@ -340,7 +381,7 @@ __device__ __forceinline__ BlockRay block_to_ray(int n_views, int n_channels, in
 
 template <int NM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void rows_kernel(ProjArgs a, const float* __restrict__ mu,
-                                                      const float* __restrict__ w, int n_chunks) {
+                                                      const float* __restrict__ w, const float* __restrict__ w2, int n_chunks) {
   __shared__ SlabRec rec[BLOCK];
   extern __shared__ float lds_dyn[];
   const int tid = threadIdx.x;
@@ -388,10 +429,10 @@ __global__ __launch_bounds__(BLOCK) void rows_kernel(ProjArgs a, const float* __
   if (NM > 0) {
     float L[NM > 0 ? NM : 1];
     ra.lengths(p, L);
-    detect_store1<(NM > 0 ? NM : 1)>(L, a, mu, w, ray);
+    detect_store1<(NM > 0 ? NM : 1)>(L, a, mu, w, w2, ray);
   } else {
     la.lengths(p);
-    detect_store_lds(la.cnt, tid, BLOCK, a, mu, w, ray);
+    detect_store_lds(la.cnt, tid, BLOCK, a, mu, w, w2, ray);
   }
 }
 
@@ -408,7 +449,7 @@ struct CrossRec {
 
 template <int NM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* __restrict__ mu,
-                                                       const float* __restrict__ w, int n_chunks) {
+                                                       const float* __restrict__ w, const float* __restrict__ w2, int n_chunks) {
   __shared__ uint32_t list_full[kSuper];
   __shared__ CrossRec list_cross[kSuper];
   __shared__ uint32_t wave_tot[kSuper / BLOCK][BLOCK / 64][2];
@@ -591,7 +632,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
 #pragma unroll
     for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
   }
-  detect_store<NM, 4>(L, a, mu, w, rays, valid);
+  detect_store<NM, 4>(L, a, mu, w, w2, rays, valid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -634,7 +675,7 @@ static int launch_rays(const ProjArgs& a, const Tables& t, hipStream_t st) {
   constexpr int B = NM > 0 ? kBlock : kLdsBlock;
   dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
   size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
-  hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w);
+  hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w, t.w2);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
@@ -646,7 +687,7 @@ static int launch_rows(const ProjArgs& a, const Tables& t, hipStream_t st) {
   const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
-  hipLaunchKernelGGL((rows_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), lds, st, a, t.mu, t.w, n_chunks);
+  hipLaunchKernelGGL((rows_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), lds, st, a, t.mu, t.w, t.w2, n_chunks);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
@@ -657,7 +698,7 @@ static int launch_rows4_b(const ProjArgs& a, const Tables& t, hipStream_t st) {
   const int n_chunks = (a.g.n_rows + rows_per_block - 1) / rows_per_block;
   const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  hipLaunchKernelGGL((rows4_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), 0, st, a, t.mu, t.w, n_chunks);
+  hipLaunchKernelGGL((rows4_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), 0, st, a, t.mu, t.w, t.w2, n_chunks);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
@@ -680,7 +721,8 @@ extern "C" {
 int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin, int32_t view_end,
                          const uint8_t* vol_yx, const uint8_t* vol_xy, const uint8_t* vol_zf, int32_t n_materials,
                          int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights, float* counts,
-                         float* pathlen, int32_t kernel, int32_t layout, void* stream) {
+                         float* pathlen, int32_t kernel, int32_t layout, const float* weights2, float* variance,
+                         void* stream) {
   if (!geom || !plan || !mu || !weights || !counts) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
@@ -694,6 +736,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   if (kernel == 3 && !can4) return DEXCT_EINVAL;
   if (kernel < 1 || kernel > 3) return DEXCT_EINVAL;
   if (layout != 0 && layout != 1) return DEXCT_EINVAL;
+  if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
   if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
   ProjArgs a;
   a.g = *geom;
@@ -707,8 +750,9 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   a.n_spectra = n_spectra;
   a.counts = counts;
   a.pathlen = pathlen;
+  a.variance = variance;
   a.layout = layout;
-  const Tables t{mu, weights};
+  const Tables t{mu, weights, weights2};
   a.view_tile = kViewTileDefault;
   if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.view_tile = t; }   // tuning knob
   hipStream_t st = as_stream(stream);

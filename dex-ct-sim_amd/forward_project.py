@@ -23,12 +23,13 @@ def effective_weights(ct, spec):
     return spec.I0 * ct.detector_response(spec.E) * spec.bin_widths()
 
 
-def merged_tables(ct, phantom, specs):
+def merged_tables(ct, phantom, specs, with_variance=False):
     """One energy grid for a fused multi-spectrum traversal.
 
     Each spectrum keeps its own quadrature: on the merged grid its weight is non-zero only at its
     own energies (no interpolation), bins that no spectrum weights are dropped.
-    Returns E [nE], mu [M, nE] (float64, 1/cm), w [S, nE] (float64).
+    Returns E [nE], mu [M, nE] (float64, 1/cm), w [S, nE] (float64) and, with ``with_variance``,
+    w2 = w * (detector signal per photon: E for an energy-integrating detector, 1 for a counting one).
     """
     E = np.unique(np.concatenate([s.E for s in specs]))
     w = np.zeros((len(specs), E.size))
@@ -36,6 +37,8 @@ def merged_tables(ct, phantom, specs):
         w[k, np.searchsorted(E, s.E)] = effective_weights(ct, s)
     keep = np.any(w != 0.0, axis=0)
     E, w = E[keep], w[:, keep]
+    if with_variance:
+        return E, phantom.mu_table(E), w, w * (E if ct.eid else 1.0)
     return E, phantom.mu_table(E), w
 
 
@@ -95,13 +98,16 @@ class Projector:
             return 1
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 
-    def project_tables(self, mu_d, w_d, want_pathlen=False, out=None, layout=0):
+    def project_tables(self, mu_d, w_d, want_pathlen=False, out=None, layout=0, w2_d=None, seed=0):
         """Device-side call: mu_d [M, nE], w_d [S, nE] float32 tensors -> counts.
 
         layout 0: counts [S, nV, rows, channels] (the reference's order); layout 1: [S, nV, channels, rows]
         (what the row-parallel kernels produce natively); ``layout=None`` returns the native one.  When
         the requested layout is not the kernel's own, the kernel writes its own layout and
-        dexct_transpose_batched converts (cheaper than scattered 4-byte stores)."""
+        dexct_transpose_batched converts (cheaper than scattered 4-byte stores).
+        ``w2_d`` (variance weights, merged_tables(with_variance=True)) switches quantum noise on: the kernel also
+        writes the signal variance and dexct_add_noise draws the sample (Philox, keyed by ``seed`` and by the
+        GLOBAL (view, row, channel, spectrum), so shards reproduce the unsharded sinogram)."""
         S, nE = w_d.shape
         M = mu_d.shape[0]
         ct = self.ct
@@ -119,10 +125,15 @@ class Projector:
         if want_pathlen:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
+        variance = torch.empty_like(counts) if w2_d is not None else None
         _native.check(self.lib.dexct_siddon_project(
             C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy),
             ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), self.kernel, run_layout,
-            stream_ptr()), 'dexct_siddon_project')
+            ptr(w2_d), ptr(variance), stream_ptr()), 'dexct_siddon_project')
+        if variance is not None:
+            _native.check(self.lib.dexct_add_noise(ptr(counts), ptr(variance), S, nV, nR, nC, run_layout,
+                                                   self.view_begin, int(seed) & (2 ** 64 - 1), stream_ptr()),
+                          'dexct_add_noise')
         if not direct:
             dst = out if out is not None else torch.empty(shape[want], dtype=torch.float32, device=self.dev)
             r, c = (nC, nR) if run_layout == 1 else (nR, nC)
@@ -133,9 +144,13 @@ class Projector:
                 pathlen = pathlen.permute(0, 2, 1, 3).contiguous()      # test-only output
         return (counts, pathlen) if want_pathlen else counts
 
-    def project(self, specs, want_pathlen=False, layout=0):
-        _, mu_d, w_d, air = self.upload_tables(specs)
-        return self.project_tables(mu_d, w_d, want_pathlen, layout=layout), air
+    def project(self, specs, want_pathlen=False, layout=0, noise=False, seed=0):
+        if not noise:
+            _, mu_d, w_d, air = self.upload_tables(specs)
+            return self.project_tables(mu_d, w_d, want_pathlen, layout=layout), air
+        _, mu, w, w2 = merged_tables(self.ct, self.phantom, specs, with_variance=True)
+        mu_d, w_d, w2_d = (to_dev(x, torch.float32, self.dev) for x in (mu, w, w2))
+        return self.project_tables(mu_d, w_d, want_pathlen, layout=layout, w2_d=w2_d, seed=seed), w.sum(axis=1)
 
     def trace(self, rays_vrc, max_seg=None):
         """Voxel-index sequence and float32 piece lengths of selected rays (views relative to the shard)."""
@@ -168,8 +183,12 @@ def _projector(ct, phantom, view_range):
     return pj
 
 
-def get_sinos(ct, phantom, specs):
+def get_sinos(ct, phantom, specs, noise=False, seed=0):
     """Several spectra from ONE traversal (path lengths are energy independent).
+
+    ``noise=True`` adds quantum noise for the dose the spectra are scaled to (compound-Poisson variance,
+    Gaussian sample, counter-based Philox RNG keyed by ``seed``; see csrc/noise.hip); the default is the
+    noise-free expectation, which is what every parity test uses.
 
     Returns a list of (sino_raw, sino_log) float32 NumPy pairs, shaped [N_proj, N_channels]
     (or [N_proj, N_rows, N_channels] for N_rows > 1).  Under torch.distributed the projection angles
@@ -177,7 +196,7 @@ def get_sinos(ct, phantom, specs):
     """
     vb, ve = _shard.my_views(ct.N_proj)
     pj = _projector(ct, phantom, (vb, ve))
-    counts, air = pj.project(specs)
+    counts, air = pj.project(specs, noise=noise, seed=seed)
     counts = _shard.gather_views(counts, ct.N_proj, view_dim=1)
     raw = counts.cpu().numpy()
     if ct.N_rows == 1:
@@ -190,6 +209,6 @@ def get_sinos(ct, phantom, specs):
     return out
 
 
-def get_sino(ct, phantom, spec):
+def get_sino(ct, phantom, spec, noise=False, seed=0):
     """Drop-in for the reference call ``sino_raw, sino_log = get_sino(ct, phantom, spec)`` (main.py:120)."""
-    return get_sinos(ct, phantom, [spec])[0]
+    return get_sinos(ct, phantom, [spec], noise=noise, seed=seed)[0]

@@ -93,6 +93,9 @@ int dexct_fan_plan(const dexct_fan_geom* geom, const double* view_cs, const doub
  *   layout 1: ray = ((view - view_begin)*n_channels + channel)*n_rows + row   (row fastest; native to
  *             the row-parallel kernels, which then store 16 B per lane; dexct_transpose_batched
  *             converts between the two)
+ *   weights2 / variance (both NULL or both given): weights2[s*n_energies + e] = weights * (detector signal
+ *             per photon); variance[s*n_rays + ray] = sum_e weights2 * exp(-...) is the variance of the
+ *             detected signal under per-bin Poisson statistics, input of dexct_add_noise
  * vol_yx / vol_xy / vol_zf as written by dexct_volume_layouts (vol_zf may be NULL: then the
  * ray-parallel kernel is used for every shape).
  * kernel: 0 = choose, 1 = ray-parallel (one thread per ray), 2 = row-parallel (one workgroup
@@ -104,7 +107,14 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
                          int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
                          const uint8_t* vol_zf, int32_t n_materials, int32_t n_energies,
                          int32_t n_spectra, const float* mu, const float* weights, float* counts,
-                         float* pathlen, int32_t kernel, int32_t layout, void* stream);
+                         float* pathlen, int32_t kernel, int32_t layout, const float* weights2, float* variance,
+                         void* stream);
+
+/* counts += sqrt(variance) * z, z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
+ * channel, spectrum) and key seed: independent of view sharding and of the layout (0 / 1 as above).
+ * Results are clipped at 1e-20 so that a log sinogram stays finite. */
+int dexct_add_noise(float* counts, const float* variance, int32_t n_spectra, int32_t n_views, int32_t n_rows,
+                    int32_t n_channels, int32_t layout, int32_t view_offset, uint64_t seed, void* stream);
 
 /* dst[b][c][r] = src[b][r][c] for b < batch: [batch][rows][cols] -> [batch][cols][rows], elements of
  * elem_bytes = 4, 8 or 16 bytes (float32 sinograms, float64, the (a0, a1) float64 pairs of the
