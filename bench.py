@@ -182,12 +182,14 @@ def main():
     out = {
         'metric': 'Siddon ray-energy integrals/sec', 'value': value, 'unit': 'ray-energy integrals/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 traversal+detection, '
-        + ('f64' if precision == 'f64' else 'f32 bulk + f64 polish') + ' Newton', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64' if precision == 'f64' else 'f32+f64', 'data': 'synthetic',
         'config': {'workload': f'{n}^3 water/bone phantom, {args.views} views/GPU x {args.channels} channels x '
                                f'{rows} rows (stacked fan), dual 140/80 kVp Kramers spectra ({n_e_spec[0]}+{n_e_spec[1]} '
                                f'energy bins), fused dual-spectrum Siddon + {args.iters}-iteration Gauss-Newton',
-                   'rays_per_gpu': n_rays, 'parallelism': f'views sharded x{world}'},
+                   'rays_per_gpu': n_rays, 'parallelism': f'views sharded x{world}',
+                   'arithmetic': 'voxel indices int64 fixed point, path lengths + detection f32, Newton '
+                                 + ('f64 (reference arithmetic)' if precision == 'f64' else 'f32 bulk + f64 polish')},
         'kernel_ms': {'siddon_project': sid_ms, 'gn_decompose': gn_ms},
         'siddon_only_integrals_per_s': n_rays * sum(n_e_spec) / (sid_ms * 1e-3),
         'siddon_rays_per_s': n_rays / (sid_ms * 1e-3),

@@ -127,3 +127,26 @@ def test_round_trip_projection_to_thickness(hip):
     back = np.stack([(i0[k] * ex).sum(-1) for k in range(2)])
     assert np.max(np.abs(back[0][keep] - r1[keep]) / r1[keep]) < 1e-6
     assert np.max(np.abs(back[1][keep] - r2[keep]) / r2[keep]) < 1e-6
+
+
+def test_full_scale_round_trip_property(hip, golden):
+    """2e7 pixels (the size class of a full sinogram): noise-free counts of known thicknesses, built on the
+    device in float64 by the test, must decompose back to those thicknesses (size-independent property)."""
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    dev = torch.device('cuda')
+    i0 = torch.tensor(g['gn0_i0'], device=dev)
+    mus = torch.tensor(g['gn0_mus'], device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    worst = 0.0
+    for _ in range(4):
+        n = 5_000_000
+        a_true = torch.stack([torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 40,
+                              torch.rand(n, generator=gen, device=dev, dtype=torch.float64) * 8], dim=1)
+        cnt = torch.empty((2, n), dtype=torch.float64, device=dev)
+        for lo in range(0, n, 500_000):
+            ex = torch.exp(-(a_true[lo:lo + 500_000] @ mus))
+            cnt[:, lo:lo + 500_000] = (i0 @ ex.T)
+        a = md.gn_device(cnt[0], cnt[1], i0, mus, 50, 'f64')
+        worst = max(worst, float(((a - a_true).abs() / a_true.abs().clamp(min=1.0)).max()))
+    assert worst < 1e-8, worst

@@ -222,3 +222,25 @@ def test_quantum_noise_statistics_and_reproducibility(hip):
     raw, log = dx.get_sino(ct, ph, sp[0], noise=True, seed=7)
     assert raw.shape == (40, 64, 64) and np.isfinite(log).all()
     assert np.array_equal(raw, n1[0].cpu().numpy())
+
+
+def test_native_layout_plus_transpose_equals_reference_layout(hip):
+    """bench.py's pipeline shape: native (row-fastest) projection, then dexct_transpose_batched, equals the
+    direct reference-order projection; pathlen likewise."""
+    from dex_ct_sim_amd import _native
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+    ct, ph = small_scan(n=40, nz=16, n_views=12, n_channels=50, n_rows=16)
+    pj = projector(ct, ph, kernel=3)
+    sp = spectra()
+    _, mu_d, w_d, _ = pj.upload_tables(sp)
+    ref = pj.project_tables(mu_d, w_d, layout=0)
+    nat = pj.project_tables(mu_d, w_d, layout=None)
+    assert pj.native_layout == 1 and nat.shape == (2, 12, 50, 16) and ref.shape == (2, 12, 16, 50)
+    assert torch.equal(nat.permute(0, 1, 3, 2), ref)
+    out = torch.empty_like(ref)
+    _native.check(pj.lib.dexct_transpose_batched(ptr(nat), ptr(out), 2 * 12, 50, 16, 4, stream_ptr()), 'transpose')
+    assert torch.equal(out, ref)
+    a = torch.randn((12, 50, 16, 2), dtype=torch.float64, device='cuda')
+    b = torch.empty((12, 16, 50, 2), dtype=torch.float64, device='cuda')
+    _native.check(pj.lib.dexct_transpose_batched(ptr(a), ptr(b), 12, 50, 16, 16, stream_ptr()), 'transpose')
+    assert torch.equal(b, a.permute(0, 2, 1, 3))
