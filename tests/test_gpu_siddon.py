@@ -244,3 +244,32 @@ def test_native_layout_plus_transpose_equals_reference_layout(hip):
     b = torch.empty((12, 16, 50, 2), dtype=torch.float64, device='cuda')
     _native.check(pj.lib.dexct_transpose_batched(ptr(a), ptr(b), 12, 50, 16, 16, stream_ptr()), 'transpose')
     assert torch.equal(b, a.permute(0, 2, 1, 3))
+
+
+def test_more_than_512_slabs_per_ray(hip):
+    """640 x 600 grid: rays cross up to 640 slabs, i.e. two staging passes of the packed-count kernel and
+    more than 248 slabs between flushes of its byte counters; all kernels still equal the oracle bit for bit."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd.system import AIR, BONE, WATER
+    rng = np.random.default_rng(9)
+    vol = np.zeros((8, 600, 640), np.uint8)
+    yy, xx = np.mgrid[0:600, 0:640]
+    disc = (xx - 320) ** 2 + (yy - 300) ** 2 < 270 ** 2
+    vol[:, disc] = 1
+    blobs = rng.integers(0, 3, (8, 600 // 20, 640 // 20), dtype=np.uint8).repeat(20, axis=1).repeat(20, axis=2)
+    vol = np.where(disc[None], np.maximum(blobs, 1), 0).astype(np.uint8)
+    ph = dx.VoxelPhantom.from_array('wide', vol, [AIR, WATER, BONE], dx=0.08, dy=0.08, dz=0.08)
+    ct = dx.FanBeamGeometry(N_channels=96, N_proj=24, gamma_fan=0.8230337, SID=60.0, SDD=100.0, N_rows=8)
+    g = oracle_geom(ct, ph)
+    mu = np.array([[0.0002, 0.0002], [0.2, 0.18], [0.6, 0.4]])
+    w = np.array([[1e4, 2e4]])
+    plan = co.plan(g, ct.view_cs(), ct.chan_cs(), 0, 24)
+    assert plan['n_slabs'].max() > 600
+    _, rpl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, 24, ph.volume, mu, w, True, n_threads=8)
+    cls = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, 24, ph.volume, mu, w, n_threads=8)
+    for kernel in (1, 2, 3):
+        c, pl = projector(ct, ph, kernel=kernel).project_tables(
+            torch.tensor(mu, dtype=torch.float32, device='cuda'), torch.tensor(w, dtype=torch.float32, device='cuda'),
+            want_pathlen=True)
+        assert np.array_equal(pl.cpu().numpy(), rpl), kernel
+        assert np.max(np.abs(c.cpu().numpy() - cls) / cls) < REL_TOL
