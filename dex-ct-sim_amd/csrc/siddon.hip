@@ -70,6 +70,10 @@ struct ProjArgs {
   float* variance;    // optional [S][ray]: variance of the detected signal (compound Poisson), needs w2
   int view_tile;      // views per locality tile of the row-parallel kernels
   int layout;         // 0: ray = (v*rows + r)*channels + c   1: ray = (v*channels + c)*rows + r
+  // material-group mode of rows4_kernel (more than 4 materials): the volume holds codes 0..3 of one group of
+  // three materials; raw accumulators (units of u) go to acc_out[(mat_base + code)*n_rays + ray], no detection
+  float* acc_out;
+  int mat_base;
 };
 
 // The attenuation and weight tables are passed as DIRECT __restrict__ kernel arguments (not inside
@@ -114,7 +118,12 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
 #pragma unroll
     for (int q = 0; q < R; ++q) acc[s][q] = 0.0f;
-  for (int e = 0; e < n_e; ++e) {
+  // Branch-free body: unused spectrum slots read row 0 of w again (their sums are never stored), so all table
+  // loads of an energy are independent scalar loads the compiler can issue together; 4 energies per trip.
+  int srow[DEXCT_MAX_SPECTRA];
+#pragma unroll
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) srow[s] = (s < a.n_spectra ? s : 0) * n_e;
+  auto one_energy = [&](int e) {
     float pe[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) pe[q] = 0.0f;
@@ -128,13 +137,20 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
 #pragma unroll
     for (int q = 0; q < R; ++q) te[q] = __builtin_amdgcn_exp2f(-pe[q]);
 #pragma unroll
-    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-      if (s < a.n_spectra) {
-        const float ws = w[s * n_e + e];
+    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) {
+      const float ws = w[srow[s] + e];
 #pragma unroll
-        for (int q = 0; q < R; ++q) acc[s][q] = fmaf(ws, te[q], acc[s][q]);
-      }
+      for (int q = 0; q < R; ++q) acc[s][q] = fmaf(ws, te[q], acc[s][q]);
+    }
+  };
+  int e = 0;
+  for (; e + 4 <= n_e; e += 4) {
+    one_energy(e);
+    one_energy(e + 1);
+    one_energy(e + 2);
+    one_energy(e + 3);
   }
+  for (; e < n_e; ++e) one_energy(e);
   if (a.variance) {
     // second pass, only when noise is requested: var_s = sum_e w2[s][e] * exp(-P_e), w2 = w * (signal per photon)
     float var[DEXCT_MAX_SPECTRA][R];
@@ -622,17 +638,118 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
     n[3] = NM > 3 ? w01[rr] : 0u;
     n[1] = w0[rr] - n[3];
     n[2] = w1[rr] - n[3];
-    float others = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) L[rr][m] = (float)(int32_t)n[m] + corr[m][rr];
+  }
+  if (a.acc_out) {       // material-group pass: hand the raw accumulators to detect_kernel, one plane per material
+    const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+    const bool vec4 = a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[3];
 #pragma unroll
     for (int m = 1; m < NM; ++m) {
-      L[rr][m] = (float)(int32_t)n[m] + corr[m][rr];
-      others += L[rr][m];
+      float* plane = a.acc_out + (size_t)(a.mat_base + m) * n_rays;
+      if (vec4) {
+        *reinterpret_cast<float4*>(plane + rays[0]) = make_float4(L[0][m], L[1][m], L[2][m], L[3][m]);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (valid[rr]) plane[rays[rr]] = L[rr][m];
+      }
     }
+    return;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    float others = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) others += L[rr][m];
     L[rr][0] = (p.chord_u - others) * p.len_per_u;
 #pragma unroll
     for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
   }
   detect_store<NM, 4>(L, a, mu, w, w2, rays, valid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Material groups (5..16 materials).  group_codes_kernel re-encodes the z-fastest volume once per group g:
+// ids 3g+1..3g+3 -> codes 1..3, everything else -> 0; rows4_kernel<4> runs once per group on its code volume
+// (counts and corrections of a material depend only on whether a voxel IS that material, so the per-material
+// accumulators are exactly those of a single pass); detect_kernel then forms L_0 from the chord and applies
+// the tables for all materials.
+__global__ __launch_bounds__(256) void group_codes_kernel(const uint8_t* __restrict__ vol, size_t n_vox, int n_groups,
+                                                          uint8_t* __restrict__ out) {
+  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n_vox) return;
+  uint32_t x = 0;
+  if (i4 + 4 <= n_vox) x = *reinterpret_cast<const uint32_t*>(vol + i4);
+  else for (size_t k = i4; k < n_vox; ++k) x |= (uint32_t)vol[k] << (8 * (k - i4));
+  for (int g = 0; g < n_groups; ++g) {
+    uint32_t y = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t id = (x >> (8 * b)) & 0xFFu, rel = id - 3u * g;      // 1..3 inside the group
+      y |= ((rel >= 1u && rel <= 3u) ? rel : 0u) << (8 * b);
+    }
+    uint8_t* o = out + (size_t)g * n_vox + i4;
+    if (i4 + 4 <= n_vox) *reinterpret_cast<uint32_t*>(o) = y;
+    else for (size_t k = i4; k < n_vox; ++k) o[k - i4] = (uint8_t)(y >> (8 * (k - i4)));
+  }
+}
+
+constexpr int kMaxGrouped = 16;
+
+// One thread per ray, in memory order of the chosen layout; NMAT = exact number of materials (fully unrolled:
+// a version with 16 predicated material slots spent its time in scalar branches).
+template <int NMAT, int R>   // R rays per thread: 4 consecutive rows (layout 1, n_rows % 4 == 0) or 1
+__global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __restrict__ mu, const float* __restrict__ w,
+                                                     const float* __restrict__ w2) {
+  const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const size_t ray0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * R;
+  if (ray0 >= n_rays) return;
+  size_t q = ray0;
+  int v, c;
+  if (a.layout == 0) { c = q % a.g.n_channels; q /= a.g.n_channels; v = (int)(q / a.g.n_rows); }
+  else               { q /= a.g.n_rows; c = q % a.g.n_channels; v = (int)(q / a.g.n_channels); }
+  const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];    // the R rays share (view, channel)
+  float L[R][NMAT];
+  float others[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) others[k] = 0.0f;
+#pragma unroll
+  for (int m = 1; m < NMAT; ++m) {
+    const float* plane = a.acc_out + (size_t)m * n_rays + ray0;
+    if (R == 4) {
+      const float4 x = *reinterpret_cast<const float4*>(plane);
+      L[0][m] = x.x; L[R > 1 ? 1 : 0][m] = x.y; L[R > 2 ? 2 : 0][m] = x.z; L[R > 3 ? 3 : 0][m] = x.w;
+    } else {
+      L[0][m] = plane[0];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) others[k] += L[k][m];
+  }
+  size_t rays[R];
+  bool valid[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    L[k][0] = (p.chord_u - others[k]) * p.len_per_u;
+#pragma unroll
+    for (int m = 1; m < NMAT; ++m) L[k][m] *= p.len_per_u;
+    rays[k] = ray0 + k;
+    valid[k] = true;
+  }
+  detect_store<NMAT, R>(L, a, mu, w, w2, rays, valid);
+}
+
+template <int NMAT>
+static int launch_detect(const ProjArgs& a, const Tables& t, hipStream_t st) {
+  const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const bool four = a.layout == 1 && (a.g.n_rows & 3) == 0;
+  const size_t n_thr = four ? n_rays / 4 : n_rays;
+  const size_t nblk = (n_thr + 255) / 256;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  if (four) hipLaunchKernelGGL((detect_kernel<NMAT, 4>), dim3((unsigned)nblk), dim3(256), 0, st, a, t.mu, t.w, t.w2);
+  else hipLaunchKernelGGL((detect_kernel<NMAT, 1>), dim3((unsigned)nblk), dim3(256), 0, st, a, t.mu, t.w, t.w2);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -751,6 +868,8 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   a.counts = counts;
   a.pathlen = pathlen;
   a.variance = variance;
+  a.acc_out = nullptr;
+  a.mat_base = 0;
   a.layout = layout;
   const Tables t{mu, weights, weights2};
   a.view_tile = kViewTileDefault;
@@ -778,6 +897,82 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
     case 2: return launch_rows4<2>(a, t, st);
     case 3: return launch_rows4<3>(a, t, st);
     default: return launch_rows4<4>(a, t, st);
+  }
+}
+
+int dexct_volume_groups(const uint8_t* vol_zf, int64_t n_voxels, int32_t n_materials, uint8_t* codes, void* stream) {
+  if (!vol_zf || !codes || n_voxels <= 0 || n_materials < 2) return DEXCT_EINVAL;
+  if (n_materials > kMaxGrouped) return DEXCT_ERANGE;
+  const int n_groups = (n_materials - 1 + 2) / 3;
+  const size_t nblk = ((size_t)n_voxels / 4 + 256) / 256;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(group_codes_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vol_zf, (size_t)n_voxels,
+                     n_groups, codes);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
+                                 int32_t view_end, const uint8_t* codes, int32_t n_materials, int32_t n_energies,
+                                 int32_t n_spectra, const float* mu, const float* weights, float* counts, float* pathlen,
+                                 float* acc_scratch, int32_t layout, const float* weights2, float* variance,
+                                 void* stream) {
+  if (!geom || !plan || !codes || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
+  if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
+  if (n_materials < 2 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
+  if (n_materials > kMaxGrouped || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
+  if (geom->z_first < 0 || geom->z_first + geom->n_rows > geom->nz) return DEXCT_EINVAL;
+  if (geom->nz % 4 != 0 || geom->z_first % 4 != 0) return DEXCT_EINVAL;
+  if ((uint64_t)geom->nx * geom->ny * geom->nz > 0xFFFFFFFEull) return DEXCT_ERANGE;
+  if (layout != 0 && layout != 1) return DEXCT_EINVAL;
+  if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
+  if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
+  ProjArgs a;
+  a.g = *geom;
+  a.plan = plan;
+  a.vol_yx = nullptr;
+  a.vol_xy = nullptr;
+  a.n_local_views = view_end - view_begin;
+  a.n_materials = n_materials;
+  a.n_energies = n_energies;
+  a.n_spectra = n_spectra;
+  a.counts = counts;
+  a.pathlen = pathlen;
+  a.variance = variance;
+  a.layout = layout;
+  a.acc_out = acc_scratch;
+  a.view_tile = kViewTileDefault;
+  if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.view_tile = t; }
+  const Tables t{mu, weights, weights2};
+  hipStream_t st = as_stream(stream);
+  const size_t n_vox = (size_t)geom->nx * geom->ny * geom->nz;
+  const int n_groups = (n_materials - 1 + 2) / 3;
+  for (int g = 0; g < n_groups; ++g) {
+    a.vol_zf = codes + (size_t)g * n_vox;
+    a.mat_base = 3 * g;
+    const int left = n_materials - 1 - 3 * g;           // materials in this group: 1..3
+    int rc;
+    if (left >= 3) rc = launch_rows4<4>(a, t, st);
+    else if (left == 2) rc = launch_rows4<3>(a, t, st);
+    else rc = launch_rows4<2>(a, t, st);
+    if (rc != DEXCT_OK) return rc;
+  }
+  switch (n_materials) {
+    case 2: return launch_detect<2>(a, t, st);
+    case 3: return launch_detect<3>(a, t, st);
+    case 4: return launch_detect<4>(a, t, st);
+    case 5: return launch_detect<5>(a, t, st);
+    case 6: return launch_detect<6>(a, t, st);
+    case 7: return launch_detect<7>(a, t, st);
+    case 8: return launch_detect<8>(a, t, st);
+    case 9: return launch_detect<9>(a, t, st);
+    case 10: return launch_detect<10>(a, t, st);
+    case 11: return launch_detect<11>(a, t, st);
+    case 12: return launch_detect<12>(a, t, st);
+    case 13: return launch_detect<13>(a, t, st);
+    case 14: return launch_detect<14>(a, t, st);
+    case 15: return launch_detect<15>(a, t, st);
+    default: return launch_detect<16>(a, t, st);
   }
 }
 

@@ -47,7 +47,8 @@ class Projector:
 
     ``view_range`` restricts the instance to a contiguous shard of projection angles (one per
     rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel (1 row per lane),
-    3 row-parallel with 4 rows per lane (<= 4 materials, Nz and z_index multiples of 4).
+    3 row-parallel with 4 rows per lane (<= 4 materials, Nz and z_index multiples of 4), 4 the same kernel
+    run once per group of three materials (5..16 materials).
     """
 
     def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
@@ -78,10 +79,21 @@ class Projector:
             raise ValueError('the volume holds a material id without a table entry')
         self.vol_yx = to_dev(phantom.volume, torch.uint8, self.dev)
         self.vol_xy = torch.empty_like(self.vol_yx)
-        want_zf = kernel in (2, 3) or (kernel == 0 and ct.N_rows >= 64)
+        want_zf = kernel in (2, 3, 4) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, phantom.Nz,
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
+        M = phantom.n_materials
+        aligned = phantom.Nz % 4 == 0 and z_first % 4 == 0
+        self.grouped = kernel == 4 or (kernel == 0 and want_zf and 4 < M <= 16 and aligned)
+        self.codes = None
+        if self.grouped:
+            if not (2 <= M <= 16 and aligned):
+                raise ValueError('kernel 4 needs 2..16 materials and Nz, z_index multiples of 4')
+            n_groups = (M - 1 + 2) // 3
+            self.codes = torch.empty((n_groups,) + tuple(self.vol_zf.shape), dtype=torch.uint8, device=self.dev)
+            _native.check(self.lib.dexct_volume_groups(ptr(self.vol_zf), self.vol_zf.numel(), M, ptr(self.codes), st),
+                          'dexct_volume_groups')
 
     @property
     def n_local_views(self):
@@ -94,7 +106,7 @@ class Projector:
     @property
     def native_layout(self):
         """1 (row fastest) when a row-parallel kernel will run, else 0 (channel fastest)."""
-        if self.kernel in (2, 3):
+        if self.kernel in (2, 3, 4):
             return 1
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 
@@ -126,10 +138,17 @@ class Projector:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
         variance = torch.empty_like(counts) if w2_d is not None else None
-        _native.check(self.lib.dexct_siddon_project(
-            C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy),
-            ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), self.kernel, run_layout,
-            ptr(w2_d), ptr(variance), stream_ptr()), 'dexct_siddon_project')
+        if self.grouped:
+            scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
+            _native.check(self.lib.dexct_siddon_project_grouped(
+                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
+                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
+                stream_ptr()), 'dexct_siddon_project_grouped')
+        else:
+            _native.check(self.lib.dexct_siddon_project(
+                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx),
+                ptr(self.vol_xy), ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
+                self.kernel, run_layout, ptr(w2_d), ptr(variance), stream_ptr()), 'dexct_siddon_project')
         if variance is not None:
             _native.check(self.lib.dexct_add_noise(ptr(counts), ptr(variance), S, nV, nR, nC, run_layout,
                                                    self.view_begin, int(seed) & (2 ** 64 - 1), stream_ptr()),

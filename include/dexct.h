@@ -110,6 +110,20 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
                          float* pathlen, int32_t kernel, int32_t layout, const float* weights2, float* variance,
                          void* stream);
 
+/* Fast path for 5..16 materials (stacked fan, nz and z_first multiples of 4).
+ * dexct_volume_groups: codes[g][voxel] for g < ceil((n_materials-1)/3): ids 3g+1..3g+3 of the z-fastest
+ *   volume -> 1..3, all other ids -> 0 (n_groups * n_voxels bytes).
+ * dexct_siddon_project_grouped: one packed-count traversal per group writes raw per-material accumulators
+ *   to acc_scratch[m*n_rays + ray] (float32, caller-provided, n_materials*n_rays values), then one
+ *   detection pass forms material 0 from the chord and applies the tables; outputs as dexct_siddon_project.
+ *   Bit-identical path lengths to the single-pass kernels (per-material sums are independent). */
+int dexct_volume_groups(const uint8_t* vol_zf, int64_t n_voxels, int32_t n_materials, uint8_t* codes, void* stream);
+int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
+                                 int32_t view_end, const uint8_t* codes, int32_t n_materials, int32_t n_energies,
+                                 int32_t n_spectra, const float* mu, const float* weights, float* counts,
+                                 float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
+                                 float* variance, void* stream);
+
 /* counts += sqrt(variance) * z, z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
  * channel, spectrum) and key seed: independent of view sharding and of the layout (0 / 1 as above).
  * Results are clipped at 1e-20 so that a log sinogram stays finite. */

@@ -91,11 +91,12 @@ def test_voxel_index_sequence_bit_exact(hip, n, nv, nc):
         assert np.array_equal(ln[k, :ns[k]], rl)
 
 
-@pytest.mark.parametrize('kernel', [1, 2, 3])
-@pytest.mark.parametrize('n_mat', [2, 3, 4, 7])
+@pytest.mark.parametrize('kernel', [1, 2, 3, 4])
+@pytest.mark.parametrize('n_mat', [2, 3, 4, 7, 13, 16])
 def test_pathlen_bit_exact_and_counts(hip, kernel, n_mat):
-    """Register accumulators (<= 4 materials), LDS accumulators (more) and the packed-count
-    4-rows-per-lane kernel; 66 rows from slice 4 of 72 (ragged last lane)."""
+    """Register accumulators (<= 4 materials), LDS accumulators (more), the packed-count 4-rows-per-lane
+    kernel and its material-group form (kernel 4, up to 16 materials); 66 rows from slice 4 of 72 (ragged
+    last lane)."""
     from dex_ct_sim_amd._native import DexctError
     from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
     ct, ph = small_scan(n=48, nz=72, n_views=24, n_channels=80, n_rows=66, z_index=4)
