@@ -150,3 +150,51 @@ def test_full_scale_round_trip_property(hip, golden):
         a = md.gn_device(cnt[0], cnt[1], i0, mus, 50, 'f64')
         worst = max(worst, float(((a - a_true).abs() / a_true.abs().clamp(min=1.0)).max()))
     assert worst < 1e-8, worst
+
+
+def test_entry_points_are_graph_capturable(hip):
+    """No entry point allocates, synchronises or touches another stream: plan + projection + max +
+    decomposition + mask + transposes captured into a HIP graph replay to the eager results."""
+    import ctypes as C
+    import dex_ct_sim_amd as dx
+    from conftest import small_scan
+    from dex_ct_sim_amd import _native, forward_project as fp, matdecomp as md, synthetic
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+    ct, ph = small_scan(n=32, nz=8, n_views=10, n_channels=40, n_rows=8)
+    specs = [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
+    pj = fp.Projector(ct, ph, kernel=3)
+    lib = pj.lib
+    _, mu_d, w_d, _ = pj.upload_tables(specs)
+    _, i0, mus = md.decomposition_tables(ct, specs[0], specs[1])
+    i0_d = torch.tensor(i0[:, None, :], device='cuda').contiguous()
+    mus_d = torch.tensor(mus, device='cuda')
+    counts = torch.zeros((2, 10, 40, 8), dtype=torch.float32, device='cuda')
+    a = torch.zeros((10, 40, 8, 2), dtype=torch.float64, device='cuda')
+    a_ref_order = torch.zeros((10, 8, 40, 2), dtype=torch.float64, device='cuda')
+    gmax = torch.zeros((), dtype=torch.float64, device='cuda')
+    ws = torch.empty(lib.dexct_gn_workspace_bytes(i0.shape[1], 1), dtype=torch.uint8, device='cuda')
+
+    def run():
+        st = stream_ptr()
+        _native.check(lib.dexct_fan_plan(C.byref(pj.geom), ptr(pj.view_cs), ptr(pj.chan_cs), 0, 10, ptr(pj.plan), st), 'plan')
+        _native.check(lib.dexct_siddon_project(C.byref(pj.geom), ptr(pj.plan), 0, 10, ptr(pj.vol_yx), ptr(pj.vol_xy),
+                                               ptr(pj.vol_zf), 3, mu_d.shape[1], 2, ptr(mu_d), ptr(w_d), ptr(counts),
+                                               None, 3, 1, None, None, st), 'project')
+        _native.check(lib.dexct_reduce_max(ptr(counts[0]), 0, counts[0].numel(), ptr(gmax), st), 'max')
+        _native.check(lib.dexct_gn_decompose(ptr(counts[0]), ptr(counts[1]), 0, counts[0].numel(), ptr(i0_d), ptr(mus_d),
+                                             i0.shape[1], 1, 1, 30, 0, 0, ptr(a), ptr(ws), st), 'gn')
+        _native.check(lib.dexct_gn_apply_mask(ptr(counts[0]), 0, counts[0].numel(), 1e30, ptr(a), st), 'mask')
+        _native.check(lib.dexct_transpose_batched(ptr(a), ptr(a_ref_order), 10, 40, 8, 16, st), 'transpose')
+
+    run()
+    torch.cuda.synchronize()
+    eager = (counts.clone(), a_ref_order.clone(), gmax.clone())
+    counts.zero_(); a.zero_(); a_ref_order.zero_(); gmax.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    counts.zero_(); a_ref_order.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(counts, eager[0]) and torch.equal(a_ref_order, eager[1]) and torch.equal(gmax, eager[2])
+    assert torch.isfinite(a_ref_order).all()
