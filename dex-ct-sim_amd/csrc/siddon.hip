@@ -481,8 +481,14 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
   const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * (uint32_t)a.g.nz;
   // lanes past the last row read the last aligned dword of the column (harmless) and store nothing
   const uint32_t zl = (uint32_t)min(a.g.z_first + r0, a.g.nz - 4);
-  const uint8_t* __restrict__ vol = a.vol_zf;      // uniform base + 32-bit per-lane offset (saddr form)
-  auto ld4 = [&](uint32_t off) { return *reinterpret_cast<const uint32_t*>(vol + (uint32_t)(off + zl)); };
+  // SRSRC buffer loads: the column offset is wave-uniform (it comes from the LDS lists) and goes into the
+  // scalar offset, the lane's row offset zl is the vector offset: no per-load address arithmetic, and an
+  // out-of-range offset reads 0 instead of faulting.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(a.vol_zf), 0, (int)((size_t)a.g.nx * a.g.ny * a.g.nz), 0x00020000);
+  auto ld4 = [&](uint32_t off) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)zl, (int)__builtin_amdgcn_readfirstlane((int)off), 0);
+  };
   // packed byte counters: bit0 plane, bit1 plane, both bits; wide per-row counters
   uint32_t c0 = 0, c1 = 0, c01 = 0;
   uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w01[4] = {0, 0, 0, 0};
