@@ -1,0 +1,67 @@
+"""The reference's own import lines (main.py:17-22, plots.py:16-18) resolve to this engine when
+dex-ct-sim_amd/dropin is put on sys.path, and main.py reproduces the reference's
+output tree."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import INPUT, ROOT
+
+DROPIN = os.path.join(ROOT, 'dex-ct-sim_amd', 'dropin')
+
+REFERENCE_IMPORTS = '''
+import sys
+sys.path.insert(0, %r)
+from xtomosim.system import read_parameter_file, xRaySpectrum          # main.py:19
+from xtomosim.forward_project import get_sino                           # main.py:20
+from xtomosim.back_project import get_recon                             # main.py:21
+from matdecomp import get_basismat_sinos                                # main.py:22
+import xcompy as xc                                                     # plots.py:16
+from xtomosim.system import FanBeamGeometry, VoxelPhantom               # plots.py:17
+from matdecomp import matcomp1, matcomp2                                # plots.py:18
+import numpy as np
+assert xc.mixatten(matcomp1, np.array([60.0])).shape == (1,)
+ct = FanBeamGeometry(N_channels=800, N_proj=1200, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=1.0, eid=True,
+                     detector_file=%r)                                  # plots.py:109-111
+print(get_sino.__module__, get_recon.__module__, get_basismat_sinos.__module__, ct.A_iso)
+'''
+
+
+def test_reference_import_lines_resolve():
+    code = REFERENCE_IMPORTS % (DROPIN, os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd='/tmp')
+    assert out.returncode == 0, out.stderr[-2000:]
+    mods = out.stdout.split()
+    assert mods[:3] == ['dex_ct_sim_amd.forward_project', 'dex_ct_sim_amd.back_project', 'dex_ct_sim_amd.matdecomp']
+
+
+@pytest.mark.gpu
+def test_main_writes_the_reference_output_tree(tmp_path):
+    params = json.load(open(os.path.join(INPUT, 'params.txt')))
+    params.update(RUN_ID='tiny', Nx=64, Ny=64, dx=0.8, dy=0.8, dz=0.8, N_channels=96, N_projections=90,
+                  N_recon_matrix=64, FOV_recon=50.0,
+                  detector_filename=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'))
+    pf = tmp_path / 'params.txt'
+    pf.write_text(json.dumps(params))
+    out_dir = tmp_path / 'output'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'dex-ct-sim_amd', 'main.py'), '--params', str(pf), '--out',
+                        str(out_dir), '--pairs', '140kV:80kV:5:5'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    base = out_dir / 'tiny'
+    expect = {'140kV_5000uGy': ['sino_raw', 'sino_log', 'recon_raw', 'recon_HU'],
+              '80kV_5000uGy': ['sino_raw', 'sino_log', 'recon_raw', 'recon_HU'],
+              'matdecomp_140kV_80kV_5000uGy_5000uGy': ['mat1_sino', 'mat2_sino', 'mat1_recon', 'mat2_recon']}
+    assert (base / 'params.txt').exists()                      # main.py:98
+    for sub, names in expect.items():
+        for nme in names:
+            f = base / sub / f'{nme}_float32.bin'
+            assert f.exists(), f
+            a = np.fromfile(f, dtype=np.float32)
+            assert a.size == (64 * 64 if 'recon' in nme else 90 * 96)
+            assert np.isfinite(a).all() or 'sino_log' in nme
+    m1 = np.fromfile(base / 'matdecomp_140kV_80kV_5000uGy_5000uGy' / 'mat1_sino_float32.bin', dtype=np.float32)
+    assert (m1 == 0).any() and (m1 > 1).any()                   # masked air rays and real thicknesses
