@@ -60,8 +60,9 @@ class Projector:
         if not (0 <= vb < ve <= ct.N_proj):
             raise ValueError(f'bad view range {view_range}')
         self.view_begin, self.view_end = int(vb), int(ve)
-        z_first = phantom.z_index
-        if z_first < 0 or z_first + ct.N_rows > phantom.Nz:
+        self.cone = bool(getattr(ct, 'cone', False))
+        z_first = 0 if self.cone else phantom.z_index
+        if not self.cone and (z_first < 0 or z_first + ct.N_rows > phantom.Nz):
             raise ValueError(f'rows {ct.N_rows} from slice {z_first} do not fit Nz={phantom.Nz}')
         half_diag = 0.5 * np.hypot(phantom.Nx * phantom.dx, phantom.Ny * phantom.dy)
         if ct.SID <= half_diag or ct.SDD - ct.SID < 0:
@@ -79,6 +80,9 @@ class Projector:
             raise ValueError('the volume holds a material id without a table entry')
         self.vol_yx = to_dev(phantom.volume, torch.uint8, self.dev)
         self.vol_xy = torch.empty_like(self.vol_yx)
+        if self.cone:
+            kernel = self.kernel = 1          # cone beam has its own ray-parallel kernel (dexct_cone_project)
+            self.row_z = to_dev(ct.row_z(), torch.float64, self.dev)
         want_zf = kernel in (2, 3, 4) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, phantom.Nz,
@@ -138,7 +142,15 @@ class Projector:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
         variance = torch.empty_like(counts) if w2_d is not None else None
-        if self.grouped:
+        if self.cone:
+            if w2_d is not None:
+                raise NotImplementedError('noise is not available for cone-beam scans')
+            _native.check(self.lib.dexct_cone_project(
+                C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                self.ct.src_z, float(np.max(np.abs(self.ct.row_z() - self.ct.src_z))), self.view_begin, self.view_end,
+                ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
+                stream_ptr()), 'dexct_cone_project')
+        elif self.grouped:
             scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
             _native.check(self.lib.dexct_siddon_project_grouped(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,

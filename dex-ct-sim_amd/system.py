@@ -41,14 +41,19 @@ class FanBeamGeometry:
     beta + pi + gamma_c with gamma_c = (c - (N_channels-1)/2) * gamma_fan / N_channels; the
     detector pixel lies on an arc of radius SDD about the source.  ``N_rows`` > 1 stacks
     identical fans along z, row r imaging phantom slice ``z_index + r`` (an extension; the
-    reference is single-row).
+    reference is single-row); ``cone=True`` instead makes the rows a real 2-D detector seen from a point
+    source (cone beam).
     """
 
     def __init__(self, N_channels=800, N_proj=1200, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=1.0,
-                 eid=True, detector_file=None, theta_tot=2 * np.pi, N_rows=1):
+                 eid=True, detector_file=None, theta_tot=2 * np.pi, N_rows=1, cone=False, src_z=0.0):
         self.N_channels = int(N_channels)
         self.N_proj = int(N_proj)
         self.N_rows = int(N_rows)
+        # cone=True: true 3-D rays (an extension): the source at height src_z [cm, 0 = centre of the phantom],
+        # detector row r at height (r - (N_rows-1)/2) * h on the detector arc, h = h_iso * SDD / SID.
+        self.cone = bool(cone)
+        self.src_z = float(src_z)
         self.gamma_fan = float(gamma_fan)
         self.theta_tot = float(theta_tot)
         self.SID = float(SID)
@@ -68,6 +73,10 @@ class FanBeamGeometry:
             self.det_eta_E = np.array([1.0, 1.0])      # ideal detector
         else:
             self.det_E, self.det_eta_E = read_half_split(detector_file)
+
+    def row_z(self):
+        """Heights [cm] of the detector rows of a cone-beam scan."""
+        return (np.arange(self.N_rows) - 0.5 * (self.N_rows - 1)) * self.h
 
     # float64 tables every implementation (HIP, oracle) starts from
     def view_cs(self):
@@ -204,13 +213,15 @@ def _one_run(p, base_dir):
             return None
         return path if os.path.isabs(path) or os.path.exists(path) else os.path.join(base_dir, path)
 
-    if p.get('scanner_geometry', 'fan_beam') != 'fan_beam':
-        raise ValueError('only scanner_geometry "fan_beam" is supported')
+    geometry = p.get('scanner_geometry', 'fan_beam')
+    if geometry not in ('fan_beam', 'cone_beam'):          # cone_beam: extension, needs "N_rows"
+        raise ValueError('scanner_geometry must be "fan_beam" or "cone_beam"')
     mode = p.get('detector_mode', 'eid')
     ct = FanBeamGeometry(N_channels=p['N_channels'], N_proj=p['N_projections'], gamma_fan=p['fan_angle_total'],
                          SID=p['SID'], SDD=p['SDD'], h_iso=p.get('detector_px_height', 1.0), eid=(mode == 'eid'),
                          detector_file=rel(p.get('detector_filename')),
-                         theta_tot=p.get('rotation_angle_total', 2 * np.pi), N_rows=p.get('N_rows', 1))
+                         theta_tot=p.get('rotation_angle_total', 2 * np.pi), N_rows=p.get('N_rows', 1),
+                         cone=(geometry == 'cone_beam'), src_z=p.get('source_z', 0.0))
     ptype = p.get('phantom_type', 'voxel')
     if ptype == 'voxel':
         phantom = VoxelPhantom(p['phantom_id'], rel(p['phantom_filename']), rel(p['matcomp_filename']),

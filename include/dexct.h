@@ -124,6 +124,17 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
                                  float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
                                  float* variance, void* stream);
 
+/* Cone-beam (3-D) projection, SURVEY 8f.4: the fan of dexct_fan_plan in the (x, y) plane, source at height
+ * src_z, detector row r at height row_z[r] (device float64 [n_rows], cm, z = 0 at the centre of the grid;
+ * geom->z_first is ignored).  max_abs_dz = max_r |row_z[r] - src_z| (the caller knows it; it bounds the z
+ * slope: at most one z-plane may be crossed per dominant-axis slab, else DEXCT_ERANGE).  One thread per ray;
+ * counts / pathlen in layout 0 of dexct_siddon_project; every material is accumulated directly. */
+int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
+                       const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
+                       int32_t view_begin, int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
+                       int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
+                       const float* weights, float* counts, float* pathlen, void* stream);
+
 /* counts += sqrt(variance) * z, z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
  * channel, spectrum) and key seed: independent of view sharding and of the layout (0 / 1 as above).
  * Results are clipped at 1e-20 so that a log sinogram stays finite. */

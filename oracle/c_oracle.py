@@ -124,3 +124,22 @@ def count_segments(g, plan_table, n_threads=0):
     plan_table = np.ascontiguousarray(plan_table)
     return lib().orc_count_segments(C.byref(g), _p(plan_table), C.c_long(plan_table.size),
                                     int(n_threads or max_threads()))
+
+
+def project_cone(g, view_cs, chan_cs, view_begin, view_end, row_z, src_z, vol, mu, w, dda=False, n_threads=1):
+    """Cone-beam projection: classic float64 3-D Siddon (dda=False) or the kernel-arithmetic mirror (dda=True).
+    Returns counts [S, nV, rows, ch] float64 and pathlen [nV, rows, ch, M] (float64 classic / float32 mirror)."""
+    mu = np.ascontiguousarray(mu, np.float64)
+    w = np.ascontiguousarray(w, np.float64)
+    vol = np.ascontiguousarray(vol, np.uint8)
+    row_z = np.ascontiguousarray(row_z, np.float64)
+    n_mat, n_e = mu.shape
+    n_spec = w.shape[0]
+    nV = view_end - view_begin
+    counts = np.zeros((n_spec, nV, g.n_rows, g.n_channels), np.float64)
+    plc = np.zeros((nV, g.n_rows, g.n_channels, n_mat), np.float64) if not dda else None
+    pld = np.zeros((nV, g.n_rows, g.n_channels, n_mat), np.float32) if dda else None
+    lib().orc_project_cone(C.byref(g), _p(view_cs), _p(chan_cs), int(view_begin), int(view_end), _p(row_z),
+                           C.c_double(src_z), _p(vol), n_mat, n_e, n_spec, _p(mu), _p(w), _p(counts), _p(plc), _p(pld),
+                           int(bool(dda)), int(n_threads))
+    return counts, (pld if dda else plc)

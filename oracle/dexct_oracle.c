@@ -357,6 +357,172 @@ void orc_project_dda(const dexct_fan_geom* g, const double* view_cs, const doubl
   }
 }
 
+
+/* ------------------------------------------------------------------ cone beam (3-D rays)
+ * SURVEY 8f.4.  Same fan in the (x, y) plane; the source sits at height src_z, detector row r at height
+ * row_z[r] (both in cm, z = 0 is the centre of the grid), so a ray climbs linearly in z along its path. */
+
+/* Textbook Siddon 1985 in three dimensions, float64.  voxel = (iz*ny + iy)*nx + ix, len in cm. */
+int orc_siddon_classic_ray3d(const dexct_fan_geom* g, const double* view_cs, const double* chan_cs, int view, int chan,
+                             double src_z, double det_z, int max_seg, int32_t* voxel, double* len) {
+  double x1, y1, ex, ey;
+  ray_endpoints(g, view_cs, chan_cs, view, chan, &x1, &y1, &ex, &ey);
+  double p1[3] = {x1, y1, src_z};
+  double p2[3] = {x1 + g->sdd * ex, y1 + g->sdd * ey, det_z};
+  double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  int n3[3] = {g->nx, g->ny, g->nz};
+  double h[3] = {g->dx, g->dy, g->dz};
+  double o[3] = {-0.5 * g->nx * g->dx, -0.5 * g->ny * g->dy, -0.5 * g->nz * g->dz};
+  double dconv = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double amin = 0.0, amax = 1.0;
+  for (int a = 0; a < 3; ++a) {
+    if (d[a] != 0.0) {
+      double a0 = (o[a] - p1[a]) / d[a], a1 = (o[a] + n3[a] * h[a] - p1[a]) / d[a];
+      amin = fmax(amin, fmin(a0, a1));
+      amax = fmin(amax, fmax(a0, a1));
+    } else if (p1[a] <= o[a] || p1[a] >= o[a] + n3[a] * h[a]) {
+      return 0;
+    }
+  }
+  if (amin >= amax) return 0;
+  int cap = g->nx + g->ny + g->nz + 6;
+  double* al = (double*)malloc(sizeof(double) * cap);
+  int n = 0;
+  al[n++] = amin;
+  al[n++] = amax;
+  for (int a = 0; a < 3; ++a)
+    if (d[a] != 0.0)
+      for (int i = 0; i <= n3[a]; ++i) {
+        double q = (o[a] + i * h[a] - p1[a]) / d[a];
+        if (q > amin && q < amax) al[n++] = q;
+      }
+  qsort(al, n, sizeof(double), cmp_double);
+  int nseg = 0;
+  for (int k = 1; k < n; ++k) {
+    double l = (al[k] - al[k - 1]) * dconv;
+    if (l <= 0.0) continue;
+    double am = 0.5 * (al[k] + al[k - 1]);
+    int idx[3], ok = 1;
+    for (int a = 0; a < 3; ++a) {
+      idx[a] = (int)floor((p1[a] + am * d[a] - o[a]) / h[a]);
+      if (idx[a] < 0 || idx[a] >= n3[a]) ok = 0;
+    }
+    if (!ok) continue;
+    if (nseg < max_seg) {
+      voxel[nseg] = (idx[2] * g->ny + idx[1]) * g->nx + idx[0];
+      len[nseg] = l;
+    }
+    ++nseg;
+  }
+  free(al);
+  return nseg;
+}
+
+/* z part of the plan of one (view, channel, row): fixed-point w(u) = (W0 + i*SW)/2^40 at the entry face of
+ * slab i, crossing factor, and the 3-D path length per unit u.  Mirrors cone_row_plan in siddon_cone.hip. */
+typedef struct { int64_t W0, SW; float kfw, len3d; uint32_t wpos; } orc_cone_row;
+
+static void cone_row_plan(const dexct_fan_geom* g, const double* view_cs, const double* chan_cs, int view, int chan,
+                          const dexct_ray_plan* p, double src_z, double det_z, orc_cone_row* c) {
+  double sx, sy, ex, ey;
+  ray_endpoints(g, view_cs, chan_cs, view, chan, &sx, &sy, &ex, &ey);
+  int axis = p->flags & 1u;
+  double su = axis == 0 ? sx / g->dx + 0.5 * g->nx : sy / g->dy + 0.5 * g->ny;
+  double eu = axis == 0 ? ex / g->dx : ey / g->dy;
+  double ws = src_z / g->dz + 0.5 * g->nz;
+  double sw = ((det_z - src_z) / g->dz) / (g->sdd * eu);
+  double w0 = ws - su * sw;
+  c->SW = (int64_t)llrint(sw * FIX_ONE);
+  c->W0 = (int64_t)llrint(w0 * FIX_ONE);
+  double inv = 16777216.0;
+  if (c->SW != 0) inv = fmin(FIX_ONE / fabs((double)c->SW), 16777216.0);
+  c->kfw = (float)(inv * (1.0 / 4294967296.0));
+  double tz = (det_z - src_z) / g->sdd;
+  c->len3d = (float)((1.0 / fabs(eu)) * sqrt(1.0 + tz * tz));
+  c->wpos = c->SW > 0 ? 0xFFFFFFFFu : 0u;
+}
+
+/* Per-material path lengths [cm] of one cone-beam ray, float32, in the kernel's arithmetic: per slab the
+ * pieces are cut at the v-crossing tv and the z-crossing tw (each at most one per slab), visited in order and
+ * added to acc[id] when inside the grid.  All materials, material 0 included, are accumulated directly. */
+void orc_cone_pathlen(const dexct_fan_geom* g, const double* view_cs, const double* chan_cs, int view, int chan,
+                      const dexct_ray_plan* p, double src_z, double det_z, const uint8_t* vol, int n_mat, float* L) {
+  orc_cone_row c;
+  cone_row_plan(g, view_cs, chan_cs, view, chan, p, src_z, det_z, &c);
+  float acc[256];
+  for (int m = 0; m < 256; ++m) acc[m] = 0.0f;
+  int axis = p->flags & 1u;
+  int nv = axis == 0 ? g->ny : g->nx;
+  for (int s = 0; s < p->n_slabs; ++s) {
+    int i = p->i_first + s;
+    int32_t ja, jb;
+    float tv, dummy;
+    dda_slab(p, i, &ja, &jb, &tv, &dummy);
+    int64_t Wa = c.W0 + (int64_t)i * c.SW, Wb = Wa + c.SW;
+    int32_t ka = (int32_t)(Wa >> DEXCT_FIX_FRAC), kb = (int32_t)(Wb >> DEXCT_FIX_FRAC);
+    uint32_t fr = (uint32_t)((uint64_t)Wa >> 8);
+    float tw = fminf((float)(fr ^ c.wpos) * c.kfw, 1.0f);
+    float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
+    int32_t jm = tv <= tw ? jb : ja, km = tv <= tw ? ka : kb;       /* the middle piece */
+    int32_t jj[3] = {ja, jm, jb}, kk[3] = {ka, km, kb};
+    float ll[3] = {t1, t2 - t1, 1.0f - t2};
+    for (int q = 0; q < 3; ++q) {
+      if (jj[q] < 0 || jj[q] >= nv || kk[q] < 0 || kk[q] >= g->nz) continue;
+      int x = axis == 0 ? i : jj[q], y = axis == 0 ? jj[q] : i;
+      int id = vol[((size_t)kk[q] * g->ny + y) * g->nx + x];
+      acc[id] += ll[q];
+    }
+  }
+  for (int m = 0; m < n_mat; ++m) L[m] = acc[m] * c.len3d;
+}
+
+/* Cone-beam projections: classic float64 (pathlen + counts) and the DDA mirror (float32 pathlen, float64
+ * detection on them).  row_z[r] detector heights [cm].  counts[((s*nV + v)*n_rows + r)*n_ch + c]. */
+void orc_project_cone(const dexct_fan_geom* g, const double* view_cs, const double* chan_cs, int view_begin,
+                      int view_end, const double* row_z, double src_z, const uint8_t* vol, int n_mat, int n_e,
+                      int n_spec, const double* mu, const double* w, double* counts, double* pathlen_classic,
+                      float* pathlen_dda, int use_dda, int n_threads) {
+  int nV = view_end - view_begin;
+  int max_seg = g->nx + g->ny + g->nz + 6;
+  long n_vr = (long)nV * g->n_rows;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+  {
+    int32_t* vox = (int32_t*)malloc(sizeof(int32_t) * max_seg);
+    double* len = (double*)malloc(sizeof(double) * max_seg);
+    double L[256], cs[DEXCT_MAX_SPECTRA];
+    float Lf[256];
+#pragma omp for schedule(dynamic, 1)
+    for (long vr = 0; vr < n_vr; ++vr) {
+      int v = (int)(vr / g->n_rows), r = (int)(vr % g->n_rows);
+      for (int c = 0; c < g->n_channels; ++c) {
+        size_t ray = ((size_t)v * g->n_rows + r) * g->n_channels + c;
+        if (use_dda) {
+          dexct_ray_plan p;
+          orc_plan_one(g, view_cs, chan_cs, view_begin + v, c, &p);
+          orc_cone_pathlen(g, view_cs, chan_cs, view_begin + v, c, &p, src_z, row_z[r], vol, n_mat, Lf);
+          for (int m = 0; m < n_mat; ++m) L[m] = (double)Lf[m];
+          if (pathlen_dda)
+            for (int m = 0; m < n_mat; ++m) pathlen_dda[ray * n_mat + m] = Lf[m];
+        } else {
+          int ns = orc_siddon_classic_ray3d(g, view_cs, chan_cs, view_begin + v, c, src_z, row_z[r], max_seg, vox, len);
+          for (int m = 0; m < n_mat; ++m) L[m] = 0.0;
+          for (int k = 0; k < ns; ++k) {
+            int id = vol[vox[k]];
+            if (id < n_mat) L[id] += len[k];
+          }
+          if (pathlen_classic)
+            for (int m = 0; m < n_mat; ++m) pathlen_classic[ray * n_mat + m] = L[m];
+        }
+        detect(L, n_mat, n_e, n_spec, mu, w, cs);
+        for (int s = 0; s < n_spec; ++s)
+          counts[(((size_t)s * nV + v) * g->n_rows + r) * g->n_channels + c] = cs[s];
+      }
+    }
+    free(vox);
+    free(len);
+  }
+}
+
 /* ------------------------------------------------------------------ Gauss-Newton (float64) */
 
 /* Restates matdecomp.py:87-127 per pixel.  i0[k][e], mus[m][e] channel-independent.
