@@ -244,6 +244,24 @@ def main():
         out['single_row'] = {'rays': args.views * args.channels, 'siddon_ms': ms1,
                              'integrals_per_s': args.views * args.channels * sum(n_e_spec) / (ms1 * 1e-3)}
 
+    # ---- cone beam (true 3-D rays, untuned one-thread-per-ray kernel) on a slice of the same scan
+    if not args.skip_single_row and rows >= 8:
+        cv = max(1, min(args.views, 100))
+        ctc = dx.FanBeamGeometry(N_channels=args.channels, N_proj=cv, gamma_fan=0.8230337, SID=60.0, SDD=100.0,
+                                 eid=True, detector_file=det, N_rows=rows, cone=True, h_iso=ph.dz)
+        pjc = fp.Projector(ctc, ph)
+        cc = torch.empty((2, cv, rows, args.channels), dtype=torch.float32, device=dev)
+        pjc.project_tables(mu_d, w_d, out=cc)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        pjc.project_tables(mu_d, w_d, out=cc)
+        e1.record()
+        torch.cuda.synchronize()
+        msc = e0.elapsed_time(e1)
+        out['cone_beam'] = {'rays': cv * rows * args.channels, 'siddon_ms': msc,
+                            'integrals_per_s': cv * rows * args.channels * sum(n_e_spec) / (msc * 1e-3)}
+        del pjc, cc
+
     # ---- CPU baseline: the oracle (float64 textbook Siddon + detection, then float64 Newton) on a bounded
     # sample of the same workload, all host cores
     if not args.no_cpu_baseline:
