@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--gn-precision', default=None, choices=[None, 'f64', 'mixed'])
     ap.add_argument('--kernel', type=int, default=0, help='0 choose, 1 ray-parallel, 2 row-parallel')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=40.0)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--skip-single-row', action='store_true')
     return ap.parse_args()
 
