@@ -70,7 +70,8 @@ def main(argv=None):
 
     import torch.distributed as dist
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
-        dist.init_process_group('nccl')
+        # RCCL; DEXCT_DIST_BACKEND=gloo rehearses the sharded flow on a box with fewer GPUs than ranks
+        dist.init_process_group(os.environ.get('DEXCT_DIST_BACKEND', 'nccl'))
     rank = dist.get_rank() if dist.is_initialized() else 0
 
     cwd = os.getcwd()
