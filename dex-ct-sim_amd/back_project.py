@@ -50,6 +50,8 @@ def recon_device(sino_d, ct, N_matrix, FOV, ramp):
         raise ValueError(f'sinogram {tuple(sino_d.shape)} does not match the scanner ({ct.N_proj} x {ct.N_channels})')
     if abs(ct.theta_tot - 2 * np.pi) > 1e-4:
         raise NotImplementedError('only full 2 pi rotations are reconstructed')
+    if getattr(ct, 'cone', False) and n_rows > 1:
+        raise NotImplementedError('cone-beam sinograms need an FDK reconstruction, which is not part of this engine')
     taps = to_dev(ramp_taps(n_ch, ct.dgamma, ramp), torch.float32, dev)
     weight = to_dev(ct.SID * np.cos(ct.gammas), torch.float32, dev)
     view_cs = to_dev(ct.view_cs(), torch.float64, dev)
