@@ -141,6 +141,16 @@ int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
 int dexct_add_noise(float* counts, const float* variance, int32_t n_spectra, int32_t n_views, int32_t n_rows,
                     int32_t n_channels, int32_t layout, int32_t view_offset, uint64_t seed, void* stream);
 
+/* Exact quantum noise: counts[s][ray] = sum_e gain[e] * Poisson(photons[s][e] * exp(-sum_m mu[m][e] * pathlen[ray][m])),
+ * from the per-material path lengths a projection wrote (pathlen [ray][n_materials], cm, same ray order =
+ * `layout`).  photons = I0 * eta * dE (detected photons per bin), gain = E for an energy-integrating detector,
+ * 1 for a counting one.  Philox counter (view_offset + view, row, channel, spectrum/energy): shard- and
+ * layout-independent.  Inversion below lambda = 30, rounded normal above. */
+int dexct_poisson_detect(const float* pathlen, const float* mu, const float* photons, const float* gain,
+                         int32_t n_materials, int32_t n_energies, int32_t n_spectra, int32_t n_views, int32_t n_rows,
+                         int32_t n_channels, int32_t layout, int32_t view_offset, uint64_t seed, float* counts,
+                         void* stream);
+
 /* dst[b][c][r] = src[b][r][c] for b < batch: [batch][rows][cols] -> [batch][cols][rows], elements of
  * elem_bytes = 4, 8 or 16 bytes (float32 sinograms, float64, the (a0, a1) float64 pairs of the
  * decomposition).  src and dst must not overlap. */

@@ -312,3 +312,41 @@ def test_cone_beam_matches_oracle(hip, n_mat):
     steep = dx.FanBeamGeometry(N_channels=48, N_proj=20, SID=60.0, SDD=100.0, h_iso=30.0, N_rows=4, cone=True)
     with pytest.raises(DexctError):
         projector(steep, ph).project(sp)
+
+
+def test_per_bin_poisson_noise(hip):
+    """noise='poisson': exact photon statistics.  High dose: standardised residuals ~ N(0, 1) against the
+    oracle's compound-Poisson variance.  Photon-counting detector at very low dose: integer counts whose mean,
+    variance and zero fraction follow Poisson(lambda_total); view shards reproduce the unsharded sample."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    ct, ph = small_scan(n=32, nz=64, n_views=40, n_channels=64, n_rows=64)
+    sp = spectra()
+    for s in sp:
+        s.rescale_counts(1e2)
+    clean, _ = projector(ct, ph, kernel=3).project(sp)
+    noisy, _ = projector(ct, ph, kernel=3).project(sp, noise='poisson', seed=11)
+    E, mu, w, w2 = fp.merged_tables(ct, ph, sp, with_variance=True)
+    g = oracle_geom(ct, ph)
+    var = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w2, n_threads=8)
+    zs = (noisy - clean).double().cpu().numpy() / np.sqrt(var)
+    assert abs(zs.mean()) < 0.01 and abs(zs.std() - 1.0) < 0.01
+    a, _ = projector(ct, ph, view_range=(0, 17), kernel=3).project(sp, noise='poisson', seed=11)
+    b, _ = projector(ct, ph, view_range=(17, 40), kernel=1).project(sp, noise='poisson', seed=11)
+    assert torch.allclose(torch.cat([a, b], dim=1), noisy, rtol=1e-6, atol=0)
+    # photon counting, ~3 photons per unattenuated ray
+    pcd = dx.FanBeamGeometry(N_channels=64, N_proj=40, gamma_fan=0.8230337, SID=60.0, SDD=100.0, eid=False, N_rows=64)
+    lo = [dx.xRaySpectrum.from_arrays('lo', s.E, s.I0_raw * 3e-6) for s in sp]
+    ph.volume[:] = 0                                   # air only: lambda is the same for every ray
+    lam = np.array([fp.effective_weights(pcd, s).sum() for s in lo])
+    mean_clean, _ = projector(pcd, ph, kernel=3).project(lo)
+    cnt, _ = projector(pcd, ph, kernel=3).project(lo, noise='poisson', seed=3)
+    c = cnt.cpu().numpy()
+    lam_air = mean_clean.cpu().numpy().mean(axis=(1, 2, 3))          # includes the (tiny) attenuation by air
+    assert np.allclose(lam_air, lam, rtol=2e-2)
+    for s in range(2):
+        x = c[s].ravel()
+        x = np.where(x < 0.5, 0.0, x)                                # the 1e-20 floor stands for 0 photons
+        assert np.all(np.abs(x - np.round(x)) < 1e-6)                # whole photons
+        assert abs(x.mean() - lam_air[s]) < 0.02 * lam_air[s] and abs(x.var() - lam_air[s]) < 0.03 * lam_air[s]
+        assert abs((x == 0).mean() - np.exp(-lam_air[s])) < 0.01
