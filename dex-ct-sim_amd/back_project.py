@@ -73,3 +73,24 @@ def get_recon(sino, ct, spec, N_matrix, FOV, ramp):
     raw = recon_device(sino_d, ct, N_matrix, FOV, ramp).cpu().numpy()
     mu_w = water_mu(ct, spec)
     return raw, (1000.0 * (raw - mu_w) / mu_w).astype(np.float32)
+
+
+def make_vmi(E0, M1, M2, HU=True, matcomp1=None, matcomp2=None):
+    """Virtual monoenergetic image at E0 [keV] from the two basis-material images - the reference's
+    ``make_vmi`` (plots.py:136-144): ``u_p_1 * M1 + u_p_2 * M2`` with the basis mass attenuations at E0, in HU
+    against water ('H(11.2)O(88.8)', plots.py:140) unless ``HU=False``.  float32 out, like the reference."""
+    from . import matdecomp as md
+    lib = _native.load()
+    dev = device()
+    E = np.array([float(E0)])
+    u1 = float(xcompy.mixatten(matcomp1 or md.matcomp1, E)[0])
+    u2 = float(xcompy.mixatten(matcomp2 or md.matcomp2, E)[0])
+    uw = float(xcompy.mixatten(WATER, E)[0])
+    m1 = to_dev(np.asarray(M1, dtype=np.float32), torch.float32, dev)
+    m2 = to_dev(np.asarray(M2, dtype=np.float32), torch.float32, dev)
+    if m1.shape != m2.shape:
+        raise ValueError('basis images differ in shape')
+    out = torch.empty_like(m1)
+    _native.check(lib.dexct_vmi(ptr(m1), ptr(m2), m1.numel(), u1, u2, uw, int(bool(HU)), ptr(out), stream_ptr()),
+                  'dexct_vmi')
+    return out.cpu().numpy()

@@ -209,6 +209,11 @@ int dexct_fbp_backproject(const float* q, const double* view_cs, int32_t n_views
                           int32_t n_rows, double sid, double dgamma, double dbeta, int32_t n_matrix, double fov,
                           float* image, void* stream);
 
+/* Virtual monoenergetic image (plots.py:136-144): out = u1*m1 + u2*m2 (basis-material images m1, m2, n pixels;
+ * u1, u2 mass attenuation of the basis materials at the chosen energy), in HU against u_water when hu != 0. */
+int dexct_vmi(const float* m1, const float* m2, int64_t n, double u1, double u2, double u_water, int32_t hu,
+              float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

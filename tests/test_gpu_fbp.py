@@ -61,3 +61,20 @@ def test_project_then_reconstruct_phantom(hip):
     bone_core = ndimage.binary_erosion(ph.volume[0] == 2, iterations=3)
     if bone_core.sum() > 10:
         assert abs(img[bone_core].mean() - truth[bone_core].mean()) < 0.05 * truth[bone_core].mean()
+
+
+def test_make_vmi_matches_reference_formula(hip):
+    """plots.py:136-144 restated in NumPy by the test: u1*M1 + u2*M2, HU against water."""
+    from dex_ct_sim_amd import back_project as bp, matdecomp as md, xcompy
+    rng = np.random.default_rng(2)
+    M1, M2 = rng.uniform(0, 1.2, (64, 64)), rng.uniform(0, 0.5, (64, 64))
+    for E0 in (40.0, 70.0, 120.0):
+        E = np.array([E0])
+        u1, u2 = xcompy.mixatten(md.matcomp1, E), xcompy.mixatten(md.matcomp2, E)
+        uw = 1.0 * xcompy.mixatten('H(11.2)O(88.8)', E)
+        vmi = u1 * M1 + u2 * M2
+        ref_hu = (1000 * (vmi - uw) / uw).astype(np.float32)
+        got = bp.make_vmi(E0, M1, M2)
+        assert got.dtype == np.float32 and got.shape == (64, 64)
+        assert np.max(np.abs(got - ref_hu)) < 2e-4 * np.abs(ref_hu).max()
+        assert np.allclose(bp.make_vmi(E0, M1, M2, HU=False), vmi.astype(np.float32), rtol=2e-6)
