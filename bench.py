@@ -275,15 +275,32 @@ def main():
                                 n_threads=threads)
         dt = time.perf_counter() - t0
         # scale the sample to about cpu_seconds of work
-        sample_views = int(max(2, min(args.views, sample_views * args.cpu_seconds * 0.5 / max(dt, 1e-3))))
+        # the Newton leg of the same rays costs about 6x the projection leg: aim the pair at cpu_seconds
+        sample_views = int(max(2, min(args.views, sample_views * args.cpu_seconds / 7.0 / max(dt, 1e-3))))
         t0 = time.perf_counter()
         cs = co.project_classic(gs, ct.view_cs(), ct.chan_cs(), 0, sample_views, ph.volume, mu64, w64,
                                 n_threads=threads)
         t_proj = time.perf_counter() - t0
         n_sample = sample_views * sample_rows * args.channels
+        # the Newton leg runs on the GPU's own (float32) sinogram values of those rays, so that its result is at
+        # the same time the parity reference for the GPU decomposition at benchmark scale
+        r0 = n // 2 - sample_rows // 2
+        have_gpu = world == 1 and rows == n and sample_views <= nV
+        g_cnt = counts[:, :sample_views, r0:r0 + sample_rows, :].double().cpu().numpy() if have_gpu else cs
         t0 = time.perf_counter()
-        co.gn_decompose(cs[0].ravel(), cs[1].ravel(), i0, mus, args.iters, n_threads=threads)
+        a_cpu = co.gn_decompose(g_cnt[0].ravel(), g_cnt[1].ravel(), i0, mus, args.iters, n_threads=threads)
         t_gn_cpu = time.perf_counter() - t0
+        if have_gpu:
+            a_gpu = a_out[:sample_views, r0:r0 + sample_rows].cpu().numpy().reshape(-1, 2)
+            live = (a_gpu != 0).any(axis=1) & np.isfinite(a_cpu).all(axis=1)        # masked air pixels are exactly 0
+            out['parity_sample'] = {
+                'rays': n_sample,
+                'sinogram_max_rel_err_vs_float64_siddon': float(np.max(np.abs(g_cnt - cs) / cs)),
+                'decomposition_max_err_vs_float64_newton': float(np.max(
+                    np.abs(a_gpu[live] - a_cpu[live]) / np.maximum(np.abs(a_cpu[live]), 1.0))),
+                'decomposed_pixels_compared': int(live.sum()),
+                'note': 'oracle (CPU) results of the cpu_baseline sample against the GPU results of the same rays of '
+                        'the timed step; tolerances of the north star: 1e-5'}
         out['cpu_baseline'] = {'value': n_sample * sum(n_e_spec) / (t_proj + t_gn_cpu), 'unit': 'ray-energy integrals/s',
                                'cores': threads, 'kind': 'port',
                                'sample': f'{sample_views} views x {sample_rows} rows x {args.channels} channels of the same '
