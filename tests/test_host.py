@@ -182,3 +182,24 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_fbp_backproject(one, one, 10, 16, 1, 60.0, 0.0, 0.1, 32, 20.0, one, None) == EINVAL
     for code, text in ((0, b'ok'), (-1, b'invalid argument'), (-3, b'HIP runtime error (see dexct_last_hip_error)')):
         assert lib.dexct_strerror(code) == text
+
+
+def test_xcom_directory_tables_override_the_surrogate(tmp_path, monkeypatch):
+    """Real NIST tables can be supplied as <Symbol>.txt files (E [keV], mu/rho [cm^2/g]); mixtures are then
+    weight-fraction sums of log-log interpolated element tables."""
+    import importlib
+    from dex_ct_sim_amd import xcompy
+    E = np.array([10.0, 100.0, 1000.0])
+    (tmp_path / 'H.txt').write_text('\n'.join(f'{e} {m}' for e, m in zip(E, [0.4, 0.3, 0.1])))
+    (tmp_path / 'O.txt').write_text('\n'.join(f'{e} {m}' for e, m in zip(E, [6.0, 0.15, 0.07])))
+    monkeypatch.setenv('DEXCT_XCOM_DIR', str(tmp_path))
+    saved = dict(xcompy._user_tables)
+    try:
+        xcompy._user_tables.clear()
+        got = xcompy.mixatten('H(11.2)O(88.8)', np.array([100.0]))[0]
+        assert np.isclose(got, 0.112 * 0.3 + 0.888 * 0.15)
+        mid = xcompy.mixatten('O(100)', np.array([np.sqrt(10.0 * 100.0)]))[0]
+        assert np.isclose(mid, np.sqrt(6.0 * 0.15))                     # log-log interpolation
+    finally:
+        xcompy._user_tables.clear()
+        xcompy._user_tables.update(saved)
