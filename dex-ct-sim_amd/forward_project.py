@@ -67,8 +67,20 @@ class Projector:
         half_diag = 0.5 * np.hypot(phantom.Nx * phantom.dx, phantom.Ny * phantom.dy)
         if ct.SID <= half_diag or ct.SDD - ct.SID < 0:
             raise ValueError('source must lie outside the phantom grid (SID > half diagonal) and SDD >= SID')
+        volume, nz = phantom.volume, phantom.Nz
+        if int(volume.max()) >= phantom.n_materials:
+            raise ValueError('the volume holds a material id without a table entry')
+        # The 4-rows-per-lane kernels read aligned dwords along z: pad the uploaded copy with empty slices so that
+        # the first imaged slice and the slice count are multiples of 4 (stacked fans only see their own slices,
+        # the in-plane geometry does not change).
+        packed_wanted = kernel in (3, 4) or (kernel == 0 and ct.N_rows >= 64 and phantom.n_materials <= 16)
+        if not self.cone and packed_wanted and (nz % 4 or z_first % 4):
+            lead = (-z_first) % 4
+            tail = (-(nz + lead)) % 4
+            volume = np.pad(volume, ((lead, tail), (0, 0), (0, 0)))
+            z_first, nz = z_first + lead, nz + lead + tail
         self.geom = _native.FanGeom(ct.N_proj, ct.N_channels, ct.N_rows, z_first, phantom.Nx, phantom.Ny,
-                                    phantom.Nz, 0, phantom.dx, phantom.dy, phantom.dz, ct.SID, ct.SDD)
+                                    nz, 0, phantom.dx, phantom.dy, phantom.dz, ct.SID, ct.SDD)
         st = stream_ptr()
         self.view_cs = to_dev(ct.view_cs(), torch.float64, self.dev)
         self.chan_cs = to_dev(ct.chan_cs(), torch.float64, self.dev)
@@ -76,19 +88,17 @@ class Projector:
         self.plan = torch.empty(n_local * ct.N_channels * _native.PLAN_BYTES, dtype=torch.uint8, device=self.dev)
         _native.check(self.lib.dexct_fan_plan(C.byref(self.geom), ptr(self.view_cs), ptr(self.chan_cs),
                                               self.view_begin, self.view_end, ptr(self.plan), st), 'dexct_fan_plan')
-        if int(phantom.volume.max()) >= phantom.n_materials:
-            raise ValueError('the volume holds a material id without a table entry')
-        self.vol_yx = to_dev(phantom.volume, torch.uint8, self.dev)
+        self.vol_yx = to_dev(volume, torch.uint8, self.dev)
         self.vol_xy = torch.empty_like(self.vol_yx)
         if self.cone:
             kernel = self.kernel = 1          # cone beam has its own ray-parallel kernel (dexct_cone_project)
             self.row_z = to_dev(ct.row_z(), torch.float64, self.dev)
         want_zf = kernel in (2, 3, 4) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
-        _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, phantom.Nz,
+        _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz,
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
         M = phantom.n_materials
-        aligned = phantom.Nz % 4 == 0 and z_first % 4 == 0
+        aligned = nz % 4 == 0 and z_first % 4 == 0
         self.grouped = kernel == 4 or (kernel == 0 and want_zf and 4 < M <= 16 and aligned)
         self.codes = None
         if self.grouped:

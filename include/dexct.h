@@ -100,7 +100,8 @@ int dexct_fan_plan(const dexct_fan_geom* geom, const double* view_cs, const doub
  * ray-parallel kernel is used for every shape).
  * kernel: 0 = choose, 1 = ray-parallel (one thread per ray), 2 = row-parallel (one workgroup
  * per (view, channel), one detector row per lane), 3 = row-parallel with 4 rows per lane and packed
- * integer counts (needs vol_zf, 2..4 materials, nz and z_first multiples of 4).
+ * integer counts (needs vol_zf, 2..4 materials, nz and z_first multiples of 4 - the Python shim pads the
+ * uploaded volume with empty slices to get there).
  * Precondition: every voxel id is < n_materials (ids outside are ignored by kernels 1 and 2 and
  * give unspecified - but memory-safe - results in kernel 3). */
 int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
