@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void group_codes_kernel(const uint8_t* __restr
   }
 }
 
-constexpr int kMaxGrouped = 16;
+constexpr int kMaxGrouped = DEXCT_MAX_MATERIALS;   // register detect kernels up to 16, LDS columns beyond
 
 // One thread per ray, in memory order of the chosen layout; NMAT = exact number of materials (fully unrolled:
 // a version with 16 predicated material slots spent its time in scalar branches).
@@ -743,6 +743,29 @@ __global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __
     valid[k] = true;
   }
   detect_store<NMAT, R>(L, a, mu, w, w2, rays, valid);
+}
+
+// More than 16 materials: lengths in per-thread LDS columns (one ray per thread), run-time material loop.
+__global__ __launch_bounds__(kLdsBlock) void detect_kernel_lds(ProjArgs a, const float* __restrict__ mu,
+                                                               const float* __restrict__ w, const float* __restrict__ w2) {
+  extern __shared__ float lds_L[];     // [n_materials][kLdsBlock]
+  const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const size_t ray = (size_t)blockIdx.x * kLdsBlock + threadIdx.x;
+  if (ray >= n_rays) return;
+  const int tid = threadIdx.x;
+  size_t q = ray;
+  int v, c;
+  if (a.layout == 0) { c = q % a.g.n_channels; q /= a.g.n_channels; v = (int)(q / a.g.n_rows); }
+  else               { q /= a.g.n_rows; c = q % a.g.n_channels; v = (int)(q / a.g.n_channels); }
+  const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];
+  float others = 0.0f;
+  for (int m = 1; m < a.n_materials; ++m) {
+    const float l = a.acc_out[(size_t)m * n_rays + ray];
+    lds_L[m * kLdsBlock + tid] = l * p.len_per_u;
+    others += l;
+  }
+  lds_L[tid] = (p.chord_u - others) * p.len_per_u;
+  detect_store_lds(lds_L, tid, kLdsBlock, a, mu, w, w2, ray);
 }
 
 template <int NMAT>
@@ -978,8 +1001,16 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
     case 13: return launch_detect<13>(a, t, st);
     case 14: return launch_detect<14>(a, t, st);
     case 15: return launch_detect<15>(a, t, st);
-    default: return launch_detect<16>(a, t, st);
+    case 16: return launch_detect<16>(a, t, st);
+    default: break;
   }
+  const size_t n_rays = (size_t)a.n_local_views * geom->n_rows * geom->n_channels;
+  const size_t nblk = (n_rays + kLdsBlock - 1) / kLdsBlock;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(detect_kernel_lds, dim3((unsigned)nblk), dim3(kLdsBlock), (size_t)n_materials * kLdsBlock * sizeof(float),
+                     st, a, t.mu, t.w, t.w2);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
 }
 
 int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const int32_t* ray_vrc, int32_t n_rays,

@@ -48,7 +48,7 @@ class Projector:
     ``view_range`` restricts the instance to a contiguous shard of projection angles (one per
     rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel (1 row per lane),
     3 row-parallel with 4 rows per lane (<= 4 materials, Nz and z_index multiples of 4), 4 the same kernel
-    run once per group of three materials (5..16 materials).
+    run once per group of three materials (5..48 materials).
     """
 
     def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
@@ -73,7 +73,7 @@ class Projector:
         # The 4-rows-per-lane kernels read aligned dwords along z: pad the uploaded copy with empty slices so that
         # the first imaged slice and the slice count are multiples of 4 (stacked fans only see their own slices,
         # the in-plane geometry does not change).
-        packed_wanted = kernel in (3, 4) or (kernel == 0 and ct.N_rows >= 64 and phantom.n_materials <= 16)
+        packed_wanted = kernel in (3, 4) or (kernel == 0 and ct.N_rows >= 64)
         if not self.cone and packed_wanted and (nz % 4 or z_first % 4):
             lead = (-z_first) % 4
             tail = (-(nz + lead)) % 4
@@ -99,11 +99,11 @@ class Projector:
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
         M = phantom.n_materials
         aligned = nz % 4 == 0 and z_first % 4 == 0
-        self.grouped = kernel == 4 or (kernel == 0 and want_zf and 4 < M <= 16 and aligned)
+        self.grouped = kernel == 4 or (kernel == 0 and want_zf and M > 4 and aligned)
         self.codes = None
         if self.grouped:
-            if not (2 <= M <= 16 and aligned):
-                raise ValueError('kernel 4 needs 2..16 materials and Nz, z_index multiples of 4')
+            if not (2 <= M <= 48 and aligned):
+                raise ValueError('kernel 4 needs 2..48 materials')
             n_groups = (M - 1 + 2) // 3
             self.codes = torch.empty((n_groups,) + tuple(self.vol_zf.shape), dtype=torch.uint8, device=self.dev)
             _native.check(self.lib.dexct_volume_groups(ptr(self.vol_zf), self.vol_zf.numel(), M, ptr(self.codes), st),

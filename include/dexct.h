@@ -111,7 +111,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
                          float* pathlen, int32_t kernel, int32_t layout, const float* weights2, float* variance,
                          void* stream);
 
-/* Fast path for 5..16 materials (stacked fan, nz and z_first multiples of 4).
+/* Fast path for 5..DEXCT_MAX_MATERIALS materials (stacked fan, nz and z_first multiples of 4).
  * dexct_volume_groups: codes[g][voxel] for g < ceil((n_materials-1)/3): ids 3g+1..3g+3 of the z-fastest
  *   volume -> 1..3, all other ids -> 0 (n_groups * n_voxels bytes).
  * dexct_siddon_project_grouped: one packed-count traversal per group writes raw per-material accumulators

@@ -88,7 +88,7 @@ def test_voxel_index_sequence_bit_exact(hip, n, nv, nc):
 
 
 @pytest.mark.parametrize('kernel', [1, 2, 3, 4])
-@pytest.mark.parametrize('n_mat', [2, 3, 4, 7, 13, 16])
+@pytest.mark.parametrize('n_mat', [2, 3, 4, 7, 13, 16, 29])
 def test_pathlen_bit_exact_and_counts(hip, kernel, n_mat):
     """Register accumulators (<= 4 materials), LDS accumulators (more), the packed-count 4-rows-per-lane
     kernel and its material-group form (kernel 4, up to 16 materials); 66 rows from slice 2 of 70: neither a
