@@ -67,7 +67,7 @@ def load():
     lib.dexct_fbp_filter.argtypes = [vp, vp, vp, i64, i32, f64, vp, vp]
     lib.dexct_fbp_backproject.argtypes = [vp, vp, i32, i32, i32, f64, f64, f64, i32, f64, vp, vp]
     lib.dexct_siddon_trace.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp, vp, vp]
-    lib.dexct_gn_decompose.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.dexct_gn_decompose.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, f64, vp, vp, vp]
     lib.dexct_gn_workspace_bytes.argtypes = [i32, i32]
     lib.dexct_gn_workspace_bytes.restype = i64
     lib.dexct_gn_apply_mask.argtypes = [vp, i32, i64, f64, vp, vp]

@@ -233,6 +233,7 @@ template <bool MIXED, bool PER_BIN>
 __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                       int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                       int n_e, int n_iters, int n_polish, int n_bins, int bin_div,
+                                                      const double* __restrict__ mask_max, double mask_frac,
                                                       double* __restrict__ out_a) {
   __shared__ double lds_pow[kPowN];     // 2^(j/2048), 16 KB
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
@@ -244,6 +245,13 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   const double* __restrict__ tab = ws + kWsHeader;
   if (PER_BIN) tab += (size_t)((p / bin_div) % n_bins) * n_e * kTab;
   const double gd0 = load_g<double>(g1, g_is_f64, p), gd1 = load_g<double>(g2, g_is_f64, p);
+  // Fused air mask of get_basismat_sinos (matdecomp.py:195-196, :204-205): a pixel with g1 >= frac * max is set
+  // to 0 afterwards whatever the iteration produced, so its iterations are not run at all.
+  if (mask_max && gd0 >= mask_frac * mask_max[0]) {
+    out_a[2 * p] = 0.0;
+    out_a[2 * p + 1] = 0.0;
+    return;
+  }
   double a0 = 1e-6, a1 = 1e-6;
   int it = 0;
   if (MIXED) {
@@ -321,7 +329,8 @@ int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins) {
 
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,
-                       int32_t precision, int32_t n_polish, double* out_a, void* workspace, void* stream) {
+                       int32_t precision, int32_t n_polish, const double* mask_max, double mask_frac, double* out_a,
+                       void* workspace, void* stream) {
   if (!g1 || !g2 || !i0 || !mus || !out_a || !workspace || n_pix <= 0 || n_energies <= 0 || n_iters < 0)
     return DEXCT_EINVAL;
   if (n_bins < 1 || bin_div < 1 || n_bins > 65535) return DEXCT_EINVAL;
@@ -338,13 +347,13 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   const dim3 grid((unsigned)nblk), block(kGnBlock);
   if (n_bins > 1) {
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, 0, n_bins, bin_div, out_a);
+                       n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, out_a);
   } else if (precision == 0) {
     hipLaunchKernelGGL((gn_kernel<false, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, 0, 1, 1, out_a);
+                       n_energies, n_iters, 0, 1, 1, mask_max, mask_frac, out_a);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, n_polish, 1, 1, out_a);
+                       n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, out_a);
   }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

@@ -45,9 +45,12 @@ def _as_device_counts(x, dev):
     return to_dev(a.astype(np.float32 if dt == torch.float32 else np.float64, copy=False), dt, dev)
 
 
-def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1):
+def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1, mask_max=None,
+              mask_frac=0.95):
     """g1, g2: device tensors of equal shape; mus: [2, nE] float64; i0: [2, nE] (one spectrum for all
     pixels) or [2, nBins, nE] (pixel p uses row (p // bin_div) % nBins: the reference's general layout).
+    ``mask_max``: device float64 scalar (the global maximum of sinogram 1) - pixels with g1 >= mask_frac * max are
+    the air pixels get_basismat_sinos zeroes (:204-205); they are written as 0 and not iterated.
     Returns a device tensor of shape g1.shape + (2,) float64."""
     lib = _native.load()
     dev = g1.device
@@ -69,7 +72,8 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, n_bins), dtype=torch.uint8, device=dev)
     _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), int(g1.dtype == torch.float64), g1.numel(), ptr(i0_d),
                                          ptr(mus_d), n_e, n_bins, int(bin_div), int(n_iters),
-                                         int(precision == 'mixed'), int(n_polish), ptr(a), ptr(ws), stream_ptr()),
+                                         int(precision == 'mixed'), int(n_polish), ptr(mask_max), float(mask_frac), ptr(a),
+                                         ptr(ws), stream_ptr()),
                   'dexct_gn_decompose')
     return a
 
@@ -143,10 +147,8 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     gmax = torch.empty((), dtype=torch.float64, device=dev)
     _native.check(lib.dexct_reduce_max(ptr(g1), is64, g1.numel(), ptr(gmax), stream_ptr()), 'dexct_reduce_max')
     gmax = _shard.global_max(gmax)
-    a = gn_device(g1, g2, i0, mus, n_iters, precision)
-    thresh = float(mask_thresh) * float(gmax.item())
-    _native.check(lib.dexct_gn_apply_mask(ptr(g1), is64, g1.numel(), thresh, ptr(a), stream_ptr()),
-                  'dexct_gn_apply_mask')
+    # the mask is applied inside the kernel (threshold read from the device scalar: no host round trip)
+    a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh))
     if full_in:
         a = _shard.gather_views(a, n_views, view_dim=0)
     if isinstance(sino_raw_1, torch.Tensor):

@@ -182,12 +182,16 @@ int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
  *              1 = float32 bulk iterations followed by float64 polish iterations; a pixel the
  *                  polish is still moving is redone in float64 from the start (n_bins == 1 only)
  *   n_polish   number of trailing float64 iterations when precision == 1
+ *   mask_max   NULL, or a device float64 scalar (e.g. from dexct_reduce_max, all-reduced over ranks): pixels with
+ *              g1 >= mask_frac * *mask_max are the air pixels get_basismat_sinos zeroes afterwards
+ *              (matdecomp.py:195-196, :204-205); they get (0, 0) directly and their iterations are skipped
  *   workspace  device scratch of dexct_gn_workspace_bytes(n_energies, n_bins) bytes (the product tables
  *              the kernel reads through the scalar cache); owned by the caller, no hidden state */
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,
-                       int32_t precision, int32_t n_polish, double* out_a, void* workspace, void* stream);
+                       int32_t precision, int32_t n_polish, const double* mask_max, double mask_frac, double* out_a,
+                       void* workspace, void* stream);
 
 /* Air mask of get_basismat_sinos (matdecomp.py:194-205): out_a[2p], out_a[2p+1] = 0 wherever
  * g1[p] >= thresh_value (thresh_value = mask_thresh * global max, computed by the caller so that a

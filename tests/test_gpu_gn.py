@@ -182,7 +182,7 @@ def test_entry_points_are_graph_capturable(hip):
                                                None, 3, 1, None, None, st), 'project')
         _native.check(lib.dexct_reduce_max(ptr(counts[0]), 0, counts[0].numel(), ptr(gmax), st), 'max')
         _native.check(lib.dexct_gn_decompose(ptr(counts[0]), ptr(counts[1]), 0, counts[0].numel(), ptr(i0_d), ptr(mus_d),
-                                             i0.shape[1], 1, 1, 30, 0, 0, ptr(a), ptr(ws), st), 'gn')
+                                             i0.shape[1], 1, 1, 30, 0, 0, None, 0.0, ptr(a), ptr(ws), st), 'gn')
         _native.check(lib.dexct_gn_apply_mask(ptr(counts[0]), 0, counts[0].numel(), 1e30, ptr(a), st), 'mask')
         _native.check(lib.dexct_transpose_batched(ptr(a), ptr(a_ref_order), 10, 40, 8, 16, st), 'transpose')
 

@@ -172,10 +172,10 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 7, None, None, None) == EINVAL   # layout
     assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 0, one, None, None) == EINVAL   # weights2 without variance
     assert lib.dexct_add_noise(one, one, 2, 4, 1, 8, 2, 0, 1, None) == EINVAL
-    assert lib.dexct_gn_decompose(one, one, 1, 0, one, one, 10, 1, 1, 5, 0, 0, one, one, None) == EINVAL    # no pixels
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 2, 0, one, one, None) == EINVAL    # precision
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 8, 1, 5, 1, 0, one, one, None) == EINVAL    # mixed + per-bin
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, one, one, None) == ERANGE  # energies
+    assert lib.dexct_gn_decompose(one, one, 1, 0, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == EINVAL    # no pixels
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 2, 0, None, 0.0, one, one, None) == EINVAL    # precision
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 8, 1, 5, 1, 0, None, 0.0, one, one, None) == EINVAL    # mixed + per-bin
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == ERANGE  # energies
     assert lib.dexct_gn_workspace_bytes(140, 1) > 140 * 14 * 12 and lib.dexct_gn_workspace_bytes(0, 1) == 0
     assert lib.dexct_transpose_batched(one, one, 1, 4, 4, 3, None) == EINVAL            # element size
     assert lib.dexct_fbp_filter(one, one, one, 1, 1, 0.01, one, None) == EINVAL
