@@ -51,7 +51,7 @@ __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ l
 // (nB), only spectrum 1 (nC); energies no spectrum weights are dropped.  A zero weight contributes exactly
 // 0 to every sum (the attenuation factor is finite thanks to the clip), so skipping those FMAs changes no
 // term of the reference's sums - only their order.
-template <int KSEL>   // 0: both measurements, 1: only k = 0, 2: only k = 1
+template <int KSEL, bool CLIP>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip
 __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 int e0, int e1, double a0, double a1, double (&nu)[2], double (&G0)[2],
                                                 double (&G1)[2], double (&H00)[2], double (&H01)[2], double (&H11)[2]) {
@@ -59,7 +59,7 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
   for (int e = e0; e < e1; ++e) {
     const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
     double x = -fma(a1, t[1], a0 * t[0]);
-    x = fmin(fmax(x, -700.0), 700.0);
+    if (CLIP) x = fmin(fmax(x, -700.0), 700.0);
     const double at = exp_tab(x, lds_pow);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -75,14 +75,29 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
   }
 }
 
-struct EnergyClasses { int nA, nB, nC; };
+// Each class is stored as [energies that always need the clip (large mu) | energies whose exponent is provably
+// within +-700 whenever |a0| * mu0_free_max + |a1| * mu1_free_max <= 700]: for the second part the clip of
+// matdecomp.py:116 is the identity and is skipped (two FP64 instructions per energy), bit for bit the same result.
+struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; };
 
 __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
   double nu[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
-  energy_sums_f64<0>(tab, lds_pow, 0, ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
-  energy_sums_f64<1>(tab, lds_pow, ec.nA, ec.nA + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
-  energy_sums_f64<2>(tab, lds_pow, ec.nA + ec.nB, ec.nA + ec.nB + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
+  const int bA = 0, bB = ec.nA, bC = ec.nA + ec.nB;
+  // the always-clipped heads of the three classes
+  energy_sums_f64<0, true>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<1, true>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<2, true>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, G0, G1, H00, H01, H11);
+  // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
+  if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 700.0) {
+    energy_sums_f64<0, false>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, false>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, false>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
+  } else {
+    energy_sums_f64<0, true>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, true>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, true>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
+  }
   const double g[2] = {g0, g1};
   double dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
 #pragma unroll
@@ -144,9 +159,10 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, E
   a1 -= (h00 * dF1 - h01 * dF0) / det;
 }
 
-// Workspace layout (doubles): [0] = scale of the float32 tables, [1..3] = nA, nB, nC (energy classes),
-// [4..7] pad, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
-constexpr int kWsHeader = 8;
+// Workspace layout (doubles): [0] = scale of the float32 tables, [1..3] = nA, nB, nC (energy classes), [4..6] =
+// how many of each class come first and always need the clip, [7..8] = max mu0 / mu1 over the clip-free parts,
+// pad to 16, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
+constexpr int kWsHeader = 16;
 
 // One block per spectrum row ("bin": 1 for the channel-independent case, else one per detector channel).
 // i0 is [2][n_bins][n_e].  With several bins the energies are NOT sorted into classes (they may differ
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
   // float32 tables are scaled by one power of two common to both measurements (the Newton step is
   // invariant under a common scaling of counts and spectra) so that sums stay near 1.
   __shared__ double s_scale;
-  __shared__ int s_n[3];
+  __shared__ int s_n[3], s_nc[3];
   const int bin = blockIdx.x;
   const double* __restrict__ i00 = i0 + (size_t)bin * n_e;                       // k = 0
   const double* __restrict__ i01 = i0 + ((size_t)n_bins + bin) * n_e;            // k = 1
@@ -170,26 +186,43 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
     frexp(fmax(s0, s1), &ex);
     s_scale = ldexp(1.0, -ex);
     int n = 0;
+    double m0f = 0.0, m1f = 0.0;
     if (n_bins == 1) {
-      // stable partition of the energies into the classes A (both), B (only 0), C (only 1)
+      // stable partition of the energies into the classes A (both), B (only 0), C (only 1), each split into
+      // [large attenuation: clip always | the rest]; kMuFree = 4 cm^2/g keeps the bound valid up to
+      // |a0| + |a1| = 175 g/cm^2, far beyond any physical ray
+      const double kMuFree = 4.0;
       for (int cls = 0; cls < 3; ++cls) {
-        int cnt = 0;
-        for (int e = 0; e < n_e; ++e) {
-          const bool z0 = i00[e] == 0.0, z1 = i01[e] == 0.0;
-          const int c = (!z0 && !z1) ? 0 : (!z0 ? 1 : (!z1 ? 2 : 3));
-          if (c == cls) { perm[n++] = e; ++cnt; }
+        for (int part = 0; part < 2; ++part) {
+          int cnt = 0;
+          for (int e = 0; e < n_e; ++e) {
+            const bool z0 = i00[e] == 0.0, z1 = i01[e] == 0.0;
+            const int c = (!z0 && !z1) ? 0 : (!z0 ? 1 : (!z1 ? 2 : 3));
+            const bool big = !(fmax(fabs(mus[e]), fabs(mus[n_e + e])) <= kMuFree);
+            if (c == cls && big == (part == 0)) {
+              perm[n++] = e;
+              ++cnt;
+              if (!big) { m0f = fmax(m0f, fabs(mus[e])); m1f = fmax(m1f, fabs(mus[n_e + e])); }
+            }
+          }
+          if (part == 0) s_nc[cls] = cnt; else s_n[cls] = s_nc[cls] + cnt;
         }
-        s_n[cls] = cnt;
       }
     } else {
       for (int e = 0; e < n_e; ++e) perm[e] = e;
       s_n[0] = n_e; s_n[1] = 0; s_n[2] = 0;
+      s_nc[0] = n_e; s_nc[1] = 0; s_nc[2] = 0;      // channel-dependent spectra: everything clipped
     }
     if (bin == 0) {
       ws[0] = s_scale;
       ws[1] = (double)s_n[0];
       ws[2] = (double)s_n[1];
       ws[3] = (double)s_n[2];
+      ws[4] = (double)s_nc[0];
+      ws[5] = (double)s_nc[1];
+      ws[6] = (double)s_nc[2];
+      ws[7] = m0f;
+      ws[8] = m1f;
     }
   }
   __syncthreads();
@@ -239,7 +272,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();
   const float* __restrict__ tab32 = reinterpret_cast<const float*>(ws + kWsHeader + (size_t)n_bins * n_e * kTab);
-  const EnergyClasses ec{(int)ws[1], (int)ws[2], (int)ws[3]};
+  const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
   const int64_t p = (int64_t)blockIdx.x * kGnBlock + threadIdx.x;
   if (p >= n_pix) return;
   const double* __restrict__ tab = ws + kWsHeader;
