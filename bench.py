@@ -228,6 +228,24 @@ def main():
                           'unit': 'TFLOP/s', 'frac': gn_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                           'avg_launch_ms': gn_ms, 'note': 'exp counted as 1 flop; unmasked pixels only; not HBM bound (24 B/pixel)'}
 
+    # ---- opt-in mixed-precision Newton (float32 bulk + float64 polish), never part of `value`
+    if precision == 'f64' and world == 1:
+        a_mixed = torch.empty_like(a_nat)
+        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'mixed', out=a_mixed, mask_max=gmax,
+                     mask_frac=0.95)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'mixed', out=a_mixed, mask_max=gmax,
+                     mask_frac=0.95)
+        e1.record()
+        torch.cuda.synchronize()
+        diff = ((a_mixed - a_nat).abs() / a_nat.abs().clamp(min=1.0))
+        out['gn_mixed_precision'] = {'gn_ms': e0.elapsed_time(e1),
+                                     'max_diff_vs_f64': float(torch.nan_to_num(diff, nan=0.0).max().item()),
+                                     'note': 'DEXCT_GN_PRECISION=mixed: first n-4 iterations float32, last 4 float64; '
+                                             'opt-in, not the reference arithmetic, not used for value'}
+        del a_mixed, diff
+
     # ---- single-row (the reference's own 2-D case), ray-parallel kernel
     if not args.skip_single_row:
         ct1 = dx.FanBeamGeometry(N_channels=args.channels, N_proj=args.views, gamma_fan=0.8230337, SID=60.0,
