@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--skip-single-row', action='store_true')
+    ap.add_argument('--skip-gn-full-loop', action='store_true',
+                    help='omit the extra full-loop gn_kernel launch (keeps rocprof per-kernel averages clean)')
     return ap.parse_args()
 
 
@@ -226,7 +228,28 @@ def main():
     out['roofline_gn'] = {'kernel': 'gn_kernel', 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
                           'achieved': gn_flops / (gn_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
                           'unit': 'TFLOP/s', 'frac': gn_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          'avg_launch_ms': gn_ms, 'note': 'exp counted as 1 flop; unmasked pixels only; not HBM bound (24 B/pixel)'}
+                          'avg_launch_ms': gn_ms,
+                          'note': 'ALGORITHMIC flops of n_iters iterations (exp counted as 1 flop; unmasked pixels only; '
+                                  'not HBM bound, 24 B/pixel).  Iterations the exact repeated-state exit skips are counted '
+                                  'as done; full_loop_* is the same launch with every iteration executed '
+                                  '(DEXCT_GN_FULL_LOOP=1), i.e. the executed-flop rate of the kernel'}
+    if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
+        os.environ['DEXCT_GN_FULL_LOOP'] = '1'
+        try:
+            a_full = torch.empty_like(a_nat)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'f64', out=a_full, mask_max=gmax,
+                         mask_frac=0.95)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop('DEXCT_GN_FULL_LOOP', None)
+        full_ms = e0.elapsed_time(e1)
+        out['roofline_gn'].update({'full_loop_ms': full_ms, 'full_loop_achieved': gn_flops / (full_ms * 1e-3) / 1e12,
+                                   'full_loop_frac': gn_flops / (full_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                   'full_loop_bit_identical': bool(torch.equal(a_full.view(torch.int64),
+                                                                               a_nat.view(torch.int64)))})
 
     # ---- opt-in mixed-precision Newton (float32 bulk + float64 polish), never part of `value`
     if precision == 'f64' and world == 1:

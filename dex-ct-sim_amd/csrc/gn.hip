@@ -16,9 +16,14 @@
 // There is no dense contraction: the kernel is bound by the FP64 vector rate (FMA + exp), not by
 // HBM (8 B read + 16 B written per pixel); per energy-iteration it issues 25 FP64 instructions
 // (2 exponent, 2 clip, 9 exp, 12 accumulate).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dexct {
+
+// States kept for the exact repeated-state exit of the float64 Newton loop (cycles up to kGnHistory + 1).
+constexpr int kGnHistory = 8;
 
 constexpr int kGnBlock = 256;
 constexpr int kTab = 14;  // mu0, mu1, then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
                                                       int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                       int n_e, int n_iters, int n_polish, int n_bins, int bin_div,
                                                       const double* __restrict__ mask_max, double mask_frac,
-                                                      double* __restrict__ out_a) {
+                                                      int exact_exit, double* __restrict__ out_a) {
   __shared__ double lds_pow[kPowN];     // 2^(j/2048), 16 KB
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();
@@ -309,7 +314,42 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
       for (it = 0; it < n_iters; ++it) newton_step_f64(tab, lds_pow, ec, gd0, gd1, a0, a1);
     }
   }
-  for (; it < n_iters; ++it) newton_step_f64(tab, lds_pow, ec, gd0, gd1, a0, a1);
+  // The Newton update is a deterministic function of the two doubles (a0, a1).  Once an iterate repeats bit for
+  // bit - a fixed point, or a short cycle in the last ulps - every later iterate is known without computing
+  // it, so the loop may stop there and still return exactly what n_iters iterations would have produced.
+  // hist[k] holds the state s_{it-1-k}; a match s_{it+1} == s_{it-1-k} makes s_m periodic with period k + 2 for
+  // m >= it-1-k, and the answer s_{n_iters} is read from the history.  (An entry is only compared once it has
+  // been written; NaN states repeat or not like any other bit pattern, which is still exact.)
+  long long h0[kGnHistory], h1[kGnHistory];
+#pragma unroll
+  for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
+  int hit = -2;                                              // -2 none, -1 fixed point, k >= 0 history slot
+  for (; it < n_iters; ++it) {
+    double n0 = a0, n1 = a1;
+    newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);
+    if (exact_exit) {
+      const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
+      if (b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1)) hit = -1;
+#pragma unroll
+      for (int k = kGnHistory - 1; k >= 0; --k)              // descending, so the smallest period wins
+        if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
+      if (hit != -2) break;
+#pragma unroll
+      for (int k = kGnHistory - 1; k > 0; --k) { h0[k] = h0[k - 1]; h1[k] = h1[k - 1]; }
+      h0[0] = __double_as_longlong(a0);
+      h1[0] = __double_as_longlong(a1);
+    }
+    a0 = n0;
+    a1 = n1;
+  }
+  if (hit >= 0) {
+    // s_m = s_{base + ((m - base) mod period)} for m >= base = it-1-hit; s_{base+j} is hist[hit-j], s_it is (a0, a1)
+    const int base = it - 1 - hit, period = hit + 2;
+    const int slot = hit - (n_iters - base) % period;        // -1 selects the current state
+#pragma unroll
+    for (int k = 0; k < kGnHistory; ++k)
+      if (slot == k) { a0 = __longlong_as_double(h0[k]); a1 = __longlong_as_double(h1[k]); }
+  }
   out_a[2 * p] = a0;
   out_a[2 * p + 1] = a1;
 }
@@ -377,16 +417,19 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   double* ws = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(gn_tables_kernel, dim3(n_bins), dim3(256), 0, st, i0, mus, n_energies, n_bins, ws);
   DEXCT_LAUNCH_CHECK();
+  // DEXCT_GN_FULL_LOOP=1 runs every iteration (to check that the repeated-state exit changes no bit)
+  const char* full = getenv("DEXCT_GN_FULL_LOOP");
+  const int exact_exit = (full && full[0] == '1') ? 0 : 1;
   const dim3 grid((unsigned)nblk), block(kGnBlock);
   if (n_bins > 1) {
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, out_a);
+                       n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, out_a);
   } else if (precision == 0) {
     hipLaunchKernelGGL((gn_kernel<false, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, 0, 1, 1, mask_max, mask_frac, out_a);
+                       n_energies, n_iters, 0, 1, 1, mask_max, mask_frac, exact_exit, out_a);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, out_a);
+                       n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, out_a);
   }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

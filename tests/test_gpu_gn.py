@@ -198,3 +198,28 @@ def test_entry_points_are_graph_capturable(hip):
     torch.cuda.synchronize()
     assert torch.equal(counts, eager[0]) and torch.equal(a_ref_order, eager[1]) and torch.equal(gmax, eager[2])
     assert torch.isfinite(a_ref_order).all()
+
+
+def test_repeated_state_exit_changes_no_bit(hip, golden):
+    """The loop stops when an iterate repeats bit for bit (fixed point or a cycle of up to 9 states);
+    DEXCT_GN_FULL_LOOP=1 runs all iterations: both must agree in every bit, for iteration counts covering every
+    residue of every detectable period, incl. the ill-posed golden case."""
+    import os
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    rng = np.random.default_rng(17)
+    i0, mus = g['gn0_i0'], g['gn0_mus']
+    a_true = np.stack([rng.uniform(0, 40, 200000), rng.uniform(0, 8, 200000)], -1)
+    ex = np.exp(-a_true @ mus)
+    cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, 200000)))
+    cases = [(cnt.reshape(2, 400, 500), i0, mus)] + [(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus']) for ci in range(3)]
+    try:
+        for data, ii, mm in cases:
+            for n_iters in (7, 23) + tuple(range(41, 52)):
+                os.environ['DEXCT_GN_FULL_LOOP'] = '1'
+                full = md.optimize_sino(data, None, ii, mm, n_iters, precision='f64')
+                os.environ['DEXCT_GN_FULL_LOOP'] = '0'
+                fast = md.optimize_sino(data, None, ii, mm, n_iters, precision='f64')
+                assert np.array_equal(full.view(np.int64), fast.view(np.int64)), n_iters
+    finally:
+        os.environ.pop('DEXCT_GN_FULL_LOOP', None)

@@ -8,10 +8,10 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py "$@" > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py "$@" --skip-gn-full-loop > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 echo "stats rc=$?"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-gn-full-loop > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
 echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row > $OUT/bench_write.json 2> $OUT/bench_write.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-gn-full-loop > $OUT/bench_write.json 2> $OUT/bench_write.err
 echo "write rc=$?"
 find $OUT -name "*.csv" | head -30

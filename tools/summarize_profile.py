@@ -36,7 +36,7 @@ def pmc(which):
 fetch, write = pmc('fetch'), pmc('write')
 bench = json.load(open(os.path.join(src, 'bench_stats.json')))
 lines = [f'# rocprofv3 summary `{tag}`', '',
-         f'command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {bench["steps"]} --warmup {bench["warmup"]}`'
+         f'command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {bench["steps"]} --warmup {bench["warmup"]} --skip-gn-full-loop`'
          ' (PMC passes: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` separately, 1 step)', '',
          '| kernel | calls | avg ms | % of GPU time |', '|---|---|---|---|']
 for r in rows[:8]:
