@@ -351,6 +351,25 @@ def main():
                                          f'{t_gn_cpu:.1f} s, OpenMP over rays / pixels)',
                                'siddon_only_integrals_per_s': n_sample * sum(n_e_spec) / t_proj,
                                'gn_pixel_solves_per_s': n_sample / t_gn_cpu}
+        # also the NumPy restatement of optimize_sino_cpu (the reference's own style of CPU code), on a
+        # few views of the same sinograms, with the thread counts that apply to it
+        from oracle import gn_oracle
+        np_views = min(16, g_cnt.shape[1])
+        g_np = g_cnt[:, :np_views, 0, :] if g_cnt.ndim == 4 else g_cnt.reshape(2, -1, args.channels)[:, :np_views]
+        t0 = time.perf_counter()
+        gn_oracle.newton_solve(g_np, i0, mus, args.iters)
+        t_np = time.perf_counter() - t0
+        blas = None
+        try:
+            from threadpoolctl import threadpool_info
+            blas = [{'api': t.get('user_api'), 'threads': t.get('num_threads')} for t in threadpool_info()]
+        except Exception:
+            pass
+        out['cpu_baseline']['numpy_restatement'] = {
+            'pixel_iters_per_s': g_np.shape[1] * g_np.shape[2] * args.iters / t_np,
+            'pixel_solves_per_s': g_np.shape[1] * g_np.shape[2] / t_np,
+            'sample': f'{g_np.shape[1]} views x {g_np.shape[2]} channels x {args.iters} iterations, {t_np:.1f} s',
+            'os_cpu_count': os.cpu_count(), 'omp_threads_c_oracle': threads, 'blas_threadpools': blas}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -20,6 +20,9 @@ def __getattr__(name):
     if name == 'get_recon':
         from . import back_project
         return back_project.get_recon
+    if name in ('make_vmi', 'measure_roi', 'vmi_roi_sweep', 'vmi_rmse_sweep'):
+        from . import plots
+        return getattr(plots, name)
     if name in ('get_basismat_sinos', 'do_matdecomp_gn', 'optimize_sino', 'optimize_sino_cpu'):
         from . import matdecomp
         return getattr(matdecomp, name)

@@ -128,3 +128,60 @@ extern "C" int dexct_vmi(const float* m1, const float* m2, int64_t n, double u1,
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
+
+// Second-order moments of one or two images per label: the sufficient statistics of every ROI measurement the
+// reference's analysis script takes (measure_roi, plots.py:146-158; the VMI RMSE and CNR sweeps, :297-303 and
+// :371-393, are closed forms in these sums because a VMI is linear in the two basis images).
+// out[label][6] = { count, S(m1), S(m2), S(m1^2), S(m1 m2), S(m2^2) } in float64.
+namespace dexct {
+constexpr int kMomBlock = 256, kMomPerThread = 16, kMomMaxLabels = 64;
+
+__global__ __launch_bounds__(kMomBlock) void label_moments_kernel(const float* __restrict__ m1,
+                                                                  const float* __restrict__ m2,
+                                                                  const uint8_t* __restrict__ labels, int64_t n,
+                                                                  int n_labels, double* __restrict__ out) {
+  __shared__ double acc[kMomMaxLabels * 6];
+  for (int i = threadIdx.x; i < n_labels * 6; i += kMomBlock) acc[i] = 0.0;
+  __syncthreads();
+  // a thread walks pixels 256 apart, so consecutive pixels of a thread lie in the same region most of the time:
+  // sums stay in registers and go to LDS only when the label changes
+  int cur = -1;
+  double c = 0, s1 = 0, s2 = 0, s11 = 0, s12 = 0, s22 = 0;
+  auto flush = [&]() {
+    if (cur >= 0 && c > 0) {
+      double* a = acc + cur * 6;
+      atomicAdd(a + 0, c); atomicAdd(a + 1, s1); atomicAdd(a + 2, s2);
+      atomicAdd(a + 3, s11); atomicAdd(a + 4, s12); atomicAdd(a + 5, s22);
+    }
+    c = s1 = s2 = s11 = s12 = s22 = 0;
+  };
+  const int64_t base = (int64_t)blockIdx.x * (kMomBlock * kMomPerThread) + threadIdx.x;
+  for (int k = 0; k < kMomPerThread; ++k) {
+    const int64_t i = base + (int64_t)k * kMomBlock;
+    if (i >= n) break;
+    const int l = labels ? (int)labels[i] : 0;
+    if (l >= n_labels) continue;
+    if (l != cur) { flush(); cur = l; }
+    const double a = (double)m1[i], b = m2 ? (double)m2[i] : 0.0;
+    c += 1.0; s1 += a; s2 += b; s11 += a * a; s12 += a * b; s22 += b * b;
+  }
+  flush();
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_labels * 6; i += kMomBlock)
+    if (acc[i] != 0.0) atomicAdd(out + i, acc[i]);
+}
+}  // namespace dexct
+
+extern "C" int dexct_label_moments(const float* m1, const float* m2, const uint8_t* labels, int64_t n, int32_t n_labels,
+                                   double* out, void* stream) {
+  using namespace dexct;
+  if (!m1 || !out || n <= 0 || n_labels <= 0) return DEXCT_EINVAL;
+  if (n_labels > kMomMaxLabels) return DEXCT_ERANGE;
+  const int64_t nblk = (n + kMomBlock * kMomPerThread - 1) / (kMomBlock * kMomPerThread);
+  if (nblk > 0x7FFFFFFFll) return DEXCT_ERANGE;
+  DEXCT_HIP_TRY(hipMemsetAsync(out, 0, sizeof(double) * 6 * n_labels, as_stream(stream)));
+  hipLaunchKernelGGL(label_moments_kernel, dim3((unsigned)nblk), dim3(kMomBlock), 0, as_stream(stream), m1, m2, labels, n,
+                     n_labels, out);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}

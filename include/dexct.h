@@ -219,6 +219,16 @@ int dexct_fbp_backproject(const float* q, const double* view_cs, int32_t n_views
 int dexct_vmi(const float* m1, const float* m2, int64_t n, double u1, double u2, double u_water, int32_t hu,
               float* out, void* stream);
 
+/* Per-label second-order moments of one or two images: the sufficient statistics of the reference's ROI
+ * measurements (measure_roi, plots.py:146-158: mean and population variance of a rectangle) and of its VMI
+ * sweeps (RMSE against ground truth plots.py:297-303, CNR :371-393), which are closed forms in these sums
+ * because a VMI is linear in the two basis-material images.
+ *   out[l][6] = { count, S m1, S m2, S m1^2, S m1*m2, S m2^2 } over the pixels i with labels[i] == l, float64;
+ *   labels == NULL: every pixel is label 0; pixels with labels[i] >= n_labels are skipped; m2 == NULL: zeros.
+ * n_labels <= 64.  out is zeroed by the call (on the stream).  Summation order is not fixed (float64 atomics). */
+int dexct_label_moments(const float* m1, const float* m2, const uint8_t* labels, int64_t n, int32_t n_labels,
+                        double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -203,3 +203,24 @@ def test_xcom_directory_tables_override_the_surrogate(tmp_path, monkeypatch):
     finally:
         xcompy._user_tables.clear()
         xcompy._user_tables.update(saved)
+
+
+def test_analysis_helpers_without_gpu():
+    """crop_img / get_xcat_mask / measure_roi(give_roi) / output-tree readers of plots.py (plots.py:146-231)."""
+    import tempfile, os
+    from dex_ct_sim_amd import plots
+    M = np.arange(100, dtype=np.float32).reshape(10, 10)
+    assert plots.crop_img(M, 4).shape == (4, 4) and plots.crop_img(M, 4)[0, 0] == M[3, 3]
+    assert plots.get_xcat_mask(np.array([[-1000.0, -899.0], [0.0, -900.0]])).tolist() == [[False, True], [True, False]]
+    assert plots.measure_roi(M, [2, 3, 2, 2], give_roi=True).tolist() == [32.0, 33.0, 42.0, 43.0]
+    with tempfile.TemporaryDirectory() as d:
+        sub = os.path.join(d, 'mvkv_p', '80kV_1000uGy')
+        os.makedirs(sub)
+        M.tofile(os.path.join(sub, 'recon_HU_float32.bin'))
+        assert np.array_equal(plots.get_img_ct('p', '80kV', 1.0, N_matrix=10, out_dir=d), M)
+        sub = os.path.join(d, 'mvkv_p', 'matdecomp_140kV_80kV_5000uGy_5000uGy')
+        os.makedirs(sub)
+        M.tofile(os.path.join(sub, 'mat1_recon_float32.bin'))
+        (2 * M).tofile(os.path.join(sub, 'mat2_recon_float32.bin'))
+        a, b = plots.get_img_basismats('p', '140kV', '80kV', 5, 5, crop=4, N_matrix=10, out_dir=d)
+        assert a.shape == (4, 4) and np.array_equal(b, 2 * a)
