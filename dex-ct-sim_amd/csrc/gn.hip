@@ -26,30 +26,44 @@ namespace dexct {
 constexpr int kGnHistory = 8;
 
 constexpr int kGnBlock = 256;
-constexpr int kTab = 14;  // mu0, mu1, then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2
+constexpr int kTab = 14;  // -mu0 K, -mu1 K (K = 2048/ln2), then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2
 
 template <typename T>
 __device__ __forceinline__ T load_g(const void* p, int is_f64, int64_t i) {
   return is_f64 ? (T) reinterpret_cast<const double*>(p)[i] : (T) reinterpret_cast<const float*>(p)[i];
 }
 
-// exp(x) for |x| <= 700: x = (2048 k + j) ln2/2048 + r, |r| <= ln2/4096; exp = 2^k * 2^(j/2048) * e^r with
-// a cubic for e^r - 1 (truncation r^4/24 < 4e-17).  The integer n = 2048 k + j comes out of the low
-// mantissa bits of fma(x, 2048/ln2, 1.5 * 2^52) (round to nearest even, like rint).  About 1 ulp.
+// exp(x) for |x| <= 700, given y = x * 2048/ln2 (the tables hold -mu * 2048/ln2, so y costs the same two
+// instructions as x would): y = n + f with n = rint(y) = 2048 k + j, |f| <= 1/2, and
+// exp(x) = 2^k * 2^(j/2048) * e^(f ln2/2048), a cubic in f for e^r - 1 (truncation r^4/24 < 4e-17, r = f ln2/2048).
+// n comes out of the low mantissa bits of y + 1.5 * 2^52 (round to nearest even, like rint); f = y - n is exact.
+// About 1 ulp.
 constexpr int kPowBits = 11;
 constexpr int kPowN = 1 << kPowBits;
-__device__ __forceinline__ double exp_tab(double x, const double* __restrict__ lds_pow) {
+constexpr double kExpScale = 0x1.71547652b82fep+11;          // 2048 / ln 2
+constexpr double kExpClip = 700.0 * kExpScale;               // the reference's clip of the exponent (matdecomp.py:116)
+__device__ __forceinline__ double exp_tab(double y, const double* __restrict__ lds_pow) {
   const double kMagic = 6755399441055744.0;   // 1.5 * 2^52
-  const double tm = fma(x, 0x1.71547652b82fep+11, kMagic);
+  constexpr double c1 = 0x1.62e42fefa39efp-12;               // ln2 / 2048
+  constexpr double c2 = c1 * c1 / 2.0, c3 = c1 * c1 * c1 / 6.0;
+  const double tm = y + kMagic;
   const int ni = __double2loint(tm);
-  const double n = tm - kMagic;
-  double r = fma(n, -0x1.62e42fefa39efp-12, x);
-  r = fma(n, -0x1.abc9e3b39803fp-67, r);
-  double q = fma(r, 1.0 / 6.0, 0.5);
-  q = fma(r, q, 1.0);
-  const double p = r * q;
+  const double f = y - (tm - kMagic);
+  double q = fma(f, c3, c2);
+  q = fma(f, q, c1);
+  const double p = f * q;
   const double tj = lds_pow[ni & (kPowN - 1)];
   return ldexp(fma(tj, p, tj), ni >> kPowBits);
+}
+
+// 1 / x by v_rcp_f64 and two Newton refinements (what a float64 division starts with, without its scaling and
+// fix-up steps: the operands here - expected counts, the Hessian's determinant - are far from the subnormal and
+// overflow ranges; zero, inf and NaN give inf or NaN, i.e. a pixel the reference could not solve either).
+__device__ __forceinline__ double rcp_f64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
 }
 
 // Energies are sorted by gn_tables_kernel into three classes: both spectra have weight (nA), only spectrum 0
@@ -63,9 +77,9 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
 #pragma unroll 2
   for (int e = e0; e < e1; ++e) {
     const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
-    double x = -fma(a1, t[1], a0 * t[0]);
-    if (CLIP) x = fmin(fmax(x, -700.0), 700.0);
-    const double at = exp_tab(x, lds_pow);
+    double y = fma(a1, t[1], a0 * t[0]);               // t[0], t[1] = -mu0, -mu1 times 2048/ln2
+    if (CLIP) y = fmin(fmax(y, -kExpClip), kExpClip);
+    const double at = exp_tab(y, lds_pow);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if ((KSEL == 1 && k == 1) || (KSEL == 2 && k == 0)) continue;
@@ -81,8 +95,9 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
 }
 
 // Each class is stored as [energies that always need the clip (large mu) | energies whose exponent is provably
-// within +-700 whenever |a0| * mu0_free_max + |a1| * mu1_free_max <= 700]: for the second part the clip of
-// matdecomp.py:116 is the identity and is skipped (two FP64 instructions per energy), bit for bit the same result.
+// within +-700 whenever |a0| * mu0_free_max + |a1| * mu1_free_max <= 699.9 (the margin covers the rounding of the
+// scaled tables)]: for the second part the clip of matdecomp.py:116 is the identity and is skipped (two FP64
+// instructions per energy), bit for bit the same result.
 struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; };
 
 __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
@@ -94,7 +109,7 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
   energy_sums_f64<1, true>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, G0, G1, H00, H01, H11);
   energy_sums_f64<2, true>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, G0, G1, H00, H01, H11);
   // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
-  if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 700.0) {
+  if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 699.9) {
     energy_sums_f64<0, false>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
     energy_sums_f64<1, false>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
     energy_sums_f64<2, false>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
@@ -107,16 +122,17 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
   double dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const double c = g[k] / nu[k] - 1.0, q = g[k] / (nu[k] * nu[k]);
+    const double inv = rcp_f64(nu[k]), ratio = g[k] * inv;
+    const double c = ratio - 1.0, q = ratio * inv;             // g / nu - 1 and g / nu^2 (matdecomp.py:122-123)
     dF0 += c * G0[k];
     dF1 += c * G1[k];
     h00 += q * (G0[k] * G0[k]) - c * H00[k];
     h01 += q * (G0[k] * G1[k]) - c * H01[k];
     h11 += q * (G1[k] * G1[k]) - c * H11[k];
   }
-  const double det = h00 * h11 - h01 * h01;
-  a0 -= (h11 * dF0 - h01 * dF1) / det;
-  a1 -= (h00 * dF1 - h01 * dF0) / det;
+  const double inv_det = rcp_f64(h00 * h11 - h01 * h01);
+  a0 -= (h11 * dF0 - h01 * dF1) * inv_det;
+  a1 -= (h00 * dF1 - h01 * dF0) * inv_det;
 }
 
 // float32 table layout per energy: [mu0*log2e, mu1*log2e, then for c in {1, mu0, mu1, mu0^2, mu0mu1, mu1^2}:
@@ -237,8 +253,8 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
     const int e = perm[j];
     const double m0 = mus[e], m1 = mus[n_e + e];
     double* t = tab + j * kTab;
-    t[0] = m0;
-    t[1] = m1;
+    t[0] = -m0 * kExpScale;                              // exponent in units of ln2/2048, see exp_tab
+    t[1] = -m1 * kExpScale;
     const double m00 = m0 * m0, m01 = m0 * m1, m11 = m1 * m1;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
