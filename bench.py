@@ -47,7 +47,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--skip-single-row', action='store_true')
     ap.add_argument('--skip-gn-full-loop', action='store_true',
-                    help='omit the extra full-loop gn_kernel launch (keeps rocprof per-kernel averages clean)')
+                    help='omit the extra full-loop Newton launch (keeps rocprof per-kernel averages clean)')
     return ap.parse_args()
 
 
@@ -225,7 +225,7 @@ def main():
     masked = float((counts_nat[0] >= 0.95 * gmax).float().mean().item())
     out['gn_masked_fraction'] = masked
     gn_flops = (1.0 - masked) * n_rays * args.iters * i0.shape[1] * (28 + 1)   # 28 flops + 1 exp per energy-iteration
-    out['roofline_gn'] = {'kernel': 'gn_kernel', 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
+    out['roofline_gn'] = {'kernel': 'gn_refill_kernel' if precision == 'f64' else 'gn_kernel<true,false>', 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
                           'achieved': gn_flops / (gn_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
                           'unit': 'TFLOP/s', 'frac': gn_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                           'avg_launch_ms': gn_ms,

@@ -370,6 +370,112 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   out_a[2 * p + 1] = a1;
 }
 
+// float64, one shared spectrum - the benchmark's path - with lane refill.  The repeated-state exit ends pixels
+// at very different iterations (from 15 to all of n_iters), and a wave is as slow as its slowest lane.  Here a
+// wave owns a contiguous run of 64 * chunk pixels and every lane whose pixel has finished takes the next one of
+// the run, so all 64 lanes keep iterating until the run is used up.  The energy loops stay wave-uniform (scalar
+// table loads) because the tables do not depend on the pixel.  Results are bit-identical to gn_kernel's.
+__global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
+                                                             int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
+                                                             int n_e, int n_iters, int chunk,
+                                                             const double* __restrict__ mask_max, double mask_frac,
+                                                             int exact_exit, double* __restrict__ out_a) {
+  __shared__ double lds_pow[kPowN];
+  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
+  __syncthreads();                        // the only barrier: waves leave the loop below independently
+  const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
+  const double* __restrict__ tab = ws + kWsHeader;
+  const int64_t run = (int64_t)kWave * chunk;
+  int64_t next = ((int64_t)blockIdx.x * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;   // wave-uniform
+  const int64_t end = next + run < n_pix ? next + run : n_pix;
+  const bool has_mask = mask_max != nullptr;
+  const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
+
+  int64_t p = -1;                         // this lane's pixel, -1: none
+  double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
+  int it = 0;
+  long long h0[kGnHistory], h1[kGnHistory];
+#pragma unroll
+  for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
+
+  for (;;) {
+    const unsigned long long want = __ballot(p < 0);
+    if (want != 0ull && next < end) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+      const int64_t np = next + rank;
+      if (p < 0 && np < end) {
+        gd0 = load_g<double>(g1, g_is_f64, np);
+        gd1 = load_g<double>(g2, g_is_f64, np);
+        if (has_mask && gd0 >= thresh) {           // air (matdecomp.py:195-196, :204-205): 0, not iterated
+          out_a[2 * np] = 0.0;
+          out_a[2 * np + 1] = 0.0;
+        } else if (n_iters <= 0) {
+          out_a[2 * np] = 1e-6;
+          out_a[2 * np + 1] = 1e-6;
+        } else {
+          p = np; a0 = 1e-6; a1 = 1e-6; it = 0;
+        }
+      }
+      next += __popcll(want);
+    }
+    if (__ballot(p >= 0) == 0ull) {
+      if (next >= end) break;
+      continue;
+    }
+    double n0 = a0, n1 = a1;
+    newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);      // idle lanes repeat their last pixel's step; unused
+    // same exit rule as gn_kernel: s_{it+1} equal to s_it (fixed point) or to hist[k] = s_{it-1-k} (cycle of
+    // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
+    // through it too and are ignored.
+    int hit = -2;
+    if (exact_exit) {
+      const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
+      if (b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1)) hit = -1;
+#pragma unroll
+      for (int k = kGnHistory - 1; k >= 0; --k)
+        if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
+    }
+    const bool advance = hit == -2;
+    // the state a cycle holds at iteration n_iters: s_m = s_{base + (m - base) mod period} for m >= base = it-1-hit,
+    // and (n_iters - base) = (n_iters - it - 1) mod period; s_{base+j} is hist[hit-j], s_it the current state (slot -1)
+    int slot = -1;
+    if (hit >= 0) {
+      const int period = hit + 2, x = n_iters - it - 1;
+      int r;
+      if (n_iters < (1 << 22)) {            // wave-uniform; small x: quotient by a float reciprocal, then corrected
+        const int q = (int)((float)x * __builtin_amdgcn_rcpf((float)period));
+        r = x - q * period;
+        r += r < 0 ? period : 0;
+        r -= r >= period ? period : 0;
+      } else {
+        r = x % period;
+      }
+      slot = hit - r;
+    }
+    double f0 = a0, f1 = a1;
+    if (__ballot(slot >= 0) != 0ull) {
+#pragma unroll
+      for (int k = 0; k < kGnHistory; ++k)
+        if (slot == k) { f0 = __longlong_as_double(h0[k]); f1 = __longlong_as_double(h1[k]); }
+    }
+#pragma unroll
+    for (int k = kGnHistory - 1; k > 0; --k) {
+      h0[k] = advance ? h0[k - 1] : h0[k];
+      h1[k] = advance ? h1[k - 1] : h1[k];
+    }
+    h0[0] = advance ? __double_as_longlong(a0) : h0[0];
+    h1[0] = advance ? __double_as_longlong(a1) : h1[0];
+    a0 = advance ? n0 : f0;
+    a1 = advance ? n1 : f1;
+    it += advance ? 1 : 0;
+    if (p >= 0 && (!advance || it >= n_iters)) {
+      out_a[2 * p] = a0;
+      out_a[2 * p + 1] = a1;
+      p = -1;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void mask_kernel(const void* __restrict__ g1, int g_is_f64, int64_t n_pix,
                                                    double thresh, double* __restrict__ out_a) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -441,8 +547,15 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, out_a);
   } else if (precision == 0) {
-    hipLaunchKernelGGL((gn_kernel<false, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, 0, 1, 1, mask_max, mask_frac, exact_exit, out_a);
+    // lane refill: each wave works through a run of 64 * chunk pixels; the run is as long as keeps ~20 waves per
+    // SIMD's worth of waves in the grid (small inputs degenerate to one pixel per lane, as gn_kernel)
+    const char* ce = getenv("DEXCT_GN_CHUNK");
+    int64_t chunk = ce ? atoll(ce) : n_pix / (kWave * 20480ll);
+    chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
+    const int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
+    const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
+    hipLaunchKernelGGL(gn_refill_kernel, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
+                       n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, out_a);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, out_a);

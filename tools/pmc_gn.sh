@@ -19,14 +19,14 @@ import csv, glob, collections
 dur = {}
 for f in glob.glob('$OUT/clk/*/*_kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
-        if 'gn_kernel' in r['Kernel_Name'] or 'rows4' in r['Kernel_Name']:
+        if ('gn_' in r['Kernel_Name'] and 'tables' not in r['Kernel_Name']) or 'rows4' in r['Kernel_Name']:
             dur.setdefault(r['Kernel_Name'][:40], []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 for k, v in dur.items(): print('duration_ns', k, v)
 for sub in ('clk', 'a', 'b'):
     for f in glob.glob('$OUT/%s/*/*_counter_collection.csv' % sub):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'gn_kernel' in r['Kernel_Name'] or 'rows4' in r['Kernel_Name']:
+            if ('gn_' in r['Kernel_Name'] and 'tables' not in r['Kernel_Name']) or 'rows4' in r['Kernel_Name']:
                 agg[(r['Kernel_Name'][:40], r['Counter_Name'])].append(float(r['Counter_Value']))
         for k in sorted(agg): print(k, ['%.5g' % x for x in agg[k]])
 PY

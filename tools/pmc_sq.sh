@@ -15,7 +15,7 @@ for sub in ('a','b'):
     for f in glob.glob('$OUT/%s/*/*_counter_collection.csv' % sub):
         agg = collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
-            if 'rows4' in r['Kernel_Name'] or 'gn_kernel' in r['Kernel_Name']:
+            if 'rows4' in r['Kernel_Name'] or ('gn_' in r['Kernel_Name'] and 'tables' not in r['Kernel_Name']):
                 agg[(r['Kernel_Name'][:28], r['Counter_Name'])] += float(r['Counter_Value'])
         for k in sorted(agg): print(k, '%.4g' % agg[k])
 PY

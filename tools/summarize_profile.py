@@ -67,7 +67,7 @@ if cal:
             traffic['siddon_fetch_bytes'] = corr * fetch[k]
             traffic['siddon_write_bytes'] = write.get(k, 0.0)
             traffic['siddon_hbm_bytes_per_launch'] = corr * fetch[k] + write.get(k, 0.0)
-        if 'gn_kernel' in k:
+        if 'gn_refill_kernel' in k or 'gn_kernel<false' in k:
             traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
             traffic['gn_write_bytes'] = write.get(k, 0.0)
     traffic['transpose_xy_fetch_bytes'] = vol_bytes
