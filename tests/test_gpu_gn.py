@@ -223,3 +223,53 @@ def test_repeated_state_exit_changes_no_bit(hip, golden):
                 assert np.array_equal(full.view(np.int64), fast.view(np.int64)), n_iters
     finally:
         os.environ.pop('DEXCT_GN_FULL_LOOP', None)
+
+
+def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
+    """gn_refill_kernel: every pixel is solved exactly once whatever the run length per wave (DEXCT_GN_CHUNK),
+    for pixel counts around the wave and run boundaries, with and without the fused air mask, and for 0 and 1
+    iterations.  All run lengths give the same bits; the result matches the C oracle."""
+    import os
+    import torch
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    i0, mus = g['gn0_i0'], g['gn0_mus']
+    rng = np.random.default_rng(23)
+    try:
+        for n_pix in (1, 63, 64, 65, 127, 1000, 4097, 64 * 64 * 3 + 5):
+            a_true = np.stack([rng.uniform(0, 35, n_pix), rng.uniform(0, 6, n_pix)], -1)
+            ex = np.exp(-a_true @ mus)
+            cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, n_pix)))
+            air = rng.random(n_pix) < 0.3
+            cnt[0, air] = 2.0 * i0[0].sum()                    # above 0.95 * max: masked
+            g1, g2 = (torch.tensor(cnt[k], device='cuda') for k in range(2))
+            gmax = g1.max().double()
+            air = cnt[0] >= 0.95 * cnt[0].max()                # what the mask rule selects (at least the maximum itself)
+            ref = co.gn_decompose(cnt[0], cnt[1], i0, mus, 30, n_threads=8)
+            results = {}
+            for chunk in ('1', '2', '7', '64'):
+                os.environ['DEXCT_GN_CHUNK'] = chunk
+                for masked in (False, True):
+                    out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+                    md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None)
+                    results[(chunk, masked)] = out.cpu().numpy()
+            base_m, base_u = results[('1', True)], results[('1', False)]
+            for (chunk, masked), r in results.items():
+                assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, chunk)
+            assert not np.isnan(base_m[air]).any() and np.all(base_m[air] == 0.0)
+            assert np.array_equal(base_m[~air].view(np.int64), base_u[~air].view(np.int64))
+            live_u = np.isfinite(ref).all(-1)                  # without the mask every pixel is solved
+            assert err(base_u[live_u], ref[live_u]) < TOL_F64
+            os.environ['DEXCT_GN_CHUNK'] = '3'
+            for n_iters, expect in ((0, 1e-6), (1, None)):
+                out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+                md.gn_device(g1, g2, i0, mus, n_iters, 'f64', out=out)
+                o = out.cpu().numpy()
+                if expect is not None:
+                    assert np.all(o == expect)
+                else:
+                    one = co.gn_decompose(cnt[0], cnt[1], i0, mus, 1, n_threads=8)
+                    ok = np.isfinite(one).all(-1)
+                    assert err(o[ok], one[ok]) < TOL_F64
+    finally:
+        os.environ.pop('DEXCT_GN_CHUNK', None)
