@@ -44,17 +44,23 @@ struct FbpGeom {
   double sid, dgamma, dbeta, pixel;   // pixel = FOV / n_matrix
 };
 
-// One thread per pixel of one slice (row).  q is [view][row][channel].
+// One thread per pixel (x, y) and R consecutive slices (rows).  q is [view][row][channel].  The geometry of a
+// (pixel, view) pair - source distance, fan angle, interpolation weight, all in float64 - is the same for every
+// row of a stacked fan, so it is computed once and applied to R rows (R = 8 for volumes, 1 for a single slice).
+template <int R>
 __global__ __launch_bounds__(kFbpBlock) void fbp_backproject_kernel(const float* __restrict__ q,
                                                                     const double* __restrict__ view_cs, FbpGeom g,
                                                                     float* __restrict__ img) {
   const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
   const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int row = blockIdx.z;
+  const int row0 = blockIdx.z * R;
   if (ix >= g.n_matrix || iy >= g.n_matrix) return;
   const double x = (ix - 0.5 * g.n_matrix + 0.5) * g.pixel, y = (iy - 0.5 * g.n_matrix + 0.5) * g.pixel;
   const double inv_dg = 1.0 / g.dgamma, half = 0.5 * (g.n_channels - 1);
-  float acc = 0.0f;
+  const int n_rows_here = g.n_rows - row0 < R ? g.n_rows - row0 : R;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.0f;
   for (int v = 0; v < g.n_views; ++v) {
     const double cb = view_cs[2 * v], sb = view_cs[2 * v + 1];   // wave-uniform
     const double dx = x - g.sid * cb, dy = y - g.sid * sb;
@@ -64,12 +70,21 @@ __global__ __launch_bounds__(kFbpBlock) void fbp_backproject_kernel(const float*
     const int k = (int)fl;
     if (k >= 0 && k < g.n_channels - 1) {
       const float w = (float)(pos - fl);
-      const float* ql = q + ((size_t)v * g.n_rows + row) * g.n_channels + k;
-      const float val = (1.0f - w) * ql[0] + w * ql[1];
-      acc += val / (float)(dx * dx + dy * dy);
+      const float l2 = (float)(dx * dx + dy * dy);
+      const float* ql = q + ((size_t)v * g.n_rows + row0) * g.n_channels + k;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r < n_rows_here) {
+          const float val = (1.0f - w) * ql[0] + w * ql[1];
+          acc[r] += val / l2;
+        }
+        ql += g.n_channels;
+      }
     }
   }
-  img[((size_t)row * g.n_matrix + iy) * g.n_matrix + ix] = acc * (float)g.dbeta;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (r < n_rows_here) img[((size_t)(row0 + r) * g.n_matrix + iy) * g.n_matrix + ix] = acc[r] * (float)g.dbeta;
 }
 
 }  // namespace dexct
@@ -96,8 +111,13 @@ int dexct_fbp_backproject(const float* q, const double* view_cs, int32_t n_views
   if (n_rows > 65535 || (n_matrix + 3) / 4 > 65535) return DEXCT_ERANGE;
   if (!(sid > 0) || !(dgamma > 0) || !(fov > 0)) return DEXCT_EINVAL;
   FbpGeom g{n_views, n_channels, n_rows, n_matrix, sid, dgamma, dbeta, fov / n_matrix};
-  dim3 grid((n_matrix + 63) / 64, (n_matrix + 3) / 4, n_rows);
-  hipLaunchKernelGGL(fbp_backproject_kernel, grid, dim3(kFbpBlock), 0, as_stream(stream), q, view_cs, g, image);
+  if (n_rows >= 8) {
+    dim3 grid((n_matrix + 63) / 64, (n_matrix + 3) / 4, (n_rows + 7) / 8);
+    hipLaunchKernelGGL(fbp_backproject_kernel<8>, grid, dim3(kFbpBlock), 0, as_stream(stream), q, view_cs, g, image);
+  } else {
+    dim3 grid((n_matrix + 63) / 64, (n_matrix + 3) / 4, n_rows);
+    hipLaunchKernelGGL(fbp_backproject_kernel<1>, grid, dim3(kFbpBlock), 0, as_stream(stream), q, view_cs, g, image);
+  }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

@@ -78,3 +78,21 @@ def test_make_vmi_matches_reference_formula(hip):
         assert got.dtype == np.float32 and got.shape == (64, 64)
         assert np.max(np.abs(got - ref_hu)) < 2e-4 * np.abs(ref_hu).max()
         assert np.allclose(bp.make_vmi(E0, M1, M2, HU=False), vmi.astype(np.float32), rtol=2e-6)
+
+
+def test_volume_backprojection_shares_geometry_bit_exactly(hip):
+    """11 rows take the 8-rows-per-thread kernel (incl. a partial last group): every slice equals the single-slice
+    reconstruction of its own sinogram bit for bit."""
+    import dex_ct_sim_amd as dx
+    import torch
+    from dex_ct_sim_amd import back_project as bp
+    rows = 11
+    ct1 = dx.FanBeamGeometry(N_channels=129, N_proj=90, gamma_fan=0.8230337, SID=60.0, SDD=100.0, N_rows=1)
+    ctn = dx.FanBeamGeometry(N_channels=129, N_proj=90, gamma_fan=0.8230337, SID=60.0, SDD=100.0, N_rows=rows)
+    rng = np.random.default_rng(4)
+    stack = rng.uniform(0.0, 3.0, (90, rows, 129)).astype(np.float32)
+    vol = bp.recon_device(torch.tensor(stack, device='cuda'), ctn, 70, 30.0, 0.9).cpu().numpy()
+    assert vol.shape == (rows, 70, 70)
+    for r in range(rows):
+        one = bp.recon_device(torch.tensor(np.ascontiguousarray(stack[:, r]), device='cuda'), ct1, 70, 30.0, 0.9)
+        assert np.array_equal(vol[r], one.cpu().numpy().reshape(70, 70)), r
