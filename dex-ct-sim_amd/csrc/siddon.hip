@@ -90,6 +90,60 @@ __device__ __forceinline__ size_t ray_index(const ProjArgs& a, int v, int r, int
                        : ((size_t)v * a.g.n_channels + c) * a.g.n_rows + r;
 }
 
+// sum_e w[s][e] * 2^(-sum_m mu[m][e] * L2[q][m]) for R rays and SLOTS spectrum slots.  Rays are handled in pairs
+// (float2 -> v_pk_fma_f32, the scalar table value broadcast to both halves); each half performs exactly the
+// scalar sequence of fmaf's, so the sums do not depend on the pairing.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NM, int R, int SLOTS>
+__device__ __forceinline__ void detect_energies(const float (&L2)[R][NM], const float* __restrict__ mu,
+                                                const float* __restrict__ w, int n_e,
+                                                const int (&srow)[DEXCT_MAX_SPECTRA],
+                                                float (&acc)[DEXCT_MAX_SPECTRA][R]) {
+  constexpr int P = (R + 1) / 2;                      // pairs; an odd last ray rides alone in a pair's low half
+  f32x2 Lp[P][NM], ap[SLOTS][P];
+#pragma unroll
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) Lp[j][m] = f32x2{L2[2 * j][m], L2[2 * j + 1 < R ? 2 * j + 1 : 2 * j][m]};
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+    for (int j = 0; j < P; ++j) ap[s][j] = f32x2{0.0f, 0.0f};
+  auto one_energy = [&](int e) {
+    f32x2 pe[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) pe[j] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const float mue = mu[m * n_e + e];
+#pragma unroll
+      for (int j = 0; j < P; ++j) pe[j] = __builtin_elementwise_fma(f32x2{mue, mue}, Lp[j][m], pe[j]);
+    }
+    f32x2 te[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) te[j] = f32x2{__builtin_amdgcn_exp2f(-pe[j].x), __builtin_amdgcn_exp2f(-pe[j].y)};
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const float ws = w[srow[s] + e];
+#pragma unroll
+      for (int j = 0; j < P; ++j) ap[s][j] = __builtin_elementwise_fma(f32x2{ws, ws}, te[j], ap[s][j]);
+    }
+  };
+  int e = 0;
+  for (; e + 4 <= n_e; e += 4) {
+    one_energy(e);
+    one_energy(e + 1);
+    one_energy(e + 2);
+    one_energy(e + 3);
+  }
+  for (; e < n_e; ++e) one_energy(e);
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+    for (int q = 0; q < R; ++q) acc[s][q] = (q & 1) ? ap[s][q / 2].y : ap[s][q / 2].x;
+}
+
 // counts[s] = sum_e w[s][e] * exp(-sum_m mu[m][e] * L[m]) (v_exp_f32 on the log2(e)-scaled exponent)
 // for R rays at once (R = 4 in rows4_kernel: one scalar table load serves 4 rays and the FMAs pair up
 // into v_pk_fma_f32).  mu and w are wave-uniform (scalar loads); NM materials in registers.
@@ -119,38 +173,16 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
 #pragma unroll
     for (int q = 0; q < R; ++q) acc[s][q] = 0.0f;
   // Branch-free body: unused spectrum slots read row 0 of w again (their sums are never stored), so all table
-  // loads of an energy are independent scalar loads the compiler can issue together; 4 energies per trip.
+  // loads of an energy are independent scalar loads the compiler can issue together; 4 energies per trip.  The
+  // kernel's time is its vector-instruction count (the detection is half of it), so the body exists for 2 slots
+  // (one or two spectra - the dual-energy scan) and for 4, and pairs of rays go through v_pk_fma_f32.
   int srow[DEXCT_MAX_SPECTRA];
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) srow[s] = (s < a.n_spectra ? s : 0) * n_e;
-  auto one_energy = [&](int e) {
-    float pe[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) pe[q] = 0.0f;
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const float mue = mu[m * n_e + e];
-#pragma unroll
-      for (int q = 0; q < R; ++q) pe[q] = fmaf(mue, L2[q][m], pe[q]);
-    }
-    float te[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) te[q] = __builtin_amdgcn_exp2f(-pe[q]);
-#pragma unroll
-    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) {
-      const float ws = w[srow[s] + e];
-#pragma unroll
-      for (int q = 0; q < R; ++q) acc[s][q] = fmaf(ws, te[q], acc[s][q]);
-    }
-  };
-  int e = 0;
-  for (; e + 4 <= n_e; e += 4) {
-    one_energy(e);
-    one_energy(e + 1);
-    one_energy(e + 2);
-    one_energy(e + 3);
-  }
-  for (; e < n_e; ++e) one_energy(e);
+  if (a.n_spectra <= 2)
+    detect_energies<NM, R, 2>(L2, mu, w, n_e, srow, acc);
+  else
+    detect_energies<NM, R, DEXCT_MAX_SPECTRA>(L2, mu, w, n_e, srow, acc);
   if (a.variance) {
     // second pass, only when noise is requested: var_s = sum_e w2[s][e] * exp(-P_e), w2 = w * (signal per photon)
     float var[DEXCT_MAX_SPECTRA][R];
