@@ -521,7 +521,13 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
   auto ld4 = [&](uint32_t off) {
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)zl, (int)__builtin_amdgcn_readfirstlane((int)off), 0);
   };
-  // packed byte counters: bit0 plane, bit1 plane, both bits; wide per-row counters
+  // Packed byte counters (one byte per row of the lane), wide per-row counters behind them.
+  //   NM <= 3 (ids 0, 1, 2):  c0 = sum of (x & 1) = n1,  c1 = sum of x = n1 + 2 n2   -> 3 vector ops per slab, or 2
+  //                           when two slabs share a v_add3_u32; a byte grows by at most 2 per slab
+  //   NM == 4 (ids 0..3):     c0 = bit-0 plane, c1 = bit-1 plane, c01 = both bits    -> 7 ops, 1 per slab and byte
+  // flush threshold: the full-slab loop stops below it, a group of 4 crossing slabs may then still be counted
+  // before the next check: 247 + 4 <= 255 increments of 1, or (122 + 4) * 2 <= 255 increments of 2
+  constexpr int kFlushAt = NM > 3 ? 248 : 123;
   uint32_t c0 = 0, c1 = 0, c01 = 0;
   uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w01[4] = {0, 0, 0, 0};
   float corr[4][4];   // [material][row]
@@ -529,12 +535,12 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) corr[m][q] = 0.0f;
-  int pending = 0;    // slabs counted into the packed bytes since the last flush (<= 255)
+  int pending = 0;    // slabs counted into the packed bytes since the last flush (<= kFlushAt)
 
   auto flush = [&]() {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      w0[q] += (c0 >> (8 * q)) & 0xFFu;
+      if (NM != 2) w0[q] += (c0 >> (8 * q)) & 0xFFu;
       w1[q] += (c1 >> (8 * q)) & 0xFFu;
       if (NM > 3) w01[q] += (c01 >> (8 * q)) & 0xFFu;
     }
@@ -542,10 +548,15 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
     pending = 0;
   };
   auto count4 = [&](uint32_t x) {
-    const uint32_t b0 = x & 0x01010101u, b1 = (x >> 1) & 0x01010101u;
-    c0 += b0;
-    c1 += b1;
-    if (NM > 3) c01 += b0 & b1;
+    if (NM > 3) {
+      const uint32_t b0 = x & 0x01010101u, b1 = (x >> 1) & 0x01010101u;
+      c0 += b0;
+      c1 += b1;
+      c01 += b0 & b1;
+    } else {
+      if (NM == 3) c0 += x & 0x01010101u;
+      c1 += x;
+    }
   };
 
   constexpr int kPasses = kSuper / BLOCK, kWaves = BLOCK / 64;
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
     // ---- full slabs: one dword (4 rows) per slab, integer counts only; 8 loads in flight
     int s = 0;
     while (s < n_full) {
-      const int batch = min(n_full - s, 248 - pending);
+      const int batch = min(n_full - s, kFlushAt - pending);
       int k = 0;
       for (; k + 8 <= batch; k += 8) {
         uint32_t x[8];
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
       for (; k < batch; ++k) count4(ld4(list_full[s + k]));
       s += batch;
       pending += batch;
-      if (pending >= 248) flush();
+      if (pending >= kFlushAt) flush();
     }
     // ---- crossing slabs: two columns; count the b voxel, correct where the two voxels differ.
     // Groups of 4 slabs: 8 loads in flight, no branch unless some row of some slab differs.
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
         any |= xa[j] ^ xb[j];
       }
       pending += 4;
-      if (pending >= 244) flush();
+      if (pending >= kFlushAt - 4) flush();
       if (any) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
       const uint32_t xa = ld4(q.offa) & (0u - (q.valid & 1u));
       const uint32_t xb = ld4(q.offb) & (0u - ((q.valid >> 1) & 1u));
       count4(xb);
-      if (++pending >= 244) flush();
+      if (++pending >= kFlushAt - 4) flush();
       if (xa != xb) correct(xa, xb, q.t);
     }
     __syncthreads();
@@ -674,8 +685,8 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
     // ids are 0..NM-1: bit-plane counts -> per-material counts
     uint32_t n[4];
     n[3] = NM > 3 ? w01[rr] : 0u;
-    n[1] = w0[rr] - n[3];
-    n[2] = w1[rr] - n[3];
+    n[1] = NM > 3 ? w0[rr] - n[3] : (NM == 3 ? w0[rr] : w1[rr]);
+    n[2] = NM > 3 ? w1[rr] - n[3] : (w1[rr] - w0[rr]) >> 1;
 #pragma unroll
     for (int m = 1; m < NM; ++m) L[rr][m] = (float)(int32_t)n[m] + corr[m][rr];
   }
