@@ -490,9 +490,9 @@ __global__ __launch_bounds__(BLOCK) void rows_kernel(ProjArgs a, const float* __
 constexpr int kSuper = 512;    // slabs staged per pass: 2 KB full list + 8 KB crossing list
 
 struct CrossRec {
-  uint32_t offa, offb;   // column offsets (0 where the piece lies outside the grid)
+  uint32_t offa, offb;   // column offsets of the two pieces
   float t;
-  uint32_t valid;        // bit0: piece a inside the grid, bit1: piece b
+  uint32_t pad;          // 16-B records (one ds_read_b128)
 };
 
 template <int NM, int BLOCK>
@@ -501,6 +501,10 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
   __shared__ uint32_t list_full[kSuper];
   __shared__ CrossRec list_cross[kSuper];
   __shared__ uint32_t wave_tot[kSuper / BLOCK][BLOCK / 64][2];
+  // A slab with one piece outside the grid exists at most twice per ray: where it enters through a v-face (piece
+  // a outside; before every crossing slab) and where it leaves through one (piece b outside; after every crossing
+  // slab).  They are kept out of the crossing list, whose records then need no validity masks.
+  __shared__ CrossRec edge_rec[2];       // [0] entering, [1] leaving; offset ~0u: absent in this pass
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const BlockRay br = block_to_ray(a.n_local_views, a.g.n_channels, n_chunks, a.view_tile);
   const int chunk = br.chunk, c = br.c, v = br.v;
@@ -567,6 +571,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
     uint32_t offa[kPasses], offb[kPasses], below_f[kPasses], below_c[kPasses];
     float tt[kPasses];
     bool is_full[kPasses], is_cross[kPasses];
+    if (tid < 2) edge_rec[tid].offa = ~0u;               // ordered before the writes below by the first barrier
 #pragma unroll
     for (int q = 0; q < kPasses; ++q) {
       const int s = q * BLOCK + tid;
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
         if (inb) offb[q] = (uint32_t)i * su + (uint32_t)sp.jb * sv;
         tt[q] = sp.t;
         is_full[q] = ina && inb && sp.ja == sp.jb;      // both pieces in one voxel column: count only
-        is_cross[q] = !is_full[q] && (ina || inb);
+        is_cross[q] = ina && inb && sp.ja != sp.jb;
       }
       const unsigned long long mf = __ballot(is_full[q]), mc = __ballot(is_cross[q]);
       const unsigned long long lower = (1ull << lane) - 1ull;
@@ -597,9 +602,12 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
       for (int k = 0; k < kWaves; ++k) {
         if (k == wid) {
           if (is_full[q]) list_full[run_f + below_f[q]] = offb[q];
-          if (is_cross[q])
-            list_cross[run_c + below_c[q]] = CrossRec{offa[q] == ~0u ? 0u : offa[q], offb[q] == ~0u ? 0u : offb[q], tt[q],
-                                                      (offa[q] != ~0u ? 1u : 0u) | (offb[q] != ~0u ? 2u : 0u)};
+          if (is_cross[q]) list_cross[run_c + below_c[q]] = CrossRec{offa[q], offb[q], tt[q], 0u};
+          if (!is_full[q] && !is_cross[q] && (offa[q] != ~0u || offb[q] != ~0u)) {
+            // one piece inside: the record keeps the inside column in offa; [0] = piece a is the outside one
+            const bool entering = offa[q] == ~0u;
+            edge_rec[entering ? 0 : 1] = CrossRec{entering ? offb[q] : offa[q], 0u, tt[q], 0u};
+          }
         }
         run_f += wave_tot[q][k][0];
         run_c += wave_tot[q][k][1];
@@ -638,6 +646,13 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
         }
       }
     };
+    // ---- the entering edge slab: piece a outside the grid (ids 0), piece b inside
+    if (edge_rec[0].offa != ~0u) {
+      const uint32_t xb = ld4(edge_rec[0].offa);
+      count4(xb);
+      if (++pending >= kFlushAt - 4) flush();
+      if (xb != 0u) correct(0u, xb, edge_rec[0].t);
+    }
     int k = 0;
     for (; k + 4 <= n_cross; k += 4) {
       uint32_t xa[4], xb[4];
@@ -645,8 +660,8 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const CrossRec q = list_cross[k + j];
-        xa[j] = ld4(q.offa) & (0u - (q.valid & 1u));           // outside the grid -> ids 0
-        xb[j] = ld4(q.offb) & (0u - ((q.valid >> 1) & 1u));
+        xa[j] = ld4(q.offa);
+        xb[j] = ld4(q.offb);
         t4[j] = q.t;
       }
       uint32_t any = 0;
@@ -665,11 +680,16 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
     }
     for (; k < n_cross; ++k) {
       const CrossRec q = list_cross[k];
-      const uint32_t xa = ld4(q.offa) & (0u - (q.valid & 1u));
-      const uint32_t xb = ld4(q.offb) & (0u - ((q.valid >> 1) & 1u));
+      const uint32_t xa = ld4(q.offa);
+      const uint32_t xb = ld4(q.offb);
       count4(xb);
       if (++pending >= kFlushAt - 4) flush();
       if (xa != xb) correct(xa, xb, q.t);
+    }
+    // ---- the leaving edge slab: piece a inside, piece b outside the grid (ids 0): nothing to count
+    if (edge_rec[1].offa != ~0u) {
+      const uint32_t xa = ld4(edge_rec[1].offa);
+      if (xa != 0u) correct(xa, 0u, edge_rec[1].t);
     }
     __syncthreads();
   }
