@@ -313,7 +313,43 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
     float fa0 = 1e-6f, fa1 = 1e-6f;
     const float fg0 = (float)(gd0 * scale), fg1 = (float)(gd1 * scale);
     const int n_bulk = n_iters > n_polish ? n_iters - n_polish : 0;
-    for (; it < n_bulk; ++it) newton_step_f32(tab32, ec, fg0, fg1, fa0, fa1);
+    // float32 bulk with the same exact repeated-state exit as the float64 loop: a state is the pair of floats,
+    // compared as one 64-bit pattern; the state the cycle holds at iteration n_bulk is what all n_bulk
+    // iterations would have produced.
+    {
+      auto pack = [](float x, float y) {
+        return ((unsigned long long)__float_as_uint(y) << 32) | (unsigned long long)__float_as_uint(x);
+      };
+      unsigned long long hs[kGnHistory];
+#pragma unroll
+      for (int k = 0; k < kGnHistory; ++k) hs[k] = 0ull;
+      int hit = -2;
+      for (; it < n_bulk; ++it) {
+        float n0 = fa0, n1 = fa1;
+        newton_step_f32(tab32, ec, fg0, fg1, n0, n1);
+        if (exact_exit) {
+          const unsigned long long b = pack(n0, n1), c = pack(fa0, fa1);
+          if (b == c) hit = -1;
+#pragma unroll
+          for (int k = kGnHistory - 1; k >= 0; --k)
+            if (k < it && b == hs[k] && hit != -1) hit = k;
+          if (hit != -2) break;
+#pragma unroll
+          for (int k = kGnHistory - 1; k > 0; --k) hs[k] = hs[k - 1];
+          hs[0] = c;
+        }
+        fa0 = n0;
+        fa1 = n1;
+      }
+      if (hit >= 0) {
+        const int base = it - 1 - hit, period = hit + 2;
+        const int slot = hit - (n_bulk - base) % period;        // -1 selects the current state
+#pragma unroll
+        for (int k = 0; k < kGnHistory; ++k)
+          if (slot == k) { fa0 = __uint_as_float((unsigned)hs[k]); fa1 = __uint_as_float((unsigned)(hs[k] >> 32)); }
+      }
+      it = n_bulk;
+    }
     if (n_bulk > 0) { a0 = (double)fa0; a1 = (double)fa1; }
     // float64 polish; a pixel whose float32 trajectory did not arrive (non-finite, or the polish
     // steps are still moving it) is redone from the start in float64, i.e. in the reference's

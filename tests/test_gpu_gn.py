@@ -216,11 +216,12 @@ def test_repeated_state_exit_changes_no_bit(hip, golden):
     try:
         for data, ii, mm in cases:
             for n_iters in (7, 23) + tuple(range(41, 52)):
-                os.environ['DEXCT_GN_FULL_LOOP'] = '1'
-                full = md.optimize_sino(data, None, ii, mm, n_iters, precision='f64')
-                os.environ['DEXCT_GN_FULL_LOOP'] = '0'
-                fast = md.optimize_sino(data, None, ii, mm, n_iters, precision='f64')
-                assert np.array_equal(full.view(np.int64), fast.view(np.int64)), n_iters
+                for precision in ('f64', 'mixed'):       # mixed: the float32 bulk loop has the same exit
+                    os.environ['DEXCT_GN_FULL_LOOP'] = '1'
+                    full = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision)
+                    os.environ['DEXCT_GN_FULL_LOOP'] = '0'
+                    fast = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision)
+                    assert np.array_equal(full.view(np.int64), fast.view(np.int64)), (n_iters, precision)
     finally:
         os.environ.pop('DEXCT_GN_FULL_LOOP', None)
 
