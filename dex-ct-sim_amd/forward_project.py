@@ -68,6 +68,10 @@ class Projector:
         if ct.SID <= half_diag or ct.SDD - ct.SID < 0:
             raise ValueError('source must lie outside the phantom grid (SID > half diagonal) and SDD >= SID')
         volume, nz = phantom.volume, phantom.Nz
+        if not self.cone and ct.N_rows < nz:
+            # a stacked fan only ever reads its own slices: upload those (one slice of a 512^3 phantom for the
+            # reference's single-row scan instead of 128 MiB)
+            volume, nz, z_first = volume[z_first:z_first + ct.N_rows], ct.N_rows, 0
         if int(volume.max()) >= phantom.n_materials:
             raise ValueError('the volume holds a material id without a table entry')
         # The 4-rows-per-lane kernels read aligned dwords along z: pad the uploaded copy with empty slices so that
