@@ -186,7 +186,12 @@ int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
  *              g1 >= mask_frac * *mask_max are the air pixels get_basismat_sinos zeroes afterwards
  *              (matdecomp.py:195-196, :204-205); they get (0, 0) directly and their iterations are skipped
  *   workspace  device scratch of dexct_gn_workspace_bytes(n_energies, n_bins) bytes (the product tables
- *              the kernel reads through the scalar cache); owned by the caller, no hidden state */
+ *              the kernel reads through the scalar cache); owned by the caller, no hidden state
+ * n_iters is the reference's fixed iteration count.  The update is a pure function of the two doubles, so the
+ * kernel stops a pixel at the first state that repeats bit for bit (fixed point or cycle of up to 9 states) and
+ * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly.
+ * Environment (read per call, for checking and tuning only): DEXCT_GN_FULL_LOOP=1 executes every iteration;
+ * DEXCT_GN_CHUNK=<1..64> pixels per lane of a wave's run in the float64 shared-spectrum kernel. */
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,
