@@ -65,8 +65,11 @@ class Projector:
         if not self.cone and (z_first < 0 or z_first + ct.N_rows > phantom.Nz):
             raise ValueError(f'rows {ct.N_rows} from slice {z_first} do not fit Nz={phantom.Nz}')
         half_diag = 0.5 * np.hypot(phantom.Nx * phantom.dx, phantom.Ny * phantom.dy)
-        if ct.SID <= half_diag or ct.SDD - ct.SID < 0:
-            raise ValueError('source must lie outside the phantom grid (SID > half diagonal) and SDD >= SID')
+        if ct.SID <= half_diag or ct.SDD - ct.SID < half_diag:
+            # line integrals run through the whole grid: a source or a detector inside it would silently see
+            # material "behind" itself
+            raise ValueError('source and detector must lie outside the phantom grid: SID > half diagonal and '
+                             'SDD - SID >= half diagonal')
         volume, nz = phantom.volume, phantom.Nz
         if not self.cone and ct.N_rows < nz:
             # a stacked fan only ever reads its own slices: upload those (one slice of a 512^3 phantom for the
