@@ -57,13 +57,16 @@ __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ l
 }
 
 // 1 / x by v_rcp_f64 and two Newton refinements (what a float64 division starts with, without its scaling and
-// fix-up steps: the operands here - expected counts, the Hessian's determinant - are far from the subnormal and
-// overflow ranges; zero, inf and NaN give inf or NaN, i.e. a pixel the reference could not solve either).
+// fix-up steps: the operands here - expected counts, the Hessian's determinant - are far from the subnormal
+// range).  For x = 0, +-inf or NaN the refinement would turn the hardware's answer (inf, 0, NaN - what IEEE
+// division gives) into NaN, so it is skipped there: a sum that overflowed during a wild transient then behaves
+// as in the reference (g / inf = 0) and the pixel can still recover.
 __device__ __forceinline__ double rcp_f64(double x) {
-  double r = __builtin_amdgcn_rcp(x);
+  const double r0 = __builtin_amdgcn_rcp(x);
+  double r = fma(r0, fma(-x, r0, 1.0), r0);
   r = fma(r, fma(-x, r, 1.0), r);
-  r = fma(r, fma(-x, r, 1.0), r);
-  return r;
+  const double ax = fabs(x);
+  return (ax > 0.0 && ax < __builtin_huge_val()) ? r : r0;
 }
 
 // Energies are sorted by gn_tables_kernel into three classes: both spectra have weight (nA), only spectrum 0
