@@ -348,6 +348,14 @@ def test_per_bin_poisson_noise(hip):
         assert abs((x == 0).mean() - np.exp(-lam_air[s])) < 0.01
 
 
+def on_plane_rays(g, ct, n_views):
+    """[views, channels] mask of rays running exactly along a grid plane (slope 0, integer intercept): the one
+    genuine tie, where the textbook algorithm and the DDA may each pick either neighbouring column
+    (tests/test_siddon_oracle.py documents it)."""
+    pl = co.plan(g, ct.view_cs(), ct.chan_cs(), 0, n_views)
+    return ((pl['SV'] == 0) & (pl['V0'] % (1 << 40) == 0)).reshape(n_views, -1)
+
+
 @pytest.mark.parametrize('seed', range(12))
 def test_random_scans_bit_exact_path_lengths(hip, seed):
     """Randomised scanner / grid combinations: non-square anisotropic grids, odd sizes, off-centre slice ranges, 2..6
@@ -379,6 +387,7 @@ def test_random_scans_bit_exact_path_lengths(hip, seed):
     E, mu, w = fp.merged_tables(ct, ph, sp)
     _, rpl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, n_views, vol, mu, w, True, n_threads=8)
     cls = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, n_views, vol, mu, w, n_threads=8)
+    tie = on_plane_rays(g, ct, n_views)[:, None, :].repeat(n_rows, 1)          # [views, rows, channels]
     for kernel in (0, 1, 2, 3, 4):
         try:
             pj = projector(ct, ph, kernel=kernel)
@@ -387,8 +396,9 @@ def test_random_scans_bit_exact_path_lengths(hip, seed):
             assert kernel in (3, 4)                           # packed kernels: material-count limits only
             continue
         assert np.array_equal(pl.cpu().numpy(), rpl), (seed, kernel)
-        rel = np.max(np.abs(counts.cpu().numpy() - cls) / cls)
-        assert rel < REL_TOL, (seed, kernel, rel)
+        rel = np.abs(counts.cpu().numpy() - cls) / cls
+        rel[:, tie] = 0.0
+        assert rel.max() < REL_TOL, (seed, kernel, rel.max())
 
 
 def test_source_and_detector_must_clear_the_grid(hip):
@@ -399,3 +409,43 @@ def test_source_and_detector_must_clear_the_grid(hip):
         ct = dx.FanBeamGeometry(N_channels=32, N_proj=8, gamma_fan=0.5, SID=sid, SDD=sdd)
         with pytest.raises(ValueError):
             projector(ct, ph)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_cone_beam_scans(hip, seed):
+    """Randomised cone-beam scans (anisotropic grids, off-centre source heights, 2..6 materials): path lengths equal
+    the oracle's mirror bit for bit, counts agree with the float64 3-D textbook Siddon."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
+    rng = np.random.default_rng(2000 + seed)
+    nx, ny, nz = int(rng.integers(9, 60)), int(rng.integers(9, 60)), int(rng.integers(2, 40))
+    dxv, dyv, dzv = (float(v) for v in rng.uniform(0.08, 0.4, 3))
+    half_diag = 0.5 * np.hypot(nx * dxv, ny * dyv)
+    sid = float(half_diag * rng.uniform(1.3, 4.0))
+    sdd = float(sid + half_diag * rng.uniform(1.0, 3.0))
+    n_rows, n_views, n_ch = int(rng.integers(1, 24)), int(rng.integers(3, 24)), int(rng.integers(5, 90))
+    # the kernel takes at most one z-plane per dominant-axis slab: |dz/du| <= 1 for every ray
+    reach = 0.6 * sdd * dzv / (max(dxv, dyv) * np.sqrt(2.0))
+    src_z = float(rng.uniform(-0.3, 0.3) * reach)
+    half_rows = max(0.5 * (n_rows - 1), 0.5)
+    h_iso = float((reach - abs(src_z)) / half_rows * sid / sdd * rng.uniform(0.2, 1.0))
+    n_mat = int(rng.integers(2, 7))
+    vol = rng.integers(0, n_mat, (nz, ny, nx), dtype=np.uint8)
+    vol[rng.random(vol.shape) < 0.4] = 0
+    mats = ([AIR, WATER, BONE] + [Material(f'm{i}', 1.0 + 0.2 * i, 'H(11.2)O(88.8)') for i in range(3, n_mat)])[:n_mat]
+    ph = dx.VoxelPhantom.from_array('rnd', vol, mats, dx=dxv, dy=dyv, dz=dzv)
+    cone = dx.FanBeamGeometry(N_channels=n_ch, N_proj=n_views, gamma_fan=float(rng.uniform(0.2, 1.6)), SID=sid, SDD=sdd,
+                              h_iso=h_iso, N_rows=n_rows, cone=True, src_z=src_z)
+    g = co.make_geom(n_views, n_ch, n_rows, 0, nx, ny, nz, dxv, dyv, dzv, sid, sdd)
+    sp = spectra()
+    E, mu, w = fp.merged_tables(cone, ph, sp)
+    (counts, pl), _ = projector(cone, ph).project(sp, want_pathlen=True)
+    _, rpl = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), src_z, vol, mu, w, dda=True,
+                             n_threads=8)
+    assert np.array_equal(pl.cpu().numpy(), rpl), seed
+    cls, _ = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), src_z, vol, mu, w, dda=False,
+                             n_threads=8)
+    rel = np.abs(counts.cpu().numpy() - cls) / cls
+    rel[:, on_plane_rays(g, cone, n_views)[:, None, :].repeat(n_rows, 1)] = 0.0
+    assert rel.max() < REL_TOL, (seed, rel.max())
