@@ -586,10 +586,14 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, out_a);
   } else if (precision == 0) {
-    // lane refill: each wave works through a run of 64 * chunk pixels; the run is as long as keeps ~20 waves per
-    // SIMD's worth of waves in the grid (small inputs degenerate to one pixel per lane, as gn_kernel)
+    // lane refill: each wave works through a run of 64 * chunk pixels.  Measured optimum (8e5 ... 4e8 pixels):
+    // up to 8 pixels per lane while that still leaves ~12 500 waves (2.4 x the 5 120 resident ones), and beyond
+    // that as many as keep the grid near 100 000 waves; small inputs degenerate to one pixel per lane.
     const char* ce = getenv("DEXCT_GN_CHUNK");
-    int64_t chunk = ce ? atoll(ce) : n_pix / (kWave * 20480ll);
+    int64_t chunk = n_pix / (kWave * 12500ll);
+    if (chunk > 8) chunk = 8;
+    if (n_pix / (kWave * 100000ll) > chunk) chunk = n_pix / (kWave * 100000ll);
+    if (ce) chunk = atoll(ce);
     chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
     const int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
     const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
