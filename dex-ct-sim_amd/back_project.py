@@ -20,12 +20,52 @@ from .forward_project import effective_weights
 WATER = 'H(11.2)O(88.8)'       # the composition plots.py:140 uses for HU
 
 
-def ramp_taps(n_channels, dgamma, ramp=1.0):
-    """Equiangular filter taps g(n dgamma), n = -(N-1)..(N-1), cutoff ``ramp`` x Nyquist (float64)."""
+WINDOWS = {                      # apodisation W(x), x = f / f_cutoff in [0, 1], applied to the ramp |f|
+    'rect': None,                                                        # band-limited ramp (Ram-Lak)
+    'sinc': lambda x: np.sinc(0.5 * x),                                  # Shepp-Logan: sin(pi x / 2) / (pi x / 2)
+    'cosine': lambda x: np.cos(0.5 * np.pi * x),
+    'hann': lambda x: 0.5 * (1.0 + np.cos(np.pi * x)),
+    'hamming': lambda x: 0.54 + 0.46 * np.cos(np.pi * x),
+}
+
+
+def default_window():
+    """The reference's README (README.md:30-31) speaks of "a sinc window filter"; its source is not available, so
+    the plain band-limited ramp stays the default and the window is a choice (``DEXCT_FBP_WINDOW``)."""
+    import os
+    return os.environ.get('DEXCT_FBP_WINDOW', 'rect')
+
+
+def _windowed_ramp(t, fc, window):
+    """h(t) = 2 int_0^fc f W(f / fc) cos(2 pi f t) df for an array of lags t, by Gauss-Legendre panels shorter
+    than half a period of the fastest cosine (float64, error ~1e-15 of h(0))."""
+    t = np.asarray(t, dtype=np.float64)
+    n_panels = int(np.ceil(4.0 * fc * np.max(np.abs(t)))) + 2
+    x, w = np.polynomial.legendre.leggauss(12)
+    edges = np.linspace(0.0, fc, n_panels + 1)
+    half = 0.5 * (edges[1:] - edges[:-1])
+    f = (0.5 * (edges[1:] + edges[:-1])[:, None] + half[:, None] * x[None, :]).ravel()       # nodes
+    wf = (half[:, None] * w[None, :]).ravel() * f * window(f / fc)
+    out = np.empty(t.shape)
+    step = max(1, int(4e6 // f.size))
+    for i in range(0, t.size, step):
+        out[i:i + step] = 2.0 * (np.cos(2.0 * np.pi * t[i:i + step, None] * f[None, :]) @ wf)
+    return out
+
+
+def ramp_taps(n_channels, dgamma, ramp=1.0, window='rect'):
+    """Equiangular filter taps g(n dgamma), n = -(N-1)..(N-1), cutoff ``ramp`` x Nyquist (float64);
+    ``window`` apodises the ramp below the cutoff (WINDOWS)."""
+    if window not in WINDOWS:
+        raise ValueError(f'unknown filter window {window!r}; choose from {sorted(WINDOWS)}')
     n = np.arange(-(n_channels - 1), n_channels, dtype=np.float64)
     c = float(ramp)
-    h = (c * c / (2 * dgamma ** 2)) * np.sinc(c * n) - (c * c / (4 * dgamma ** 2)) * np.sinc(c * n / 2) ** 2
     t = n * dgamma
+    if WINDOWS[window] is None:
+        h = (c * c / (2 * dgamma ** 2)) * np.sinc(c * n) - (c * c / (4 * dgamma ** 2)) * np.sinc(c * n / 2) ** 2
+    else:
+        pos = _windowed_ramp(t[n_channels - 1:], c / (2.0 * dgamma), WINDOWS[window])      # h is even in t
+        h = np.concatenate([pos[:0:-1], pos])
     with np.errstate(invalid='ignore', divide='ignore'):
         ratio = np.where(n == 0, 1.0, t / np.sin(t))
     return 0.5 * ratio ** 2 * h
@@ -37,7 +77,7 @@ def water_mu(ct, spec):
     return float(np.sum(w * xcompy.mixatten(WATER, spec.E)) / np.sum(w))
 
 
-def recon_device(sino_d, ct, N_matrix, FOV, ramp):
+def recon_device(sino_d, ct, N_matrix, FOV, ramp, window=None):
     """sino_d: device float32 [N_proj, N_channels] or [N_proj, N_rows, N_channels] -> image tensor
     [N_matrix, N_matrix] or [N_rows, N_matrix, N_matrix] (float32, 1/cm)."""
     lib = _native.load()
@@ -52,7 +92,7 @@ def recon_device(sino_d, ct, N_matrix, FOV, ramp):
         raise NotImplementedError('only full 2 pi rotations are reconstructed')
     if getattr(ct, 'cone', False) and n_rows > 1:
         raise NotImplementedError('cone-beam sinograms need an FDK reconstruction, which is not part of this engine')
-    taps = to_dev(ramp_taps(n_ch, ct.dgamma, ramp), torch.float32, dev)
+    taps = to_dev(ramp_taps(n_ch, ct.dgamma, ramp, window or default_window()), torch.float32, dev)
     weight = to_dev(ct.SID * np.cos(ct.gammas), torch.float32, dev)
     view_cs = to_dev(ct.view_cs(), torch.float64, dev)
     q = torch.empty_like(s)
@@ -66,11 +106,12 @@ def recon_device(sino_d, ct, N_matrix, FOV, ramp):
     return img if three_d else img[0]
 
 
-def get_recon(sino, ct, spec, N_matrix, FOV, ramp):
-    """Drop-in for ``recon_raw, recon_HU = get_recon(sino, ct, spec, N_matrix, FOV, ramp)`` (main.py:134)."""
+def get_recon(sino, ct, spec, N_matrix, FOV, ramp, window=None):
+    """Drop-in for ``recon_raw, recon_HU = get_recon(sino, ct, spec, N_matrix, FOV, ramp)`` (main.py:134).
+    ``window``: apodisation of the ramp (WINDOWS; default ``DEXCT_FBP_WINDOW`` or the plain band-limited ramp)."""
     dev = device()
     sino_d = to_dev(np.asarray(sino, dtype=np.float32), torch.float32, dev)
-    raw = recon_device(sino_d, ct, N_matrix, FOV, ramp).cpu().numpy()
+    raw = recon_device(sino_d, ct, N_matrix, FOV, ramp, window).cpu().numpy()
     mu_w = water_mu(ct, spec)
     return raw, (1000.0 * (raw - mu_w) / mu_w).astype(np.float32)
 

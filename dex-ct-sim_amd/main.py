@@ -66,6 +66,8 @@ def main(argv=None):
                     help='spec1:spec2:dose1_mGy:dose2_mGy (reference default, main.py:101)')
     ap.add_argument('--n-iters', type=int, default=50)
     ap.add_argument('--show', action='store_true')
+    ap.add_argument('--window', default=None, choices=['rect', 'sinc', 'cosine', 'hann', 'hamming'],
+                    help='apodisation of the reconstruction ramp (default: DEXCT_FBP_WINDOW or rect)')
     args = ap.parse_args(argv)
 
     import torch.distributed as dist
@@ -104,7 +106,7 @@ def main(argv=None):
                     if do_bp:
                         print('Back projecting!')
                         spec = specs[0] if spec_id == s1 else specs[1]
-                        recon_raw, recon_HU = get_recon(sino_log, ct, spec, N_matrix, FOV, ramp)
+                        recon_raw, recon_HU = get_recon(sino_log, ct, spec, N_matrix, FOV, ramp, window=args.window)
                         recon_raw.astype(np.float32).tofile(sub_dir + 'recon_raw_float32.bin')
                         recon_HU.astype(np.float32).tofile(sub_dir + 'recon_HU_float32.bin')
                         if args.show:
@@ -123,7 +125,7 @@ def main(argv=None):
                 if do_bp:
                     print('Back projecting basis material sinograms!')
                     for i, matsino in enumerate([matsino1, matsino2]):
-                        recon_raw, _ = get_recon(matsino, ct, specs[0], N_matrix, FOV, ramp)    # spec is filler (:168)
+                        recon_raw, _ = get_recon(matsino, ct, specs[0], N_matrix, FOV, ramp, window=args.window)    # spec is filler (:168)
                         recon_raw.astype(np.float32).tofile(sub_dir + f'mat{i + 1}_recon_float32.bin')
                 print(f'matdecomp finished for {s1}-{s2} : t={time() - t0:.2f}s')
 

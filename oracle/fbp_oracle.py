@@ -18,23 +18,50 @@ between channels).  Pins: reconstruction of analytically projected discs (tests/
 import numpy as np
 
 
-def ramp_taps(n_channels, dgamma, ramp=1.0):
+WINDOWS = {          # W(x), x = f / f_cutoff: apodisation of the ramp (Shepp-Logan "sinc", cosine, Hann, Hamming)
+    'sinc': lambda x: np.sinc(0.5 * x),
+    'cosine': lambda x: np.cos(0.5 * np.pi * x),
+    'hann': lambda x: 0.5 * (1.0 + np.cos(np.pi * x)),
+    'hamming': lambda x: 0.54 + 0.46 * np.cos(np.pi * x),
+}
+
+
+def windowed_ramp(t, fc, window):
+    """h(t) = 2 int_0^fc f W(f / fc) cos(2 pi f t) df by QUADPACK's oscillatory rule (scipy quad, weight='cos'),
+    one lag at a time - an algorithm unrelated to the product's Gauss-Legendre panels."""
+    from scipy.integrate import quad
+    W = WINDOWS[window]
+    out = np.empty(len(t))
+    for i, ti in enumerate(np.asarray(t, dtype=np.float64)):
+        if ti == 0.0:
+            out[i] = 2.0 * quad(lambda f: f * W(f / fc), 0.0, fc, epsabs=0, epsrel=1e-13, limit=400)[0]
+        else:
+            out[i] = 2.0 * quad(lambda f: f * W(f / fc), 0.0, fc, weight='cos', wvar=2.0 * np.pi * abs(ti),
+                                epsabs=1e-9 * fc * fc, epsrel=1e-12, limit=400)[0]
+    return out
+
+
+def ramp_taps(n_channels, dgamma, ramp=1.0, window='rect'):
     """g((n) dg) for n = -(N-1) .. (N-1): the equiangular filter with cutoff ramp * Nyquist."""
     n = np.arange(-(n_channels - 1), n_channels, dtype=np.float64)
     c = float(ramp)
-    h = (c * c / (2 * dgamma ** 2)) * np.sinc(c * n) - (c * c / (4 * dgamma ** 2)) * np.sinc(c * n / 2) ** 2
+    if window == 'rect':
+        h = (c * c / (2 * dgamma ** 2)) * np.sinc(c * n) - (c * c / (4 * dgamma ** 2)) * np.sinc(c * n / 2) ** 2
+    else:
+        pos = windowed_ramp(n[n_channels - 1:] * dgamma, c / (2.0 * dgamma), window)
+        h = np.concatenate([pos[:0:-1], pos])
     t = n * dgamma
     with np.errstate(invalid='ignore', divide='ignore'):
         ratio = np.where(n == 0, 1.0, t / np.sin(t))
     return 0.5 * ratio ** 2 * h
 
 
-def filter_sino(sino, gammas, sid, ramp=1.0):
+def filter_sino(sino, gammas, sid, ramp=1.0, window='rect'):
     """sino [..., N_channels] line integrals -> Q [..., N_channels]."""
     sino = np.asarray(sino, dtype=np.float64)
     n = sino.shape[-1]
     dg = float(gammas[1] - gammas[0])
-    g = ramp_taps(n, dg, ramp)
+    g = ramp_taps(n, dg, ramp, window)
     rp = sino * (sid * np.cos(gammas))
     idx = np.arange(n)[:, None] - np.arange(n)[None, :] + (n - 1)      # taps[n - m]
     return dg * np.einsum('...m,nm->...n', rp, g[idx])
@@ -68,7 +95,7 @@ def back_project(q, thetas, gammas, sid, n_matrix, fov):
     return img * dbeta
 
 
-def get_recon(sino_log, thetas, gammas, sid, n_matrix, fov, ramp, mu_water=None):
-    raw = back_project(filter_sino(sino_log, gammas, sid, ramp), thetas, gammas, sid, n_matrix, fov)
+def get_recon(sino_log, thetas, gammas, sid, n_matrix, fov, ramp, mu_water=None, window='rect'):
+    raw = back_project(filter_sino(sino_log, gammas, sid, ramp, window), thetas, gammas, sid, n_matrix, fov)
     hu = None if mu_water is None else 1000.0 * (raw - mu_water) / mu_water
     return raw, hu

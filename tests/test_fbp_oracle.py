@@ -1,6 +1,7 @@
 """Pins of the FBP oracle (parity unpinned: the reference's get_recon source is absent).  Analytic
 sinograms of discs must reconstruct to the disc densities."""
 import numpy as np
+import pytest
 
 from oracle import fbp_oracle as fo
 
@@ -56,3 +57,28 @@ def test_ramlak_taps():
     assert np.isclose(g[4], 0.5 / (4 * 0.01 ** 2))
     assert np.allclose(g[[2, 6]], 0.0, atol=1e-9)                  # even offsets vanish
     assert np.isclose(g[5], 0.5 * (0.01 / np.sin(0.01)) ** 2 * (-1 / (np.pi ** 2 * 0.01 ** 2)))
+
+
+def test_windowed_ramp_taps_product_vs_oracle_and_properties():
+    """Apodised ramps (Shepp-Logan 'sinc' - the reference's README names a sinc window -, cosine, Hann, Hamming): the
+    product's Gauss-Legendre taps agree with the oracle's QUADPACK oscillatory rule; every ramp has no DC response;
+    a window only removes high frequencies, so h(0) = 2 int f W df shrinks in the order rect > sinc > cosine > hann."""
+    from dex_ct_sim_amd import back_project as bp
+    n, dg = 96, 0.8230337 / 96
+    h0 = {}
+    for window in ('rect', 'sinc', 'cosine', 'hann', 'hamming'):
+        for ramp in (1.0, 0.55):
+            got = bp.ramp_taps(n, dg, ramp, window)
+            ref = fo.ramp_taps(n, dg, ramp, window)
+            assert got.shape == (2 * n - 1,)
+            assert np.max(np.abs(got - ref)) < 1e-9 * np.abs(ref).max(), (window, ramp)
+            assert np.array_equal(got, got[::-1])
+        long = bp.ramp_taps(2000, dg, 1.0, window)
+        t = np.arange(-1999, 2000) * dg
+        with np.errstate(invalid='ignore', divide='ignore'):
+            h = long / np.where(t == 0, 0.5, 0.5 * (t / np.sin(t)) ** 2)          # back to the parallel-beam taps
+        assert abs(h.sum()) < 2e-3 * h[1999], window                             # H(0) = 0 up to the truncated tails
+        h0[window] = h[1999]
+    assert h0['rect'] > h0['sinc'] > h0['cosine'] > h0['hann']
+    with pytest.raises(ValueError):
+        bp.ramp_taps(16, dg, 1.0, 'boxcar')
