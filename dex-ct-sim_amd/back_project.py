@@ -77,9 +77,16 @@ def water_mu(ct, spec):
     return float(np.sum(w * xcompy.mixatten(WATER, spec.E)) / np.sum(w))
 
 
-def recon_device(sino_d, ct, N_matrix, FOV, ramp, window=None):
+def default_slices(ct):
+    """Slice grid of a cone-beam reconstruction when none is given: one slice per detector row, spaced by the row
+    height at the isocentre, centred on z = 0 (the centre of the phantom grid)."""
+    return ct.N_rows, -0.5 * (ct.N_rows - 1) * ct.h_iso, ct.h_iso
+
+
+def recon_device(sino_d, ct, N_matrix, FOV, ramp, window=None, slices=None):
     """sino_d: device float32 [N_proj, N_channels] or [N_proj, N_rows, N_channels] -> image tensor
-    [N_matrix, N_matrix] or [N_rows, N_matrix, N_matrix] (float32, 1/cm)."""
+    [N_matrix, N_matrix] or [N_rows, N_matrix, N_matrix] (float32, 1/cm).  A cone-beam scanner (``ct.cone``) is
+    reconstructed with Feldkamp's algorithm onto ``slices = (n_slices, z_first [cm], dz [cm])``."""
     lib = _native.load()
     dev = sino_d.device
     three_d = sino_d.dim() == 3
@@ -90,8 +97,7 @@ def recon_device(sino_d, ct, N_matrix, FOV, ramp, window=None):
         raise ValueError(f'sinogram {tuple(sino_d.shape)} does not match the scanner ({ct.N_proj} x {ct.N_channels})')
     if abs(ct.theta_tot - 2 * np.pi) > 1e-4:
         raise NotImplementedError('only full 2 pi rotations are reconstructed')
-    if getattr(ct, 'cone', False) and n_rows > 1:
-        raise NotImplementedError('cone-beam sinograms need an FDK reconstruction, which is not part of this engine')
+    cone = bool(getattr(ct, 'cone', False)) and n_rows > 1
     taps = to_dev(ramp_taps(n_ch, ct.dgamma, ramp, window or default_window()), torch.float32, dev)
     weight = to_dev(ct.SID * np.cos(ct.gammas), torch.float32, dev)
     view_cs = to_dev(ct.view_cs(), torch.float64, dev)
@@ -99,6 +105,18 @@ def recon_device(sino_d, ct, N_matrix, FOV, ramp, window=None):
     st = stream_ptr()
     _native.check(lib.dexct_fbp_filter(ptr(s), ptr(taps), ptr(weight), n_views * n_rows, n_ch, ct.dgamma, ptr(q), st),
                   'dexct_fbp_filter')
+    if cone:
+        if n_rows != ct.N_rows:
+            raise ValueError(f'sinogram has {n_rows} rows, the scanner {ct.N_rows}')
+        n_slices, z0, dz = slices if slices is not None else default_slices(ct)
+        row_z = ct.row_z()
+        row_w = to_dev(ct.SDD / np.sqrt(ct.SDD ** 2 + (row_z - ct.src_z) ** 2), torch.float32, dev)
+        img = torch.empty((int(n_slices), N_matrix, N_matrix), dtype=torch.float32, device=dev)
+        _native.check(lib.dexct_fdk_backproject(ptr(q), ptr(view_cs), ptr(row_w), n_views, n_ch, n_rows, ct.SID, ct.SDD,
+                                                ct.dgamma, ct.theta_tot / ct.N_proj, float(row_z[0]), float(ct.h),
+                                                float(ct.src_z), int(N_matrix), float(FOV), int(n_slices), float(z0),
+                                                float(dz), ptr(img), st), 'dexct_fdk_backproject')
+        return img
     img = torch.empty((n_rows, N_matrix, N_matrix), dtype=torch.float32, device=dev)
     _native.check(lib.dexct_fbp_backproject(ptr(q), ptr(view_cs), n_views, n_ch, n_rows, ct.SID, ct.dgamma,
                                             ct.theta_tot / ct.N_proj, int(N_matrix), float(FOV), ptr(img), st),
@@ -106,12 +124,14 @@ def recon_device(sino_d, ct, N_matrix, FOV, ramp, window=None):
     return img if three_d else img[0]
 
 
-def get_recon(sino, ct, spec, N_matrix, FOV, ramp, window=None):
+def get_recon(sino, ct, spec, N_matrix, FOV, ramp, window=None, slices=None):
     """Drop-in for ``recon_raw, recon_HU = get_recon(sino, ct, spec, N_matrix, FOV, ramp)`` (main.py:134).
-    ``window``: apodisation of the ramp (WINDOWS; default ``DEXCT_FBP_WINDOW`` or the plain band-limited ramp)."""
+    ``window``: apodisation of the ramp (WINDOWS; default ``DEXCT_FBP_WINDOW`` or the plain band-limited ramp).
+    Cone-beam sinograms ([N_proj, N_rows, N_channels] of a ``cone=True`` scanner) are reconstructed with Feldkamp's
+    algorithm into ``slices = (n_slices, z_first, dz)`` (default: default_slices)."""
     dev = device()
     sino_d = to_dev(np.asarray(sino, dtype=np.float32), torch.float32, dev)
-    raw = recon_device(sino_d, ct, N_matrix, FOV, ramp, window).cpu().numpy()
+    raw = recon_device(sino_d, ct, N_matrix, FOV, ramp, window, slices).cpu().numpy()
     mu_w = water_mu(ct, spec)
     return raw, (1000.0 * (raw - mu_w) / mu_w).astype(np.float32)
 

@@ -87,6 +87,69 @@ __global__ __launch_bounds__(kFbpBlock) void fbp_backproject_kernel(const float*
     if (r < n_rows_here) img[((size_t)(row0 + r) * g.n_matrix + iy) * g.n_matrix + ix] = acc[r] * (float)g.dbeta;
 }
 
+// Cone-beam (FDK) back-projection for the cylindrical detector of dexct_cone_project: equiangular in the fan,
+// rows equally spaced in height on the cylinder of radius SDD around the source axis.  Feldkamp's algorithm is the
+// fan-beam FBP above with two changes: the projections are weighted by the cosine of the cone angle,
+// cos kappa_r = SDD / sqrt(SDD^2 + (row_z[r] - src_z)^2) - a per-row constant, so it commutes with the row-wise
+// filter and is applied here -, and the voxel (x, y, z) reads the detector at height
+// src_z + (z - src_z) * SDD / L (L = in-plane source-voxel distance), linearly interpolated between rows.
+struct FdkGeom {
+  int n_views, n_channels, n_rows, n_matrix, n_slices;
+  double sid, sdd, dgamma, dbeta, pixel;
+  double row_z0, row_dz, src_z, z0, dz;     // detector rows: row_z0 + r*row_dz; slices: z0 + k*dz  [cm]
+};
+
+template <int R>
+__global__ __launch_bounds__(kFbpBlock) void fdk_backproject_kernel(const float* __restrict__ q,
+                                                                    const double* __restrict__ view_cs,
+                                                                    const float* __restrict__ row_weight, FdkGeom g,
+                                                                    float* __restrict__ img) {
+  const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int k0 = blockIdx.z * R;
+  if (ix >= g.n_matrix || iy >= g.n_matrix) return;
+  const double x = (ix - 0.5 * g.n_matrix + 0.5) * g.pixel, y = (iy - 0.5 * g.n_matrix + 0.5) * g.pixel;
+  const double inv_dg = 1.0 / g.dgamma, half = 0.5 * (g.n_channels - 1), inv_rdz = 1.0 / g.row_dz;
+  const int n_here = g.n_slices - k0 < R ? g.n_slices - k0 : R;
+  float acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+  for (int v = 0; v < g.n_views; ++v) {
+    const double cb = view_cs[2 * v], sb = view_cs[2 * v + 1];
+    const double dx = x - g.sid * cb, dy = y - g.sid * sb;
+    const double dot = -(cb * dx + sb * dy), cross = -(cb * dy - sb * dx);
+    const double pos = atan2(cross, dot) * inv_dg + half;
+    const double fl = floor(pos);
+    const int k = (int)fl;
+    if (k < 0 || k >= g.n_channels - 1) continue;
+    const float w = (float)(pos - fl);
+    const double l2 = dx * dx + dy * dy;
+    const float inv_l2 = (float)(1.0 / l2);
+    const double mag = g.sdd / sqrt(l2);                  // magnification of heights from the voxel to the detector
+    const float* qv = q + (size_t)v * g.n_rows * g.n_channels + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < n_here) {
+        const double z = g.z0 + (k0 + r) * g.dz;
+        const double rpos = (g.src_z + (z - g.src_z) * mag - g.row_z0) * inv_rdz;
+        const double rfl = floor(rpos);
+        const int r0 = (int)rfl;
+        if (r0 >= 0 && r0 < g.n_rows - 1) {
+          const float wr = (float)(rpos - rfl);
+          const float* qa = qv + (size_t)r0 * g.n_channels;
+          const float* qb = qa + g.n_channels;
+          const float va = ((1.0f - w) * qa[0] + w * qa[1]) * row_weight[r0];
+          const float vb = ((1.0f - w) * qb[0] + w * qb[1]) * row_weight[r0 + 1];
+          acc[r] += ((1.0f - wr) * va + wr * vb) * inv_l2;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (r < n_here) img[((size_t)(k0 + r) * g.n_matrix + iy) * g.n_matrix + ix] = acc[r] * (float)g.dbeta;
+}
+
 }  // namespace dexct
 
 using namespace dexct;
@@ -118,6 +181,24 @@ int dexct_fbp_backproject(const float* q, const double* view_cs, int32_t n_views
     dim3 grid((n_matrix + 63) / 64, (n_matrix + 3) / 4, n_rows);
     hipLaunchKernelGGL(fbp_backproject_kernel<1>, grid, dim3(kFbpBlock), 0, as_stream(stream), q, view_cs, g, image);
   }
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+int dexct_fdk_backproject(const float* q, const double* view_cs, const float* row_weight, int32_t n_views,
+                          int32_t n_channels, int32_t n_rows, double sid, double sdd, double dgamma, double dbeta,
+                          double row_z0, double row_dz, double src_z, int32_t n_matrix, double fov, int32_t n_slices,
+                          double z0, double dz, float* image, void* stream) {
+  if (!q || !view_cs || !row_weight || !image || n_views <= 0 || n_channels < 2 || n_rows < 2 || n_matrix <= 0 ||
+      n_slices <= 0)
+    return DEXCT_EINVAL;
+  if (!(sid > 0) || !(sdd >= sid) || !(dgamma > 0) || !(fov > 0) || !(row_dz > 0) || !(dz > 0)) return DEXCT_EINVAL;
+  if ((n_slices + 3) / 4 > 65535 || (n_matrix + 3) / 4 > 65535) return DEXCT_ERANGE;
+  FdkGeom g{n_views, n_channels, n_rows, n_matrix, n_slices, sid, sdd, dgamma, dbeta, fov / n_matrix,
+            row_z0, row_dz, src_z, z0, dz};
+  dim3 grid((n_matrix + 63) / 64, (n_matrix + 3) / 4, (n_slices + 3) / 4);
+  hipLaunchKernelGGL(fdk_backproject_kernel<4>, grid, dim3(kFbpBlock), 0, as_stream(stream), q, view_cs, row_weight, g,
+                     image);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

@@ -219,6 +219,16 @@ int dexct_fbp_backproject(const float* q, const double* view_cs, int32_t n_views
                           int32_t n_rows, double sid, double dgamma, double dbeta, int32_t n_matrix, double fov,
                           float* image, void* stream);
 
+/* Cone-beam (Feldkamp) back-projection for the detector of dexct_cone_project: q [view][row][channel] filtered row by
+ * row with dexct_fbp_filter (same weights and taps as the fan); row r at height row_z0 + r*row_dz [cm] on the
+ * detector cylinder, row_weight[r] = cos(cone angle of row r) = SDD / sqrt(SDD^2 + (row_z[r] - src_z)^2);
+ * image [slice][iy][ix] float32 in 1/cm, slice k at z0 + k*dz, z = 0 at the centre of the phantom grid like src_z.
+ * (An extension: the reference is fan-beam only.) */
+int dexct_fdk_backproject(const float* q, const double* view_cs, const float* row_weight, int32_t n_views,
+                          int32_t n_channels, int32_t n_rows, double sid, double sdd, double dgamma, double dbeta,
+                          double row_z0, double row_dz, double src_z, int32_t n_matrix, double fov, int32_t n_slices,
+                          double z0, double dz, float* image, void* stream);
+
 /* Virtual monoenergetic image (plots.py:136-144): out = u1*m1 + u2*m2 (basis-material images m1, m2, n pixels;
  * u1, u2 mass attenuation of the basis materials at the chosen energy), in HU against u_water when hu != 0. */
 int dexct_vmi(const float* m1, const float* m2, int64_t n, double u1, double u2, double u_water, int32_t hu,

@@ -99,3 +99,42 @@ def get_recon(sino_log, thetas, gammas, sid, n_matrix, fov, ramp, mu_water=None,
     raw = back_project(filter_sino(sino_log, gammas, sid, ramp, window), thetas, gammas, sid, n_matrix, fov)
     hu = None if mu_water is None else 1000.0 * (raw - mu_water) / mu_water
     return raw, hu
+
+
+def fdk_recon(sino, thetas, gammas, sid, sdd, row_z, src_z, n_matrix, fov, ramp, slices_z, window='rect'):
+    """Feldkamp reconstruction for the cylindrical detector of the cone-beam projector (rows at heights row_z on the
+    cylinder of radius sdd around the source axis, source at height src_z): the fan algorithm above with the
+    projections weighted by cos(kappa_r) = sdd / sqrt(sdd^2 + (row_z[r] - src_z)^2) and voxel (x, y, z) reading
+    the detector at height src_z + (z - src_z) * sdd / L, L the in-plane source-voxel distance (Feldkamp, Davis,
+    Kress 1984, adapted to equiangular rays as in Kak & Slaney 3.6).  sino [N_proj, N_rows, N_channels] ->
+    [len(slices_z), n_matrix, n_matrix].  PARITY UNPINNED (the reference has no cone beam)."""
+    sino = np.asarray(sino, dtype=np.float64)
+    n_views, n_rows, n_ch = sino.shape
+    row_z = np.asarray(row_z, dtype=np.float64)
+    q = filter_sino(sino, gammas, sid, ramp, window) * (sdd / np.sqrt(sdd ** 2 + (row_z - src_z) ** 2))[None, :, None]
+    dg = float(gammas[1] - gammas[0])
+    dbeta = float(thetas[1] - thetas[0]) if n_views > 1 else 2 * np.pi
+    dzr = float(row_z[1] - row_z[0])
+    c = (np.arange(n_matrix) - n_matrix / 2 + 0.5) * (fov / n_matrix)
+    x, y = np.meshgrid(c, c)
+    vol = np.zeros((len(slices_z), n_matrix, n_matrix))
+    for i in range(n_views):
+        cb, sb = np.cos(thetas[i]), np.sin(thetas[i])
+        dx, dy = x - sid * cb, y - sid * sb
+        gam = np.arctan2(-cb * dy + sb * dx, -(cb * dx + sb * dy))
+        pos = gam / dg + 0.5 * (n_ch - 1)
+        k = np.floor(pos).astype(np.int64)
+        w = pos - k
+        ok = (k >= 0) & (k < n_ch - 1)
+        kk = np.clip(k, 0, n_ch - 2)
+        l2 = dx * dx + dy * dy
+        for s_i, z in enumerate(slices_z):
+            rpos = (src_z + (z - src_z) * sdd / np.sqrt(l2) - row_z[0]) / dzr
+            r0 = np.floor(rpos).astype(np.int64)
+            wr = rpos - r0
+            okr = ok & (r0 >= 0) & (r0 < n_rows - 1)
+            rr = np.clip(r0, 0, n_rows - 2)
+            va = (1 - w) * q[i, rr, kk] + w * q[i, rr, kk + 1]
+            vb = (1 - w) * q[i, rr + 1, kk] + w * q[i, rr + 1, kk + 1]
+            vol[s_i] += np.where(okr, ((1 - wr) * va + wr * vb) / l2, 0.0)
+    return vol * dbeta
