@@ -307,7 +307,9 @@ def main():
 
     # ---- CPU baseline: the oracle (float64 textbook Siddon + detection, then float64 Newton) on a bounded
     # sample of the same workload, all host cores
-    if not args.no_cpu_baseline:
+    if world > 1:
+        out['cpu_baseline'] = None          # timed at N = 1 only (rank 0 shares its host cores with the other ranks here)
+    elif not args.no_cpu_baseline:
         threads = co.max_threads()
         sample_rows, sample_views = 8, 2
         gs = co.make_geom(ct.N_proj, ct.N_channels, sample_rows, n // 2 - sample_rows // 2, n, n, n, ph.dx, ph.dy,
