@@ -251,6 +251,30 @@ def main():
                                    'full_loop_bit_identical': bool(torch.equal(a_full.view(torch.int64),
                                                                                a_nat.view(torch.int64)))})
 
+    # ---- opt-in tolerance stop (float64, DEXCT_GN_STOP_TOL), never part of `value`: what giving up "exactly the
+    # reference's 50 iterations" would buy
+    if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
+        os.environ['DEXCT_GN_STOP_TOL'] = '1e-12'
+        try:
+            a_tol = torch.empty_like(a_nat)
+            md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'f64', out=a_tol, mask_max=gmax,
+                         mask_frac=0.95)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'f64', out=a_tol, mask_max=gmax,
+                         mask_frac=0.95)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop('DEXCT_GN_STOP_TOL', None)
+        diff = ((a_tol - a_nat).abs() / a_nat.abs().clamp(min=1.0))
+        out['gn_stop_tol'] = {'tol': 1e-12, 'gn_ms': e0.elapsed_time(e1),
+                              'max_diff_vs_exact': float(torch.nan_to_num(diff, nan=0.0).max().item()),
+                              'note': 'DEXCT_GN_STOP_TOL=1e-12: float64, a pixel also stops when a step moves it by '
+                                      '<= tol * max(|a|, 1); opt-in, not the fixed iteration count of the reference, '
+                                      'not used for value'}
+        del a_tol
+
     # ---- opt-in mixed-precision Newton (float32 bulk + float64 polish), never part of `value`
     if precision == 'f64' and world == 1:
         a_mixed = torch.empty_like(a_nat)

@@ -418,7 +418,8 @@ __global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __re
                                                              int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, int chunk,
                                                              const double* __restrict__ mask_max, double mask_frac,
-                                                             int exact_exit, double* __restrict__ out_a) {
+                                                             int exact_exit, double stop_tol,
+                                                             double* __restrict__ out_a) {
   __shared__ double lds_pow[kPowN];
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
@@ -474,7 +475,14 @@ __global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __re
       for (int k = kGnHistory - 1; k >= 0; --k)
         if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
     }
-    const bool advance = hit == -2;
+    // opt-in (DEXCT_GN_STOP_TOL, off by default): also stop when the step no longer moves the pixel by more than
+    // stop_tol relative to max(|a|, 1) - not the reference's fixed count any more, but within stop_tol of it
+    bool converged = false;
+    if (stop_tol > 0.0) {
+      const double size = fmax(fmax(fabs(n0), fabs(n1)), 1.0);
+      converged = fmax(fabs(n0 - a0), fabs(n1 - a1)) <= stop_tol * size;      // NaN compares false
+    }
+    const bool advance = hit == -2 && !converged;
     // the state a cycle holds at iteration n_iters: s_m = s_{base + (m - base) mod period} for m >= base = it-1-hit,
     // and (n_iters - base) = (n_iters - it - 1) mod period; s_{base+j} is hist[hit-j], s_it the current state (slot -1)
     int slot = -1;
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __re
       }
       slot = hit - r;
     }
-    double f0 = a0, f1 = a1;
+    double f0 = converged ? n0 : a0, f1 = converged ? n1 : a1;
     if (__ballot(slot >= 0) != 0ull) {
 #pragma unroll
       for (int k = 0; k < kGnHistory; ++k)
@@ -597,8 +605,11 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
     const int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
     const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
+    const char* te = getenv("DEXCT_GN_STOP_TOL");
+    const double stop_tol = te ? atof(te) : 0.0;
     hipLaunchKernelGGL(gn_refill_kernel, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, out_a);
+                       n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, stop_tol > 0.0 ? stop_tol : 0.0,
+                       out_a);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, out_a);

@@ -322,3 +322,27 @@ def test_random_tables_against_numpy_oracle(hip, seed):
         assert ok.mean() > 0.5, (n_e, n_iters, ok.mean())
     if ok.any():
         assert err(got[ok], ref[ok]) < 1e-7, (seed, n_e, n_bins, n_iters, err(got[ok], ref[ok]))
+
+
+def test_opt_in_tolerance_stop(hip, golden):
+    """DEXCT_GN_STOP_TOL: off by default (bit-identical results with the variable unset or 0); when set, every
+    well-conditioned pixel ends within the tolerance of the 50-iteration result."""
+    import os
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    rng = np.random.default_rng(31)
+    i0, mus = g['gn0_i0'], g['gn0_mus']
+    a_true = np.stack([rng.uniform(0, 40, 50000), rng.uniform(0, 8, 50000)], -1)
+    ex = np.exp(-a_true @ mus)
+    cnt = (np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, 50000)))).reshape(2, 100, 500)
+    try:
+        exact = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64')
+        os.environ['DEXCT_GN_STOP_TOL'] = '0'
+        assert np.array_equal(md.optimize_sino(cnt, None, i0, mus, 50, precision='f64').view(np.int64), exact.view(np.int64))
+        for tol in (1e-12, 1e-8):
+            os.environ['DEXCT_GN_STOP_TOL'] = repr(tol)
+            fast = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64')
+            ok = np.isfinite(exact).all(-1)
+            assert err(fast[ok], exact[ok]) < 20 * tol
+    finally:
+        os.environ.pop('DEXCT_GN_STOP_TOL', None)
