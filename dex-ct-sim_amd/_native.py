@@ -12,7 +12,7 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_siddon_project', 'dexct_siddon_trace', 'dexct_gn_decompose', 'dexct_gn_apply_mask',
            'dexct_reduce_max', 'dexct_transpose_batched', 'dexct_fbp_filter', 'dexct_fbp_backproject',
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
-           'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject',
+           'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather',
            'dexct_gn_workspace_bytes']
 
 
@@ -59,6 +59,7 @@ def load():
     lib.dexct_volume_groups.argtypes = [vp, i64, i32, vp, vp]
     lib.dexct_vmi.argtypes = [vp, vp, i64, f64, f64, f64, i32, vp, vp]
     lib.dexct_label_moments.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    lib.dexct_sino_allgather.argtypes = [vp, vp, i64, vp, vp]
     lib.dexct_fdk_backproject.argtypes = [vp, vp, vp, i32, i32, i32, f64, f64, f64, f64, f64, f64, f64, i32, f64, i32,
                                           f64, f64, vp, vp]
     lib.dexct_poisson_detect.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp]

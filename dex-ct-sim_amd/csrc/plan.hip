@@ -7,6 +7,7 @@
 // what makes voxel-index sequences reproducible bit for bit (oracle/dexct_oracle.c orc_plan_one
 // restates the same operations in the same order; build with -ffp-contract=off).
 #include "common.h"
+#include <dlfcn.h>
 
 namespace dexct {
 
@@ -156,11 +157,46 @@ const char* dexct_strerror(int code) {
     case DEXCT_EINVAL: return "invalid argument";
     case DEXCT_ERANGE: return "size out of supported range";
     case DEXCT_EHIP: return "HIP runtime error (see dexct_last_hip_error)";
+    case DEXCT_ERCCL: return "RCCL library not found, or the collective failed (see dexct_last_hip_error)";
     default: return "unknown dexct error";
   }
 }
 
 int dexct_abi_version(void) { return DEXCT_ABI_VERSION; }
+
+// The one data-path collective of the sharded scan: every rank contributes its view shard of the sinogram and
+// receives all of them (ncclAllGather over xGMI).  The library does not link RCCL: the symbol is taken from the
+// copy the process has already loaded (the host framework's, e.g. torch's) or, failing that, from librccl.so.1 -
+// two RCCL instances in one process must not happen.
+typedef int (*dexct_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+
+static dexct_allgather_fn find_allgather() {
+  static dexct_allgather_fn fn = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+      if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names)
+      if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (h) fn = reinterpret_cast<dexct_allgather_fn>(dlsym(h, "ncclAllGather"));
+  }
+  return fn;
+}
+
+int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_rank, void* rccl_comm, void* stream) {
+  if (!local || !gathered || !rccl_comm || count_per_rank <= 0) return DEXCT_EINVAL;
+  dexct_allgather_fn fn = find_allgather();
+  if (!fn) return DEXCT_ERCCL;
+  const int rc = fn(local, gathered, (size_t)count_per_rank, /* ncclFloat32 */ 7, rccl_comm, as_stream(stream));
+  if (rc != 0) {
+    g_last_hip_error = rc;          // ncclResult_t of the failed call
+    return DEXCT_ERCCL;
+  }
+  return DEXCT_OK;
+}
 
 int dexct_last_hip_error(void) { return g_last_hip_error; }
 

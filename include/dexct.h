@@ -27,6 +27,8 @@ extern "C" {
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
 #define DEXCT_ERANGE (-2)   /* a size exceeds what the kernels support (see DEXCT_MAX_*) */
 #define DEXCT_EHIP (-3)     /* a HIP runtime call failed; dexct_last_hip_error() has the code */
+#define DEXCT_ERCCL (-4)    /* RCCL not found in the process, or ncclAllGather failed (its ncclResult_t is then
+                               what dexct_last_hip_error() returns) */
 
 #define DEXCT_MAX_MATERIALS 48 /* material ids 0..47 in the uint8 volume */
 #define DEXCT_MAX_SPECTRA 4    /* spectra detected per traversal */
@@ -166,6 +168,14 @@ int dexct_transpose_batched(const void* src, void* dst, int64_t batch, int32_t r
 int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const int32_t* ray_vrc,
                        int32_t n_rays, int32_t max_seg, int32_t* seg_voxel, float* seg_len,
                        int32_t* n_seg, void* stream);
+
+/* Assembling the sinogram of a view-sharded scan (one all-gather over xGMI): rank r passes its
+ * count_per_rank float32 values (equal on all ranks: pad the last shard) and receives the shards of all ranks in
+ * rank order in gathered[world * count_per_rank]; in place when local == gathered + rank*count_per_rank.
+ * rccl_comm is the caller's ncclComm_t (one process per GPU).  The library does not link RCCL; it uses the copy
+ * already loaded in the process, else librccl.so.1.  The Python host reaches the same ncclAllGather through
+ * torch.distributed (dex-ct-sim_amd/_shard.py). */
+int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_rank, void* rccl_comm, void* stream);
 
 /* Per-pixel Newton (Gauss-Newton) basis-material decomposition: replaces optimize_sino_cpu
  * (matdecomp.py:87-127).

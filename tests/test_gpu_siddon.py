@@ -449,3 +449,31 @@ def test_random_cone_beam_scans(hip, seed):
     rel = np.abs(counts.cpu().numpy() - cls) / cls
     rel[:, on_plane_rays(g, cone, n_views)[:, None, :].repeat(n_rows, 1)] = 0.0
     assert rel.max() < REL_TOL, (seed, rel.max())
+
+
+def test_sino_allgather_entry_point_single_rank(hip):
+    """dexct_sino_allgather with a one-rank RCCL communicator created through the RCCL copy torch has loaded: the
+    gathered buffer equals the shard, out of place and in place (the 8-rank use is the driver's; ranks > 1 are
+    covered by the gloo tests of _shard.py)."""
+    import ctypes as C
+    import os
+    from dex_ct_sim_amd import _native
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+    lib = _native.load()
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'))
+    comm = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, dev) == 0
+    try:
+        a = torch.arange(100000, dtype=torch.float32, device='cuda') * 0.5
+        out = torch.zeros_like(a)
+        _native.check(lib.dexct_sino_allgather(ptr(a), ptr(out), a.numel(), comm, stream_ptr()), 'dexct_sino_allgather')
+        torch.cuda.synchronize()
+        assert torch.equal(out, a)
+        _native.check(lib.dexct_sino_allgather(ptr(out), ptr(out), out.numel(), comm, stream_ptr()), 'in place')
+        torch.cuda.synchronize()
+        assert torch.equal(out, a)
+        assert lib.dexct_sino_allgather(ptr(a), ptr(out), 0, comm, None) == -1
+        assert lib.dexct_sino_allgather(ptr(a), ptr(out), 10, None, None) == -1
+    finally:
+        rccl.ncclCommDestroy(comm)

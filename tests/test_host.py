@@ -181,9 +181,11 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_fbp_filter(one, one, one, 1, 1, 0.01, one, None) == EINVAL
     assert lib.dexct_fbp_backproject(one, one, 10, 16, 1, 60.0, 0.0, 0.1, 32, 20.0, one, None) == EINVAL
     assert lib.dexct_label_moments(None, None, None, 16, 1, one, None) == EINVAL
+    assert lib.dexct_sino_allgather(one, one, 16, None, None) == EINVAL                    # no communicator
     assert lib.dexct_label_moments(one, None, None, 16, 65, one, None) == ERANGE          # more than 64 labels
     assert lib.dexct_vmi(one, one, 16, 0.2, 0.3, 0.0, 1, one, None) == EINVAL              # HU without water
-    for code, text in ((0, b'ok'), (-1, b'invalid argument'), (-3, b'HIP runtime error (see dexct_last_hip_error)')):
+    for code, text in ((0, b'ok'), (-1, b'invalid argument'), (-3, b'HIP runtime error (see dexct_last_hip_error)'),
+                       (-4, b'RCCL library not found, or the collective failed (see dexct_last_hip_error)')):
         assert lib.dexct_strerror(code) == text
 
 
