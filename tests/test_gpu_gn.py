@@ -346,3 +346,24 @@ def test_opt_in_tolerance_stop(hip, golden):
             assert err(fast[ok], exact[ok]) < 20 * tol
     finally:
         os.environ.pop('DEXCT_GN_STOP_TOL', None)
+
+
+def test_integration_md_ctypes_stub_runs(hip, golden):
+    """The reference-side binding shown in INTEGRATION.md (a ctypes optimize_sino_cpu) is executed as written and
+    reproduces the reference's golden result."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    stub = [b for b in blocks if 'def optimize_sino_cpu' in b]
+    assert len(stub) == 1
+    code = stub[0].replace("C.CDLL('dex-ct-sim_amd/libdexct_hip.so')",
+                           f"C.CDLL({os.path.join(root, 'dex-ct-sim_amd', 'libdexct_hip.so')!r})")
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    g = golden
+    i0 = np.repeat(g['gn0_i0'][:, None, :], g['gn0_g'].shape[2], axis=1)          # the reference's [2, nBins, nE]
+    for spectra in (i0[:, :1], i0):                   # one shared spectrum (fast path) / the tiled [2, nBins, nE] as is
+        a = ns['optimize_sino_cpu'](g['gn0_g'], None, spectra, g['gn0_mus'], 50, verbose=False)
+        assert err(a, g['gn0_a_iters50']) < TOL_F64
