@@ -131,6 +131,13 @@ def get_recon(sino, ct, spec, N_matrix, FOV, ramp, window=None, slices=None):
     algorithm into ``slices = (n_slices, z_first, dz)`` (default: default_slices)."""
     dev = device()
     sino_d = to_dev(np.asarray(sino, dtype=np.float32), torch.float32, dev)
+    bad = int((~torch.isfinite(sino_d)).sum().item())
+    if bad:
+        # one NaN (a photon-starved ray whose decomposition diverged, ln of a zero count) would spread over its whole
+        # detector line in the filter and over the whole image in the back-projection
+        import warnings
+        warnings.warn(f'get_recon: {bad} non-finite sinogram value(s) set to 0 before filtering', RuntimeWarning)
+        sino_d = torch.nan_to_num(sino_d, nan=0.0, posinf=0.0, neginf=0.0)
     raw = recon_device(sino_d, ct, N_matrix, FOV, ramp, window, slices).cpu().numpy()
     mu_w = water_mu(ct, spec)
     return raw, (1000.0 * (raw - mu_w) / mu_w).astype(np.float32)

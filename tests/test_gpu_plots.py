@@ -148,3 +148,20 @@ def test_image_quality_of_the_whole_chain(hip):
         k = len(wy) // 2
         sw = plots.vmi_roi_sweep(Evals, M1, M2, [x0, y0, 3, 3], [int(wx[k]) - 3, int(wy[k]) - 3, 6, 6])
         assert np.all(sw['u_signal'] > sw['u_background'] + 200)      # bone well above water in HU at every energy
+
+
+def test_example_script_runs(hip):
+    """examples/dual_energy_vmi.py (the reference's whole workflow on one page) runs and reports a sane RMSE curve."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('dual_energy_vmi', os.path.join(root, 'examples', 'dual_energy_vmi.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ['dual_energy_vmi.py', '--n', '96', '--views', '180', '--channels', '160']
+    try:
+        rmse = mod.main()
+    finally:
+        sys.argv = argv
+    assert rmse.shape == (11,) and np.all(np.isfinite(rmse)) and rmse.min() < 400.0
