@@ -99,3 +99,29 @@ def test_main_sharded_over_two_ranks_writes_identical_files(tmp_path):
                 assert np.array_equal(a, b, equal_nan=True), fn
                 n += 1
     assert n == 6
+
+
+@pytest.mark.gpu
+def test_main_cone_beam_run_with_window(tmp_path):
+    """A cone-beam parameter file (extension keys scanner_geometry = cone_beam, N_rows) through main.py: cone
+    projection, decomposition, Feldkamp reconstructions with an apodised ramp (--window)."""
+    params = json.load(open(os.path.join(INPUT, 'params.txt')))
+    params.update(RUN_ID='cone', Nx=48, Ny=48, Nz=16, dx=0.6, dy=0.6, dz=0.6, N_channels=80, N_projections=72,
+                  N_recon_matrix=40, FOV_recon=28.0, scanner_geometry='cone_beam', N_rows=12, detector_px_height=0.6,
+                  detector_filename=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'))
+    pf = tmp_path / 'params.txt'
+    pf.write_text(json.dumps(params))
+    out_dir = tmp_path / 'output'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'dex-ct-sim_amd', 'main.py'), '--params', str(pf), '--out',
+                        str(out_dir), '--pairs', '140kV:80kV:5:5', '--window', 'hann'], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    base = out_dir / 'cone'
+    sino = np.fromfile(base / '140kV_5000uGy' / 'sino_log_float32.bin', dtype=np.float32)
+    assert sino.size == 72 * 12 * 80
+    rec = np.fromfile(base / '140kV_5000uGy' / 'recon_raw_float32.bin', dtype=np.float32)
+    assert rec.size == 12 * 40 * 40 and np.isfinite(rec).all()             # one slice per detector row by default
+    vol = rec.reshape(12, 40, 40)
+    assert 0.1 < vol[6, 18:22, 18:22].mean() < 0.3                          # water at the centre of the mid-plane [1/cm]
+    m1 = np.fromfile(base / 'matdecomp_140kV_80kV_5000uGy_5000uGy' / 'mat1_recon_float32.bin', dtype=np.float32)
+    assert m1.size == 12 * 40 * 40 and np.isfinite(m1).all()
