@@ -66,6 +66,10 @@ def main(argv=None):
                     help='spec1:spec2:dose1_mGy:dose2_mGy (reference default, main.py:101)')
     ap.add_argument('--n-iters', type=int, default=50)
     ap.add_argument('--show', action='store_true')
+    ap.add_argument('--noise', default='off', choices=['off', 'gaussian', 'poisson'],
+                    help='quantum noise for the dose of each spectrum (default off: the noise-free expectation); '
+                         'gaussian: compound-Poisson variance, normal sample; poisson: per-energy-bin photon counts')
+    ap.add_argument('--seed', type=int, default=0, help='seed of the counter-based noise generator')
     ap.add_argument('--window', default=None, choices=['rect', 'sinc', 'cosine', 'hann', 'hamming'],
                     help='apodisation of the reconstruction ramp (default: DEXCT_FBP_WINDOW or rect)')
     args = ap.parse_args(argv)
@@ -93,7 +97,8 @@ def main(argv=None):
             t0 = time()
             specs = [load_spectrum(ct, s1, d1, args.input_dir), load_spectrum(ct, s2, d2, args.input_dir)]
             print('Forward projecting!')
-            sinos = get_sinos(ct, phantom, specs)
+            sinos = get_sinos(ct, phantom, specs, noise={'off': False, 'gaussian': True, 'poisson': 'poisson'}[args.noise],
+                              seed=args.seed)
             for (spec_id, dose), (sino_raw, sino_log) in zip(((s1, d1), (s2, d2)), sinos):
                 sub_dir = os.path.join(out_dir, f'{spec_id}_{int(dose * 1000):04}uGy/')
                 if rank == 0:

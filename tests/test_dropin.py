@@ -125,3 +125,42 @@ def test_main_cone_beam_run_with_window(tmp_path):
     assert 0.1 < vol[6, 18:22, 18:22].mean() < 0.3                          # water at the centre of the mid-plane [1/cm]
     m1 = np.fromfile(base / 'matdecomp_140kV_80kV_5000uGy_5000uGy' / 'mat1_recon_float32.bin', dtype=np.float32)
     assert m1.size == 12 * 40 * 40 and np.isfinite(m1).all()
+
+
+@pytest.mark.gpu
+def test_main_noise_switch_follows_the_dose(tmp_path):
+    """--noise: the dose of a spectrum (mGy, main.py:68) sets the noise of its sinogram - four times the dose, half
+    the relative noise; the same seed reproduces the files, the default stays noise-free."""
+    params = json.load(open(os.path.join(INPUT, 'params.txt')))
+    params.update(RUN_ID='n', Nx=64, Ny=64, dx=0.4, dy=0.4, dz=0.4, N_channels=96, N_projections=60, back_project=False,
+                  detector_filename=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'))
+    pf = tmp_path / 'params.txt'
+    pf.write_text(json.dumps(params))
+    main_py = os.path.join(ROOT, 'dex-ct-sim_amd', 'main.py')
+
+    def run(tag, pairs, *extra):
+        out = tmp_path / tag
+        r = subprocess.run([sys.executable, main_py, '--params', str(pf), '--out', str(out), '--pairs', pairs, *extra],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return out / 'n'
+
+    clean = run('clean', '140kV:80kV:0.001:0.004')
+    a = run('a', '140kV:80kV:0.001:0.004', '--noise', 'gaussian', '--seed', '5')
+    b = run('b', '140kV:80kV:0.001:0.004', '--noise', 'gaussian', '--seed', '5')
+
+    def rel_noise(base, sub, ref_base):
+        x = np.fromfile(base / sub / 'sino_raw_float32.bin', dtype=np.float32).astype(np.float64)
+        m = np.fromfile(ref_base / sub / 'sino_raw_float32.bin', dtype=np.float32).astype(np.float64)
+        air = m > 0.9 * m.max()
+        return np.std(x[air] / m[air] - 1.0)
+
+    n_lo, n_hi = rel_noise(a, '140kV_0001uGy', clean), rel_noise(a, '80kV_0004uGy', clean)
+    assert n_lo > 0 and n_hi > 0
+    assert rel_noise(clean, '140kV_0001uGy', clean) == 0.0
+    for sub in ('140kV_0001uGy', '80kV_0004uGy'):
+        assert (a / sub / 'sino_raw_float32.bin').read_bytes() == (b / sub / 'sino_raw_float32.bin').read_bytes()
+    # noise ~ 1 / sqrt(photons): compare each spectrum at two doses
+    c = run('c', '140kV:80kV:0.004:0.016', '--noise', 'gaussian', '--seed', '5')
+    clean4 = run('clean4', '140kV:80kV:0.004:0.016')
+    assert abs(rel_noise(c, '140kV_0004uGy', clean4) / n_lo - 0.5) < 0.1
