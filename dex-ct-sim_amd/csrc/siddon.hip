@@ -96,16 +96,12 @@ __device__ __forceinline__ size_t ray_index(const ProjArgs& a, int v, int r, int
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NM, int R, int SLOTS>
-__device__ __forceinline__ void detect_energies(const float (&L2)[R][NM], const float* __restrict__ mu,
+__device__ __forceinline__ void detect_energies(const f32x2 (&Lp)[(R + 1) / 2][NM], const float* __restrict__ mu,
                                                 const float* __restrict__ w, int n_e,
                                                 const int (&srow)[DEXCT_MAX_SPECTRA],
                                                 float (&acc)[DEXCT_MAX_SPECTRA][R]) {
   constexpr int P = (R + 1) / 2;                      // pairs; an odd last ray rides alone in a pair's low half
-  f32x2 Lp[P][NM], ap[SLOTS][P];
-#pragma unroll
-  for (int j = 0; j < P; ++j)
-#pragma unroll
-    for (int m = 0; m < NM; ++m) Lp[j][m] = f32x2{L2[2 * j][m], L2[2 * j + 1 < R ? 2 * j + 1 : 2 * j][m]};
+  f32x2 ap[SLOTS][P];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
@@ -179,10 +175,17 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
   int srow[DEXCT_MAX_SPECTRA];
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) srow[s] = (s < a.n_spectra ? s : 0) * n_e;
+  // (the pairs are formed here, not in the callee: handing the float array over by reference left it in scratch
+  // memory for NM = 2 and 4)
+  f32x2 Lp[(R + 1) / 2][NM];
+#pragma unroll
+  for (int j = 0; j < (R + 1) / 2; ++j)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) Lp[j][m] = f32x2{L2[2 * j][m], L2[2 * j + 1 < R ? 2 * j + 1 : 2 * j][m]};
   if (a.n_spectra <= 2)
-    detect_energies<NM, R, 2>(L2, mu, w, n_e, srow, acc);
+    detect_energies<NM, R, 2>(Lp, mu, w, n_e, srow, acc);
   else
-    detect_energies<NM, R, DEXCT_MAX_SPECTRA>(L2, mu, w, n_e, srow, acc);
+    detect_energies<NM, R, DEXCT_MAX_SPECTRA>(Lp, mu, w, n_e, srow, acc);
   if (a.variance) {
     // second pass, only when noise is requested: var_s = sum_e w2[s][e] * exp(-P_e), w2 = w * (signal per photon)
     float var[DEXCT_MAX_SPECTRA][R];
