@@ -498,7 +498,9 @@ struct CrossRec {
   uint32_t pad;          // 16-B records (one ds_read_b128)
 };
 
-template <int NM, int BLOCK>
+// GROUPED: a material-group pass (a.acc_out set): raw accumulators out, no detection.  A template parameter rather
+// than a run-time branch so that the detection loop's registers do not set the occupancy of the group passes.
+template <int NM, int BLOCK, bool GROUPED>
 __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* __restrict__ mu,
                                                        const float* __restrict__ w, const float* __restrict__ w2, int n_chunks) {
   __shared__ uint32_t list_full[kSuper];
@@ -667,6 +669,9 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
         xb[j] = ld4(q.offb);
         t4[j] = q.t;
       }
+      // all 8 loads leave before the first result is used (for 4 materials the scheduler otherwise interleaved
+      // each load with the arithmetic on the previous one: one memory latency per slab instead of one per batch)
+      __builtin_amdgcn_sched_barrier(0);
       uint32_t any = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
 #pragma unroll
     for (int m = 1; m < NM; ++m) L[rr][m] = (float)(int32_t)n[m] + corr[m][rr];
   }
-  if (a.acc_out) {       // material-group pass: hand the raw accumulators to detect_kernel, one plane per material
+  if (GROUPED) {         // material-group pass: hand the raw accumulators to detect_kernel, one plane per material
     const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
     const bool vec4 = a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[3];
 #pragma unroll
@@ -910,7 +915,10 @@ static int launch_rows4_b(const ProjArgs& a, const Tables& t, hipStream_t st) {
   const int n_chunks = (a.g.n_rows + rows_per_block - 1) / rows_per_block;
   const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  hipLaunchKernelGGL((rows4_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), 0, st, a, t.mu, t.w, t.w2, n_chunks);
+  if (a.acc_out)
+    hipLaunchKernelGGL((rows4_kernel<NM, B, true>), dim3((unsigned)nblk), dim3(B), 0, st, a, t.mu, t.w, t.w2, n_chunks);
+  else
+    hipLaunchKernelGGL((rows4_kernel<NM, B, false>), dim3((unsigned)nblk), dim3(B), 0, st, a, t.mu, t.w, t.w2, n_chunks);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
