@@ -629,6 +629,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
         uint32_t x[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[q] = ld4(list_full[s + k + q]);
+        __builtin_amdgcn_sched_barrier(0);              // all 8 loads in flight before the first count (see below)
 #pragma unroll
         for (int q = 0; q < 8; ++q) count4(x[q]);
       }
