@@ -5,9 +5,13 @@
 // treatment as the minor in-plane coordinate: w(i) = (W0 + i*SW) / 2^40 at the entry face of dominant-axis
 // slab i (40-bit fixed point, exact voxel slices), and at most one z-plane is crossed per slab (|dw/du| <= 1 is
 // required and checked by the caller).  A slab therefore splits into up to three pieces, cut at the v-crossing
-// tv and the z-crossing tw; they are visited in order and added to the accumulator of their material.  Here
-// every material, material 0 included, is accumulated directly (the chord trick of the 2-D kernels would need
-// the 3-D clip of every ray).  oracle/dexct_oracle.c: orc_cone_pathlen mirrors the arithmetic.
+// tv and the z-crossing tw: (a: t1), (middle: t2 - t1), (b: 1 - t2) with t1 = min(tv, tw), t2 = max(tv, tw).
+// As in the 2-D kernels the sum over pieces is rewritten so that the common case costs integer work only:
+//   sum_q l_q [id_q == m] = [idb == m] + t2 ([idm == m] - [idb == m]) + t1 ([ida == m] - [idm == m]),
+// an integer count of the b voxel plus float32 corrections that vanish unless the slab straddles a material
+// boundary (a piece outside the grid has no material).  L_m = ((float)count_m + corr_m) * len3d.  Every material,
+// material 0 included, is accumulated (the chord trick of the 2-D kernels would need the 3-D clip of every
+// ray).  oracle/dexct_oracle.c: orc_cone_pathlen mirrors the arithmetic.
 //
 // Mapping: one thread per ray, lanes over adjacent channels of one (view, row) - neighbouring rays visit
 // neighbouring voxels of the same slices.  Accumulators in registers (<= 4 materials) or per-lane LDS columns.
@@ -35,7 +39,7 @@ struct ConeArgs {
 template <int NM>
 __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const float* __restrict__ mu,
                                                           const float* __restrict__ w) {
-  extern __shared__ float lds_acc[];     // NM == 0: [n_materials][kConeBlock]
+  extern __shared__ float lds_acc[];     // NM == 0: counts then corrections, [n_materials][kConeBlock] each
   const int tid = threadIdx.x;
   const int c = blockIdx.x * kConeBlock + tid;
   const int r = blockIdx.y, v = blockIdx.z;
@@ -68,12 +72,16 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
 
   const uint8_t* __restrict__ base = axis == 0 ? a.vol_xy : a.vol_yx;
   const uint32_t slice = (uint32_t)a.g.nx * (uint32_t)a.g.ny;
-  float acc[NM > 0 ? NM : 1];
+  // NM > 0: counts and corrections in registers; NM == 0: per-lane LDS columns [n_materials][kConeBlock] of each
+  int32_t cnt[NM > 0 ? NM : 1];
+  float corr[NM > 0 ? NM : 1];
+  int32_t* lds_cnt = reinterpret_cast<int32_t*>(lds_acc);
+  float* lds_corr = lds_acc + (size_t)a.n_materials * kConeBlock;
   if (NM > 0) {
 #pragma unroll
-    for (int m = 0; m < (NM > 0 ? NM : 1); ++m) acc[m] = 0.0f;
+    for (int m = 0; m < (NM > 0 ? NM : 1); ++m) { cnt[m] = 0; corr[m] = 0.0f; }
   } else {
-    for (int m = 0; m < a.n_materials; ++m) lds_acc[m * kConeBlock + tid] = 0.0f;
+    for (int m = 0; m < a.n_materials; ++m) { lds_cnt[m * kConeBlock + tid] = 0; lds_corr[m * kConeBlock + tid] = 0.0f; }
   }
   long long V = p.V0 + (long long)p.i_first * p.SV;
   long long W = W0 + (long long)p.i_first * SW;
@@ -85,20 +93,32 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
     const float tw = fminf((float)((uint32_t)((unsigned long long)W >> 8) ^ wpos) * kfw, 1.0f);
     const float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
     const bool v_first = tv <= tw;
-    const int32_t jj[3] = {ja, v_first ? jb : ja, jb};
-    const int32_t kk[3] = {ka, v_first ? ka : kb, kb};
-    const float ll[3] = {t1, t2 - t1, 1.0f - t2};
+    const int32_t jm = v_first ? jb : ja, km = v_first ? ka : kb;
+    auto voxel = [&](int32_t j, int32_t k) -> uint32_t {      // material id, 0xFF outside the grid (or an id >= n_materials)
+      const bool in = (uint32_t)j < (uint32_t)nv && (uint32_t)k < (uint32_t)a.g.nz;
+      return in ? (uint32_t)base[(uint32_t)k * slice + off + (uint32_t)j] : 0xFFu;
+    };
+    const uint32_t ida = voxel(ja, ka), idm = voxel(jm, km), idb = voxel(jb, kb);
+    if (NM > 0) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const bool in = (uint32_t)jj[q] < (uint32_t)nv && (uint32_t)kk[q] < (uint32_t)a.g.nz;
-      if (NM > 0) {
-        const uint32_t id = in ? base[(uint32_t)kk[q] * slice + off + (uint32_t)jj[q]] : 0xFFu;
+      for (int m = 0; m < (NM > 0 ? NM : 1); ++m) cnt[m] += (idb == (uint32_t)m) ? 1 : 0;
+      if (ida != idm || idm != idb) {
 #pragma unroll
-        for (int m = 0; m < (NM > 0 ? NM : 1); ++m) acc[m] += (id == (uint32_t)m) ? ll[q] : 0.0f;
-      } else if (in) {
-        const uint32_t id = base[(uint32_t)kk[q] * slice + off + (uint32_t)jj[q]];
-        if (id < (uint32_t)a.n_materials)
-          __hip_atomic_fetch_add(&lds_acc[id * kConeBlock + tid], ll[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int m = 0; m < (NM > 0 ? NM : 1); ++m) {
+          corr[m] += (idm == (uint32_t)m) ? t2 : 0.0f;
+          corr[m] -= (idb == (uint32_t)m) ? t2 : 0.0f;
+          corr[m] += (ida == (uint32_t)m) ? t1 : 0.0f;
+          corr[m] -= (idm == (uint32_t)m) ? t1 : 0.0f;
+        }
+      }
+    } else {
+      const uint32_t nm = (uint32_t)a.n_materials;
+      if (idb < nm) lds_cnt[idb * kConeBlock + tid] += 1;       // a lane owns its column: plain read-modify-write
+      if (ida != idm || idm != idb) {
+        if (idm < nm) lds_corr[idm * kConeBlock + tid] += t2;
+        if (idb < nm) lds_corr[idb * kConeBlock + tid] -= t2;
+        if (ida < nm) lds_corr[ida * kConeBlock + tid] += t1;
+        if (idm < nm) lds_corr[idm * kConeBlock + tid] -= t1;
       }
     }
     V += p.SV;
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
     float L2[NM > 0 ? NM : 1];
 #pragma unroll
     for (int m = 0; m < (NM > 0 ? NM : 1); ++m) {
-      const float l = acc[m] * len3d;
+      const float l = ((float)cnt[m] + corr[m]) * len3d;
       if (a.pathlen) a.pathlen[ray * n_mat + m] = l;
       L2[m] = l * 1.44269504088896340736f;
     }
@@ -133,13 +153,13 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
     }
   } else {
     for (int m = 0; m < n_mat; ++m) {
-      const float l = lds_acc[m * kConeBlock + tid] * len3d;
+      const float l = ((float)lds_cnt[m * kConeBlock + tid] + lds_corr[m * kConeBlock + tid]) * len3d;
       if (a.pathlen) a.pathlen[ray * n_mat + m] = l;
-      lds_acc[m * kConeBlock + tid] = l * 1.44269504088896340736f;
+      lds_corr[m * kConeBlock + tid] = l * 1.44269504088896340736f;
     }
     for (int e = 0; e < n_e; ++e) {
       float pe = 0.0f;
-      for (int m = 0; m < n_mat; ++m) pe = fmaf(mu[m * n_e + e], lds_acc[m * kConeBlock + tid], pe);
+      for (int m = 0; m < n_mat; ++m) pe = fmaf(mu[m * n_e + e], lds_corr[m * kConeBlock + tid], pe);
       const float t = __builtin_amdgcn_exp2f(-pe);
 #pragma unroll
       for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = fmaf(w[srow[s] + e], t, accs[s]);
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
 template <int NM>
 static int launch_cone(const ConeArgs& a, const float* mu, const float* w, hipStream_t st) {
   dim3 grid((a.g.n_channels + kConeBlock - 1) / kConeBlock, a.g.n_rows, a.n_local_views);
-  const size_t lds = NM > 0 ? 0 : (size_t)a.n_materials * kConeBlock * sizeof(float);
+  const size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * kConeBlock * sizeof(float);
   hipLaunchKernelGGL(cone_kernel<NM>, grid, dim3(kConeBlock), lds, st, a, mu, w);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

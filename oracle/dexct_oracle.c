@@ -443,14 +443,16 @@ static void cone_row_plan(const dexct_fan_geom* g, const double* view_cs, const 
 }
 
 /* Per-material path lengths [cm] of one cone-beam ray, float32, in the kernel's arithmetic: per slab the
- * pieces are cut at the v-crossing tv and the z-crossing tw (each at most one per slab), visited in order and
- * added to acc[id] when inside the grid.  All materials, material 0 included, are accumulated directly. */
+ * pieces are cut at the v-crossing tv and the z-crossing tw (each at most one per slab); their sum is taken as an
+ * integer count of the b voxel plus float32 corrections where the slab straddles a material boundary (same
+ * identity as the 2-D form).  All materials, material 0 included, are accumulated. */
 void orc_cone_pathlen(const dexct_fan_geom* g, const double* view_cs, const double* chan_cs, int view, int chan,
                       const dexct_ray_plan* p, double src_z, double det_z, const uint8_t* vol, int n_mat, float* L) {
   orc_cone_row c;
   cone_row_plan(g, view_cs, chan_cs, view, chan, p, src_z, det_z, &c);
-  float acc[256];
-  for (int m = 0; m < 256; ++m) acc[m] = 0.0f;
+  int32_t cnt[256];
+  float corr[256];
+  for (int m = 0; m < 256; ++m) { cnt[m] = 0; corr[m] = 0.0f; }
   int axis = p->flags & 1u;
   int nv = axis == 0 ? g->ny : g->nx;
   for (int s = 0; s < p->n_slabs; ++s) {
@@ -465,15 +467,23 @@ void orc_cone_pathlen(const dexct_fan_geom* g, const double* view_cs, const doub
     float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
     int32_t jm = tv <= tw ? jb : ja, km = tv <= tw ? ka : kb;       /* the middle piece */
     int32_t jj[3] = {ja, jm, jb}, kk[3] = {ka, km, kb};
-    float ll[3] = {t1, t2 - t1, 1.0f - t2};
+    int id[3];
     for (int q = 0; q < 3; ++q) {
+      id[q] = 255;                                                  /* outside the grid: no material */
       if (jj[q] < 0 || jj[q] >= nv || kk[q] < 0 || kk[q] >= g->nz) continue;
       int x = axis == 0 ? i : jj[q], y = axis == 0 ? jj[q] : i;
-      int id = vol[((size_t)kk[q] * g->ny + y) * g->nx + x];
-      acc[id] += ll[q];
+      id[q] = vol[((size_t)kk[q] * g->ny + y) * g->nx + x];
+    }
+    /* t1 [ida] + (t2 - t1) [idm] + (1 - t2) [idb] = [idb] + t2 ([idm] - [idb]) + t1 ([ida] - [idm]) */
+    cnt[id[2]] += 1;
+    if (id[0] != id[1] || id[1] != id[2]) {
+      corr[id[1]] += t2;
+      corr[id[2]] -= t2;
+      corr[id[0]] += t1;
+      corr[id[1]] -= t1;
     }
   }
-  for (int m = 0; m < n_mat; ++m) L[m] = acc[m] * c.len3d;
+  for (int m = 0; m < n_mat; ++m) L[m] = ((float)cnt[m] + corr[m]) * c.len3d;
 }
 
 /* Cone-beam projections: classic float64 (pathlen + counts) and the DDA mirror (float32 pathlen, float64
