@@ -4,7 +4,6 @@ single-row form next to it.  Prints one markdown table row per line."""
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
