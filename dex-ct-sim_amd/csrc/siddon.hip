@@ -377,11 +377,7 @@ __global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a, const float* __
     const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
     const uint32_t ida = ina ? base[off + (uint32_t)sp.ja] : 0u;
     const uint32_t idb = inb ? base[off + (uint32_t)sp.jb] : 0u;
-#ifdef DEXCT_RAYS_FLAT
-    if (NM > 0) ra.slab_flat(ida, idb, sp.t); else la.slab(ida, idb, sp.t);
-#else
     if (NM > 0) ra.slab(ida, idb, sp.t); else la.slab(ida, idb, sp.t);
-#endif
     V += p.SV;
     off += (uint32_t)nv;
   }
