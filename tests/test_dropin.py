@@ -24,6 +24,7 @@ import xcompy as xc                                                     # plots.
 from xtomosim.system import FanBeamGeometry, VoxelPhantom               # plots.py:17
 from matdecomp import matcomp1, matcomp2                                # plots.py:18
 import numpy as np
+from plots import make_vmi, measure_roi, crop_img, get_xcat_mask        # helpers plots.py defines itself (:136-231)
 assert xc.mixatten(matcomp1, np.array([60.0])).shape == (1,)
 ct = FanBeamGeometry(N_channels=800, N_proj=1200, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=1.0, eid=True,
                      detector_file=%r)                                  # plots.py:109-111
