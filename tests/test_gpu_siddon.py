@@ -477,3 +477,29 @@ def test_sino_allgather_entry_point_single_rank(hip):
         assert lib.dexct_sino_allgather(ptr(a), ptr(out), 10, None, None) == -1
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_degenerate_shapes_through_the_public_calls(hip):
+    """1-2 views, 1-3 channels, 1-voxel phantoms, 1-64 rows through get_sinos / get_basismat_sinos / get_recon:
+    right shapes, finite positive counts, no crash."""
+    import itertools
+    import warnings
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd.system import AIR, BONE, WATER
+    hi, lo = spectra()
+    rng = np.random.default_rng(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for n_proj, n_ch, n, nz, rows in itertools.product((1, 2, 5), (1, 2, 65), (1, 2, 7), (1, 4, 64), (1, 4, 64)):
+            if rows > nz:
+                continue
+            ct = dx.FanBeamGeometry(N_channels=n_ch, N_proj=n_proj, gamma_fan=0.5, SID=60.0, SDD=100.0, N_rows=rows)
+            ph = dx.VoxelPhantom.from_array('t', rng.integers(0, 3, (nz, n, n), dtype=np.uint8), [AIR, WATER, BONE], dx=0.5)
+            (r1, l1), (r2, _) = dx.get_sinos(ct, ph, [hi, lo])
+            expect = (n_proj, n_ch) if rows == 1 else (n_proj, rows, n_ch)
+            assert r1.shape == expect and np.isfinite(r1).all() and (r1 > 0).all(), (n_proj, n_ch, n, nz, rows)
+            m1, m2 = dx.get_basismat_sinos(ct, r1, r2, hi, lo, n_iters=5)
+            assert m1.shape == expect and m2.shape == expect
+            if n_ch >= 2:
+                img, _ = dx.get_recon(l1, ct, hi, 8, 10.0, 1.0)
+                assert img.shape == ((8, 8) if rows == 1 else (rows, 8, 8))
