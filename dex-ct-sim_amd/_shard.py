@@ -64,13 +64,17 @@ def gather_views(local, n_views, view_dim=0, async_op=False):
 
 
 def global_max(value):
-    """max over ranks of a 0-d tensor (device or CPU)."""
+    """max over ranks of a 0-d tensor (device or CPU).  NaN-propagating like np.max (matdecomp.py:195-196): the
+    collective's MAX does not define what a NaN does, so the NaN flag travels as a second element."""
     r, w = world()
     if w > 1:
-        if _needs_cpu_staging(value):
-            v = value.cpu()
+        nan = torch.isnan(value)
+        pair = torch.stack([torch.where(nan, torch.full_like(value, float('-inf')), value), nan.to(value.dtype)])
+        if _needs_cpu_staging(pair):
+            v = pair.cpu()
             dist.all_reduce(v, op=dist.ReduceOp.MAX)
-            value.copy_(v)
+            pair = v.to(value.device)
         else:
-            dist.all_reduce(value, op=dist.ReduceOp.MAX)
+            dist.all_reduce(pair, op=dist.ReduceOp.MAX)
+        value.copy_(torch.where(pair[1] > 0, torch.full_like(value, float('nan')), pair[0]))
     return value

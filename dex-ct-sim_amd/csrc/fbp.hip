@@ -209,12 +209,14 @@ int dexct_fdk_backproject(const float* q, const double* view_cs, const float* ro
 // vmi = u1 * m1 + u2 * m2, optionally in Hounsfield units against water.
 namespace dexct {
 __global__ __launch_bounds__(256) void vmi_kernel(const float* __restrict__ m1, const float* __restrict__ m2, int64_t n,
-                                                  float u1, float u2, float u_water, int hu, float* __restrict__ out) {
+                                                  double u1, double u2, double u_water, int hu, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float v = u1 * m1[i] + u2 * m2[i];
-  if (hu) v = 1000.0f * (v - u_water) / u_water;
-  out[i] = v;
+  // float64 like the reference (its float64 coefficient arrays promote the float32 images, plots.py:141), same
+  // operation order, no contraction (-ffp-contract=off), one rounding to float32 at the end (:144): bit-identical
+  double v = u1 * (double)m1[i] + u2 * (double)m2[i];
+  if (hu) v = 1000.0 * (v - u_water) / u_water;
+  out[i] = (float)v;
 }
 }  // namespace dexct
 
@@ -224,8 +226,7 @@ extern "C" int dexct_vmi(const float* m1, const float* m2, int64_t n, double u1,
   if (!m1 || !m2 || !out || n <= 0 || (hu && !(u_water > 0))) return DEXCT_EINVAL;
   const int64_t nblk = (n + 255) / 256;
   if (nblk > 0x7FFFFFFFll) return DEXCT_ERANGE;
-  hipLaunchKernelGGL(vmi_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), m1, m2, n, (float)u1, (float)u2,
-                     (float)u_water, hu, out);
+  hipLaunchKernelGGL(vmi_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), m1, m2, n, u1, u2, u_water, hu, out);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

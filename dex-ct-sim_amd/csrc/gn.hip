@@ -535,21 +535,29 @@ __global__ __launch_bounds__(256) void mask_kernel(const void* __restrict__ g1, 
 
 __global__ void max_init_kernel(double* out) { *out = -__builtin_huge_val(); }
 
+// NaN-propagating, like np.max (matdecomp.py:195-196): one NaN count makes the maximum NaN, every comparison
+// `g >= thresh * NaN` is then false and NO pixel is masked - exactly what the reference does with such a sinogram.
+__device__ __forceinline__ double nanmax(double m, double v) {
+  return (v != v || m != m) ? __builtin_nan("") : fmax(m, v);
+}
+
 __global__ __launch_bounds__(256) void max_kernel(const void* __restrict__ g1, int g_is_f64, int64_t n_pix,
                                                   double* __restrict__ out) {
   __shared__ double part[4];
   double m = -__builtin_huge_val();
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * 256)
-    m = fmax(m, load_g<double>(g1, g_is_f64, p));
+    m = nanmax(m, load_g<double>(g1, g_is_f64, p));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+  for (int o = 32; o > 0; o >>= 1) m = nanmax(m, __shfl_down(m, o, 64));
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m = fmax(fmax(part[0], part[1]), fmax(part[2], part[3]));
+    m = nanmax(nanmax(part[0], part[1]), nanmax(part[2], part[3]));
     unsigned long long* addr = reinterpret_cast<unsigned long long*>(out);
     unsigned long long old = *addr;
-    while (__longlong_as_double((long long)old) < m) {
+    for (;;) {
+      const double cur = __longlong_as_double((long long)old);
+      if (cur != cur || !(m != m || cur < m)) break;        // a published NaN stays; otherwise publish NaN or a larger value
       const unsigned long long seen = atomicCAS(addr, old, (unsigned long long)__double_as_longlong(m));
       if (seen == old) break;
       old = seen;

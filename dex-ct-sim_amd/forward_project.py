@@ -241,8 +241,27 @@ class Projector:
 _cache = {}
 
 
+def _fingerprint(ct, phantom, view_range):
+    """Everything the device-resident state (volume layouts, ray plans) depends on.  The reference rebuilds its
+    state on every get_sino call; here the state is reused only while the scanner numbers, the voxel sizes and
+    the volume's bytes (crc32, ~0.1 s per 128 MiB on the host) are what they were when it was built - in-place
+    edits of ``phantom.volume`` or of ``ct.SID`` between two calls are therefore seen."""
+    import zlib
+    vol = np.ascontiguousarray(phantom.volume)
+    return (id(ct), id(phantom), view_range, ct.N_proj, ct.N_channels, ct.N_rows, ct.SID, ct.SDD,
+            zlib.crc32(np.ascontiguousarray(ct.thetas).data), zlib.crc32(np.ascontiguousarray(ct.gammas).data),
+            ct.h_iso, bool(getattr(ct, 'cone', False)), float(getattr(ct, 'src_z', 0.0)),
+            phantom.z_index, phantom.Nx, phantom.Ny, phantom.Nz, phantom.dx, phantom.dy, phantom.dz,
+            phantom.n_materials, vol.shape, zlib.crc32(vol.data))
+
+
+def invalidate():
+    """Drop the cached device state (the next get_sino call rebuilds it)."""
+    _cache.clear()
+
+
 def _projector(ct, phantom, view_range):
-    key = (id(ct), id(phantom), view_range, ct.N_proj, ct.N_channels, ct.N_rows, phantom.z_index)
+    key = _fingerprint(ct, phantom, view_range)
     pj = _cache.get(key)
     if pj is None or pj.ct is not ct or pj.phantom is not phantom:
         _cache.clear()                      # keep one (scanner, phantom) pair resident

@@ -80,10 +80,11 @@ def main(argv=None):
         dist.init_process_group(os.environ.get('DEXCT_DIST_BACKEND', 'nccl'))
     rank = dist.get_rank() if dist.is_initialized() else 0
 
-    cwd = os.getcwd()
-    os.chdir(os.path.dirname(args.input_dir.rstrip('/')))      # './input/...' paths of the params file
-    all_params = dx.read_parameter_file(args.params)
-    os.chdir(cwd)
+    # './input/...' paths of the params file resolve against the folder that holds the input directory; the
+    # working directory stays where it is (relative --params / --input-dir / --out keep their meaning)
+    args.params = os.path.abspath(args.params)
+    args.input_dir = os.path.abspath(args.input_dir)
+    all_params = dx.read_parameter_file(args.params, base_dir=os.path.dirname(args.input_dir))
     for params in all_params:
         run_id, do_fp, do_bp = params[:3]
         ct, phantom, _ = params[3:6]            # the spectrum entry is ignored, as in main.py:92

@@ -10,6 +10,8 @@ and moves arrays.  There is no NumPy or CuPy compute path here.
 Error behaviour: the reference raises ``numpy.linalg.LinAlgError`` when a pixel's 2x2 Hessian is
 exactly singular (matdecomp.py:125); the kernel never traps and leaves inf/NaN in such a pixel
 (masked air pixels are set to 0 afterwards exactly as in the reference, :204-205).
+``get_basismat_sinos(..., strict=True)`` restores an exception: it raises ``SingularHessianError`` (a
+``LinAlgError``) when a pixel outside the air mask ends non-finite.
 """
 import os
 
@@ -26,6 +28,11 @@ density1 = 1.06  # [g/cm3]
 mat2 = 'ICRU bone'
 matcomp2 = 'H(3.4)C(15.5)N(4.2)O(43.5)Na(0.1)Mg(0.2)P(10.3)S(0.3)Ca(22.5)'
 density2 = 1.92  # [g/cm3]
+
+class SingularHessianError(np.linalg.LinAlgError):
+    """A pixel outside the air mask ended inf/NaN: its 2x2 Hessian became singular on the way (the reference's
+    ``np.linalg.inv`` raises LinAlgError for an exactly singular one, matdecomp.py:125)."""
+
 
 # 'f64': float64 throughout (the reference's arithmetic).  'mixed': float32 bulk iterations, then
 # N_POLISH float64 iterations (same total count).  Override with DEXCT_GN_PRECISION.
@@ -123,7 +130,8 @@ def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None):
     return a if isinstance(sino1, torch.Tensor) else a.cpu().numpy()
 
 
-def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None):
+def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None,
+                       strict=False):
     """Basis-material sinograms (matdecomp.py:167-207): air mask from sinogram 1
     (``>= mask_thresh * max``), Newton decomposition, masked pixels set to exactly 0.
 
@@ -131,6 +139,8 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     in -> device tensors out.  Under torch.distributed the inputs are either each rank's own view
     shard or the full gathered sinograms (then each rank decomposes its own views and the result
     is all-gathered); the mask threshold always uses the all-reduced global maximum.
+    ``strict=True``: raise ``SingularHessianError`` (a ``numpy.linalg.LinAlgError``, what :125 raises) if a pixel
+    outside the air mask ends non-finite; the default returns the inf/NaN in place, as documented above.
     """
     lib = _native.load()
     dev = device()
@@ -149,6 +159,18 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     gmax = _shard.global_max(gmax)
     # the mask is applied inside the kernel (threshold read from the device scalar: no host round trip)
     a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh))
+    if strict:
+        bad = ~torch.isfinite(a).all(dim=-1)          # masked pixels are exactly 0, hence finite
+        n_bad = int(bad.sum().item())
+        if world > 1:
+            t = torch.tensor(float(n_bad), dtype=torch.float64,
+                             device='cpu' if torch.distributed.get_backend() == 'gloo' else dev)
+            torch.distributed.all_reduce(t)            # every rank raises, or none
+            n_bad = int(t.item())
+        if n_bad:
+            first = bad.flatten().nonzero()[:1].flatten().tolist()
+            raise SingularHessianError(f'Singular matrix: {n_bad} pixel(s) outside the air mask ended non-finite '
+                                       f'after {n_iters} Newton iterations (first flat index on this rank: {first})')
     if full_in:
         a = _shard.gather_views(a, n_views, view_dim=0)
     if isinstance(sino_raw_1, torch.Tensor):

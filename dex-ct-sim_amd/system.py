@@ -243,13 +243,16 @@ def _one_run(p, base_dir):
     return out
 
 
-def read_parameter_file(filename):
-    """JSON parameter file -> list of runs (main.py:89-94).  A file may hold one object or a list."""
+def read_parameter_file(filename, base_dir=None):
+    """JSON parameter file -> list of runs (main.py:89-94).  A file may hold one object or a list.
+
+    Paths in the reference's file are relative to the working directory ('./input/...').  A path that
+    does not exist there is looked up under ``base_dir`` (default: the directory above the params
+    file's own 'input/' folder); the process working directory is never changed."""
     with open(filename) as f:
         data = json.load(f)
     runs = data if isinstance(data, list) else [data]
-    base = os.path.dirname(os.path.abspath(filename))
-    # paths in the reference's file are relative to the working directory ('./input/...');
-    # fall back to the directory above the params file's own 'input/' folder.
-    base = os.path.dirname(base) if os.path.basename(base) == 'input' else base
-    return [_one_run(p, base) for p in runs]
+    if base_dir is None:
+        base_dir = os.path.dirname(os.path.abspath(filename))
+        base_dir = os.path.dirname(base_dir) if os.path.basename(base_dir) == 'input' else base_dir
+    return [_one_run(p, os.path.abspath(base_dir)) for p in runs]

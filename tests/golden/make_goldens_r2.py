@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Second set of golden vectors from the REAL reference (round 2): cases the first set screens out.
+
+Runs only in the build container (needs /root/reference); writes ``ref_extra.npz`` next to this file.
+Only arrays are stored - never reference source text.
+
+  (a) ``uns_*``  the reference's LIVE default spectrum pair (detunedMV / 80 kV at doses 9 / 1, main.py:101) with
+      NO redraw loop: every pixel is drawn once and handed to ``optimize_sino_cpu`` (matdecomp.py:87-127) on its
+      own (pixels are independent problems; a single ill-posed pixel makes the reference raise LinAlgError for the
+      whole sinogram, :125).  Stored per pixel: whether the reference raised, the iteration it raised at, its
+      result after 50 iterations where it completed, and a conditioning flag (does a change of the counts by a
+      few ulps move the reference's OWN answer by more than 1e-6, or make it raise?).
+  (b) ``nan_*``  ``get_basismat_sinos`` (:167-207) on a sinogram pair whose first sinogram holds one NaN:
+      ``np.max`` propagates it, every comparison with the threshold is False and nothing is masked (:195-196).
+  (c) ``vmi_*`` / ``roi_*``  ``make_vmi`` and ``measure_roi`` (plots.py:136-158).  plots.py cannot be imported
+      (module-level code loads phantoms that are not in the checkout), so the two function definitions are
+      selected from its syntax tree and executed with the same ``xc`` stub the Newton goldens use.
+
+    python tests/golden/make_goldens_r2.py
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_goldens import REF, forward_counts, half_split, load_pkg_module, load_reference  # noqa: E402
+
+
+def load_plots_functions(ref_md, xc):
+    """make_vmi / measure_roi of the reference's plots.py, compiled from its syntax tree (nothing else of the
+    module is executed)."""
+    path = os.path.join(REF, 'plots.py')
+    tree = ast.parse(open(path).read(), filename=path)
+    wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('make_vmi', 'measure_roi')]
+    assert sorted(n.name for n in wanted) == ['make_vmi', 'measure_roi']
+    ns = {'np': np, 'xc': xc, 'matcomp1': ref_md.matcomp1, 'matcomp2': ref_md.matcomp2}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), path, 'exec'), ns)
+    return ns['make_vmi'], ns['measure_roi']
+
+
+def main():
+    ref = load_reference()
+    xc = load_pkg_module('xcompy')
+    ref.xc.mixatten = xc.mixatten
+    out = {}
+
+    # ---- tables of the live default pair, captured from do_matdecomp_gn
+    captured = {}
+    real_opt = ref.optimize_sino_cpu
+
+    def spy(Sino_gg, ee, i0, mus, n_iters, verbose=True):
+        captured.update(ee=np.array(ee), i0=np.array(i0), mus=np.array(mus))
+        return real_opt(Sino_gg, ee, i0, mus, n_iters, verbose=False)
+
+    ref.optimize_sino_cpu = spy
+    det = half_split(f'{REF}/input/detector/eta_eid_mv.bin')
+    s1, s2 = half_split(f'{REF}/input/spectrum/detunedMV_1mGy_float32.bin'), half_split(
+        f'{REF}/input/spectrum/80kV_1mGy_float32.bin')
+    ct = types.SimpleNamespace(det_E=det[0], det_eta_E=det[1], eid=True)
+    sp1 = types.SimpleNamespace(E=s1[0], I0=s1[1] * 9.0 * 1e-4)
+    sp2 = types.SimpleNamespace(E=s2[0], I0=s2[1] * 1.0 * 1e-4)
+    ref.do_matdecomp_gn(ct, np.ones((1, 2)), np.ones((1, 2)), sp1, sp2, 1)
+    ref.optimize_sino_cpu = real_opt
+    ee, i0, mus = captured['ee'], captured['i0'][:, 0, :], captured['mus']
+
+    # ---- (a) unscreened pixels
+    rng = np.random.default_rng(20261004)
+    nV, nB, n_iters = 6, 32, 50
+    a_true = np.stack([rng.uniform(0.0, 35.0, (nV, nB)), rng.uniform(0.0, 6.0, (nV, nB))], axis=-1)
+    a_true[:, :2] = 0.0                                   # two air channels per view
+    g = forward_counts(a_true, i0, mus)                   # [2, nV, nB]
+    raised = np.zeros((nV, nB), dtype=bool)
+    raised_at = np.full((nV, nB), -1, dtype=np.int32)
+    a50 = np.full((nV, nB, 2), np.nan)
+    ill = np.zeros((nV, nB), dtype=bool)
+    i0_1 = i0[:, None, :]
+    with np.errstate(all='ignore'):
+        for j in range(nV):
+            for b in range(nB):
+                gp = g[:, j:j + 1, b:b + 1]
+                try:
+                    a50[j, b] = real_opt(gp, ee, i0_1, mus, n_iters, verbose=False)[0, 0]
+                except np.linalg.LinAlgError:
+                    raised[j, b] = True
+                    for it in range(1, n_iters + 1):      # first iteration count at which the reference raises
+                        try:
+                            real_opt(gp, ee, i0_1, mus, it, verbose=False)
+                        except np.linalg.LinAlgError:
+                            raised_at[j, b] = it
+                            break
+                    continue
+                # conditioning of the reference's own answer: counts moved by a few ulps, one measurement at a time
+                # and together (an undamped Newton trajectory that passes a near-singular Hessian amplifies
+                # rounding by decades per step: such a pixel's result is not a parity target for ANY other
+                # implementation of the same formulas, only its finiteness is)
+                for d1, d2 in ((1, 0), (0, 1), (-1, 0), (0, -1), (2, 2), (-2, -2), (3, -3), (-3, 3)):
+                    gq = gp.copy()
+                    for _ in range(abs(d1)):
+                        gq[0] = np.nextafter(gq[0], np.inf if d1 > 0 else -np.inf)
+                    for _ in range(abs(d2)):
+                        gq[1] = np.nextafter(gq[1], np.inf if d2 > 0 else -np.inf)
+                    try:
+                        ap = real_opt(gq, ee, i0_1, mus, n_iters, verbose=False)[0, 0]
+                        d = np.abs(ap - a50[j, b]) / np.maximum(np.abs(a50[j, b]), 1.0)
+                        ill[j, b] |= not np.all(d <= 1e-6)
+                    except np.linalg.LinAlgError:
+                        ill[j, b] = True
+    out.update(uns_ee=ee, uns_i0=i0, uns_mus=mus, uns_a_true=a_true, uns_g=g, uns_raised=raised,
+               uns_raised_at=raised_at, uns_a50=a50, uns_ill=ill, uns_n_iters=np.array(n_iters),
+               uns_spec1_E=sp1.E, uns_spec1_I0=sp1.I0, uns_spec2_E=sp2.E, uns_spec2_I0=sp2.I0,
+               uns_det_E=ct.det_E, uns_det_eta=ct.det_eta_E)
+    ok = ~raised & ~ill
+    err = np.abs(a50[ok] - a_true[ok]) / np.maximum(np.abs(a_true[ok]), 1.0)
+    print(f'(a) unscreened detunedMV/80kV: {raised.sum()} of {raised.size} pixels raise LinAlgError, {ill.sum()} more are '
+          f'ill conditioned, {np.isfinite(a50).all(axis=-1).sum()} finite; well-posed ones recover truth to {err.max():.2e}')
+
+    # ---- (b) NaN in sinogram 1: nothing is masked
+    g0 = np.load(os.path.join(HERE, 'gn_reference.npz'))
+    gg = np.array(g0['gn0_g'])
+    spA = types.SimpleNamespace(E=g0['gn0_spec1_E'], I0=g0['gn0_spec1_I0'])
+    spB = types.SimpleNamespace(E=g0['gn0_spec2_E'], I0=g0['gn0_spec2_I0'])
+    ctA = types.SimpleNamespace(det_E=g0['gn0_det_E'], det_eta_E=g0['gn0_det_eta'], eid=bool(g0['gn0_eid']))
+    gn = gg.copy()
+    gn[0, 2, 17] = np.nan
+    with np.errstate(all='ignore'):
+        m1, m2 = ref.get_basismat_sinos(ctA, gn[0].copy(), gn[1].copy(), spA, spB, n_iters=30)
+    out.update(nan_g=gn, nan_mat1=m1, nan_mat2=m2)
+    air = g0['gn0_a_true'][..., 0] == 0
+    print(f'(b) NaN pixel: result NaN there: {np.isnan(m1[2, 17])}; air pixels zeroed: {bool(np.all(m1[air] == 0))} '
+          f'(reference masks nothing when max is NaN)')
+
+    # ---- (c) make_vmi / measure_roi of plots.py
+    make_vmi, measure_roi = load_plots_functions(ref, xc)
+    rng = np.random.default_rng(7)
+    M1 = (rng.normal(1.0, 0.05, (96, 80)) * (rng.random((96, 80)) > 0.2)).astype(np.float32)
+    M2 = rng.normal(0.15, 0.04, (96, 80)).astype(np.float32)
+    energies = np.array([40.0, 70.0, 100.0, 140.0, 511.0])
+    out.update(vmi_M1=M1, vmi_M2=M2, vmi_E=energies)
+    for k, E0 in enumerate(energies):
+        out[f'vmi_hu_{k}'] = make_vmi(E0, M1, M2)
+        out[f'vmi_raw_{k}'] = make_vmi(E0, M1, M2, HU=False)
+    img = make_vmi(70.0, M1, M2)
+    rois = np.array([[10, 12, 20, 20], [0, 0, 80, 96], [70, 90, 20, 20], [5, 7, 1, 1], [33, 40, 3, 17]])
+    out.update(roi_img=img, roi_info=rois,
+               roi_mean_var=np.array([[float(x) for x in measure_roi(img, r)] for r in rois]),
+               roi_pixels_2=measure_roi(img, rois[2], give_roi=True))
+    print('(c) make_vmi dtype', out['vmi_hu_0'].dtype, 'measure_roi', out['roi_mean_var'][0])
+
+    path = os.path.join(HERE, 'ref_extra.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes,', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

@@ -165,3 +165,27 @@ def test_example_script_runs(hip):
     finally:
         sys.argv = argv
     assert rmse.shape == (11,) and np.all(np.isfinite(rmse)) and rmse.min() < 400.0
+
+
+def test_vmi_and_roi_against_the_reference_functions(hip):
+    """make_vmi / measure_roi of the REAL reference (plots.py:136-158; the two definitions compiled from its syntax
+    tree by tests/golden/make_goldens_r2.py) against dexct_vmi / dexct_label_moments."""
+    import os
+    from conftest import GOLDEN
+    from dex_ct_sim_amd import plots
+    e = np.load(os.path.join(GOLDEN, 'ref_extra.npz'))
+    M1, M2 = e['vmi_M1'], e['vmi_M2']
+    for k, E0 in enumerate(e['vmi_E']):
+        for key, hu in (('hu', True), ('raw', False)):
+            got = plots.make_vmi(float(E0), M1, M2, HU=hu)
+            ref = e[f'vmi_{key}_{k}']
+            assert got.dtype == np.float32 and got.shape == ref.shape
+            assert np.array_equal(got, ref), (E0, key, np.abs(got - ref).max())      # same float64 ops, one rounding
+    img = e['roi_img']
+    for roi, (u_ref, v_ref) in zip(e['roi_info'], e['roi_mean_var']):
+        u, v = plots.measure_roi(img, [int(x) for x in roi])
+        # the reference's np.mean / np.var run in float32 (pairwise sums); the kernel sums in float64
+        assert abs(u - u_ref) <= 2e-6 * max(abs(u_ref), 1.0), (roi, u, u_ref)
+        assert abs(v - v_ref) <= 1e-5 * max(v_ref, 1e-12), (roi, v, v_ref)
+    px = plots.measure_roi(img, [int(x) for x in e['roi_info'][2]], give_roi=True)
+    assert np.array_equal(px, e['roi_pixels_2'])
