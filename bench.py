@@ -10,11 +10,15 @@ Detector rows: BASELINE.json does not name a row count and a single row touches 
 512^3 volume, so the workload is the stacked fan N_rows = Nz = 512; the
 single-row case is reported under "single_row".  Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]            (N > 1: starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: projection angles are sharded; weak scaling - every rank projects `--views` angles of an
-N x views scan of the same phantom.
+Multi-GPU: projection angles are sharded contiguously over the ranks (one process per GPU, RCCL).
+  --scaling strong (default): the scan is FIXED - the metric's 1000 x 800 scan (or --workload config3: BASELINE
+      configs[3], 2000 views x 1024 channels) - and rank r projects and decomposes views/N of it; one all-gather
+      of the raw sinograms over xGMI, overlapped with the Newton kernel, plus one scalar all-reduce(max).
+  --scaling weak: every rank projects `--views` angles of an N x views scan of the same phantom.
+At N = 1 both are the same workload (BASELINE configs[2]).
 """
 import argparse
 import json
@@ -29,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64
+CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md: max clock (the traversal kernel holds ~2.2 under load)
 
 
 def parse():
@@ -37,8 +42,11 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--n', type=int, default=512, help='phantom is n^3')
-    ap.add_argument('--views', type=int, default=1000, help='views per GPU')
-    ap.add_argument('--channels', type=int, default=800)
+    ap.add_argument('--views', type=int, default=None, help='views of the scan (strong) / per GPU (weak)')
+    ap.add_argument('--channels', type=int, default=None)
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])
+    ap.add_argument('--workload', default='config2', choices=['config2', 'config3'],
+                    help='config2: 1000 views x 800 channels (the metric); config3: 2000 x 1024 (BASELINE configs[3])')
     ap.add_argument('--rows', type=int, default=0, help='detector rows (0: n)')
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--gn-precision', default=None, choices=[None, 'f64', 'mixed'])
@@ -48,7 +56,62 @@ def parse():
     ap.add_argument('--skip-single-row', action='store_true')
     ap.add_argument('--skip-gn-full-loop', action='store_true',
                     help='omit the extra full-loop Newton launch (keeps rocprof per-kernel averages clean)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    dv, dc = {'config2': (1000, 800), 'config3': (2000, 1024)}[args.workload]
+    args.views = args.views or dv
+    args.channels = args.channels or dc
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes from here - BEFORE this process
+    makes any GPU call, and as children (never an exec of a process that has touched the GPU) - relay rank 0's
+    JSON line and exit non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               LOCAL_WORLD_SIZE=str(args.gpus))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if 'DEXCT_DIST_BACKEND' not in env:
+        import torch          # device_count() does not initialise the GPU
+        if torch.cuda.device_count() < args.gpus:
+            # fewer devices than ranks (a one-GPU box): ranks share devices, which RCCL cannot do - rehearse the
+            # N-rank control flow over gloo (collectives staged through the host) and say so in the output
+            env['DEXCT_DIST_BACKEND'] = 'gloo'
+            print(f'bench.py: {torch.cuda.device_count()} device(s) for {args.gpus} ranks - gloo rehearsal, ranks share '
+                  f'devices (not an RCCL measurement)', file=sys.stderr)
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies leaves the others waiting in a collective: watch all of them, and when one fails end the
+    # others (exactly the processes started above)
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(buf).decode())
+    sys.stdout.flush()
+    if failed or any(codes):
+        print(f'bench.py: rank exit codes {codes}', file=sys.stderr)
+        return 1
+    return 0
 
 
 def segment_count(co, geom, view_cs, chan_cs, n_views_total, view_begin, view_end):
@@ -59,6 +122,8 @@ def segment_count(co, geom, view_cs, chan_cs, n_views_total, view_begin, view_en
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -74,13 +139,17 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher sets WORLD_SIZE; plain '
+                         f'`python bench.py --gpus N` starts its own ranks)')
+    backend = (os.environ.get('DEXCT_DIST_BACKEND', 'nccl') if world > 1 else None)
     import dex_ct_sim_amd as dx
     from dex_ct_sim_amd import _shard, forward_project as fp, matdecomp as md, synthetic
 
     dev = torch.device('cuda', local_rank)
     n, rows = args.n, (args.rows or args.n)
-    total_views = args.views * world
+    # strong: the scan is fixed (args.views angles in all), each rank takes views/N of it; weak: args.views per rank
+    total_views = args.views if args.scaling == 'strong' else args.views * world
     det = os.path.join(ROOT, 'dex-ct-sim_amd', 'input', 'detector', 'eta_eid_mv.bin')
     ct = dx.FanBeamGeometry(N_channels=args.channels, N_proj=total_views, gamma_fan=0.8230337, SID=60.0, SDD=100.0,
                             eid=True, detector_file=det, N_rows=rows)
@@ -108,7 +177,7 @@ def main():
     counts = torch.empty((2, nV, rows, args.channels), dtype=torch.float32, device=dev) if native == 1 else counts_nat
     a_out = torch.empty((nV, rows, args.channels, 2), dtype=torch.float64, device=dev) if native == 1 else a_nat
     gmax = torch.empty((), dtype=torch.float64, device=dev)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     precision = args.gn_precision or md.DEFAULT_PRECISION
 
     def step(timed):
@@ -146,7 +215,12 @@ def main():
         if world > 1:
             # basis-material sinograms stay view-sharded (each rank owns its angles, as a view-sharded
             # back-projection would consume them); only the raw sinogram is assembled, as the north star says
-            return finish_gather(), a_out
+            if timed:
+                ev[4].record()
+            full = finish_gather()          # the stream waits here for whatever of the gather is not yet done
+            if timed:
+                ev[5].record()
+            return full, a_out
         return counts, a_out
 
     def barrier():
@@ -157,13 +231,15 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
-    t_sid, t_gn = [], []
+    t_sid, t_gn, t_exposed = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
         torch.cuda.synchronize()
         t_sid.append(ev[0].elapsed_time(ev[1]))
         t_gn.append(ev[2].elapsed_time(ev[3]))
+        if world > 1:
+            t_exposed.append(ev[4].elapsed_time(ev[5]))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -171,24 +247,58 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    integrals_per_step = world * n_rays * sum(n_e_spec)
+    rays_all = total_views * rows * args.channels           # rays of all ranks together (ragged shards included)
+    integrals_per_step = rays_all * sum(n_e_spec)
     value = integrals_per_step / (elapsed / args.steps)
+    sid_ms, gn_ms = float(np.mean(t_sid)), float(np.mean(t_gn))
+
+    multi = None
+    if world > 1:
+        # the gather on its own (not overlapped with anything), outside the timed region
+        _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows, 4,
+                                                  stream_ptr()), 'transpose counts')
+        barrier()
+        g0 = time.perf_counter()
+        for _ in range(3):
+            _shard.gather_views(counts, total_views, view_dim=1)
+            torch.cuda.synchronize()
+        gather_alone_ms = 1e3 * (time.perf_counter() - g0) / 3
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {'rank': rank, 'views': [vb, ve], 'siddon_ms': sid_ms, 'gn_ms': gn_ms,
+                                          'gather_exposed_ms': float(np.mean(t_exposed)),
+                                          'gather_alone_ms': gather_alone_ms})
+        gathered_bytes = 2 * total_views * rows * args.channels * 4
+        multi = {'backend': 'nccl (RCCL)' if backend == 'nccl' else f'{backend} (REHEARSAL: ranks share devices, host-staged '
+                                                                      f'collectives; not an RCCL measurement)',
+                 'collectives_per_step': 'all_gather_into_tensor of the raw sinograms (reference order) + all_reduce(max) '
+                                         'of one float64',
+                 'gathered_bytes_per_rank_per_step': gathered_bytes,
+                 'gather_ms': max(r['gather_alone_ms'] for r in per_rank),
+                 'gather_exposed_ms': max(r['gather_exposed_ms'] for r in per_rank),
+                 'gather_GBps_per_rank': gathered_bytes * (world - 1) / world / (max(r['gather_alone_ms'] for r in per_rank) * 1e-3) / 1e9,
+                 'per_rank': per_rank,
+                 'note': 'gather_ms: the all-gather alone; gather_exposed_ms: what the step still waits for after the '
+                         'Newton kernel has finished (the collective is started before it and overlaps it)'}
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    sid_ms, gn_ms = float(np.mean(t_sid)), float(np.mean(t_gn))
     out = {
         'metric': 'Siddon ray-energy integrals/sec', 'value': value, 'unit': 'ray-energy integrals/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
         'dtype': 'f64' if precision == 'f64' else 'f32+f64', 'data': 'synthetic',
-        'config': {'workload': f'{n}^3 water/bone phantom, {args.views} views/GPU x {args.channels} channels x '
+        'config': {'workload': f'{n}^3 water/bone phantom, {total_views} views x {args.channels} channels x '
                                f'{rows} rows (stacked fan), dual 140/80 kVp Kramers spectra ({n_e_spec[0]}+{n_e_spec[1]} '
                                f'energy bins), fused dual-spectrum Siddon + {args.iters}-iteration Gauss-Newton',
-                   'rays_per_gpu': n_rays, 'parallelism': f'views sharded x{world}',
+                   'baseline_config': 'configs[2]' if (args.workload == 'config2' and total_views == 1000) else
+                                      ('configs[3]' if args.workload == 'config3' else 'configs[2] x N views (weak scaling)'),
+                   'n': n, 'rays_per_gpu': n_rays, 'rays_total': rays_all,
+                   'parallelism': f'{total_views} views sharded x{world} ({args.scaling} scaling: '
+                                  + ('fixed scan, views/N per rank)' if args.scaling == 'strong' else
+                                     f'{args.views} views per rank)'),
                    'arithmetic': 'voxel indices int64 fixed point, path lengths + detection f32, Newton '
                                  + ('f64 (reference arithmetic)' if precision == 'f64' else 'f32 bulk + f64 polish')},
         'kernel_ms': {'siddon_project': sid_ms, 'gn_decompose': gn_ms},
@@ -196,43 +306,90 @@ def main():
         'siddon_rays_per_s': n_rays / (sid_ms * 1e-3),
         'gn_pixel_solves_per_s': n_rays / (gn_ms * 1e-3),
     }
+    if multi is not None:
+        out['multi_gpu'] = multi
 
-    # ---- roofline of the traversal kernel: algorithmic bytes = exact segment count x 1 B + outputs
+    # ---- rooflines.  The step's dominant kernel is the Newton kernel (98 % of the time): FP64 vector bound.  The
+    # traversal kernel is stated against the bound its counters show: vector issue while the
+    # volume is cache resident (<= 256 MiB Infinity Cache), HBM beyond.  No fraction here can exceed 1.
     from oracle import c_oracle as co
+    import glob
     geom = co.make_geom(ct.N_proj, ct.N_channels, rows, ph.z_index, n, n, n, ph.dx, ph.dy, ph.dz, ct.SID, ct.SDD)
     seg_vc, _ = segment_count(co, geom, ct.view_cs(), ct.chan_cs(), total_views, vb, ve)
     alg_bytes = seg_vc * rows * 1 + 4 * 2 * n_rays
-    achieved = alg_bytes / (sid_ms * 1e-3) / 1e9
+    alg_gbps = alg_bytes / (sid_ms * 1e-3) / 1e9
     kname = {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel'}[args.kernel or (3 if native == 1 else 1)]
-    traffic = None
-    import glob
-    pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
-    if pmc:      # newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_gpu.sh)
-        j = json.load(open(pmc[-1]))
-        if j.get('rays_per_gpu') == n_rays and kname in j.get('siddon_kernel', ''):   # same workload and kernel only
-            traffic = j.get('siddon_hbm_bytes_per_launch')
-    out['roofline'] = {'kernel': kname,
-                       'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                       'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                       'traffic_GBps': None if traffic is None else traffic / (sid_ms * 1e-3) / 1e9,
-                       'note': 'achieved = ALGORITHMIC bytes / launch time; the 128 MiB volume is resident in L2 + '
-                               'Infinity Cache, so it can exceed the HBM peak; traffic = PMC FETCH_SIZE + WRITE_SIZE '
-                               '(fabric side, calibrated as in profiles/*_summary.md).  True-HBM regime (1024^3 volume): '
-                               'profiles/r01d_1024_*',
-                       'algorithmic_bytes_per_launch': alg_bytes, 'segments_per_launch': seg_vc * rows,
-                       'avg_launch_ms': sid_ms}
+    traffic = traffic_src = None
+    prof = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), key=os.path.getmtime):
+        j = json.load(open(f))         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_gpu.sh)
+        if j.get('rays_per_gpu') == n_rays and kname in j.get('siddon_kernel', '') and j.get('n', 512) == n:
+            prof, traffic_src = j, 'profiles/' + os.path.basename(f)        # same workload and kernel only; newest wins
+    traffic = prof.get('siddon_hbm_bytes_per_launch')
+    vol_bytes = n * n * n
+    cache_resident = vol_bytes <= 256 * 2 ** 20
+    # vector-issue floor of the packed traversal + detection: per lane (= 4 detector rows)
+    #   2 vector instructions per voxel-dword visited (bit-plane AND + its add; the weighted-sum add shared by two
+    #   visits through v_add3) and, per energy bin any spectrum weights, 6 v_pk_fma (3 materials x 2 ray pairs) +
+    #   4 v_exp_f32 (2 issue slots each) + 2 v_pk_fma per spectrum that weights the bin; one slot = 4 cycles of one
+    #   of the 1024 SIMDs.
+    n_e_any = int(((w_d != 0).any(dim=0)).sum().item())
+    lanes = n_rays / 4.0
+    floor_slots = 2.0 * seg_vc * rows / 4.0 + lanes * (14.0 * n_e_any + 2.0 * sum(n_e_spec))
+    slots_per_s = 1024 * CLOCK_GHZ * 1e9 / 4.0 / 64.0          # wave-instruction issue slots per second, whole chip
+    floor_ms = floor_slots / 64.0 / slots_per_s * 1e3
+    sid = {'kernel': kname, 'avg_launch_ms': sid_ms,
+           'algorithmic_bytes_per_launch': alg_bytes, 'segments_per_launch': seg_vc * rows,
+           'algorithmic_GBps': alg_gbps, 'traffic': traffic, 'traffic_source': traffic_src,
+           'traffic_GBps': None if traffic is None else traffic / (sid_ms * 1e-3) / 1e9,
+           'traffic_frac_of_hbm_peak': None if traffic is None else traffic / (sid_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           'volume_cache_resident': cache_resident,
+           'valu_floor': {'floor_wave_instructions': floor_slots / 64.0, 'floor_ms_at_%.1f_GHz' % CLOCK_GHZ: floor_ms,
+                          'achieved_over_floor': floor_ms / sid_ms,
+                          'measured_valu_instructions': prof.get('siddon_valu_insts'),
+                          'measured_valu_busy': prof.get('siddon_valu_busy'), 'counters_source': traffic_src}}
+    if cache_resident:
+        sid.update({'bound': 'valu_issue', 'achieved': floor_slots / 64.0 / (sid_ms * 1e-3) / 1e9, 'peak': slots_per_s / 1e9,
+                    'unit': 'G wave-instructions/s', 'frac': floor_ms / sid_ms,
+                    'note': 'the %d MiB volume is L2 / Infinity-Cache resident: the algorithmic byte rate (%.0f GB/s) is not '
+                            'an HBM rate and is reported as algorithmic_GBps only; the counters show vector issue as the '
+                            'binding resource, so frac = instruction floor / time' % (vol_bytes >> 20, alg_gbps)})
+    else:
+        hbm_gbps = sid['traffic_GBps']
+        sid.update({'bound': 'hbm', 'achieved': hbm_gbps if hbm_gbps is not None else min(alg_gbps, HBM_PEAK_GBS),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': (hbm_gbps if hbm_gbps is not None else min(alg_gbps, HBM_PEAK_GBS)) / HBM_PEAK_GBS,
+                    'note': 'volume larger than the Infinity Cache: achieved = measured fabric traffic (PMC) when a '
+                            'matching profile exists, else the algorithmic byte rate capped at the peak; '
+                            'traffic / algorithmic bytes = %s' % (None if traffic is None else round(traffic / alg_bytes, 3))})
+    out['roofline_siddon'] = sid
+
     # air pixels (zeroed by the mask afterwards, matdecomp.py:204-205) are not iterated: count the others only
     masked = float((counts_nat[0] >= 0.95 * gmax).float().mean().item())
     out['gn_masked_fraction'] = masked
-    gn_flops = (1.0 - masked) * n_rays * args.iters * i0.shape[1] * (28 + 1)   # 28 flops + 1 exp per energy-iteration
-    out['roofline_gn'] = {'kernel': 'gn_refill_kernel' if precision == 'f64' else 'gn_kernel<true,false>', 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
-                          'achieved': gn_flops / (gn_ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
-                          'unit': 'TFLOP/s', 'frac': gn_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          'avg_launch_ms': gn_ms,
-                          'note': 'ALGORITHMIC flops of n_iters iterations (exp counted as 1 flop; unmasked pixels only; '
-                                  'not HBM bound, 24 B/pixel).  Iterations the exact repeated-state exit skips are counted '
-                                  'as done; full_loop_* is the same launch with every iteration executed '
-                                  '(DEXCT_GN_FULL_LOOP=1), i.e. the executed-flop rate of the kernel'}
+    # 28 flops + 1 exp per energy-iteration
+    flops_per_pixel_iter = i0.shape[1] * (28 + 1)
+    gn_flops_all = (1.0 - masked) * n_rays * args.iters * flops_per_pixel_iter
+    gn_name = 'gn_refill_kernel' if precision == 'f64' else 'gn_kernel<true,false>'
+    gstats = md.last_gn_stats() if hasattr(md, 'last_gn_stats') else None
+    roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
+            'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': gn_ms,
+            'traffic': (prof.get('gn_fetch_bytes_x2_corrected', 0) + prof.get('gn_write_bytes', 0)) or None,
+            'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': 24 * n_rays,
+            'bound_note': 'neither HBM (24 B/pixel against ~2e5 flops/pixel) nor MFMA (no dense contraction; FP64 MFMA and '
+                          'FP64 VALU do not overlap on gfx950, DESIGN.md 4.4): bound = FP64 vector issue'}
+    if gstats and gstats.get('pixel_iterations'):
+        # EXECUTED work of the timed launch itself: the kernel counts the pixel-iterations it ran
+        ex_flops = gstats['pixel_iterations'] * flops_per_pixel_iter
+        roof.update({'achieved': ex_flops / (gn_ms * 1e-3) / 1e12, 'frac': ex_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     'executed_pixel_iterations': gstats['pixel_iterations'],
+                     'mean_iterations_per_unmasked_pixel': gstats['pixel_iterations'] / max((1.0 - masked) * n_rays, 1.0),
+                     'exit_saving': 1.0 - gstats['pixel_iterations'] / max((1.0 - masked) * n_rays * args.iters, 1.0),
+                     'note': 'achieved = flops of the iterations the timed launch EXECUTED (counted by the kernel; SURVEY 8d: '
+                             '28 flops + 1 exp per energy and iteration, unmasked pixels) / its time.  exit_saving = share of '
+                             'the n_iters x pixels iterations the exact repeated-state exit proved unnecessary - reported '
+                             'separately, not as throughput'})
+    out['roofline'] = roof
     if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
         os.environ['DEXCT_GN_FULL_LOOP'] = '1'
         try:
@@ -246,10 +403,18 @@ def main():
         finally:
             os.environ.pop('DEXCT_GN_FULL_LOOP', None)
         full_ms = e0.elapsed_time(e1)
-        out['roofline_gn'].update({'full_loop_ms': full_ms, 'full_loop_achieved': gn_flops / (full_ms * 1e-3) / 1e12,
-                                   'full_loop_frac': gn_flops / (full_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                   'full_loop_bit_identical': bool(torch.equal(a_full.view(torch.int64),
-                                                                               a_nat.view(torch.int64)))})
+        roof.update({'full_loop_ms': full_ms, 'full_loop_achieved': gn_flops_all / (full_ms * 1e-3) / 1e12,
+                     'full_loop_frac': gn_flops_all / (full_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     'full_loop_bit_identical': bool(torch.equal(a_full.view(torch.int64), a_nat.view(torch.int64))),
+                     'exit_speedup': full_ms / gn_ms})
+        if 'frac' not in roof:
+            roof.update({'achieved': roof['full_loop_achieved'], 'frac': roof['full_loop_frac'],
+                         'note': 'achieved = flops of ALL n_iters iterations / time of the launch that executes all of '
+                                 'them (DEXCT_GN_FULL_LOOP=1); the timed launch skips iterations proved unnecessary '
+                                 '(exit_speedup), which is not throughput'})
+        del a_full
+    if 'frac' not in roof:
+        roof.update({'achieved': None, 'frac': None, 'note': 'executed-iteration count not available in this mode'})
 
     # ---- opt-in tolerance stop (float64, DEXCT_GN_STOP_TOL), never part of `value`: what giving up "exactly the
     # reference's 50 iterations" would buy
@@ -294,7 +459,7 @@ def main():
         del a_mixed, diff
 
     # ---- single-row (the reference's own 2-D case), ray-parallel kernel
-    if not args.skip_single_row:
+    if not args.skip_single_row and world == 1:
         ct1 = dx.FanBeamGeometry(N_channels=args.channels, N_proj=args.views, gamma_fan=0.8230337, SID=60.0,
                                  SDD=100.0, eid=True, detector_file=det, N_rows=1)
         ph1 = synthetic.make_phantom(n, 1, extent=51.2, seed=1234)
@@ -312,7 +477,7 @@ def main():
                              'integrals_per_s': args.views * args.channels * sum(n_e_spec) / (ms1 * 1e-3)}
 
     # ---- cone beam (true 3-D rays, untuned one-thread-per-ray kernel) on a slice of the same scan
-    if not args.skip_single_row and rows >= 8:
+    if not args.skip_single_row and rows >= 8 and world == 1:
         cv = max(1, min(args.views, 100))
         ctc = dx.FanBeamGeometry(N_channels=args.channels, N_proj=cv, gamma_fan=0.8230337, SID=60.0, SDD=100.0,
                                  eid=True, detector_file=det, N_rows=rows, cone=True, h_iso=ph.dz)

@@ -1,0 +1,58 @@
+"""bench.py as the driver calls it: the plain command with --gpus N must start its own ranks (no launcher), run the
+sharded step (view shards, all-gather of the raw sinograms, all-reduced air-mask maximum) and print one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ['--n', '64', '--views', '48', '--channels', '96', '--iters', '10', '--steps', '1', '--warmup', '1',
+         '--no-cpu-baseline', '--skip-single-row', '--skip-gn-full-loop']
+
+
+def run_bench(*extra, env=None):
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *SMALL, *extra], capture_output=True, text=True,
+                       timeout=900, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0]), p.stderr
+
+
+def test_plain_command_single_gpu(hip):
+    out, _ = run_bench()
+    assert out['n_gpus'] == 1 and out['scaling'] == 'strong' and out['value'] > 0
+    assert out['roofline']['kernel'] == 'gn_refill_kernel' and 'roofline_siddon' in out
+    for r in (out['roofline'], out['roofline_siddon']):
+        assert r['frac'] is None or 0 < r['frac'] <= 1.0, r
+
+
+@pytest.mark.parametrize('scaling', ['strong', 'weak'])
+def test_plain_command_two_ranks(hip, scaling):
+    """`python bench.py --gpus 2` (no torchrun): on a one-GPU box the two ranks share the device and rehearse over
+    gloo; with two devices the same command runs RCCL."""
+    out, err = run_bench('--gpus', '2', '--scaling', scaling)
+    assert out['n_gpus'] == 2 and out['scaling'] == scaling
+    m = out['multi_gpu']
+    assert len(m['per_rank']) == 2 and m['gather_ms'] > 0
+    views = [r['views'] for r in sorted(m['per_rank'], key=lambda r: r['rank'])]
+    total = 48 if scaling == 'strong' else 96
+    assert views[0][0] == 0 and views[0][1] == views[1][0] and views[1][1] == total
+    assert out['config']['rays_total'] == total * 64 * 96
+    one, _ = run_bench('--scaling', scaling)
+    # same rays per GPU (weak) or same total (strong): value is whole-job throughput over the same definition
+    assert one['config']['rays_total'] == (48 * 64 * 96)
+
+
+def test_world_size_mismatch_is_an_error(hip):
+    e = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *SMALL, '--gpus', '2'], capture_output=True,
+                       text=True, timeout=600, env=e)
+    assert p.returncode != 0 and 'WORLD_SIZE' in (p.stderr + p.stdout)

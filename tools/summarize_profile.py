@@ -72,6 +72,7 @@ if cal:
             traffic['gn_write_bytes'] = write.get(k, 0.0)
     traffic['transpose_xy_fetch_bytes'] = vol_bytes
     traffic['rays_per_gpu'] = bench['config']['rays_per_gpu']
+    traffic['n'] = bench['config'].get('n', 512)
 json.dump(traffic, open(os.path.join('profiles', f'{tag}_pmc_traffic.json'), 'w'), indent=1)
 json.dump(bench, open(os.path.join('profiles', f'{tag}_bench.json'), 'w'), indent=1)
 open(os.path.join('profiles', f'{tag}_summary.md'), 'w').write('\n'.join(lines) + '\n')
