@@ -336,7 +336,7 @@ def main():
     n_e_any = int(((w_d != 0).any(dim=0)).sum().item())
     lanes = n_rays / 4.0
     floor_slots = 2.0 * seg_vc * rows / 4.0 + lanes * (14.0 * n_e_any + 2.0 * sum(n_e_spec))
-    slots_per_s = 1024 * CLOCK_GHZ * 1e9 / 4.0 / 64.0          # wave-instruction issue slots per second, whole chip
+    slots_per_s = 1024 * CLOCK_GHZ * 1e9 / 4.0                 # wave-instruction issue slots per second, whole chip
     floor_ms = floor_slots / 64.0 / slots_per_s * 1e3
     sid = {'kernel': kname, 'avg_launch_ms': sid_ms,
            'algorithmic_bytes_per_launch': alg_bytes, 'segments_per_launch': seg_vc * rows,

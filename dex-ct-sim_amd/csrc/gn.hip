@@ -53,7 +53,13 @@ __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ l
   q = fma(f, q, c1);
   const double p = f * q;
   const double tj = lds_pow[ni & (kPowN - 1)];
-  return ldexp(fma(tj, p, tj), ni >> kPowBits);
+  // 2^k by adding k to the exponent field: two 32-bit integer operations on the high dword instead of a shift and
+  // v_ldexp_f64.  Exact here - t = tj (1 + p) lies in [1, 2 + 4e-4) and |k| <= 1010 (the reference's clip at 700
+  // bounds the exponent), so t 2^k is a normal number and ldexp would perform the same exponent addition; a NaN
+  // argument has ni = 0 and stays the NaN it is.
+  const double t = fma(tj, p, tj);
+  const int hi = __double2hiint(t) + ((ni & ~(kPowN - 1)) << (20 - kPowBits));
+  return __hiloint2double(hi, __double2loint(t));
 }
 
 // 1 / x by v_rcp_f64 and two Newton refinements (what a float64 division starts with, without its scaling and
@@ -185,6 +191,7 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, E
 
 // Workspace layout (doubles): [0] = scale of the float32 tables, [1..3] = nA, nB, nC (energy classes), [4..6] =
 // how many of each class come first and always need the clip, [7..8] = max mu0 / mu1 over the clip-free parts,
+// [9] = (uint64, diagnostic) pixel-iterations the last gn_refill_kernel launch on this workspace executed,
 // pad to 16, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
 constexpr int kWsHeader = 16;
 
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
       ws[6] = (double)s_nc[2];
       ws[7] = m0f;
       ws[8] = m1f;
+      reinterpret_cast<unsigned long long*>(ws)[9] = 0ull;      // executed pixel-iterations, counted by gn_refill_kernel
     }
   }
   __syncthreads();
@@ -414,12 +422,14 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
 // wave owns a contiguous run of 64 * chunk pixels and every lane whose pixel has finished takes the next one of
 // the run, so all 64 lanes keep iterating until the run is used up.  The energy loops stay wave-uniform (scalar
 // table loads) because the tables do not depend on the pixel.  Results are bit-identical to gn_kernel's.
-__global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
+template <int MINW>      // minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
+__global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, int chunk,
                                                              const double* __restrict__ mask_max, double mask_frac,
                                                              int exact_exit, double stop_tol,
-                                                             double* __restrict__ out_a) {
+                                                             double* __restrict__ out_a,
+                                                             unsigned long long* __restrict__ executed) {
   __shared__ double lds_pow[kPowN];
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
@@ -432,6 +442,7 @@ __global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __re
   const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
 
   int64_t p = -1;                         // this lane's pixel, -1: none
+  unsigned n_exec = 0;                    // Newton steps this wave executed (< 2^32: 64 lanes x chunk x n_iters)
   double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
   int it = 0;
   long long h0[kGnHistory], h1[kGnHistory];
@@ -458,10 +469,12 @@ __global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __re
       }
       next += __popcll(want);
     }
-    if (__ballot(p >= 0) == 0ull) {
+    const unsigned long long busy = __ballot(p >= 0);
+    if (busy == 0ull) {
       if (next >= end) break;
       continue;
     }
+    n_exec += (unsigned)__popcll(busy);                        // wave-uniform (scalar) count of Newton steps run
     double n0 = a0, n1 = a1;
     newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);      // idle lanes repeat their last pixel's step; unused
     // same exit rule as gn_kernel: s_{it+1} equal to s_it (fixed point) or to hist[k] = s_{it-1-k} (cycle of
@@ -521,6 +534,7 @@ __global__ __launch_bounds__(kGnBlock, 5) void gn_refill_kernel(const void* __re
       p = -1;
     }
   }
+  if (executed && (threadIdx.x & 63) == 0) atomicAdd(executed, (unsigned long long)n_exec);   // one atomic per wave
 }
 
 __global__ __launch_bounds__(256) void mask_kernel(const void* __restrict__ g1, int g_is_f64, int64_t n_pix,
@@ -615,9 +629,15 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     const char* te = getenv("DEXCT_GN_STOP_TOL");
     const double stop_tol = te ? atof(te) : 0.0;
-    hipLaunchKernelGGL(gn_refill_kernel, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, stop_tol > 0.0 ? stop_tol : 0.0,
-                       out_a);
+    const char* ve = getenv("DEXCT_GN_MINW");               // tuning knob: 4 trades occupancy for a spill-free allocation
+    if (ve && atoi(ve) == 4)
+      hipLaunchKernelGGL(gn_refill_kernel<4>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
+                         n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, stop_tol > 0.0 ? stop_tol : 0.0,
+                         out_a, reinterpret_cast<unsigned long long*>(ws) + 9);
+    else
+      hipLaunchKernelGGL(gn_refill_kernel<5>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
+                         n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, stop_tol > 0.0 ? stop_tol : 0.0,
+                         out_a, reinterpret_cast<unsigned long long*>(ws) + 9);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, out_a);

@@ -394,6 +394,126 @@ __global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a, const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// wave_ray_kernel: ONE WAVEFRONT PER RAY - the mapping BASELINE.json's north star names.  The 64 lanes own
+// consecutive dominant-axis slabs (i = i_first + 64 k + lane) and read their voxels from the layout whose DOMINANT
+// axis is contiguous (x-dominant rays: vol_yx, y-dominant: vol_xy), so a wave's load is one contiguous run per
+// minor-axis row the ray crosses in those 64 slabs ("coalesced reads of phantom slabs along the dominant
+// voxel-stepping axis").  Per-lane integer counts are reduced with wavefront shuffles; the float32 corrections -
+// which only arise where a crossing separates two materials - are applied by the whole wave in slab order
+// (ballot + readlane), so the per-material path lengths stay bit-identical to every other kernel and to the oracle.
+// Detection: tables staged in LDS once per workgroup, lanes over energy bins, shuffle reduction of the sums.
+// A workgroup is persistent (grid-stride over rays) so that the table staging is paid once, not per ray.
+// It exists for rays that share nothing with their neighbours (single-row scans) and as the measured A/B of the
+// mapping argument in DESIGN.md section 4.1; <= 4 materials, <= 2 spectra ... DEXCT_MAX_SPECTRA.
+template <int NM>
+__global__ __launch_bounds__(256) void wave_ray_kernel(ProjArgs a, const float* __restrict__ mu,
+                                                        const float* __restrict__ w, long long n_rays_total) {
+  extern __shared__ float lds_tab[];             // mu [NM][nE] (scaled by log2 e), then w [S][nE]
+  const int n_e = a.n_energies, n_s = a.n_spectra;
+  for (int k = threadIdx.x; k < NM * n_e; k += 256) lds_tab[k] = mu[k] * kLog2e;
+  for (int k = threadIdx.x; k < n_s * n_e; k += 256) lds_tab[NM * n_e + k] = w[k];
+  __syncthreads();
+  const float* lmu = lds_tab;
+  const float* lw = lds_tab + NM * n_e;
+  const int lane = threadIdx.x & 63;
+  const long long n_waves = (long long)gridDim.x * 4;
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_rays_total; q += n_waves) {
+    const int c = (int)(q % a.g.n_channels);
+    const long long vr = q / a.g.n_channels;
+    const int r = (int)(vr % a.g.n_rows), v = (int)(vr / a.g.n_rows);
+    const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];       // wave-uniform
+    const int axis = p.flags & 1u;
+    const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
+    const int nv = axis == 0 ? a.g.ny : a.g.nx;
+    const int nu = axis == 0 ? a.g.nx : a.g.ny;
+    // dominant axis contiguous: x-dominant rays read [z][y][x], y-dominant rays [z][x][y]
+    const uint8_t* __restrict__ base = (axis == 0 ? a.vol_yx : a.vol_xy) + (size_t)(a.g.z_first + r) * a.g.nx * a.g.ny;
+    int32_t cnt[NM > 1 ? NM : 2];
+    float corr[NM > 1 ? NM : 2];          // wave-uniform
+#pragma unroll
+    for (int m = 0; m < (NM > 1 ? NM : 2); ++m) { cnt[m] = 0; corr[m] = 0.0f; }
+    for (int s0 = 0; s0 < p.n_slabs; s0 += 64) {
+      const int s = s0 + lane;
+      const bool live = s < p.n_slabs;
+      const int i = p.i_first + s;
+      const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
+      const bool ina = live && (uint32_t)sp.ja < (uint32_t)nv, inb = live && (uint32_t)sp.jb < (uint32_t)nv;
+      const uint32_t ida = ina ? base[(uint32_t)sp.ja * (uint32_t)nu + (uint32_t)i] : 0u;
+      const uint32_t idb = inb ? base[(uint32_t)sp.jb * (uint32_t)nu + (uint32_t)i] : 0u;
+#pragma unroll
+      for (int m = 1; m < NM; ++m) cnt[m] += (idb == (uint32_t)m) ? 1 : 0;
+      // corrections in slab order = lane order: the wave walks the lanes that have one
+      unsigned long long ev = __ballot(live && ida != idb);
+      while (ev) {
+        const int l = __builtin_ctzll(ev);
+        ev &= ev - 1ull;
+        const float t = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sp.t), l));
+        const uint32_t ia = __builtin_amdgcn_readlane(ida, l), ib = __builtin_amdgcn_readlane(idb, l);
+#pragma unroll
+        for (int m = 1; m < NM; ++m) {
+          corr[m] += (ia == (uint32_t)m) ? t : 0.0f;
+          corr[m] -= (ib == (uint32_t)m) ? t : 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < NM; ++m)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt[m] += __shfl_xor(cnt[m], o, 64);
+    float L[NM];
+    float others = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) {
+      L[m] = (float)cnt[m] + corr[m];
+      others += L[m];
+    }
+    L[0] = (p.chord_u - others) * p.len_per_u;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) L[m] *= p.len_per_u;
+    const size_t ray = ray_index(a, v, r, c);
+    if (a.pathlen) {
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+        if (lane == m) a.pathlen[ray * NM + m] = L[m];
+    }
+    // detection: lanes over the energy bins
+    float acc[DEXCT_MAX_SPECTRA];
+#pragma unroll
+    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) acc[sI] = 0.0f;
+    for (int e = lane; e < n_e; e += 64) {
+      float pe = 0.0f;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) pe = fmaf(lmu[m * n_e + e], L[m], pe);
+      const float t = __builtin_amdgcn_exp2f(-pe);
+#pragma unroll
+      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
+        if (sI < n_s) acc[sI] = fmaf(lw[sI * n_e + e], t, acc[sI]);
+    }
+#pragma unroll
+    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
+      if (sI < n_s) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[sI] += __shfl_xor(acc[sI], o, 64);
+        if (lane == 0) a.counts[ray + sI * sstride] = acc[sI];
+      }
+  }
+}
+
+template <int NM>
+static int launch_wave_ray(const ProjArgs& a, const Tables& t, hipStream_t st) {
+  const long long n_rays = (long long)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const size_t lds = (size_t)(NM + a.n_spectra) * a.n_energies * sizeof(float);
+  if (lds > 64 * 1024) return DEXCT_ERANGE;
+  long long nblk = (n_rays + 3) / 4;
+  const long long cap = 256ll * 8 * 4;                  // persistent: 8 workgroups per CU, each strides over the rays
+  if (nblk > cap) nblk = cap;
+  hipLaunchKernelGGL((wave_ray_kernel<NM>), dim3((unsigned)nblk), dim3(256), lds, st, a, t.mu, t.w, n_rays);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // rows_kernel: one workgroup per (view, channel, chunk of BLOCK rows), one row per lane.
 struct SlabRec {
   uint32_t offa, offb;  // byte offsets of the (x, y) columns in the z-fastest layout (0 where outside the grid)
@@ -744,6 +864,272 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// rows4t_kernel: the packed 4-rows-per-lane traversal with several (view, channel) pairs per workgroup walking the
+// volume IN STEP.  Why: a ray plane's voxel columns are read by ~250 other ray planes of the scan, but in
+// rows4_kernel every workgroup runs at its own pace (a workgroup lives ~1400 slab steps and starts whenever a slot
+// frees), so two workgroups that touch the same column do so hundreds of microseconds apart and the 4 MiB L2 of an
+// XCD has long replaced it: at 1024^3 the L2 -> fabric traffic equals the algorithmic bytes (no reuse at all, 87x
+// the compulsory bytes).  Here a workgroup is a TILE of NPAIR = TV x TC neighbouring
+// (view, channel) pairs, one wave per pair, each wave covering 256 detector rows (64 lanes x 4 rows) of one
+// z-chunk.  All waves loop over the same ABSOLUTE slab windows (slab i = plane u = i of the volume) and meet at a
+// workgroup barrier every SUB slabs, so at any time the tile reads the few adjacent columns its rays share in
+// plane i: the first wave's miss is the other waves' L1 / L2 hit.
+// Per wave the structure is rows4_kernel's: every lane classifies one slab of a 64-slab window, ballots compact
+// the window into a full list and a crossing list (wave-local LDS, slab order kept), the lanes then sweep the
+// lists with packed-byte counts; corrections are applied in slab order, so per-material path lengths stay
+// bit-identical to rows4_kernel's and the oracle's.
+constexpr int kTW = 64;   // slabs per geometry window: one per lane
+
+template <int NM, int NPAIR, int SUB, bool GROUPED, int FB = 8>      // FB: dword loads in flight per lane and batch
+__global__ __launch_bounds__(NPAIR * 64) void rows4t_kernel(ProjArgs a, const float* __restrict__ mu,
+                                                              const float* __restrict__ w, const float* __restrict__ w2,
+                                                              int tile_v, int n_zchunks) {
+  // SUB = 128: no barrier at all (the waves of a tile start together and do the same amount of work per window)
+  static_assert(SUB == 128 || (kTW % SUB == 0 && SUB >= 8), "sub-windows of at least 8 slabs that divide the window");
+  constexpr int kSub = SUB > kTW ? kTW : SUB;
+  __shared__ uint32_t list_full[NPAIR][kTW];
+  __shared__ CrossRec list_cross[NPAIR][kTW];
+  __shared__ CrossRec edge_rec[NPAIR][2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_c = NPAIR / tile_v;
+  // block -> (z-chunk fastest, then view tile, then channel tile), a contiguous range of logical ids per XCD
+  const uint32_t nblk = gridDim.x, b = blockIdx.x, per = nblk >> 3;
+  uint32_t logical = (b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
+  const int zc = logical % (uint32_t)n_zchunks;
+  logical /= (uint32_t)n_zchunks;
+  const int n_tv = (a.n_local_views + tile_v - 1) / tile_v;
+  const int tv = logical % (uint32_t)n_tv, tc = logical / (uint32_t)n_tv;
+  const int v = tv * tile_v + wid % tile_v, c = tc * tile_c + wid / tile_v;
+  const bool pair_live = v < a.n_local_views && c < a.g.n_channels;      // wave-uniform
+  dexct_ray_plan p;
+  if (pair_live) {
+    const dexct_ray_plan q = a.plan[(size_t)v * a.g.n_channels + c];
+    // the plan is the same for the whole wave: keep it in scalar registers
+    p.V0 = ((long long)__builtin_amdgcn_readfirstlane((int)(q.V0 >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)q.V0);
+    p.SV = ((long long)__builtin_amdgcn_readfirstlane((int)(q.SV >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)q.SV);
+    p.i_first = __builtin_amdgcn_readfirstlane(q.i_first);
+    p.n_slabs = __builtin_amdgcn_readfirstlane(q.n_slabs);
+    p.kf = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.kf)));
+    p.len_per_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.len_per_u)));
+    p.chord_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.chord_u)));
+    p.flags = __builtin_amdgcn_readfirstlane(q.flags);
+  } else {
+    p.V0 = 0; p.SV = 0; p.i_first = 0; p.n_slabs = 0; p.kf = 0; p.len_per_u = 0; p.chord_u = 0; p.flags = 0;
+  }
+  const int axis = p.flags & 1u;
+  const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
+  const int nv = axis == 0 ? a.g.ny : a.g.nx;
+  const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * (uint32_t)a.g.nz;
+  const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * (uint32_t)a.g.nz;
+  const int r0 = zc * 256 + lane * 4;                    // first of this lane's 4 rows
+  const uint32_t zl = (uint32_t)min(a.g.z_first + r0, a.g.nz - 4);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(a.vol_zf), 0, (int)((size_t)a.g.nx * a.g.ny * a.g.nz), 0x00020000);
+  auto ld4 = [&](uint32_t off) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)zl, (int)__builtin_amdgcn_readfirstlane((int)off), 0);
+  };
+  constexpr int kFlushAt = NM > 3 ? 248 : 123;
+  uint32_t c0 = 0, c1 = 0, c01 = 0;
+  uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w01[4] = {0, 0, 0, 0};
+  float corr[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) corr[m][q] = 0.0f;
+  int pending = 0;
+  auto flush = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (NM != 2) w0[q] += (c0 >> (8 * q)) & 0xFFu;
+      w1[q] += (c1 >> (8 * q)) & 0xFFu;
+      if (NM > 3) w01[q] += (c01 >> (8 * q)) & 0xFFu;
+    }
+    c0 = c1 = c01 = 0;
+    pending = 0;
+  };
+  auto count4 = [&](uint32_t x) {
+    if (NM > 3) {
+      const uint32_t b0 = x & 0x01010101u, b1 = (x >> 1) & 0x01010101u;
+      c0 += b0;
+      c1 += b1;
+      c01 += b0 & b1;
+    } else {
+      if (NM == 3) c0 += x & 0x01010101u;
+      c1 += x;
+    }
+  };
+  auto correct = [&](uint32_t xa, uint32_t xb, float t) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const uint32_t ia = (xa >> (8 * rr)) & 0xFFu, ib = (xb >> (8 * rr)) & 0xFFu;
+      const float td = ia != ib ? t : 0.0f;
+#pragma unroll
+      for (int m = 1; m < NM; ++m) {
+        corr[m][rr] += (ia == (uint32_t)m) ? td : 0.0f;
+        corr[m][rr] -= (ib == (uint32_t)m) ? td : 0.0f;
+      }
+    }
+  };
+  const int n_u = max(a.g.nx, a.g.ny);                  // the same trip count for every wave: the barriers need it
+  const int i_end = p.i_first + p.n_slabs;
+  for (int W0 = 0; W0 < n_u; W0 += kTW) {
+    // ---- geometry of slabs W0 .. W0 + 63 (absolute slab index = plane of the volume), one per lane
+    unsigned long long mf = 0ull, mc = 0ull;
+    const bool window_live = W0 < i_end && W0 + kTW > p.i_first;       // wave-uniform
+    if (window_live) {
+      const int i = W0 + lane;
+      bool is_full = false, is_cross = false;
+      uint32_t offa = ~0u, offb = ~0u;
+      float tt = 0.0f;
+      if (i >= p.i_first && i < i_end) {
+        const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
+        const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
+        if (ina) offa = (uint32_t)i * su + (uint32_t)sp.ja * sv;
+        if (inb) offb = (uint32_t)i * su + (uint32_t)sp.jb * sv;
+        tt = sp.t;
+        is_full = ina && inb && sp.ja == sp.jb;
+        is_cross = ina && inb && sp.ja != sp.jb;
+      }
+      mf = __ballot(is_full);
+      mc = __ballot(is_cross);
+      const unsigned long long lower = (1ull << lane) - 1ull;
+      if (lane < 2) edge_rec[wid][lane].offa = ~0u;
+      if (is_full) list_full[wid][__popcll(mf & lower)] = offb;
+      if (is_cross) list_cross[wid][__popcll(mc & lower)] = CrossRec{offa, offb, tt, 0u};
+      if (!is_full && !is_cross && (offa != ~0u || offb != ~0u)) {
+        const bool entering = offa == ~0u;
+        edge_rec[wid][entering ? 0 : 1] = CrossRec{entering ? offb : offa, 0u, tt, (uint32_t)lane};
+      }
+    }
+    // (no barrier needed here: the lists are wave-local and a wave's LDS operations execute in order)
+    // the entering edge slab precedes every crossing slab of the ray, the leaving one follows them all
+    if (window_live && edge_rec[wid][0].offa != ~0u) {
+      const uint32_t xb = ld4(edge_rec[wid][0].offa);
+      count4(xb);
+      if (++pending >= kFlushAt - 2 * FB) flush();
+      if (xb != 0u) correct(0u, xb, edge_rec[wid][0].t);
+    }
+#pragma unroll 1
+    for (int sub = 0; sub < kTW; sub += kSub) {
+      if (window_live) {
+        const unsigned long long below = (sub == 0) ? 0ull : ((1ull << sub) - 1ull);
+        const unsigned long long upto = (sub + kSub >= 64) ? ~0ull : ((1ull << (sub + kSub)) - 1ull);
+        const int f0 = __popcll(mf & below), f1 = __popcll(mf & upto);
+        const int x0 = __popcll(mc & below), x1 = __popcll(mc & upto);
+        // ---- full slabs of this sub-window: 8 dword loads in flight, integer counts only.  Whole batches first;
+        // the tail batch re-reads the last entry for its missing slots (an L1 hit) and masks those values to 0, so
+        // that its loads, too, leave together instead of one basic block - and one LDS latency - at a time.
+        int k = f0;
+        for (; k + FB <= f1; k += FB) {
+          uint32_t x[FB];
+#pragma unroll
+          for (int q = 0; q < FB; ++q) x[q] = ld4(list_full[wid][k + q]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < FB; ++q) count4(x[q]);
+          pending += FB;
+          if (pending >= kFlushAt - 2 * FB) flush();
+        }
+        if (k < f1) {
+          uint32_t x[FB];
+#pragma unroll
+          for (int q = 0; q < FB; ++q) x[q] = ld4(list_full[wid][min(k + q, f1 - 1)]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < FB; ++q) count4(x[q] & ((k + q < f1) ? ~0u : 0u));      // uniform mask
+          pending += f1 - k;
+          if (pending >= kFlushAt - 2 * FB) flush();
+        }
+        // ---- crossing slabs of this sub-window: two columns each, FB loads in flight
+        constexpr int CB = FB / 2;
+        for (k = x0; k < x1; k += CB) {
+          uint32_t xa[CB], xb[CB];
+          float t4[CB];
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            const CrossRec q = list_cross[wid][min(k + j, x1 - 1)];
+            xa[j] = ld4(q.offa);
+            xb[j] = ld4(q.offb);
+            t4[j] = q.t;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (k + CB > x1) {                    // tail batch: the repeated last entry counts and corrects nothing
+#pragma unroll
+            for (int j = 1; j < CB; ++j)
+              if (k + j >= x1) { xa[j] = 0u; xb[j] = 0u; }
+          }
+          uint32_t any = 0;
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            count4(xb[j]);
+            any |= xa[j] ^ xb[j];
+          }
+          pending += CB;
+          if (pending >= kFlushAt - 2 * FB) flush();
+          if (any) {
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+              if (xa[j] != xb[j]) correct(xa[j], xb[j], t4[j]);
+          }
+        }
+      }
+      if (sub + kSub >= kTW && window_live && edge_rec[wid][1].offa != ~0u) {
+        const uint32_t xa = ld4(edge_rec[wid][1].offa);
+        if (xa != 0u) correct(xa, 0u, edge_rec[wid][1].t);
+      }
+      if (SUB <= kTW) __syncthreads();          // pace the tile: no wave runs more than SUB slabs ahead of the others
+    }
+  }
+  if (!pair_live) return;
+  flush();
+  float L[4][NM];
+  size_t rays[4];
+  bool valid[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = r0 + rr;
+    valid[rr] = r < a.g.n_rows;
+    rays[rr] = ray_index(a, v, valid[rr] ? r : 0, c);
+    uint32_t n[4];
+    n[3] = NM > 3 ? w01[rr] : 0u;
+    n[1] = NM > 3 ? w0[rr] - n[3] : (NM == 3 ? w0[rr] : w1[rr]);
+    n[2] = NM > 3 ? w1[rr] - n[3] : (w1[rr] - w0[rr]) >> 1;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) L[rr][m] = (float)(int32_t)n[m] + corr[m][rr];
+  }
+  if (!valid[0]) return;                                  // lanes past the last row of a ragged z-chunk
+  if (GROUPED) {
+    const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+    const bool vec4 = a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[3];
+#pragma unroll
+    for (int m = 1; m < NM; ++m) {
+      float* plane = a.acc_out + (size_t)(a.mat_base + m) * n_rays;
+      if (vec4) {
+        *reinterpret_cast<float4*>(plane + rays[0]) = make_float4(L[0][m], L[1][m], L[2][m], L[3][m]);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (valid[rr]) plane[rays[rr]] = L[rr][m];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    float others = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) others += L[rr][m];
+    L[rr][0] = (p.chord_u - others) * p.len_per_u;
+#pragma unroll
+    for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
+  }
+  detect_store<NM, 4>(L, a, mu, w, w2, rays, valid);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Material groups (5..16 materials).  group_codes_kernel re-encodes the z-fastest volume once per group g:
 // ids 3g+1..3g+3 -> codes 1..3, everything else -> 0; rows4_kernel<4> runs once per group on its code volume
 // (counts and corrections of a material depend only on whether a voxel IS that material, so the per-material
@@ -929,6 +1315,72 @@ static int launch_rows4(const ProjArgs& a, const Tables& t, hipStream_t st) {
   return launch_rows4_b<NM, 256>(a, t, st);
 }
 
+template <int NM, int NPAIR, int SUB>
+static int launch_rows4t_s(const ProjArgs& a, const Tables& t, hipStream_t st, int tile_v) {
+  if (const char* e = getenv("DEXCT_TILE_FB")) {
+    if (atoi(e) == 16 && !a.acc_out && SUB >= 64) {
+      const int tile_c16 = NPAIR / tile_v;
+      const int n_z16 = (a.g.n_rows + 255) / 256;
+      const size_t nb16 = (size_t)((a.n_local_views + tile_v - 1) / tile_v) * ((a.g.n_channels + tile_c16 - 1) / tile_c16) * n_z16;
+      if (nb16 > 0x7FFFFFFFull) return DEXCT_ERANGE;
+      hipLaunchKernelGGL((rows4t_kernel<NM, NPAIR, SUB, false, 16>), dim3((unsigned)nb16), dim3(NPAIR * 64), 0, st, a, t.mu,
+                         t.w, t.w2, tile_v, n_z16);
+      DEXCT_LAUNCH_CHECK();
+      return DEXCT_OK;
+    }
+  }
+  const int tile_c = NPAIR / tile_v;
+  const int n_z = (a.g.n_rows + 255) / 256;
+  const size_t nblk = (size_t)((a.n_local_views + tile_v - 1) / tile_v) * ((a.g.n_channels + tile_c - 1) / tile_c) * n_z;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  if (a.acc_out)
+    hipLaunchKernelGGL((rows4t_kernel<NM, NPAIR, SUB, true>), dim3((unsigned)nblk), dim3(NPAIR * 64), 0, st, a, t.mu, t.w, t.w2,
+                       tile_v, n_z);
+  else
+    hipLaunchKernelGGL((rows4t_kernel<NM, NPAIR, SUB, false>), dim3((unsigned)nblk), dim3(NPAIR * 64), 0, st, a, t.mu, t.w, t.w2,
+                       tile_v, n_z);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+// Tile shape of rows4t_kernel: NPAIR pairs = tile_v views x (NPAIR / tile_v) channels, barrier every SUB slabs.
+// Defaults are the measured optimum; DEXCT_TILE_PAIRS / DEXCT_TILE_V / DEXCT_TILE_SUB override.
+template <int NM>
+static int launch_rows4t(const ProjArgs& a, const Tables& t, hipStream_t st) {
+  int pairs = 16, tile_v = 4, sub = 16;
+  if (const char* e = getenv("DEXCT_TILE_PAIRS")) pairs = atoi(e);
+  if (const char* e = getenv("DEXCT_TILE_V")) tile_v = atoi(e);
+  if (const char* e = getenv("DEXCT_TILE_SUB")) sub = atoi(e);
+  if (pairs != 4 && pairs != 8 && pairs != 16) return DEXCT_EINVAL;
+  if (tile_v < 1 || tile_v > pairs || pairs % tile_v) return DEXCT_EINVAL;
+  if (pairs == 4) {
+    switch (sub) {
+      case 16: return launch_rows4t_s<NM, 4, 16>(a, t, st, tile_v);
+      case 64: return launch_rows4t_s<NM, 4, 64>(a, t, st, tile_v);
+      case 128: return launch_rows4t_s<NM, 4, 128>(a, t, st, tile_v);
+      default: return DEXCT_EINVAL;
+    }
+  }
+  if (pairs == 8) {
+    switch (sub) {
+      case 128: return launch_rows4t_s<NM, 8, 128>(a, t, st, tile_v);
+      case 8: return launch_rows4t_s<NM, 8, 8>(a, t, st, tile_v);
+      case 16: return launch_rows4t_s<NM, 8, 16>(a, t, st, tile_v);
+      case 32: return launch_rows4t_s<NM, 8, 32>(a, t, st, tile_v);
+      case 64: return launch_rows4t_s<NM, 8, 64>(a, t, st, tile_v);
+      default: return DEXCT_EINVAL;
+    }
+  }
+  switch (sub) {
+    case 128: return launch_rows4t_s<NM, 16, 128>(a, t, st, tile_v);
+    case 8: return launch_rows4t_s<NM, 16, 8>(a, t, st, tile_v);
+    case 16: return launch_rows4t_s<NM, 16, 16>(a, t, st, tile_v);
+    case 32: return launch_rows4t_s<NM, 16, 32>(a, t, st, tile_v);
+    case 64: return launch_rows4t_s<NM, 16, 64>(a, t, st, tile_v);
+    default: return DEXCT_EINVAL;
+  }
+}
+
 }  // namespace dexct
 
 using namespace dexct;
@@ -950,8 +1402,9 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   if (kernel == 0) kernel = (vol_zf && geom->n_rows >= 64) ? (can4 ? 3 : 2) : 1;
   if (kernel == 1 && (!vol_yx || !vol_xy)) return DEXCT_EINVAL;
   if (kernel == 2 && !vol_zf) return DEXCT_EINVAL;
-  if (kernel == 3 && !can4) return DEXCT_EINVAL;
-  if (kernel < 1 || kernel > 3) return DEXCT_EINVAL;
+  if ((kernel == 3 || kernel == 5) && !can4) return DEXCT_EINVAL;
+  if (kernel < 1 || kernel > 6 || kernel == 4) return DEXCT_EINVAL;
+  if (kernel == 6 && (!vol_yx || !vol_xy || n_materials > 4 || variance)) return DEXCT_EINVAL;
   if (layout != 0 && layout != 1) return DEXCT_EINVAL;
   if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
   if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
@@ -991,6 +1444,21 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
       case 3: return launch_rows<3>(a, t, st);
       case 4: return launch_rows<4>(a, t, st);
       default: return launch_rows<0>(a, t, st);
+    }
+  }
+  if (kernel == 6) {        // one wavefront per ray (the north-star mapping; A/B and single-row scans)
+    switch (n_materials) {
+      case 1: return launch_wave_ray<1>(a, t, st);
+      case 2: return launch_wave_ray<2>(a, t, st);
+      case 3: return launch_wave_ray<3>(a, t, st);
+      default: return launch_wave_ray<4>(a, t, st);
+    }
+  }
+  if (kernel == 5) {        // tiled lockstep form: several (view, channel) pairs per workgroup, 256 rows per wave
+    switch (n_materials) {
+      case 2: return launch_rows4t<2>(a, t, st);
+      case 3: return launch_rows4t<3>(a, t, st);
+      default: return launch_rows4t<4>(a, t, st);
     }
   }
   switch (n_materials) {

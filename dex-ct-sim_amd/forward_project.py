@@ -48,7 +48,11 @@ class Projector:
     ``view_range`` restricts the instance to a contiguous shard of projection angles (one per
     rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel (1 row per lane),
     3 row-parallel with 4 rows per lane (<= 4 materials, Nz and z_index multiples of 4), 4 the same kernel
-    run once per group of three materials (5..48 materials).
+    run once per group of three materials (5..48 materials), 5 the 4-rows-per-lane kernel with a tile of
+    neighbouring (view, channel) pairs per workgroup walking the volume in step (rows4t_kernel: what kernel 0
+    picks for stacked fans of >= 256 rows; same bits as kernel 3), 6 one wavefront per ray (lanes over
+    dominant-axis slabs, shuffle reductions, tables in LDS: the mapping BASELINE.json's north star names; <= 4
+    materials).
     """
 
     def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
@@ -80,7 +84,7 @@ class Projector:
         # The 4-rows-per-lane kernels read aligned dwords along z: pad the uploaded copy with empty slices so that
         # the first imaged slice and the slice count are multiples of 4 (stacked fans only see their own slices,
         # the in-plane geometry does not change).
-        packed_wanted = kernel in (3, 4) or (kernel == 0 and ct.N_rows >= 64)
+        packed_wanted = kernel in (3, 4, 5) or (kernel == 0 and ct.N_rows >= 64)
         if not self.cone and packed_wanted and (nz % 4 or z_first % 4):
             lead = (-z_first) % 4
             tail = (-(nz + lead)) % 4
@@ -100,7 +104,7 @@ class Projector:
         if self.cone:
             kernel = self.kernel = 1          # cone beam has its own ray-parallel kernel (dexct_cone_project)
             self.row_z = to_dev(ct.row_z(), torch.float64, self.dev)
-        want_zf = kernel in (2, 3, 4) or (kernel == 0 and ct.N_rows >= 64)
+        want_zf = kernel in (2, 3, 4, 5) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz,
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
@@ -127,7 +131,7 @@ class Projector:
     @property
     def native_layout(self):
         """1 (row fastest) when a row-parallel kernel will run, else 0 (channel fastest)."""
-        if self.kernel in (2, 3, 4):
+        if self.kernel in (2, 3, 4, 5):
             return 1
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 

@@ -52,6 +52,18 @@ def _as_device_counts(x, dev):
     return to_dev(a.astype(np.float32 if dt == torch.float32 else np.float64, copy=False), dt, dev)
 
 
+_last_ws = None
+
+
+def last_gn_stats():
+    """Diagnostics of the most recent gn_device call (synchronises): ``pixel_iterations`` = Newton steps the float64
+    lane-refill kernel actually executed (the exact repeated-state exit ends pixels before n_iters; masked air
+    pixels run none).  0 for the mixed-precision and per-channel-spectrum kernels, which do not count."""
+    if _last_ws is None:
+        return None
+    return {'pixel_iterations': int(_last_ws[72:80].view(torch.int64).item())}
+
+
 def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1, mask_max=None,
               mask_frac=0.95):
     """g1, g2: device tensors of equal shape; mus: [2, nE] float64; i0: [2, nE] (one spectrum for all
@@ -82,6 +94,8 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
                                          int(precision == 'mixed'), int(n_polish), ptr(mask_max), float(mask_frac), ptr(a),
                                          ptr(ws), stream_ptr()),
                   'dexct_gn_decompose')
+    global _last_ws
+    _last_ws = ws
     return a
 
 

@@ -196,7 +196,10 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *              g1 >= mask_frac * *mask_max are the air pixels get_basismat_sinos zeroes afterwards
  *              (matdecomp.py:195-196, :204-205); they get (0, 0) directly and their iterations are skipped
  *   workspace  device scratch of dexct_gn_workspace_bytes(n_energies, n_bins) bytes (the product tables
- *              the kernel reads through the scalar cache); owned by the caller, no hidden state
+ *              the kernel reads through the scalar cache); owned by the caller, no hidden state.  After the call
+ *              the uint64 at byte offset 72 holds, as a diagnostic, the number of pixel-iterations the float64
+ *              shared-spectrum kernel executed (what bench.py's executed-flop rate is computed from; 0 for the
+ *              other kernels)
  * n_iters is the reference's fixed iteration count.  The update is a pure function of the two doubles, so the
  * kernel stops a pixel at the first state that repeats bit for bit (fixed point or cycle of up to 9 states) and
  * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly.

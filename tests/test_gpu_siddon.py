@@ -60,7 +60,7 @@ def test_plan_nonsquare_anisotropic(hip):
         assert np.array_equal(got[f], ref[f]), f
     E = np.array([40.0, 60.0, 80.0])
     mu, w = ph.mu_table(E), np.array([[1e4, 2e4, 1e4]])
-    for kernel in (1, 2, 3):       # nz = 2 is not a multiple of 4: the host pads the uploaded copy for kernel 3
+    for kernel in (1, 2, 3, 5, 6): # nz = 2 is not a multiple of 4: the host pads the uploaded copy for kernel 3
         pj = projector(ct, ph, kernel=kernel)
         c, pl = pj.project_tables(torch.tensor(mu, dtype=torch.float32, device='cuda'),
                                   torch.tensor(w, dtype=torch.float32, device='cuda'), want_pathlen=True)
@@ -87,7 +87,7 @@ def test_voxel_index_sequence_bit_exact(hip, n, nv, nc):
         assert np.array_equal(ln[k, :ns[k]], rl)
 
 
-@pytest.mark.parametrize('kernel', [1, 2, 3, 4])
+@pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('n_mat', [2, 3, 4, 7, 13, 16, 29])
 def test_pathlen_bit_exact_and_counts(hip, kernel, n_mat):
     """Register accumulators (<= 4 materials), LDS accumulators (more), the packed-count 4-rows-per-lane
@@ -99,9 +99,9 @@ def test_pathlen_bit_exact_and_counts(hip, kernel, n_mat):
     if n_mat == 2:
         ph.volume = np.minimum(ph.volume, 1).astype(np.uint8)
         ph.materials = [AIR, WATER]
-    if kernel == 3 and n_mat > 4:
+    if kernel in (3, 5, 6) and n_mat > 4:
         with pytest.raises(DexctError):
-            projector(ct, ph_many(ph, n_mat), kernel=3).project(spectra())
+            projector(ct, ph_many(ph, n_mat), kernel=kernel).project(spectra())
         return
     if n_mat > 3:
         ph = ph_many(ph, n_mat)
@@ -264,7 +264,7 @@ def test_more_than_512_slabs_per_ray(hip):
     assert plan['n_slabs'].max() > 600
     _, rpl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, 24, ph.volume, mu, w, True, n_threads=8)
     cls = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, 24, ph.volume, mu, w, n_threads=8)
-    for kernel in (1, 2, 3):
+    for kernel in (1, 2, 3, 5, 6):
         c, pl = projector(ct, ph, kernel=kernel).project_tables(
             torch.tensor(mu, dtype=torch.float32, device='cuda'), torch.tensor(w, dtype=torch.float32, device='cuda'),
             want_pathlen=True)
@@ -388,12 +388,12 @@ def test_random_scans_bit_exact_path_lengths(hip, seed):
     _, rpl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, n_views, vol, mu, w, True, n_threads=8)
     cls = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, n_views, vol, mu, w, n_threads=8)
     tie = on_plane_rays(g, ct, n_views)[:, None, :].repeat(n_rows, 1)          # [views, rows, channels]
-    for kernel in (0, 1, 2, 3, 4):
+    for kernel in (0, 1, 2, 3, 4, 5, 6):
         try:
             pj = projector(ct, ph, kernel=kernel)
             (counts, pl), _ = pj.project(sp, want_pathlen=True)
         except (DexctError, ValueError):
-            assert kernel in (3, 4)                           # packed kernels: material-count limits only
+            assert kernel in (3, 4, 5, 6)                     # packed / wave-per-ray kernels: material-count limits only
             continue
         assert np.array_equal(pl.cpu().numpy(), rpl), (seed, kernel)
         rel = np.abs(counts.cpu().numpy() - cls) / cls
