@@ -48,6 +48,11 @@ def parse():
     ap.add_argument('--workload', default='config2', choices=['config2', 'config3'],
                     help='config2: 1000 views x 800 channels (the metric); config3: 2000 x 1024 (BASELINE configs[3])')
     ap.add_argument('--rows', type=int, default=0, help='detector rows (0: n)')
+    ap.add_argument('--shard-of', type=int, default=0,
+                    help='single-GPU measurement of ONE rank\'s share of a K-GPU strong-scaling run (no collectives): '
+                         'views [rank K-th] of the fixed scan; e.g. --workload config3 --shard-of 8 is the per-GPU work of '
+                         'BASELINE configs[3]')
+    ap.add_argument('--shard-rank', type=int, default=0)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--gn-precision', default=None, choices=[None, 'f64', 'mixed'])
     ap.add_argument('--kernel', type=int, default=0, help='0 choose, 1 ray-parallel, 2 row-parallel')
@@ -156,6 +161,10 @@ def main():
     ph = synthetic.make_phantom(n, n, extent=51.2, seed=1234)
     specs = [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
     vb, ve = _shard.split(total_views, rank, world)
+    if args.shard_of > 1:
+        if world != 1 or args.scaling != 'strong':
+            raise SystemExit('--shard-of is a single-process, strong-scaling rehearsal')
+        vb, ve = _shard.split(total_views, args.shard_rank, args.shard_of)
     pj = fp.Projector(ct, ph, view_range=(vb, ve), kernel=args.kernel)
     E, mu_d, w_d, air = pj.upload_tables(specs)
     n_e_spec = [int((w_d[k] != 0).sum().item()) for k in range(2)]
@@ -248,6 +257,8 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     rays_all = total_views * rows * args.channels           # rays of all ranks together (ragged shards included)
+    if args.shard_of > 1:
+        rays_all = n_rays                                   # only this shard is computed here
     integrals_per_step = rays_all * sum(n_e_spec)
     value = integrals_per_step / (elapsed / args.steps)
     sid_ms, gn_ms = float(np.mean(t_sid)), float(np.mean(t_gn))
@@ -296,6 +307,8 @@ def main():
                    'baseline_config': 'configs[2]' if (args.workload == 'config2' and total_views == 1000) else
                                       ('configs[3]' if args.workload == 'config3' else 'configs[2] x N views (weak scaling)'),
                    'n': n, 'rays_per_gpu': n_rays, 'rays_total': rays_all,
+                   'shard': None if args.shard_of <= 1 else f'views [{vb}, {ve}) = rank {args.shard_rank} of {args.shard_of} '
+                                                            f'(one rank\'s share, measured alone on one GPU)',
                    'parallelism': f'{total_views} views sharded x{world} ({args.scaling} scaling: '
                                   + ('fixed scan, views/N per rank)' if args.scaling == 'strong' else
                                      f'{args.views} views per rank)'),

@@ -42,6 +42,7 @@ constexpr int kPowBits = 11;
 constexpr int kPowN = 1 << kPowBits;
 constexpr double kExpScale = 0x1.71547652b82fep+11;          // 2048 / ln 2
 constexpr double kExpClip = 700.0 * kExpScale;               // the reference's clip of the exponent (matdecomp.py:116)
+template <bool IEXP = false>
 __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ lds_pow) {
   const double kMagic = 6755399441055744.0;   // 1.5 * 2^52
   constexpr double c1 = 0x1.62e42fefa39efp-12;               // ln2 / 2048
@@ -53,11 +54,12 @@ __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ l
   q = fma(f, q, c1);
   const double p = f * q;
   const double tj = lds_pow[ni & (kPowN - 1)];
-  // 2^k by adding k to the exponent field: two 32-bit integer operations on the high dword instead of a shift and
-  // v_ldexp_f64.  Exact here - t = tj (1 + p) lies in [1, 2 + 4e-4) and |k| <= 1010 (the reference's clip at 700
-  // bounds the exponent), so t 2^k is a normal number and ldexp would perform the same exponent addition; a NaN
-  // argument has ni = 0 and stays the NaN it is.
   const double t = fma(tj, p, tj);
+  if (!IEXP) return ldexp(t, ni >> kPowBits);
+  // IEXP (A/B variant): 2^k by adding k to the exponent field - two 32-bit integer operations on the high dword
+  // instead of a shift and v_ldexp_f64.  Exact here: t = tj (1 + p) lies in [1, 2 + 4e-4) and |k| <= 1010 (the
+  // reference's clip at 700 bounds the exponent), so t 2^k is a normal number and ldexp performs the same exponent
+  // addition; a NaN argument has ni = 0 and stays the NaN it is.
   const int hi = __double2hiint(t) + ((ni & ~(kPowN - 1)) << (20 - kPowBits));
   return __hiloint2double(hi, __double2loint(t));
 }
@@ -79,7 +81,7 @@ __device__ __forceinline__ double rcp_f64(double x) {
 // (nB), only spectrum 1 (nC); energies no spectrum weights are dropped.  A zero weight contributes exactly
 // 0 to every sum (the attenuation factor is finite thanks to the clip), so skipping those FMAs changes no
 // term of the reference's sums - only their order.
-template <int KSEL, bool CLIP>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip
+template <int KSEL, bool CLIP, bool IEXP = false>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip
 __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 int e0, int e1, double a0, double a1, double (&nu)[2], double (&G0)[2],
                                                 double (&G1)[2], double (&H00)[2], double (&H01)[2], double (&H11)[2]) {
@@ -88,7 +90,7 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
     const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
     double y = fma(a1, t[1], a0 * t[0]);               // t[0], t[1] = -mu0, -mu1 times 2048/ln2
     if (CLIP) y = fmin(fmax(y, -kExpClip), kExpClip);
-    const double at = exp_tab(y, lds_pow);
+    const double at = exp_tab<IEXP>(y, lds_pow);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if ((KSEL == 1 && k == 1) || (KSEL == 2 && k == 0)) continue;
@@ -109,23 +111,24 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
 // instructions per energy), bit for bit the same result.
 struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; };
 
+template <bool IEXP = false>
 __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
   double nu[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
   const int bA = 0, bB = ec.nA, bC = ec.nA + ec.nB;
   // the always-clipped heads of the three classes
-  energy_sums_f64<0, true>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, G0, G1, H00, H01, H11);
-  energy_sums_f64<1, true>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, G0, G1, H00, H01, H11);
-  energy_sums_f64<2, true>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, G0, G1, H00, H01, H11);
   // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
   if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 699.9) {
-    energy_sums_f64<0, false>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, false>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, false>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, false, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, false, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, false, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
   } else {
-    energy_sums_f64<0, true>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, true>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, true>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
   }
   const double g[2] = {g0, g1};
   double dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
 // wave owns a contiguous run of 64 * chunk pixels and every lane whose pixel has finished takes the next one of
 // the run, so all 64 lanes keep iterating until the run is used up.  The energy loops stay wave-uniform (scalar
 // table loads) because the tables do not depend on the pixel.  Results are bit-identical to gn_kernel's.
-template <int MINW>      // minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
+template <int MINW, bool IEXP>      // MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, int chunk,
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     }
     n_exec += (unsigned)__popcll(busy);                        // wave-uniform (scalar) count of Newton steps run
     double n0 = a0, n1 = a1;
-    newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);      // idle lanes repeat their last pixel's step; unused
+    newton_step_f64<IEXP>(tab, lds_pow, ec, gd0, gd1, n0, n1);      // idle lanes repeat their last pixel's step; unused
     // same exit rule as gn_kernel: s_{it+1} equal to s_it (fixed point) or to hist[k] = s_{it-1-k} (cycle of
     // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
     // through it too and are ignored.
@@ -629,15 +632,22 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     const char* te = getenv("DEXCT_GN_STOP_TOL");
     const double stop_tol = te ? atof(te) : 0.0;
-    const char* ve = getenv("DEXCT_GN_MINW");               // tuning knob: 4 trades occupancy for a spill-free allocation
-    if (ve && atoi(ve) == 4)
-      hipLaunchKernelGGL(gn_refill_kernel<4>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                         n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, stop_tol > 0.0 ? stop_tol : 0.0,
-                         out_a, reinterpret_cast<unsigned long long*>(ws) + 9);
-    else
-      hipLaunchKernelGGL(gn_refill_kernel<5>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                         n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, stop_tol > 0.0 ? stop_tol : 0.0,
-                         out_a, reinterpret_cast<unsigned long long*>(ws) + 9);
+    // tuning knobs for A/B runs (defaults are the measured optimum): DEXCT_GN_MINW=4 trades occupancy
+    // for a spill-free register allocation, DEXCT_GN_IEXP=1 scales by 2^k with integer adds instead of v_ldexp_f64
+    const char* ve = getenv("DEXCT_GN_MINW");
+    const char* ie = getenv("DEXCT_GN_IEXP");
+    const int minw = (ve && atoi(ve) == 4) ? 4 : 5;
+    const int iexp = (ie && atoi(ie) == 1) ? 1 : 0;
+    unsigned long long* stat = reinterpret_cast<unsigned long long*>(ws) + 9;
+    const double tol = stop_tol > 0.0 ? stop_tol : 0.0;
+#define DEXCT_GN_LAUNCH(MW, IE)                                                                                         \
+  hipLaunchKernelGGL((gn_refill_kernel<MW, IE>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,            \
+                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat)
+    if (minw == 4 && iexp) DEXCT_GN_LAUNCH(4, true);
+    else if (minw == 4) DEXCT_GN_LAUNCH(4, false);
+    else if (iexp) DEXCT_GN_LAUNCH(5, true);
+    else DEXCT_GN_LAUNCH(5, false);
+#undef DEXCT_GN_LAUNCH
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, out_a);

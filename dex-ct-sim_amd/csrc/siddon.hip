@@ -40,23 +40,6 @@ namespace dexct {
 constexpr int kBlock = 256;
 constexpr float kLog2e = 1.44269504088896340736f;
 
-struct SlabPieces {
-  int32_t ja, jb;
-  float t;
-};
-
-// One slab of the fixed-point DDA (mirror: oracle/dexct_oracle.c dda_slab).
-__device__ __forceinline__ SlabPieces dda_slab(long long Va, long long SV, uint32_t smask, float kf) {
-  SlabPieces s;
-  const long long Vb = Va + SV;
-  s.ja = (int32_t)(Va >> DEXCT_FIX_FRAC);
-  s.jb = (int32_t)(Vb >> DEXCT_FIX_FRAC);
-  const uint32_t fr = (uint32_t)((unsigned long long)Va >> 8);
-  const float d = (float)(fr ^ smask);
-  s.t = fminf(d * kf, 1.0f);
-  return s;
-}
-
 struct ProjArgs {
   dexct_fan_geom g;
   const dexct_ray_plan* plan;

@@ -15,6 +15,8 @@
 //
 // Mapping: one thread per ray, lanes over adjacent channels of one (view, row) - neighbouring rays visit
 // neighbouring voxels of the same slices.  Accumulators in registers (<= 4 materials) or per-lane LDS columns.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dexct {
@@ -179,6 +181,235 @@ static int launch_cone(const ConeArgs& a, const float* mu, const float* w, hipSt
   return DEXCT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// cone_rows_kernel: the cone-beam traversal with the rows of one (view, channel) pair as lanes.
+//
+// All detector rows of a (view, channel) pair share the in-plane trajectory (same V0, SV, slab range, v-crossings);
+// only z differs per row.  So a workgroup = one pair (chunk of 256 rows), the in-plane slab records are computed
+// once per workgroup into LDS (as in rows_kernel), and a lane carries only its z DDA: W += SW (exact 64-bit add),
+// k = W >> 40.  Lanes (neighbouring rows) read neighbouring bytes of one voxel column of a z-fastest volume.
+//
+// The volume is the GUARDED z-fastest layout of dexct_cone_layout: column (x, y) holds nz + 2 bytes
+// [3, id(z=0), ..., id(z=nz-1), 3] and one extra column of all 3 stands for every (x, y) outside the grid, so a
+// voxel outside the grid reads as code 3 = "no material" without a bounds test (ids < 3: at most 3 materials).
+//
+// Per slab and lane the oracle's sum (orc_cone_pathlen)
+//     [idb] + t2 ([idm] - [idb]) + t1 ([ida] - [idm])
+// needs the b voxel (jb, kb) always; the a voxel (ja, ka) is a different voxel only where the slab has a v-crossing
+// (uniform per slab) or the lane a z-crossing, and the middle voxel is a third one only where it has BOTH; the
+// corrections vanish unless the ids differ.  Fast path: count the b voxel (packed byte counters, one v_lshl_add),
+// load the a voxel / the two possible corner voxels only for the lanes that have the crossing; only lanes that see
+// differing ids enter the exact path, which evaluates the oracle's formula operation for operation - per-material
+// path lengths are bit-identical to cone_kernel's.
+struct ConeRec {
+  uint32_t colb, cola;   // byte offsets of the b / a voxel columns in the guarded layout (outside column if out of the grid)
+  float tv;
+  uint32_t flags;        // bit 0: the slab has a v-crossing (ja != jb)
+};
+
+constexpr int kConeRows = 256;
+
+template <int NM, int kB = 4>      // kB: slabs per batch
+__global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
+                                                               const float* __restrict__ mu, const float* __restrict__ w,
+                                                               int n_chunks, int view_tile) {
+  __shared__ ConeRec rec[kConeRows];
+  const int tid = threadIdx.x;
+  // block -> (view, channel, row chunk): contiguous logical ids per XCD, views fastest inside a tile of view_tile
+  const uint32_t nblk = gridDim.x, bid = blockIdx.x, per = nblk >> 3;
+  const uint32_t logical = (bid < (per << 3)) ? (bid & 7u) * per + (bid >> 3) : bid;
+  const uint32_t group = (uint32_t)view_tile * a.g.n_channels * n_chunks;
+  const uint32_t gq = logical / group, rem = logical - gq * group;
+  const uint32_t views_here = min((uint32_t)view_tile, (uint32_t)a.n_local_views - gq * view_tile);
+  const int chunk = rem % n_chunks;
+  const uint32_t qq = rem / n_chunks;
+  const int v = gq * view_tile + qq % views_here, c = qq / views_here;
+  const int r = chunk * kConeRows + tid;
+  const bool live = r < a.g.n_rows;
+  const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];      // uniform
+  const int axis = p.flags & 1u;
+  const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
+  const int nv = axis == 0 ? a.g.ny : a.g.nx;
+  const uint32_t zs = (uint32_t)a.g.nz + 2u;                             // bytes per column
+  const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * zs;
+  const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * zs;
+  const uint32_t col_out = (uint32_t)a.g.nx * (uint32_t)a.g.ny * zs;    // the all-3 column
+  // ---- z part of the plan, float64, operation for operation as cone_kernel / the oracle's cone_row_plan
+  const int view = a.view_begin + v;
+  const double cb = a.view_cs[2 * view], sb = a.view_cs[2 * view + 1];
+  const double cg = a.chan_cs[2 * c], sg = a.chan_cs[2 * c + 1];
+  const double sx = a.g.sid * cb, sy = a.g.sid * sb;
+  const double ex = -(cb * cg - sb * sg), ey = -(sb * cg + cb * sg);
+  const double su_d = axis == 0 ? sx / a.g.dx + 0.5 * a.g.nx : sy / a.g.dy + 0.5 * a.g.ny;
+  const double eu = axis == 0 ? ex / a.g.dx : ey / a.g.dy;
+  const double det_z = a.row_z[live ? r : 0];
+  const double kOne = 1099511627776.0;
+  const double ws = a.src_z / a.g.dz + 0.5 * a.g.nz;
+  const double sw = ((det_z - a.src_z) / a.g.dz) / (a.g.sdd * eu);
+  const double w0 = ws - su_d * sw;
+  const long long SW = llrint(sw * kOne);
+  const long long W0 = llrint(w0 * kOne);
+  double inv = 16777216.0;
+  if (SW != 0) inv = fmin(kOne / fabs((double)SW), 16777216.0);
+  const float kfw = (float)(inv * (1.0 / 4294967296.0));
+  const double tz = (det_z - a.src_z) / a.g.sdd;
+  const float len3d = (float)((1.0 / fabs(eu)) * sqrt(1.0 + tz * tz));
+  const uint32_t wpos = SW > 0 ? 0xFFFFFFFFu : 0u;
+
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(vol_zc), 0, (int)(col_out + zs), 0x00020000);
+  const int nz = a.g.nz;
+  uint32_t acc = 0;                       // four byte counters: codes 0..3 of the b voxels since the last flush
+  uint32_t cnt[3] = {0, 0, 0};
+  float corr[3] = {0.0f, 0.0f, 0.0f};
+  int since_flush = 0;
+  // W carries a bias of one slice: (W >> 40) is then k + 1, the byte index inside a guarded column
+  long long W = W0 + (long long)p.i_first * SW + (1ll << DEXCT_FIX_FRAC);
+  const int k_hi = nz + 1;
+  auto slice = [&](long long Wx) {                              // clamp((int)(Wx >> 40), 0, nz + 1): v_ashr + v_med3_i32
+    int kq;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(kq) : "v"((int)(Wx >> DEXCT_FIX_FRAC)), "v"(k_hi));
+    return kq;
+  };
+  auto ldk = [&](uint32_t col, int kc) {
+    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, kc, (int)__builtin_amdgcn_readfirstlane((int)col), 0);
+  };
+  for (int s0 = 0; s0 < p.n_slabs; s0 += kConeRows) {
+    const int n_here = min(kConeRows, p.n_slabs - s0);
+    const int n_pad = (n_here + kB - 1) / kB * kB;      // the last batch is filled with null records (all "outside")
+    if (tid < n_pad) {
+      ConeRec q{col_out, col_out, 0.0f, 0u};
+      if (tid < n_here) {
+        const int i = p.i_first + s0 + tid;
+        const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
+        const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
+        q.cola = ina ? (uint32_t)i * su + (uint32_t)sp.ja * sv : col_out;
+        q.colb = inb ? (uint32_t)i * su + (uint32_t)sp.jb * sv : col_out;
+        q.tv = sp.t;
+        q.flags = sp.ja != sp.jb ? 1u : 0u;
+      }
+      rec[tid] = q;
+    }
+    __syncthreads();
+    for (int s = 0; s < n_pad; s += kB) {
+      // ---- all voxel bytes of kB slabs first (no data-dependent branch in between): b = (jb, kb), a = (ja, ka) and,
+      // in a slab with a v-crossing, the two possible middle voxels (jb, ka) and (ja, kb).  Without a crossing these
+      // are the same byte again (an L1 hit); what differs is found by comparing the ids afterwards.
+      ConeRec q[kB];
+      int kc[kB + 1];
+      uint32_t x[kB], xa[kB], c1[kB], c2[kB];
+      bool vx[kB];
+      const long long Wb = W;
+      kc[0] = slice(W);
+#pragma unroll
+      for (int j = 0; j < kB; ++j) q[j] = rec[s + j];            // uniform; all LDS reads first
+#pragma unroll
+      for (int j = 0; j < kB; ++j) {
+        W += SW;
+        kc[j + 1] = slice(W);
+        x[j] = ldk(q[j].colb, kc[j + 1]);
+        xa[j] = ldk(q[j].cola, kc[j]);
+        c1[j] = c2[j] = 0u;                                      // (constants: no wait on the loads above)
+        // a v-crossing slab has two different columns (two outside pieces share the all-3 column: nothing to tell apart)
+        vx[j] = __builtin_amdgcn_readfirstlane((int)q[j].colb) != __builtin_amdgcn_readfirstlane((int)q[j].cola);
+        if (vx[j]) {                                             // uniform
+          c1[j] = ldk(q[j].colb, kc[j]);
+          c2[j] = ldk(q[j].cola, kc[j + 1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      uint32_t dif[kB];                                          // non-zero: the slab's ids differ for this lane
+      uint32_t any = 0;
+#pragma unroll
+      for (int j = 0; j < kB; ++j) {
+        acc = (1u << (x[j] << 3)) + acc;                         // count the b voxel: v_lshlrev + v_lshl_add
+        // with a single crossing (c1, c2) is (x, xa) or (xa, x): nothing new; with both, the middle voxel is one of them
+        dif[j] = xa[j] ^ x[j];
+        if (vx[j]) dif[j] |= (c1[j] ^ x[j]) | (c2[j] ^ x[j]);    // uniform branch
+        any |= dif[j];
+      }
+      if (__ballot(any != 0u) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < kB; ++j) {
+          if (dif[j] != 0u) {
+            // the oracle's slab, operation for operation (orc_cone_pathlen); W of the slab's entry face without the bias
+            const long long Wj = Wb + (long long)j * SW - (1ll << DEXCT_FIX_FRAC);
+            const float tv = q[j].tv;
+            const float tw = fminf((float)((uint32_t)((unsigned long long)Wj >> 8) ^ wpos) * kfw, 1.0f);
+            const float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
+            const bool v_first = tv <= tw;
+            // middle voxel (jm, km) = v_first ? (jb, ka) : (ja, kb)
+            const uint32_t idm = vx[j] ? (v_first ? c1[j] : c2[j]) : (v_first ? xa[j] : x[j]);
+            const uint32_t ida = xa[j], idb = x[j];
+            if (ida != idm || idm != idb) {
+#pragma unroll
+              for (int m = 0; m < NM; ++m) {
+                corr[m] += (idm == (uint32_t)m) ? t2 : 0.0f;
+                corr[m] -= (idb == (uint32_t)m) ? t2 : 0.0f;
+                corr[m] += (ida == (uint32_t)m) ? t1 : 0.0f;
+                corr[m] -= (idm == (uint32_t)m) ? t1 : 0.0f;
+              }
+            }
+          }
+        }
+      }
+      since_flush += kB;
+      if (since_flush > 255 - kB) {                              // uniform
+#pragma unroll
+        for (int m = 0; m < NM; ++m) cnt[m] += (acc >> (8 * m)) & 0xFFu;
+        acc = 0;
+        since_flush = 0;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < NM; ++m) cnt[m] += (acc >> (8 * m)) & 0xFFu;
+  if (!live) return;
+  // ---- detection (same weighting as the other kernels)
+  const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const int n_e = a.n_energies;
+  float L2[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const float l = ((float)(int32_t)cnt[m] + corr[m]) * len3d;
+    if (a.pathlen) a.pathlen[ray * a.n_materials + m] = l;
+    L2[m] = l * 1.44269504088896340736f;
+  }
+  float accs[DEXCT_MAX_SPECTRA];
+#pragma unroll
+  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = 0.0f;
+  int srow[DEXCT_MAX_SPECTRA];
+#pragma unroll
+  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) srow[sI] = (sI < a.n_spectra ? sI : 0) * n_e;
+  for (int e = 0; e < n_e; ++e) {
+    float pe = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
+    const float t = __builtin_amdgcn_exp2f(-pe);
+#pragma unroll
+    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = fmaf(w[srow[sI] + e], t, accs[sI]);
+  }
+#pragma unroll
+  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
+    if (sI < a.n_spectra) a.counts[ray + sI * sstride] = accs[sI];
+}
+
+// vol [nz][ny][nx] -> guarded z-fastest layout [(ny*nx + 1)][nz + 2]: guard slices and the extra column hold 3.
+__global__ __launch_bounds__(256) void cone_layout_kernel(const uint8_t* __restrict__ vol, int nx, int ny, int nz,
+                                                          uint8_t* __restrict__ out) {
+  const size_t zs = (size_t)nz + 2;
+  const size_t total = ((size_t)nx * ny + 1) * zs;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t col = i / zs;
+  const int kz = (int)(i - col * zs) - 1;
+  uint8_t val = 3;
+  if (col < (size_t)nx * ny && kz >= 0 && kz < nz) val = vol[(size_t)kz * nx * ny + col];      // col = y*nx + x
+  out[i] = val;
+}
+
 }  // namespace dexct
 
 using namespace dexct;
@@ -224,4 +455,70 @@ extern "C" int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_pl
     case 4: return launch_cone<4>(a, mu, weights, st);
     default: return launch_cone<0>(a, mu, weights, st);
   }
+}
+
+
+extern "C" int64_t dexct_cone_layout_bytes(int32_t nx, int32_t ny, int32_t nz) {
+  if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+  return ((int64_t)nx * ny + 1) * ((int64_t)nz + 2);
+}
+
+extern "C" int dexct_cone_layout(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, uint8_t* vol_zc, void* stream) {
+  if (!vol || !vol_zc || nx <= 0 || ny <= 0 || nz <= 0) return DEXCT_EINVAL;
+  const int64_t total = dexct_cone_layout_bytes(nx, ny, nz);
+  if (total > 0xFFFFFFFEll) return DEXCT_ERANGE;
+  const int64_t nblk = (total + 255) / 256;
+  hipLaunchKernelGGL(cone_layout_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vol, nx, ny, nz, vol_zc);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
+                                       const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
+                                       int32_t view_begin, int32_t view_end, const uint8_t* vol_zc,
+                                       int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
+                                       const float* weights, float* counts, float* pathlen, void* stream) {
+  if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_zc || !mu || !weights || !counts) return DEXCT_EINVAL;
+  if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
+  if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
+  if (n_materials > 3 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;      // code 3 is "outside the grid"
+  if (dexct_cone_layout_bytes(geom->nx, geom->ny, geom->nz) > 0xFFFFFFFEll) return DEXCT_ERANGE;
+  if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
+  const double dmax = geom->dx > geom->dy ? geom->dx : geom->dy;
+  if (!(max_abs_dz >= 0) || max_abs_dz / geom->sdd / geom->dz * dmax * 1.4142135623730951 > 1.0) return DEXCT_ERANGE;
+  ConeArgs a;
+  a.g = *geom;
+  a.plan = plan;
+  a.view_cs = view_cs;
+  a.chan_cs = chan_cs;
+  a.row_z = row_z;
+  a.src_z = src_z;
+  a.vol_yx = nullptr;
+  a.vol_xy = nullptr;
+  a.view_begin = view_begin;
+  a.n_local_views = view_end - view_begin;
+  a.n_materials = n_materials;
+  a.n_energies = n_energies;
+  a.n_spectra = n_spectra;
+  a.counts = counts;
+  a.pathlen = pathlen;
+  const int n_chunks = (geom->n_rows + kConeRows - 1) / kConeRows;
+  const size_t nblk = (size_t)a.n_local_views * geom->n_channels * n_chunks;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipStream_t st = as_stream(stream);
+  const int view_tile = 8;
+  switch (n_materials) {
+    case 1: hipLaunchKernelGGL(cone_rows_kernel<1>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
+    case 2: hipLaunchKernelGGL(cone_rows_kernel<2>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
+    default: {
+      const char* e = getenv("DEXCT_CONE_BATCH");         // tuning knob
+      const int kb = e ? atoi(e) : 4;
+      if (kb == 8) hipLaunchKernelGGL((cone_rows_kernel<3, 8>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
+      else if (kb == 2) hipLaunchKernelGGL((cone_rows_kernel<3, 2>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
+      else hipLaunchKernelGGL((cone_rows_kernel<3, 4>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
+      break;
+    }
+  }
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
 }

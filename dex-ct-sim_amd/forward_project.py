@@ -101,9 +101,21 @@ class Projector:
                                               self.view_begin, self.view_end, ptr(self.plan), st), 'dexct_fan_plan')
         self.vol_yx = to_dev(volume, torch.uint8, self.dev)
         self.vol_xy = torch.empty_like(self.vol_yx)
+        self.vol_zc = None
         if self.cone:
-            kernel = self.kernel = 1          # cone beam has its own ray-parallel kernel (dexct_cone_project)
+            # cone beam: kernel 1 = one thread per ray (dexct_cone_project, any number of materials), 2 = the rows of a
+            # (view, channel) pair as lanes (dexct_cone_project_rows, <= 3 materials); 0 picks 2 where it applies
+            rows_ok = phantom.n_materials <= 3
+            if kernel == 2 and not rows_ok:
+                raise ValueError('the row-parallel cone kernel takes at most 3 materials')
+            self.cone_rows = kernel == 2 or (kernel == 0 and rows_ok and ct.N_rows >= 32)
+            kernel = self.kernel = 1
             self.row_z = to_dev(ct.row_z(), torch.float64, self.dev)
+            if self.cone_rows:
+                nb = self.lib.dexct_cone_layout_bytes(phantom.Nx, phantom.Ny, nz)
+                self.vol_zc = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+                _native.check(self.lib.dexct_cone_layout(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz, ptr(self.vol_zc), st),
+                              'dexct_cone_layout')
         want_zf = kernel in (2, 3, 4, 5) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz,
@@ -166,11 +178,17 @@ class Projector:
         if self.cone:
             if w2_d is not None:
                 raise NotImplementedError('noise is not available for cone-beam scans')
-            _native.check(self.lib.dexct_cone_project(
-                C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
-                self.ct.src_z, float(np.max(np.abs(self.ct.row_z() - self.ct.src_z))), self.view_begin, self.view_end,
-                ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
-                stream_ptr()), 'dexct_cone_project')
+            max_dz = float(np.max(np.abs(self.ct.row_z() - self.ct.src_z)))
+            if self.cone_rows:
+                _native.check(self.lib.dexct_cone_project_rows(
+                    C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                    self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
+                    ptr(w_d), ptr(counts), ptr(pathlen), stream_ptr()), 'dexct_cone_project_rows')
+            else:
+                _native.check(self.lib.dexct_cone_project(
+                    C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                    self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
+                    ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), stream_ptr()), 'dexct_cone_project')
         elif self.grouped:
             scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
             _native.check(self.lib.dexct_siddon_project_grouped(

@@ -138,6 +138,20 @@ int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
                        int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
                        const float* weights, float* counts, float* pathlen, void* stream);
 
+/* The same projection with the ROWS of one (view, channel) pair as lanes (cone_rows_kernel): the in-plane slab
+ * records are computed once per pair and shared by all its rows, a lane carries only its z DDA and reads one voxel
+ * byte per slab (the a voxel of a slab is the previous slab's b voxel).  <= 3 materials.  It reads the guarded
+ * z-fastest layout written by dexct_cone_layout: vol_zc[(y*nx + x)*(nz + 2) + 1 + z] = id, guard slices and one
+ * extra column hold 3 ("outside the grid"); dexct_cone_layout_bytes gives its size.  Same outputs, bit-identical
+ * per-material path lengths. */
+int64_t dexct_cone_layout_bytes(int32_t nx, int32_t ny, int32_t nz);
+int dexct_cone_layout(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, uint8_t* vol_zc, void* stream);
+int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
+                            const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
+                            int32_t view_begin, int32_t view_end, const uint8_t* vol_zc, int32_t n_materials,
+                            int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights,
+                            float* counts, float* pathlen, void* stream);
+
 /* counts += sqrt(variance) * z, z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
  * channel, spectrum) and key seed: independent of view sharding and of the layout (0 / 1 as above).
  * Results are clipped at 1e-20 so that a log sinogram stays finite. */

@@ -109,6 +109,32 @@ def main():
                         ill[j, b] |= not np.all(d <= 1e-6)
                     except np.linalg.LinAlgError:
                         ill[j, b] = True
+    # second screen: the 2x2 Hessian's condition number along the reference's OWN trajectory (iterates from the
+    # reference; the Hessian re-evaluated here with the formula of matdecomp.py:116-123 purely as a criterion).  A
+    # pixel whose trajectory passes a Hessian with cond > 1e13 takes a step that is rounding noise (1e-16 x 1e13):
+    # the reference's answer there is reproducible only by the reference's exact operation order, not by any other
+    # arithmetic (closed-form 2x2 solve, another summation order), even if its final answer is stable to the
+    # perturbations above.
+    cond = np.full((nV, nB), np.nan)
+    with np.errstate(all='ignore'):
+        for j in range(nV):
+            for b in range(nB):
+                if raised[j, b]:
+                    continue
+                gp = g[:, j:j + 1, b:b + 1]
+                a, worst = np.array([1e-6, 1e-6]), 0.0
+                for it in range(n_iters):
+                    at = np.exp(np.clip(-(a @ mus), -700, 700))
+                    nu = (i0 * at).sum(-1)
+                    gr = -(i0[:, None, :] * mus[None] * at).sum(-1)
+                    hs = (i0[:, None, None, :] * (mus[None, :, None, :] * mus[None, None, :, :]) * at).sum(-1)
+                    c, q = gp[:, 0, 0] / nu - 1, gp[:, 0, 0] / nu ** 2
+                    H = -(c[:, None, None] * hs - q[:, None, None] * gr[:, :, None] * gr[:, None, :]).sum(0)
+                    worst = max(worst, np.linalg.cond(H)) if np.isfinite(H).all() else np.inf
+                    a = real_opt(gp, ee, i0_1, mus, it + 1, verbose=False)[0, 0]
+                cond[j, b] = worst
+    ill |= ~raised & ~(cond <= 1e13)
+    out['uns_cond'] = cond
     out.update(uns_ee=ee, uns_i0=i0, uns_mus=mus, uns_a_true=a_true, uns_g=g, uns_raised=raised,
                uns_raised_at=raised_at, uns_a50=a50, uns_ill=ill, uns_n_iters=np.array(n_iters),
                uns_spec1_E=sp1.E, uns_spec1_I0=sp1.I0, uns_spec2_E=sp2.E, uns_spec2_I0=sp2.I0,

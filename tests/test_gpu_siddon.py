@@ -286,13 +286,19 @@ def test_cone_beam_matches_oracle(hip, n_mat):
     sp = spectra()
     from dex_ct_sim_amd import forward_project as fp
     E, mu, w = fp.merged_tables(cone, ph, sp)
-    (counts, pl), _ = projector(cone, ph).project(sp, want_pathlen=True)
     _, rpl = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, 20, cone.row_z(), 0.3, ph.volume, mu, w, dda=True,
                              n_threads=8)
-    assert np.array_equal(pl.cpu().numpy(), rpl)
     cls, _ = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, 20, cone.row_z(), 0.3, ph.volume, mu, w, dda=False,
                              n_threads=8)
-    assert np.max(np.abs(counts.cpu().numpy() - cls) / cls) < REL_TOL
+    # kernel 1: one thread per ray (any number of materials); kernel 2: the rows of a (view, channel) pair as lanes
+    # with the shared in-plane records and one byte load per slab (<= 3 materials) - the same bits
+    for kernel in ((1, 2) if n_mat <= 3 else (1,)):
+        (counts, pl), _ = projector(cone, ph, kernel=kernel).project(sp, want_pathlen=True)
+        assert np.array_equal(pl.cpu().numpy(), rpl), kernel
+        assert np.max(np.abs(counts.cpu().numpy() - cls) / cls) < REL_TOL
+    if n_mat > 3:
+        with pytest.raises(ValueError):
+            projector(cone, ph, kernel=2)
     # zero cone angle through the centre of slice 7 == the 2-D fan of slice 7
     flat = dx.FanBeamGeometry(N_channels=48, N_proj=20, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=1.0,
                               eid=True, detector_file=ct.detector_file, N_rows=1, cone=True,
@@ -411,7 +417,7 @@ def test_source_and_detector_must_clear_the_grid(hip):
             projector(ct, ph)
 
 
-@pytest.mark.parametrize('seed', range(8))
+@pytest.mark.parametrize('seed', range(14))
 def test_random_cone_beam_scans(hip, seed):
     """Randomised cone-beam scans (anisotropic grids, off-centre source heights, 2..6 materials): path lengths equal
     the oracle's mirror bit for bit, counts agree with the float64 3-D textbook Siddon."""
@@ -440,15 +446,16 @@ def test_random_cone_beam_scans(hip, seed):
     g = co.make_geom(n_views, n_ch, n_rows, 0, nx, ny, nz, dxv, dyv, dzv, sid, sdd)
     sp = spectra()
     E, mu, w = fp.merged_tables(cone, ph, sp)
-    (counts, pl), _ = projector(cone, ph).project(sp, want_pathlen=True)
     _, rpl = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), src_z, vol, mu, w, dda=True,
                              n_threads=8)
-    assert np.array_equal(pl.cpu().numpy(), rpl), seed
     cls, _ = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), src_z, vol, mu, w, dda=False,
                              n_threads=8)
-    rel = np.abs(counts.cpu().numpy() - cls) / cls
-    rel[:, on_plane_rays(g, cone, n_views)[:, None, :].repeat(n_rows, 1)] = 0.0
-    assert rel.max() < REL_TOL, (seed, rel.max())
+    for kernel in ((1, 2) if n_mat <= 3 else (1,)):
+        (counts, pl), _ = projector(cone, ph, kernel=kernel).project(sp, want_pathlen=True)
+        assert np.array_equal(pl.cpu().numpy(), rpl), (seed, kernel)
+        rel = np.abs(counts.cpu().numpy() - cls) / cls
+        rel[:, on_plane_rays(g, cone, n_views)[:, None, :].repeat(n_rows, 1)] = 0.0
+        assert rel.max() < REL_TOL, (seed, kernel, rel.max())
 
 
 def test_sino_allgather_entry_point_single_rank(hip):

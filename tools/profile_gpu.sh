@@ -14,4 +14,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-gn-full-loop > $OUT/bench_write.json 2> $OUT/bench_write.err
 echo "write rc=$?"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-gn-full-loop > $OUT/bench_sq.json 2> $OUT/bench_sq.err
+echo "sq rc=$?"
 find $OUT -name "*.csv" | head -30

@@ -34,6 +34,20 @@ def pmc(which):
 
 
 fetch, write = pmc('fetch'), pmc('write')
+
+
+def pmc_raw(which):
+    """{kernel: {counter: mean value per dispatch}} of a multi-counter pass (no unit scaling)."""
+    out = {}
+    files = glob.glob(os.path.join(src, f'pmc_{which}', '*', '*_counter_collection.csv'))
+    if not files:
+        return out
+    for r in csv.DictReader(open(files[0])):
+        out.setdefault(r['Kernel_Name'], {}).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in out.items()}
+
+
+sq = pmc_raw('sq')
 bench = json.load(open(os.path.join(src, 'bench_stats.json')))
 lines = [f'# rocprofv3 summary `{tag}`', '',
          f'command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {bench["steps"]} --warmup {bench["warmup"]} --skip-gn-full-loop`'
@@ -59,7 +73,7 @@ if cal:
         if 'dexct' in k:
             lines.append(f'| `{k[:60]}` | {fetch[k] / 1e9:.3f} | {write.get(k, 0) / 1e9:.3f} |')
     for k in fetch:
-        if 'rows' in k and 'kernel' in k:
+        if 'rows' in k and 'kernel' in k and 'siddon_kernel' not in traffic:
             traffic['siddon_kernel'] = k
             # 4-B-per-lane dword loads (rows4) are tallied at half, like gn_kernel's float32 input stream
             corr = 2.0 if 'rows4' in k else 1.0
@@ -70,6 +84,14 @@ if cal:
         if 'gn_refill_kernel' in k or 'gn_kernel<false' in k:
             traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
             traffic['gn_write_bytes'] = write.get(k, 0.0)
+    for k, d in sq.items():
+        if ('rows' in k and 'kernel' in k) or 'gn_refill_kernel' in k:
+            tag2 = 'siddon' if 'rows' in k else 'gn'
+            traffic[f'{tag2}_valu_insts'] = d.get('SQ_INSTS_VALU')
+            if d.get('GRBM_GUI_ACTIVE'):
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's waves; GRBM_GUI_ACTIVE sums the 8 XCDs
+                traffic[f'{tag2}_valu_busy'] = d.get('SQ_ACTIVE_INST_VALU', 0) * 4.0 / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0)
+                traffic[f'{tag2}_wait_any_share'] = (d.get('SQ_WAIT_ANY', 0) / d['SQ_WAVE_CYCLES']) if d.get('SQ_WAVE_CYCLES') else None
     traffic['transpose_xy_fetch_bytes'] = vol_bytes
     traffic['rays_per_gpu'] = bench['config']['rays_per_gpu']
     traffic['n'] = bench['config'].get('n', 512)
