@@ -486,26 +486,45 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms1 = e0.elapsed_time(e1) / 10
-        out['single_row'] = {'rays': args.views * args.channels, 'siddon_ms': ms1,
+        out['single_row'] = {'rays': args.views * args.channels, 'siddon_ms': ms1, 'kernel': 'rays_kernel (lanes = channels)',
                              'integrals_per_s': args.views * args.channels * sum(n_e_spec) / (ms1 * 1e-3)}
+        # the same scan with ONE WAVEFRONT PER RAY (the north star's mapping): A/B of DESIGN.md section 4.1
+        pj6 = fp.Projector(ct1, ph1, kernel=6)
+        pj6.project_tables(mu_d, w_d, out=c1)
+        e0.record()
+        for _ in range(10):
+            pj6.project_tables(mu_d, w_d, out=c1)
+        e1.record()
+        torch.cuda.synchronize()
+        ms6 = e0.elapsed_time(e1) / 10
+        out['single_row']['wave_per_ray'] = {'kernel': 'wave_ray_kernel (lanes = slabs of one ray)', 'siddon_ms': ms6,
+                                             'integrals_per_s': args.views * args.channels * sum(n_e_spec) / (ms6 * 1e-3)}
+        del pj6
 
-    # ---- cone beam (true 3-D rays, untuned one-thread-per-ray kernel) on a slice of the same scan
+    # ---- cone beam (true 3-D rays) on a slice of the same scan: the row-parallel kernel (what the host picks for
+    # <= 3 materials) and the one-thread-per-ray kernel beside it
     if not args.skip_single_row and rows >= 8 and world == 1:
         cv = max(1, min(args.views, 100))
         ctc = dx.FanBeamGeometry(N_channels=args.channels, N_proj=cv, gamma_fan=0.8230337, SID=60.0, SDD=100.0,
                                  eid=True, detector_file=det, N_rows=rows, cone=True, h_iso=ph.dz)
-        pjc = fp.Projector(ctc, ph)
         cc = torch.empty((2, cv, rows, args.channels), dtype=torch.float32, device=dev)
-        pjc.project_tables(mu_d, w_d, out=cc)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        pjc.project_tables(mu_d, w_d, out=cc)
-        e1.record()
-        torch.cuda.synchronize()
-        msc = e0.elapsed_time(e1)
-        out['cone_beam'] = {'rays': cv * rows * args.channels, 'siddon_ms': msc,
-                            'integrals_per_s': cv * rows * args.channels * sum(n_e_spec) / (msc * 1e-3)}
-        del pjc, cc
+        res = {}
+        for kk, name in ((0, 'cone_rows_kernel'), (1, 'cone_kernel')):
+            pjc = fp.Projector(ctc, ph, kernel=kk)
+            pjc.project_tables(mu_d, w_d, out=cc)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            pjc.project_tables(mu_d, w_d, out=cc)
+            e1.record()
+            torch.cuda.synchronize()
+            msc = e0.elapsed_time(e1)
+            res[name] = {'siddon_ms': msc, 'rays_per_s': cv * rows * args.channels / (msc * 1e-3),
+                         'integrals_per_s': cv * rows * args.channels * sum(n_e_spec) / (msc * 1e-3)}
+            del pjc
+        out['cone_beam'] = {'rays': cv * rows * args.channels, **res['cone_rows_kernel'],
+                            'kernel': 'cone_rows_kernel (rows of a (view, channel) pair as lanes)',
+                            'thread_per_ray': res['cone_kernel']}
+        del cc
 
     # ---- CPU baseline: the oracle (float64 textbook Siddon + detection, then float64 Newton) on a bounded
     # sample of the same workload, all host cores

@@ -195,6 +195,7 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, E
 // Workspace layout (doubles): [0] = scale of the float32 tables, [1..3] = nA, nB, nC (energy classes), [4..6] =
 // how many of each class come first and always need the clip, [7..8] = max mu0 / mu1 over the clip-free parts,
 // [9] = (uint64, diagnostic) pixel-iterations the last gn_refill_kernel launch on this workspace executed,
+// [10] = (uint64, progress) pixels that launch has finished so far (added wave by wave while it runs),
 // pad to 16, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
 constexpr int kWsHeader = 16;
 
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
       ws[7] = m0f;
       ws[8] = m1f;
       reinterpret_cast<unsigned long long*>(ws)[9] = 0ull;      // executed pixel-iterations, counted by gn_refill_kernel
+      reinterpret_cast<unsigned long long*>(ws)[10] = 0ull;     // finished pixels (progress of the running launch)
     }
   }
   __syncthreads();
@@ -537,7 +539,11 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
       p = -1;
     }
   }
-  if (executed && (threadIdx.x & 63) == 0) atomicAdd(executed, (unsigned long long)n_exec);   // one atomic per wave
+  if (executed && (threadIdx.x & 63) == 0) {
+    atomicAdd(executed, (unsigned long long)n_exec);            // one atomic per wave
+    const int64_t first = ((int64_t)blockIdx.x * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;
+    if (end > first) atomicAdd(executed + 1, (unsigned long long)(end - first));    // this wave's run of pixels is done
+  }
 }
 
 __global__ __launch_bounds__(256) void mask_kernel(const void* __restrict__ g1, int g_is_f64, int64_t n_pix,

@@ -268,11 +268,11 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   const int k_hi = nz + 1;
   auto slice = [&](long long Wx) {                              // clamp((int)(Wx >> 40), 0, nz + 1): v_ashr + v_med3_i32
     int kq;
-    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(kq) : "v"((int)(Wx >> DEXCT_FIX_FRAC)), "v"(k_hi));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(kq) : "v"((int)(Wx >> DEXCT_FIX_FRAC)), "s"(k_hi));
     return kq;
   };
-  auto ldk = [&](uint32_t col, int kc) {
-    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, kc, (int)__builtin_amdgcn_readfirstlane((int)col), 0);
+  auto ldk = [&](int col_s, int kc) {                          // col_s: the column's byte offset, already a scalar
+    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, kc, col_s, 0);
   };
   for (int s0 = 0; s0 < p.n_slabs; s0 += kConeRows) {
     const int n_here = min(kConeRows, p.n_slabs - s0);
@@ -307,14 +307,14 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
       for (int j = 0; j < kB; ++j) {
         W += SW;
         kc[j + 1] = slice(W);
-        x[j] = ldk(q[j].colb, kc[j + 1]);
-        xa[j] = ldk(q[j].cola, kc[j]);
-        c1[j] = c2[j] = 0u;                                      // (constants: no wait on the loads above)
+        const int sb = __builtin_amdgcn_readfirstlane((int)q[j].colb), sa = __builtin_amdgcn_readfirstlane((int)q[j].cola);
+        x[j] = ldk(sb, kc[j + 1]);
+        xa[j] = ldk(sa, kc[j]);
         // a v-crossing slab has two different columns (two outside pieces share the all-3 column: nothing to tell apart)
-        vx[j] = __builtin_amdgcn_readfirstlane((int)q[j].colb) != __builtin_amdgcn_readfirstlane((int)q[j].cola);
-        if (vx[j]) {                                             // uniform
-          c1[j] = ldk(q[j].colb, kc[j]);
-          c2[j] = ldk(q[j].cola, kc[j + 1]);
+        vx[j] = sb != sa;
+        if (vx[j]) {                                             // uniform; c1 / c2 are only ever read under vx[j]
+          c1[j] = ldk(sb, kc[j]);
+          c2[j] = ldk(sa, kc[j + 1]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);

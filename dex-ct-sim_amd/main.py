@@ -120,7 +120,7 @@ def main(argv=None):
             sub_dir = os.path.join(out_dir, f'matdecomp_{s1}_{s2}_{int(d1 * 1000):04}uGy_{int(d2 * 1000):04}uGy/')
             print('Decomposing into basis material sinograms!')
             matsino1, matsino2 = get_basismat_sinos(ct, sinos[0][0], sinos[1][0], specs[0], specs[1],
-                                                    n_iters=args.n_iters)
+                                                    n_iters=args.n_iters, verbose=True)     # progress lines of :111-112
             if rank == 0:
                 os.makedirs(sub_dir, exist_ok=True)
                 print(f'\n*** {sub_dir} ***')

@@ -99,8 +99,32 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     return a
 
 
+def _progress_lines(ws, n_views, n_bins, done_event, t0, every=20, poll_s=0.05):
+    """The reference's progress line ``j / nViews t=...s`` (matdecomp.py:111-112, one per 20 views), driven by the
+    kernel's own finished-pixel counter (workspace byte 80), read on a side stream while the kernel runs."""
+    import time
+    side = torch.cuda.Stream()
+    host = torch.zeros(1, dtype=torch.int64).pin_memory()
+    counter = ws[80:88].view(torch.int64)
+    next_view = 0
+    while True:
+        finished = done_event.query()
+        with torch.cuda.stream(side):
+            host.copy_(counter, non_blocking=True)
+        side.synchronize()
+        views_done = n_views if finished else min(int(host.item()) // max(n_bins, 1), n_views)
+        while next_view < n_views and next_view <= views_done:
+            print(next_view, '/', n_views, f't={time.time() - t0:.2f}s')
+            next_view += every
+        if finished:
+            return
+        time.sleep(poll_s)
+
+
 def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None):
     """Newton iterations for every pixel (signature of matdecomp.py:20 / :87).
+    ``verbose`` prints the reference's progress line every 20 views (:111-112) from the kernel's finished-pixel
+    counter; the drop-in callers below pass verbose=False unless asked (a benchmark should not print).
 
     Sino_gg [2, nViews, nBins] counts; i0 [2, nBins, nEnergies] (channel-dependent spectra are handled by a
     slower per-lane-table kernel; the tiled spectrum do_matdecomp_gn builds, :151, takes the fast path) or
@@ -114,7 +138,13 @@ def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, preci
         raise ValueError('i0 has a different number of bins than the sinogram')
     dev = device()
     g = _as_device_counts(np.asarray(Sino_gg), dev)
+    import time
+    t0 = time.time()
     a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision)
+    if verbose:
+        done = torch.cuda.Event()
+        done.record()
+        _progress_lines(_last_ws, int(g.shape[1]), int(g[0].numel() // max(int(g.shape[1]), 1)), done, t0)
     return a.cpu().numpy()
 
 
@@ -145,7 +175,7 @@ def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None):
 
 
 def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None,
-                       strict=False):
+                       strict=False, verbose=False):
     """Basis-material sinograms (matdecomp.py:167-207): air mask from sinogram 1
     (``>= mask_thresh * max``), Newton decomposition, masked pixels set to exactly 0.
 
@@ -153,6 +183,8 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     in -> device tensors out.  Under torch.distributed the inputs are either each rank's own view
     shard or the full gathered sinograms (then each rank decomposes its own views and the result
     is all-gathered); the mask threshold always uses the all-reduced global maximum.
+    ``verbose=True`` prints the reference's progress line every 20 views (matdecomp.py:111-112; the reference always
+    prints it) from the kernel's finished-pixel counter.
     ``strict=True``: raise ``SingularHessianError`` (a ``numpy.linalg.LinAlgError``, what :125 raises) if a pixel
     outside the air mask ends non-finite; the default returns the inf/NaN in place, as documented above.
     """
@@ -172,7 +204,13 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     _native.check(lib.dexct_reduce_max(ptr(g1), is64, g1.numel(), ptr(gmax), stream_ptr()), 'dexct_reduce_max')
     gmax = _shard.global_max(gmax)
     # the mask is applied inside the kernel (threshold read from the device scalar: no host round trip)
+    import time
+    t0 = time.time()
     a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh))
+    if verbose and rank == 0 and g1.dim() >= 2:
+        done = torch.cuda.Event()
+        done.record()
+        _progress_lines(_last_ws, int(g1.shape[0]), int(g1.numel() // max(int(g1.shape[0]), 1)), done, t0)
     if strict:
         bad = ~torch.isfinite(a).all(dim=-1)          # masked pixels are exactly 0, hence finite
         n_bad = int(bad.sum().item())

@@ -213,7 +213,9 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *              the kernel reads through the scalar cache); owned by the caller, no hidden state.  After the call
  *              the uint64 at byte offset 72 holds, as a diagnostic, the number of pixel-iterations the float64
  *              shared-spectrum kernel executed (what bench.py's executed-flop rate is computed from; 0 for the
- *              other kernels)
+ *              other kernels), and the uint64 at byte offset 80 the number of pixels it has finished - updated wave
+ *              by wave WHILE the kernel runs, so a host thread may read it (on another stream) as a progress
+ *              indicator: the reference prints a line every 20 views, matdecomp.py:111-112
  * n_iters is the reference's fixed iteration count.  The update is a pure function of the two doubles, so the
  * kernel stops a pixel at the first state that repeats bit for bit (fixed point or cycle of up to 9 states) and
  * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly.

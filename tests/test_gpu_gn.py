@@ -18,7 +18,7 @@ def err(a, b):
 
 def run(g, i0, mus, n_iters, precision):
     from dex_ct_sim_amd import matdecomp as md
-    return md.optimize_sino(g, None, i0, mus, n_iters, precision=precision)
+    return md.optimize_sino(g, None, i0, mus, n_iters, verbose=False, precision=precision)
 
 
 @pytest.mark.parametrize('ci', [0, 1, 2])
@@ -472,3 +472,23 @@ def test_opt_in_modes_against_all_reference_cases(hip, golden, ci, monkeypatch):
         assert np.isfinite(a_mix).all() and np.mean(e < TOL_NS) > 0.9
     else:
         assert e.max() < TOL_NS
+
+
+def test_verbose_progress_lines(hip, golden, capsys):
+    """verbose=True prints the reference's ``j / nViews t=..s`` line for j = 0, 20, 40, ... (matdecomp.py:111-112),
+    driven by the kernel's finished-pixel counter; verbose=False prints nothing; the result does not change."""
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    gg = np.tile(g['gn0_g'], (1, 12, 1))[:, :45]                        # 45 views x 32 bins
+    quiet = md.optimize_sino(gg, None, g['gn0_i0'], g['gn0_mus'], 30, verbose=False)
+    assert capsys.readouterr().out == ''
+    loud = md.optimize_sino(gg, None, g['gn0_i0'], g['gn0_mus'], 30, verbose=True)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ' / 45 ' in ln]
+    assert [ln.split(' / ')[0] for ln in lines] == ['0', '20', '40']
+    assert all(ln.split('t=')[1].endswith('s') for ln in lines)
+    assert np.array_equal(quiet, loud)
+    ct = types.SimpleNamespace(det_E=g['gn0_det_E'], det_eta_E=g['gn0_det_eta'], eid=bool(g['gn0_eid']))
+    s1 = types.SimpleNamespace(E=g['gn0_spec1_E'], I0=g['gn0_spec1_I0'])
+    s2 = types.SimpleNamespace(E=g['gn0_spec2_E'], I0=g['gn0_spec2_I0'])
+    md.get_basismat_sinos(ct, gg[0].copy(), gg[1].copy(), s1, s2, n_iters=5, verbose=True)
+    assert [ln.split(' / ')[0] for ln in capsys.readouterr().out.splitlines() if ' / 45 ' in ln] == ['0', '20', '40']
