@@ -165,3 +165,80 @@ def test_main_noise_switch_follows_the_dose(tmp_path):
     c = run('c', '140kV:80kV:0.004:0.016', '--noise', 'gaussian', '--seed', '5')
     clean4 = run('clean4', '140kV:80kV:0.004:0.016')
     assert abs(rel_noise(c, '140kV_0004uGy', clean4) / n_lo - 0.5) < 0.1
+
+
+@pytest.mark.gpu
+def test_config1_default_params_full_size_relative_paths(tmp_path):
+    """BASELINE configs[0]: the bundled default params.txt at FULL size (512^2 phantom, 1200 views x 800 channels,
+    80 / 140 kVp spectra, reconstructions at 512^2) through main.py, started the way the reference is (``cd`` next to
+    ``input/`` and relative paths: --input-dir input --params input/params.txt; main.py must not change directory);
+    the raw sinograms against the float64 Siddon oracle on a sample of views, the decomposition against the float64
+    Newton oracle on the same counts."""
+    import shutil
+    from oracle import c_oracle as co
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp, matdecomp as md
+    work = tmp_path / 'work'
+    shutil.copytree(INPUT, work / 'input')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'dex-ct-sim_amd', 'main.py'), '--input-dir', 'input', '--params',
+                        os.path.join('input', 'params.txt'), '--out', 'output', '--pairs', '140kV:80kV:5:5'],
+                       capture_output=True, text=True, timeout=900, cwd=str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '1180 / 1200' in r.stdout                                  # the reference's progress lines (matdecomp.py:111-112)
+    base = work / 'output' / 'synthetic_512'
+    nV, nC = 1200, 800
+    raw = {k: np.fromfile(base / f'{k}_5000uGy' / 'sino_raw_float32.bin', dtype=np.float32).reshape(nV, nC)
+           for k in ('140kV', '80kV')}
+    run = dx.read_parameter_file(str(work / 'input' / 'params.txt'))[0]
+    ct, ph = run[3], run[4]
+    specs = []
+    for sid in ('140kV', '80kV'):
+        s = dx.xRaySpectrum(str(work / 'input' / 'spectrum' / f'{sid}_1mGy_float32.bin'), sid)
+        s.rescale_counts(ct.A_iso * 5.0 / ct.N_proj)
+        specs.append(s)
+    _, mu64, w64 = fp.merged_tables(ct, ph, specs)
+    g = co.make_geom(ct.N_proj, ct.N_channels, 1, ph.z_index, ph.Nx, ph.Ny, ph.Nz, ph.dx, ph.dy, ph.dz, ct.SID, ct.SDD)
+    for v in (0, 150, 300, 601, 1199):
+        ref = co.project_classic(g, ct.view_cs(), ct.chan_cs(), v, v + 1, ph.volume, mu64, w64, n_threads=8)[:, 0, 0, :]
+        for k, key in enumerate(('140kV', '80kV')):
+            assert np.max(np.abs(raw[key][v] - ref[k]) / ref[k]) < 1e-5, (v, key)
+    m = [np.fromfile(base / 'matdecomp_140kV_80kV_5000uGy_5000uGy' / f'mat{i}_sino_float32.bin', dtype=np.float32).reshape(nV, nC)
+         for i in (1, 2)]
+    _, i0, mus = md.decomposition_tables(ct, specs[0], specs[1])
+    air = raw['140kV'] >= 0.95 * raw['140kV'].max()
+    assert air.any() and np.all(m[0][air] == 0) and np.all(m[1][air] == 0)
+    views = [0, 300, 601]
+    a = co.gn_decompose(raw['140kV'][views].astype(np.float64).ravel(), raw['80kV'][views].astype(np.float64).ravel(), i0, mus,
+                        50, n_threads=8).reshape(len(views), nC, 2)
+    live = ~air[views] & np.isfinite(a).all(-1)
+    for i in (0, 1):
+        got, want = m[i][views][live], a[..., i][live]
+        assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1.0)) < 1e-6          # files are float32
+    for sub, names in (('140kV_5000uGy', ['recon_raw', 'recon_HU']), ('matdecomp_140kV_80kV_5000uGy_5000uGy', ['mat1_recon'])):
+        for nme in names:
+            img = np.fromfile(base / sub / f'{nme}_float32.bin', dtype=np.float32)
+            assert img.size == 512 * 512 and np.isfinite(img).all()
+
+
+@pytest.mark.gpu
+def test_get_sino_sees_in_place_changes():
+    """The reference rebuilds its state on every get_sino call; the cached device state here is keyed on the geometry
+    numbers and a checksum of the volume, so an in-place edit of phantom.volume or of a scanner number is seen."""
+    import dex_ct_sim_amd as dx
+    from conftest import small_scan
+    from dex_ct_sim_amd import synthetic
+    ct, ph = small_scan(n=48, n_views=30, n_channels=64)
+    spec = synthetic.kramers_spectrum(100)
+    a, _ = dx.get_sino(ct, ph, spec)
+    b, _ = dx.get_sino(ct, ph, spec)
+    assert np.array_equal(a, b)
+    ph.volume[0, 20:28, 20:28] = 2                                      # in place: a bone block
+    c, _ = dx.get_sino(ct, ph, spec)
+    assert not np.array_equal(a, c)
+    fresh_ct, fresh_ph = small_scan(n=48, n_views=30, n_channels=64)
+    fresh_ph.volume[0, 20:28, 20:28] = 2
+    d, _ = dx.get_sino(fresh_ct, fresh_ph, spec)
+    assert np.array_equal(c, d)
+    ct.SID = 70.0                                                       # a scanner number changed in place
+    e, _ = dx.get_sino(ct, ph, spec)
+    assert not np.array_equal(c, e)
