@@ -239,6 +239,6 @@ def test_get_sino_sees_in_place_changes():
     fresh_ph.volume[0, 20:28, 20:28] = 2
     d, _ = dx.get_sino(fresh_ct, fresh_ph, spec)
     assert np.array_equal(c, d)
-    ct.SID = 70.0                                                       # a scanner number changed in place
+    ct.SID = 55.0                                                       # a scanner number changed in place
     e, _ = dx.get_sino(ct, ph, spec)
     assert not np.array_equal(c, e)
