@@ -20,7 +20,11 @@ def _worker(rank, world, port, n_views, q):
     b, e = _shard.my_views(n_views)
     got = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1)
     mx = _shard.global_max(torch.tensor(float(rank + 1), dtype=torch.float64))
-    q.put((rank, (b, e), bool(torch.equal(got, full)), float(mx)))
+    # np.max semantics over ranks (matdecomp.py:195-196): one rank's NaN makes the global maximum NaN on every rank;
+    # -inf on a rank (an empty shard) does not disturb the others' values
+    nan_mx = _shard.global_max(torch.tensor(float('nan') if rank == world - 1 else 5.0, dtype=torch.float64))
+    inf_mx = _shard.global_max(torch.tensor(float('-inf') if rank == 0 else 2.5, dtype=torch.float64))
+    q.put((rank, (b, e), bool(torch.equal(got, full)), float(mx), float(nan_mx), float(inf_mx)))
     dist.destroy_process_group()
 
 
@@ -37,8 +41,9 @@ def test_gather_views_and_global_max(world, n_views):
         p.join(timeout=60)
         assert p.exitcode == 0
     covered = []
-    for rank, (b, e), ok, mx in res:
+    for rank, (b, e), ok, mx, nan_mx, inf_mx in res:
         assert ok and mx == float(world)
+        assert np.isnan(nan_mx) and inf_mx == 2.5
         covered += list(range(b, e))
     assert covered == list(range(n_views))       # contiguous, disjoint, complete
 
