@@ -1,0 +1,342 @@
+// rows16_kernel: the stacked-fan traversal on a 2-BIT PACKED volume with bit-sliced counters (gfx950).
+//
+// Material ids of the fast path are < 3, so a voxel needs 2 bits, not 8.  dexct_volume_pack2 stores the z-fastest
+// volume with four voxels per byte: column (x, y) is nz / 4 bytes, row z in bits 2(z % 16), 2(z % 16) + 1 of dword
+// z / 16.  One dword load then serves SIXTEEN detector rows (rows4_kernel: four), the volume is a quarter of the bytes
+// (a 1024^3 phantom is 256 MiB: it fits the Infinity Cache) and a (view, channel) pair of 1024 rows is one wave.
+//
+// Counting.  The loaded word x IS 32 one-bit flags: bit 2r = "row r sees id 1", bit 2r + 1 = "row r sees id 2" (ids
+// 0, 1, 2).  n_1 and n_2 per row are therefore per-bit-position population counts over the slabs of the ray.  They are
+// kept BIT-SLICED (Harley-Seal): words ones / twos / fours hold bits 0..2 of the 32 counters, hi[0..7] bits 3..10; eight
+// loaded words are folded by seven carry-save adders (3 logic instructions each: a ^ b, (a ^ b) ^ c, majority by bit
+// select) and one ripple of the carry into hi[]: 37 instructions per 8 dwords = 0.29 per row and slab against 0.75 (+ a
+// v_readfirstlane per 4 rows) in rows4_kernel.  The counters are un-sliced once per ray plane.
+// Corrections (float32, in slab order, only where a crossing separates two materials) are applied per row exactly as
+// in rows4_kernel, so per-material path lengths are bit-identical to every other kernel and to the oracle.
+//
+// Lanes: a pair of n_rows rows needs n_rows / 16 lanes.  For n_rows / 16 < 64 a wave carries 64 / (n_rows / 16)
+// neighbouring channels of one view (per-lane pair index; each pair has its own slab lists in LDS and list entries
+// beyond a pair's count point outside the buffer, which reads as air and counts nothing).
+#include <cstdlib>
+
+#include "common.h"
+#include "siddon_detect.h"
+
+namespace dexct {
+
+constexpr int kP16Super = 128;      // slabs staged per pass
+constexpr uint32_t kOob = 0xF0000000u;   // a list offset outside every buffer (< 3.75 GiB): the load returns 0 (air), no traffic
+
+struct PackedArgs {
+  ProjArgs a;
+  const uint8_t* vol_z2;   // [ny][nx][nz / 4]
+  int lanes_per_pair;      // n_rows / 16 (16, 32 or 64)
+  int n_zchunks;           // ceil(n_rows / 1024)
+  int view_tile;
+};
+
+// carry-save adder on 32 one-bit lanes: (h, l) = a + b + c
+__device__ __forceinline__ void csa(uint32_t& h, uint32_t& l, uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t u = a ^ b;
+  h = (a & b) | (u & c);
+  l = u ^ c;
+}
+
+struct Sliced {
+  uint32_t ones = 0, twos = 0, fours = 0;
+  uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // bits 3..10 of the 32 counters
+  __device__ __forceinline__ void add_eights(uint32_t carry) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t t = hi[k] & carry;
+      hi[k] ^= carry;
+      carry = t;
+    }
+  }
+  __device__ __forceinline__ void add8(const uint32_t (&x)[8]) {
+    uint32_t ta, tb, fa, fb, e;
+    csa(ta, ones, ones, x[0], x[1]);
+    csa(tb, ones, ones, x[2], x[3]);
+    csa(fa, twos, twos, ta, tb);
+    csa(ta, ones, ones, x[4], x[5]);
+    csa(tb, ones, ones, x[6], x[7]);
+    csa(fb, twos, twos, ta, tb);
+    csa(e, fours, fours, fa, fb);
+    add_eights(e);
+  }
+  __device__ __forceinline__ void add4(const uint32_t (&x)[4]) {
+    uint32_t ta, tb, fa;
+    csa(ta, ones, ones, x[0], x[1]);
+    csa(tb, ones, ones, x[2], x[3]);
+    csa(fa, twos, twos, ta, tb);
+    const uint32_t e = fours & fa;
+    fours ^= fa;
+    add_eights(e);
+  }
+  // counter of bit position p
+  __device__ __forceinline__ uint32_t value(int p) const {
+    uint32_t n = ((ones >> p) & 1u) | (((twos >> p) & 1u) << 1) | (((fours >> p) & 1u) << 2);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) n |= ((hi[k] >> p) & 1u) << (3 + k);
+    return n;
+  }
+};
+
+template <int NM, bool GROUPED>
+__global__ __launch_bounds__(64) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
+                                                    const float* __restrict__ w2) {
+  static_assert(NM == 2 || NM == 3, "ids 0..2");
+  extern __shared__ uint32_t lds_lists[];          // per pair: kP16Super crossing records (16 B), then kP16Super offsets
+  const ProjArgs& a = pa.a;
+  const int lane = threadIdx.x;
+  const int lpp = pa.lanes_per_pair, n_pairs = 64 / lpp;
+  CrossRec (*list_cross)[kP16Super] = reinterpret_cast<CrossRec (*)[kP16Super]>(lds_lists);
+  uint32_t (*list_full)[kP16Super] = reinterpret_cast<uint32_t (*)[kP16Super]>(lds_lists + (size_t)n_pairs * kP16Super * 4);
+  const int g = lane / lpp, li = lane - g * lpp;                 // this lane's pair and its index inside the pair
+  // block -> (view, channel group, z-chunk): contiguous logical ids per XCD, views fastest inside a tile
+  const int n_cg = (a.g.n_channels + n_pairs - 1) / n_pairs;
+  const uint32_t nblk = gridDim.x, bid = blockIdx.x, per = nblk >> 3;
+  const uint32_t logical = (bid < (per << 3)) ? (bid & 7u) * per + (bid >> 3) : bid;
+  const uint32_t group = (uint32_t)pa.view_tile * n_cg * pa.n_zchunks;
+  const uint32_t gq = logical / group, rem = logical - gq * group;
+  const uint32_t views_here = min((uint32_t)pa.view_tile, (uint32_t)a.n_local_views - gq * pa.view_tile);
+  const int zc = rem % pa.n_zchunks;
+  const uint32_t qq = rem / pa.n_zchunks;
+  const int v = gq * pa.view_tile + qq % views_here;
+  const int c = (qq / views_here) * n_pairs + g;
+  const bool pair_live = c < a.g.n_channels;
+  dexct_ray_plan p;
+  if (pair_live) p = a.plan[(size_t)v * a.g.n_channels + c];
+  else { p.V0 = 0; p.SV = 0; p.i_first = 0; p.n_slabs = 0; p.kf = 0; p.len_per_u = 0; p.chord_u = 0; p.flags = 0; }
+  const int axis = p.flags & 1u;
+  const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
+  const int nv = axis == 0 ? a.g.ny : a.g.nx;
+  const uint32_t zb = (uint32_t)a.g.nz >> 2;                               // bytes per column
+  const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * zb;
+  const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * zb;
+  const int r0 = (zc * 64 + li) * 16;                                      // first of this lane's 16 rows
+  // byte offset of the lane's dword inside a column; lanes past the last row read the last dword and store nothing
+  const uint32_t zoff = (uint32_t)min((a.g.z_first + r0) >> 2, (int)zb - 4);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(pa.vol_z2), 0, (int)((size_t)a.g.nx * a.g.ny * zb), 0x00020000);
+  auto ld16 = [&](uint32_t off) {           // off + zoff beyond the buffer (list padding, edge pieces): 0, no access
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(off + zoff), 0, 0);
+  };
+  Sliced cnt;
+  float corr[2][16];                         // [material - 1][row]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) corr[m][q] = 0.0f;
+  auto correct = [&](uint32_t xa, uint32_t xb, float t) {
+    const uint32_t d = xa ^ xb;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      if ((d >> (2 * rr)) & 3u) {
+        const uint32_t ia = (xa >> (2 * rr)) & 3u, ib = (xb >> (2 * rr)) & 3u;
+#pragma unroll
+        for (int m = 1; m < NM; ++m) {
+          corr[m - 1][rr] += (ia == (uint32_t)m) ? t : 0.0f;
+          corr[m - 1][rr] -= (ib == (uint32_t)m) ? t : 0.0f;
+        }
+      }
+    }
+  };
+  // the longest ray of the wave sets the trip count (wave-uniform)
+  int n_slabs_max = 0;
+  for (int k = 0; k < n_pairs; ++k) n_slabs_max = max(n_slabs_max, __builtin_amdgcn_readlane(p.n_slabs, k * lpp));
+  const unsigned long long group_mask = (lpp == 64 ? ~0ull : ((1ull << lpp) - 1ull)) << (g * lpp);
+  const unsigned long long below_mask = group_mask & ((1ull << lane) - 1ull);
+  for (int s0 = 0; s0 < n_slabs_max; s0 += kP16Super) {
+    // ---- geometry: the lanes of a pair classify its slabs s0 + li, s0 + li + lpp, ... (slab order kept per pair)
+    int run_f = 0, run_c = 0;               // per pair (identical in all lanes of a pair)
+    for (int q0 = 0; q0 < kP16Super; q0 += lpp) {
+      const int s = s0 + q0 + li;
+      bool is_full = false, is_cross = false;
+      uint32_t offa = kOob, offb = kOob;
+      float tt = 0.0f;
+      if (s < p.n_slabs) {
+        const int i = p.i_first + s;
+        const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
+        const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
+        if (ina) offa = (uint32_t)i * su + (uint32_t)sp.ja * sv;
+        if (inb) offb = (uint32_t)i * su + (uint32_t)sp.jb * sv;
+        tt = sp.t;
+        is_full = ina && inb && sp.ja == sp.jb;
+        // everything else that touches the grid goes to the crossing list: a piece outside the grid keeps kOob and
+        // reads as air, which is what the edge slabs of rows4_kernel do (count b, correct against id 0)
+        is_cross = !is_full && (ina || inb);
+      }
+      const unsigned long long mf = __ballot(is_full), mc = __ballot(is_cross);
+      if (is_full) list_full[g][run_f + __popcll(mf & below_mask)] = offb;
+      if (is_cross) list_cross[g][run_c + __popcll(mc & below_mask)] = CrossRec{offa, offb, tt, 0u};
+      run_f += __popcll(mf & group_mask);
+      run_c += __popcll(mc & group_mask);
+    }
+    // pad each pair's lists to the wave's longest (whole batches), so that the sweeps below need no per-pair bounds
+    int n_full = 0, n_cross = 0;
+    for (int k = 0; k < n_pairs; ++k) {
+      n_full = max(n_full, __builtin_amdgcn_readlane(run_f, k * lpp));
+      n_cross = max(n_cross, __builtin_amdgcn_readlane(run_c, k * lpp));
+    }
+    n_full = (n_full + 7) & ~7;
+    n_cross = (n_cross + 3) & ~3;
+    for (int k = run_f + li; k < n_full; k += lpp) list_full[g][k] = kOob;
+    for (int k = run_c + li; k < n_cross; k += lpp) list_cross[g][k] = CrossRec{kOob, kOob, 0.0f, 0u};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- full slabs: 8 dword loads (16 rows each) in flight, seven carry-save adders
+    for (int k = 0; k < n_full; k += 8) {
+      uint32_t x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = ld16(list_full[g][k + q]);
+      __builtin_amdgcn_sched_barrier(0);
+      cnt.add8(x);
+    }
+    // ---- crossing slabs (and the edge slabs): count the b voxel, correct where the two voxels differ
+    for (int k = 0; k < n_cross; k += 4) {
+      uint32_t xa[4], xb[4];
+      float t4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const CrossRec q = list_cross[g][k + j];
+        xa[j] = ld16(q.offa);
+        xb[j] = ld16(q.offb);
+        t4[j] = q.t;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      cnt.add4(xb);
+      uint32_t any = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) any |= xa[j] ^ xb[j];
+      if (any) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (xa[j] != xb[j]) correct(xa[j], xb[j], t4[j]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!pair_live || r0 >= a.g.n_rows) return;
+  // ---- un-slice the counters, form the lengths, detect 4 rows at a time
+  const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    float L[4][NM];
+    size_t rays[4];
+    bool valid[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * q4 + rr, r = r0 + row;
+      valid[rr] = r < a.g.n_rows;
+      rays[rr] = ray_index(a, v, valid[rr] ? r : 0, c);
+      L[rr][1] = (float)(int32_t)cnt.value(2 * row) + corr[0][row];
+      if (NM > 2) L[rr][NM - 1] = (float)(int32_t)cnt.value(2 * row + 1) + corr[1][row];
+    }
+    if (!valid[0]) break;
+    if (GROUPED) {
+      const bool vec4 = a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[3];
+#pragma unroll
+      for (int m = 1; m < NM; ++m) {
+        float* plane = a.acc_out + (size_t)(a.mat_base + m) * n_rays;
+        if (vec4) {
+          *reinterpret_cast<float4*>(plane + rays[0]) = make_float4(L[0][m], L[1][m], L[2][m], L[3][m]);
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            if (valid[rr]) plane[rays[rr]] = L[rr][m];
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      float others = 0.0f;
+#pragma unroll
+      for (int m = 1; m < NM; ++m) others += L[rr][m];
+      L[rr][0] = (p.chord_u - others) * p.len_per_u;
+#pragma unroll
+      for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
+    }
+    detect_store<NM, 4>(L, a, mu, w, w2, rays, valid);
+  }
+}
+
+// vol_zf [ny][nx][nz] (one byte per voxel, ids < 4) -> vol_z2 [ny][nx][nz / 4] (2 bits per voxel, z fastest)
+__global__ __launch_bounds__(256) void pack2_kernel(const uint8_t* __restrict__ vol_zf, size_t n_bytes_out,
+                                                    uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_bytes_out) return;
+  const uint32_t x = *reinterpret_cast<const uint32_t*>(vol_zf + 4 * i);
+  out[i] = (uint8_t)((x & 3u) | (((x >> 8) & 3u) << 2) | (((x >> 16) & 3u) << 4) | (((x >> 24) & 3u) << 6));
+}
+
+}  // namespace dexct
+
+using namespace dexct;
+
+extern "C" {
+
+int dexct_volume_pack2(const uint8_t* vol_zf, int64_t n_voxels, uint8_t* vol_z2, void* stream) {
+  if (!vol_zf || !vol_z2 || n_voxels <= 0 || (n_voxels & 3)) return DEXCT_EINVAL;
+  const size_t nb = (size_t)n_voxels / 4;
+  const size_t nblk = (nb + 255) / 256;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vol_zf, nb, vol_z2);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
+                                int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
+                                int32_t n_spectra, const float* mu, const float* weights, float* counts, float* pathlen,
+                                int32_t layout, void* stream) {
+  if (!geom || !plan || !vol_z2 || !mu || !weights || !counts) return DEXCT_EINVAL;
+  if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
+  if (n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
+  if (n_materials < 2 || n_materials > 3 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;     // ids 0..2
+  if (geom->z_first < 0 || geom->z_first + geom->n_rows > geom->nz) return DEXCT_EINVAL;
+  if (geom->nz % 16 != 0 || geom->z_first % 16 != 0 || geom->n_rows % 16 != 0) return DEXCT_EINVAL;
+  const int lanes = geom->n_rows / 16;
+  if (lanes != 16 && lanes != 32 && lanes % 64 != 0) return DEXCT_EINVAL;
+  if ((uint64_t)geom->nx * geom->ny * (geom->nz / 4) > 0xEFFF0000ull) return DEXCT_ERANGE;     // below kOob
+  if (geom->nx > 2047 || geom->ny > 2047) return DEXCT_ERANGE;             // 11-bit sliced counters: one count per slab
+  if (layout != 0 && layout != 1) return DEXCT_EINVAL;
+  if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
+  PackedArgs pa;
+  ProjArgs& a = pa.a;
+  a.g = *geom;
+  a.plan = plan;
+  a.vol_yx = nullptr;
+  a.vol_xy = nullptr;
+  a.vol_zf = nullptr;
+  a.n_local_views = view_end - view_begin;
+  a.n_materials = n_materials;
+  a.n_energies = n_energies;
+  a.n_spectra = n_spectra;
+  a.counts = counts;
+  a.pathlen = pathlen;
+  a.variance = nullptr;
+  a.acc_out = nullptr;
+  a.mat_base = 0;
+  a.layout = layout;
+  a.view_tile = 8;
+  pa.vol_z2 = vol_z2;
+  pa.lanes_per_pair = lanes >= 64 ? 64 : lanes;
+  pa.n_zchunks = lanes >= 64 ? lanes / 64 : 1;
+  pa.view_tile = 8;
+  if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) pa.view_tile = t; }
+  const int n_pairs = 64 / pa.lanes_per_pair;
+  const size_t nblk = (size_t)a.n_local_views * ((geom->n_channels + n_pairs - 1) / n_pairs) * pa.n_zchunks;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipStream_t st = as_stream(stream);
+  const size_t lds = (size_t)n_pairs * kP16Super * (sizeof(CrossRec) + sizeof(uint32_t));
+  if (n_materials == 2)
+    hipLaunchKernelGGL((rows16_kernel<2, false>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+  else
+    hipLaunchKernelGGL((rows16_kernel<3, false>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+}  // extern "C"

@@ -52,7 +52,8 @@ class Projector:
     neighbouring (view, channel) pairs per workgroup walking the volume in step (rows4t_kernel: what kernel 0
     picks for stacked fans of >= 256 rows; same bits as kernel 3), 6 one wavefront per ray (lanes over
     dominant-axis slabs, shuffle reductions, tables in LDS: the mapping BASELINE.json's north star names; <= 4
-    materials).
+    materials), 7 the stacked fan on a 2-bit packed volume with bit-sliced counters (rows16_kernel: 16 rows per
+    lane; <= 3 materials, rows a multiple of 256 or 512 or of 1024).
     """
 
     def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
@@ -84,10 +85,11 @@ class Projector:
         # The 4-rows-per-lane kernels read aligned dwords along z: pad the uploaded copy with empty slices so that
         # the first imaged slice and the slice count are multiples of 4 (stacked fans only see their own slices,
         # the in-plane geometry does not change).
-        packed_wanted = kernel in (3, 4, 5) or (kernel == 0 and ct.N_rows >= 64)
-        if not self.cone and packed_wanted and (nz % 4 or z_first % 4):
-            lead = (-z_first) % 4
-            tail = (-(nz + lead)) % 4
+        packed_wanted = kernel in (3, 4, 5, 7) or (kernel == 0 and ct.N_rows >= 64)
+        align = 16 if kernel == 7 else 4
+        if not self.cone and packed_wanted and (nz % align or z_first % align):
+            lead = (-z_first) % align
+            tail = (-(nz + lead)) % align
             volume = np.pad(volume, ((lead, tail), (0, 0), (0, 0)))
             z_first, nz = z_first + lead, nz + lead + tail
         self.geom = _native.FanGeom(ct.N_proj, ct.N_channels, ct.N_rows, z_first, phantom.Nx, phantom.Ny,
@@ -116,11 +118,19 @@ class Projector:
                 self.vol_zc = torch.empty(nb, dtype=torch.uint8, device=self.dev)
                 _native.check(self.lib.dexct_cone_layout(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz, ptr(self.vol_zc), st),
                               'dexct_cone_layout')
-        want_zf = kernel in (2, 3, 4, 5) or (kernel == 0 and ct.N_rows >= 64)
+        want_zf = kernel in (2, 3, 4, 5, 7) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz,
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
         M = phantom.n_materials
+        self.vol_z2 = None
+        if kernel == 7:
+            lanes = ct.N_rows // 16
+            if not (2 <= M <= 3 and ct.N_rows % 16 == 0 and (lanes in (16, 32) or lanes % 64 == 0)):
+                raise ValueError('kernel 7 (2-bit packed volume) needs 2..3 materials and 256, 512 or a multiple of 1024 rows')
+            self.vol_z2 = torch.empty(self.vol_zf.numel() // 4, dtype=torch.uint8, device=self.dev)
+            _native.check(self.lib.dexct_volume_pack2(ptr(self.vol_zf), self.vol_zf.numel(), ptr(self.vol_z2), st),
+                          'dexct_volume_pack2')
         aligned = nz % 4 == 0 and z_first % 4 == 0
         self.grouped = kernel == 4 or (kernel == 0 and want_zf and M > 4 and aligned)
         self.codes = None
@@ -143,7 +153,7 @@ class Projector:
     @property
     def native_layout(self):
         """1 (row fastest) when a row-parallel kernel will run, else 0 (channel fastest)."""
-        if self.kernel in (2, 3, 4, 5):
+        if self.kernel in (2, 3, 4, 5, 7):
             return 1
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 
@@ -189,6 +199,12 @@ class Projector:
                     C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
                     self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
                     ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), stream_ptr()), 'dexct_cone_project')
+        elif self.kernel == 7:
+            if w2_d is not None:
+                raise NotImplementedError('noise is not wired for the packed-volume kernel')
+            _native.check(self.lib.dexct_siddon_project_packed(
+                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_z2), M, nE, S,
+                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, stream_ptr()), 'dexct_siddon_project_packed')
         elif self.grouped:
             scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
             _native.check(self.lib.dexct_siddon_project_grouped(
@@ -263,18 +279,28 @@ class Projector:
 _cache = {}
 
 
+def _checksum(a):
+    """64-bit checksum of an array's bytes: xxh3 where the xxhash module is present (16 ms per 128 MiB), else crc32
+    (0.13 s per 128 MiB)."""
+    a = np.ascontiguousarray(a)
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(a.data)
+    except ImportError:
+        import zlib
+        return zlib.crc32(a.data)
+
+
 def _fingerprint(ct, phantom, view_range):
     """Everything the device-resident state (volume layouts, ray plans) depends on.  The reference rebuilds its
     state on every get_sino call; here the state is reused only while the scanner numbers, the voxel sizes and
-    the volume's bytes (crc32, ~0.1 s per 128 MiB on the host) are what they were when it was built - in-place
+    the volume's bytes (checksummed on the host at every call) are what they were when it was built - in-place
     edits of ``phantom.volume`` or of ``ct.SID`` between two calls are therefore seen."""
-    import zlib
-    vol = np.ascontiguousarray(phantom.volume)
     return (id(ct), id(phantom), view_range, ct.N_proj, ct.N_channels, ct.N_rows, ct.SID, ct.SDD,
-            zlib.crc32(np.ascontiguousarray(ct.thetas).data), zlib.crc32(np.ascontiguousarray(ct.gammas).data),
+            _checksum(ct.thetas), _checksum(ct.gammas),
             ct.h_iso, bool(getattr(ct, 'cone', False)), float(getattr(ct, 'src_z', 0.0)),
             phantom.z_index, phantom.Nx, phantom.Ny, phantom.Nz, phantom.dx, phantom.dy, phantom.dz,
-            phantom.n_materials, vol.shape, zlib.crc32(vol.data))
+            phantom.n_materials, np.shape(phantom.volume), _checksum(phantom.volume))
 
 
 def invalidate():

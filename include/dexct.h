@@ -127,6 +127,18 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
                                  float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
                                  float* variance, void* stream);
 
+/* The stacked-fan projection on a 2-BIT PACKED volume (rows16_kernel; <= 3 materials, i.e. ids 0..2): a voxel is 2
+ * bits, one dword load serves 16 detector rows, the per-row material counts are kept bit-sliced (carry-save adders).
+ * dexct_volume_pack2: vol_zf [ny][nx][nz] bytes -> vol_z2 [ny][nx][nz/4] bytes (row z of a column in bits
+ *   2(z%4).. of byte z/4); n_voxels = nx*ny*nz, a multiple of 4.
+ * dexct_siddon_project_packed: same outputs and layouts as dexct_siddon_project; nz, z_first and n_rows multiples of
+ *   16 and n_rows/16 one of 16, 32 or a multiple of 64; nx, ny <= 2047.  Bit-identical per-material path lengths. */
+int dexct_volume_pack2(const uint8_t* vol_zf, int64_t n_voxels, uint8_t* vol_z2, void* stream);
+int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
+                                int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
+                                int32_t n_spectra, const float* mu, const float* weights, float* counts,
+                                float* pathlen, int32_t layout, void* stream);
+
 /* Cone-beam (3-D) projection, SURVEY 8f.4: the fan of dexct_fan_plan in the (x, y) plane, source at height
  * src_z, detector row r at height row_z[r] (device float64 [n_rows], cm, z = 0 at the centre of the grid;
  * geom->z_first is ignored).  max_abs_dz = max_r |row_z[r] - src_z| (the caller knows it; it bounds the z

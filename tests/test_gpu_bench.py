@@ -51,6 +51,14 @@ def test_plain_command_two_ranks(hip, scaling):
     assert one['config']['rays_total'] == (48 * 64 * 96)
 
 
+def test_plain_command_four_ranks_ragged(hip):
+    """Four ranks (gloo rehearsal on a one-GPU box) over a scan whose views do not divide evenly: 50 = 13+13+12+12."""
+    out, _ = run_bench('--gpus', '4', '--views', '50')
+    assert out['n_gpus'] == 4 and out['config']['rays_total'] == 50 * 64 * 96
+    views = [r['views'] for r in sorted(out['multi_gpu']['per_rank'], key=lambda r: r['rank'])]
+    assert views == [[0, 13], [13, 26], [26, 38], [38, 50]]
+
+
 def test_world_size_mismatch_is_an_error(hip):
     e = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *SMALL, '--gpus', '2'], capture_output=True,

@@ -510,3 +510,44 @@ def test_degenerate_shapes_through_the_public_calls(hip):
             if n_ch >= 2:
                 img, _ = dx.get_recon(l1, ct, hi, 8, 10.0, 1.0)
                 assert img.shape == ((8, 8) if rows == 1 else (rows, 8, 8))
+
+
+@pytest.mark.parametrize('n_rows,nz,z_index', [(256, 256, 0), (256, 270, 2), (512, 512, 0), (1024, 1024, 0), (2048, 2048, 0)])
+@pytest.mark.parametrize('n_mat', [2, 3])
+def test_packed_volume_kernel_bit_identical(hip, n_rows, nz, z_index, n_mat):
+    """rows16_kernel (kernel 7): 2 bits per voxel, 16 rows per lane, bit-sliced counters.  4, 2 or 1 (view, channel)
+    pairs per wave (256 / 512 / >= 1024 rows), ragged channel groups (53 channels), an unaligned first slice (the host
+    pads the uploaded volume to multiples of 16): per-material path lengths bit-identical to rows4_kernel and to the
+    oracle mirror, counts equal to rows4_kernel's (same detection code) and within 1e-5 of the float64 Siddon."""
+    from dex_ct_sim_amd import forward_project as fp
+    from dex_ct_sim_amd.system import AIR, WATER
+    ct, ph = small_scan(n=40, nz=nz, n_views=7, n_channels=53, n_rows=n_rows, z_index=z_index)
+    if n_mat == 2:
+        ph.volume = np.minimum(ph.volume, 1).astype(np.uint8)
+        ph.materials = [AIR, WATER]
+    rng = np.random.default_rng(nz + n_mat)
+    speck = rng.random(ph.volume.shape) < 0.02                      # isolated voxels: corrections in many rows
+    ph.volume[speck] = rng.integers(0, n_mat, int(speck.sum()), dtype=np.uint8)
+    sp = spectra()
+    (c3, p3), _ = projector(ct, ph, kernel=3).project(sp, want_pathlen=True)
+    (c7, p7), _ = projector(ct, ph, kernel=7).project(sp, want_pathlen=True)
+    assert torch.equal(p7, p3)
+    assert torch.equal(c7, c3)
+    g = oracle_geom(ct, ph)
+    E, mu, w = fp.merged_tables(ct, ph, sp)
+    sub = co.make_geom(ct.N_proj, ct.N_channels, 16, z_index + n_rows - 16, ph.Nx, ph.Ny, ph.Nz, ph.dx, ph.dy, ph.dz,
+                       ct.SID, ct.SDD)                               # the last 16 rows
+    _, rpl = co.project_dda(sub, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w, True, n_threads=8)
+    assert np.array_equal(p7[:, n_rows - 16:].cpu().numpy(), rpl)
+    cls = co.project_classic(sub, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w, n_threads=8)
+    assert np.max(np.abs(c7[:, :, n_rows - 16:].cpu().numpy() - cls) / cls) < REL_TOL
+
+
+def test_packed_volume_kernel_refuses_what_it_cannot_do(hip):
+    from dex_ct_sim_amd._native import DexctError
+    ct, ph = small_scan(n=40, nz=256, n_views=4, n_channels=16, n_rows=256)
+    with pytest.raises(ValueError):
+        projector(ct, ph_many(ph, 5), kernel=7)                      # ids above 2
+    ct2, ph2 = small_scan(n=40, nz=96, n_views=4, n_channels=16, n_rows=96)
+    with pytest.raises(ValueError):
+        projector(ct2, ph2, kernel=7)                                # 96 rows: not 256, 512 or a multiple of 1024

@@ -55,6 +55,13 @@ out = torch.empty_like(ref)
 ms3 = timed(lambda: pj3.project_tables(mu_d, w_d, out=out, layout=None), args.reps)
 n_rays = ref[0].numel()
 print(f'rows4_kernel  (kernel 3)            {ms3:8.2f} ms  {n_rays / ms3 * 1e3:.3g} rays/s  ({n_rays:.3g} rays, n={n})', flush=True)
+pj7 = fp.Projector(ct, ph, view_range=(args.view_begin, args.view_begin + args.views), kernel=7)
+got, pl = pj7.project_tables(mu_d, w_d, want_pathlen=True, layout=None)
+same = bool(torch.equal(pl, ref_pl)) and bool(torch.equal(got, ref))
+del got, pl
+ms7 = timed(lambda: pj7.project_tables(mu_d, w_d, out=out, layout=None), args.reps)
+print(f'rows16_kernel (kernel 7, 2-bit volume) {ms7:8.2f} ms  {n_rays / ms7 * 1e3:.3g} rays/s  bit-identical to kernel 3: {same}', flush=True)
+del pj7
 pj5 = fp.Projector(ct, ph, view_range=(args.view_begin, args.view_begin + args.views), kernel=5)
 for var in args.variants:
     pairs, tv, sub, *fb = var.split(':')
