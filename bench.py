@@ -329,9 +329,12 @@ def main():
     import glob
     geom = co.make_geom(ct.N_proj, ct.N_channels, rows, ph.z_index, n, n, n, ph.dx, ph.dy, ph.dz, ct.SID, ct.SDD)
     seg_vc, _ = segment_count(co, geom, ct.view_cs(), ct.chan_cs(), total_views, vb, ve)
-    alg_bytes = seg_vc * rows * 1 + 4 * 2 * n_rays
+    # algorithmic bytes: S_ray x bytes per stored voxel + outputs; the packed volume stores a voxel in 2 bits
+    b_vox = 0.25 if getattr(pj, 'use_packed', False) else 1.0
+    alg_bytes = seg_vc * rows * b_vox + 4 * 2 * n_rays
     alg_gbps = alg_bytes / (sid_ms * 1e-3) / 1e9
-    kname = {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel'}[args.kernel or (3 if native == 1 else 1)]
+    kname = 'rows16_kernel' if getattr(pj, 'use_packed', False) else \
+        {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel', 5: 'rows4t_kernel', 6: 'wave_ray_kernel'}[args.kernel or (3 if native == 1 else 1)]
     traffic = traffic_src = None
     prof = {}
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), key=os.path.getmtime):
@@ -339,16 +342,19 @@ def main():
         if j.get('rays_per_gpu') == n_rays and kname in j.get('siddon_kernel', '') and j.get('n', 512) == n:
             prof, traffic_src = j, 'profiles/' + os.path.basename(f)        # same workload and kernel only; newest wins
     traffic = prof.get('siddon_hbm_bytes_per_launch')
-    vol_bytes = n * n * n
+    vol_bytes = int(n * n * n * b_vox)
     cache_resident = vol_bytes <= 256 * 2 ** 20
-    # vector-issue floor of the packed traversal + detection: per lane (= 4 detector rows)
-    #   2 vector instructions per voxel-dword visited (bit-plane AND + its add; the weighted-sum add shared by two
-    #   visits through v_add3) and, per energy bin any spectrum weights, 6 v_pk_fma (3 materials x 2 ray pairs) +
-    #   4 v_exp_f32 (2 issue slots each) + 2 v_pk_fma per spectrum that weights the bin; one slot = 4 cycles of one
-    #   of the 1024 SIMDs.
+    # vector-issue floor of the packed traversal + detection: per voxel dword visited
+    #   rows4_kernel (1 B / voxel, 4 rows per dword): 2 vector instructions (bit-plane AND + its add; the weighted-sum
+    #     add shared by two visits through v_add3)
+    #   rows16_kernel (2 bits / voxel, 16 rows per dword): 3 (the lane's address add + 21 / 8 for the seven carry-save
+    #     adders per 8 words; the ripple into the high counter bits can be amortised away)
+    # and, per 4 rays and energy bin that any spectrum weights, 6 v_pk_fma (3 materials x 2 ray pairs) + 4 v_exp_f32
+    # (2 issue slots each) + 2 v_pk_fma per spectrum that weights the bin; one slot = 4 cycles of one of the 1024 SIMDs.
     n_e_any = int(((w_d != 0).any(dim=0)).sum().item())
     lanes = n_rays / 4.0
-    floor_slots = 2.0 * seg_vc * rows / 4.0 + lanes * (14.0 * n_e_any + 2.0 * sum(n_e_spec))
+    rows_per_dword, per_visit = (16.0, 3.0) if kname == 'rows16_kernel' else (4.0, 2.0)
+    floor_slots = per_visit * seg_vc * rows / rows_per_dword + lanes * (14.0 * n_e_any + 2.0 * sum(n_e_spec))
     slots_per_s = 1024 * CLOCK_GHZ * 1e9 / 4.0                 # wave-instruction issue slots per second, whole chip
     floor_ms = floor_slots / 64.0 / slots_per_s * 1e3
     sid = {'kernel': kname, 'avg_launch_ms': sid_ms,

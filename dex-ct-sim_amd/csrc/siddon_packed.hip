@@ -82,8 +82,8 @@ struct Sliced {
   }
 };
 
-template <int NM, bool GROUPED>
-__global__ __launch_bounds__(64) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
+template <int NM, bool GROUPED, int MINW = 4>      // MINW: waves per SIMD the register allocation must allow
+__global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
                                                     const float* __restrict__ w2) {
   static_assert(NM == 2 || NM == 3, "ids 0..2");
   extern __shared__ uint32_t lds_lists[];          // per pair: kP16Super crossing records (16 B), then kP16Super offsets
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(64) void rows16_kernel(PackedArgs pa, const float* 
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
+    __builtin_amdgcn_sched_barrier(0);       // one round of 4 rows at a time: keeps the un-sliced values of later rounds out of registers
     float L[4][NM];
     size_t rays[4];
     bool valid[4];
@@ -331,8 +332,16 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   hipStream_t st = as_stream(stream);
   const size_t lds = (size_t)n_pairs * kP16Super * (sizeof(CrossRec) + sizeof(uint32_t));
+  int minw = 4;
+  if (const char* e = getenv("DEXCT_P16_MINW")) minw = atoi(e);      // tuning knob
   if (n_materials == 2)
     hipLaunchKernelGGL((rows16_kernel<2, false>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+  else if (minw == 5)
+    hipLaunchKernelGGL((rows16_kernel<3, false, 5>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+  else if (minw == 6)
+    hipLaunchKernelGGL((rows16_kernel<3, false, 6>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+  else if (minw == 8)
+    hipLaunchKernelGGL((rows16_kernel<3, false, 8>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
   else
     hipLaunchKernelGGL((rows16_kernel<3, false>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
   DEXCT_LAUNCH_CHECK();

@@ -86,7 +86,15 @@ class Projector:
         # the first imaged slice and the slice count are multiples of 4 (stacked fans only see their own slices,
         # the in-plane geometry does not change).
         packed_wanted = kernel in (3, 4, 5, 7) or (kernel == 0 and ct.N_rows >= 64)
-        align = 16 if kernel == 7 else 4
+        # the 2-bit packed volume with bit-sliced counters (rows16_kernel): what kernel 0 picks where it applies
+        lanes16 = ct.N_rows // 16
+        packed2_ok = (not self.cone and 2 <= phantom.n_materials <= 3 and ct.N_rows % 16 == 0
+                      and (lanes16 in (16, 32) or (lanes16 >= 64 and lanes16 % 64 == 0))
+                      and max(phantom.Nx, phantom.Ny) <= 2047)
+        self.use_packed = (kernel == 7) or (kernel == 0 and packed2_ok)
+        if kernel == 7 and not packed2_ok:
+            raise ValueError('kernel 7 (2-bit packed volume) needs 2..3 materials and 256, 512 or a multiple of 1024 rows')
+        align = 16 if self.use_packed else 4
         if not self.cone and packed_wanted and (nz % align or z_first % align):
             lead = (-z_first) % align
             tail = (-(nz + lead)) % align
@@ -124,10 +132,7 @@ class Projector:
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
         M = phantom.n_materials
         self.vol_z2 = None
-        if kernel == 7:
-            lanes = ct.N_rows // 16
-            if not (2 <= M <= 3 and ct.N_rows % 16 == 0 and (lanes in (16, 32) or lanes % 64 == 0)):
-                raise ValueError('kernel 7 (2-bit packed volume) needs 2..3 materials and 256, 512 or a multiple of 1024 rows')
+        if self.use_packed:
             self.vol_z2 = torch.empty(self.vol_zf.numel() // 4, dtype=torch.uint8, device=self.dev)
             _native.check(self.lib.dexct_volume_pack2(ptr(self.vol_zf), self.vol_zf.numel(), ptr(self.vol_z2), st),
                           'dexct_volume_pack2')
@@ -199,9 +204,7 @@ class Projector:
                     C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
                     self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
                     ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), stream_ptr()), 'dexct_cone_project')
-        elif self.kernel == 7:
-            if w2_d is not None:
-                raise NotImplementedError('noise is not wired for the packed-volume kernel')
+        elif self.use_packed and w2_d is None:           # (with noise the byte-volume kernel below runs: it carries the variance)
             _native.check(self.lib.dexct_siddon_project_packed(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_z2), M, nE, S,
                 ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, stream_ptr()), 'dexct_siddon_project_packed')
@@ -215,7 +218,8 @@ class Projector:
             _native.check(self.lib.dexct_siddon_project(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx),
                 ptr(self.vol_xy), ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
-                self.kernel, run_layout, ptr(w2_d), ptr(variance), stream_ptr()), 'dexct_siddon_project')
+                3 if self.kernel == 7 else self.kernel, run_layout, ptr(w2_d), ptr(variance), stream_ptr()),
+                'dexct_siddon_project')
         if variance is not None:
             _native.check(self.lib.dexct_add_noise(ptr(counts), ptr(variance), S, nV, nR, nC, run_layout,
                                                    self.view_begin, int(seed) & (2 ** 64 - 1), stream_ptr()),

@@ -11,7 +11,7 @@ echo "rc=$?"
 python3 - <<PY
 import csv, glob
 for f in glob.glob('$OUT/fetch/*/*_counter_collection.csv'):
-    rows = [r for r in csv.DictReader(open(f)) if 'rows4' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(f)) if 'rows' in r['Kernel_Name']]
     for r in rows:
         name = r['Kernel_Name'].split('(')[0].replace('void dexct::', '')
         print('%-40s dispatch %6s  FETCH_SIZE %.2f GB (x2 for dword-per-lane loads: %.2f GB)' % (

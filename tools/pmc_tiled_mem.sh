@@ -21,7 +21,7 @@ import csv, glob, collections
 last = collections.OrderedDict()
 for f in sorted(glob.glob('$OUT/g*/*/*_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        if 'rows4' not in r['Kernel_Name']:
+        if 'rows' not in r['Kernel_Name']:
             continue
         name = r['Kernel_Name'].split('(')[0].replace('void dexct::', '')
         last[(name, r['Counter_Name'])] = float(r['Counter_Value'])       # the last dispatch of each kernel wins

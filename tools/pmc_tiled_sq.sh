@@ -16,7 +16,7 @@ for sub in ('a', 'b'):
     for f in glob.glob('$OUT/%s/*/*_counter_collection.csv' % sub):
         seen = collections.OrderedDict()
         for r in csv.DictReader(open(f)):
-            if 'rows4' not in r['Kernel_Name']:
+            if 'rows' not in r['Kernel_Name']:
                 continue
             name = r['Kernel_Name'].split('(')[0].replace('void dexct::', '')
             key = (name, r['Dispatch_Id'])

@@ -76,7 +76,7 @@ if cal:
         if 'rows' in k and 'kernel' in k and 'siddon_kernel' not in traffic:
             traffic['siddon_kernel'] = k
             # 4-B-per-lane dword loads (rows4) are tallied at half, like gn_kernel's float32 input stream
-            corr = 2.0 if 'rows4' in k else 1.0
+            corr = 2.0 if ('rows4' in k or 'rows16' in k) else 1.0
             traffic['siddon_fetch_correction'] = corr
             traffic['siddon_fetch_bytes'] = corr * fetch[k]
             traffic['siddon_write_bytes'] = write.get(k, 0.0)
