@@ -9,8 +9,9 @@
 // 0, 1, 2).  n_1 and n_2 per row are therefore per-bit-position population counts over the slabs of the ray.  They are
 // kept BIT-SLICED (Harley-Seal): words ones / twos / fours hold bits 0..2 of the 32 counters, hi[0..7] bits 3..10; eight
 // loaded words are folded by seven carry-save adders (3 logic instructions each: a ^ b, (a ^ b) ^ c, majority by bit
-// select) and one ripple of the carry into hi[]: 37 instructions per 8 dwords = 0.29 per row and slab against 0.75 (+ a
-// v_readfirstlane per 4 rows) in rows4_kernel.  The counters are un-sliced once per ray plane.
+// select); two of the resulting weight-8 words meet in an eighth adder and the carry ripples into hi[] once per 16
+// words: 30 instructions per 8 dwords = 0.23 per row and slab against 0.75 (+ a v_readfirstlane per 4 rows) in
+// rows4_kernel.  The counters are un-sliced once per ray plane.
 // Corrections (float32, in slab order, only where a crossing separates two materials) are applied per row exactly as
 // in rows4_kernel, so per-material path lengths are bit-identical to every other kernel and to the oracle.
 //
@@ -43,14 +44,37 @@ __device__ __forceinline__ void csa(uint32_t& h, uint32_t& l, uint32_t a, uint32
 }
 
 struct Sliced {
-  uint32_t ones = 0, twos = 0, fours = 0;
-  uint32_t hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // bits 3..10 of the 32 counters
-  __device__ __forceinline__ void add_eights(uint32_t carry) {
+  uint32_t ones = 0, twos = 0, fours = 0, eights = 0;
+  uint32_t hi[7] = {0, 0, 0, 0, 0, 0, 0};         // bits 4..10 of the 32 counters
+  uint32_t pend = 0;                               // a word of weight 8 waiting for a partner
+  bool have_pend = false;                          // wave-uniform
+  __device__ __forceinline__ void add_sixteens(uint32_t carry) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 7; ++k) {
       const uint32_t t = hi[k] & carry;
       hi[k] ^= carry;
       carry = t;
+    }
+  }
+  // a word of weight 8: two of them and the running eights go through one more carry-save adder, so the ripple into
+  // the high bits runs once per 16 loaded words
+  __device__ __forceinline__ void add_eights(uint32_t e) {
+    if (!have_pend) {
+      pend = e;
+      have_pend = true;
+    } else {
+      uint32_t c;
+      csa(c, eights, eights, pend, e);
+      add_sixteens(c);
+      have_pend = false;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (have_pend) {
+      const uint32_t c = eights & pend;
+      eights ^= pend;
+      add_sixteens(c);
+      have_pend = false;
     }
   }
   __device__ __forceinline__ void add8(const uint32_t (&x)[8]) {
@@ -73,11 +97,11 @@ struct Sliced {
     fours ^= fa;
     add_eights(e);
   }
-  // counter of bit position p
+  // counter of bit position p (after finish())
   __device__ __forceinline__ uint32_t value(int p) const {
-    uint32_t n = ((ones >> p) & 1u) | (((twos >> p) & 1u) << 1) | (((fours >> p) & 1u) << 2);
+    uint32_t n = ((ones >> p) & 1u) | (((twos >> p) & 1u) << 1) | (((fours >> p) & 1u) << 2) | (((eights >> p) & 1u) << 3);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) n |= ((hi[k] >> p) & 1u) << (3 + k);
+    for (int k = 0; k < 7; ++k) n |= ((hi[k] >> p) & 1u) << (4 + k);
     return n;
   }
 };
@@ -217,6 +241,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
     }
     __builtin_amdgcn_wave_barrier();
   }
+  cnt.finish();
   if (!pair_live || r0 >= a.g.n_rows) return;
   // ---- un-slice the counters, form the lengths, detect 4 rows at a time
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
