@@ -106,7 +106,7 @@ struct Sliced {
   }
 };
 
-template <int NM, bool GROUPED, int MINW = 4>      // MINW: waves per SIMD the register allocation must allow
+template <int NM, int MINW = 4>      // MINW: waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
                                                     const float* __restrict__ w2) {
   static_assert(NM == 2 || NM == 3, "ids 0..2");
@@ -244,7 +244,6 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   cnt.finish();
   if (!pair_live || r0 >= a.g.n_rows) return;
   // ---- un-slice the counters, form the lengths, detect 4 rows at a time
-  const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
     __builtin_amdgcn_sched_barrier(0);       // one round of 4 rows at a time: keeps the un-sliced values of later rounds out of registers
@@ -260,21 +259,6 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
       if (NM > 2) L[rr][NM - 1] = (float)(int32_t)cnt.value(2 * row + 1) + corr[1][row];
     }
     if (!valid[0]) break;
-    if (GROUPED) {
-      const bool vec4 = a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[3];
-#pragma unroll
-      for (int m = 1; m < NM; ++m) {
-        float* plane = a.acc_out + (size_t)(a.mat_base + m) * n_rays;
-        if (vec4) {
-          *reinterpret_cast<float4*>(plane + rays[0]) = make_float4(L[0][m], L[1][m], L[2][m], L[3][m]);
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            if (valid[rr]) plane[rays[rr]] = L[rr][m];
-        }
-      }
-      continue;
-    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       float others = 0.0f;
@@ -360,15 +344,15 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   int minw = 4;
   if (const char* e = getenv("DEXCT_P16_MINW")) minw = atoi(e);      // tuning knob
   if (n_materials == 2)
-    hipLaunchKernelGGL((rows16_kernel<2, false>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<2>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
   else if (minw == 5)
-    hipLaunchKernelGGL((rows16_kernel<3, false, 5>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3, 5>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
   else if (minw == 6)
-    hipLaunchKernelGGL((rows16_kernel<3, false, 6>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3, 6>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
   else if (minw == 8)
-    hipLaunchKernelGGL((rows16_kernel<3, false, 8>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3, 8>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
   else
-    hipLaunchKernelGGL((rows16_kernel<3, false>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

@@ -551,3 +551,20 @@ def test_packed_volume_kernel_refuses_what_it_cannot_do(hip):
     ct2, ph2 = small_scan(n=40, nz=96, n_views=4, n_channels=16, n_rows=96)
     with pytest.raises(ValueError):
         projector(ct2, ph2, kernel=7)                                # 96 rows: not 256, 512 or a multiple of 1024
+
+
+def test_packed_volume_is_the_default_and_noise_falls_back(hip):
+    """kernel=0 picks the packed-volume kernel for <= 3 materials and 256 rows; with quantum noise the byte-volume
+    kernel runs instead (it carries the variance) and gives the sample kernel 3 gives for the same seed."""
+    ct, ph = small_scan(n=40, nz=256, n_views=6, n_channels=40, n_rows=256)
+    sp = spectra()
+    auto = projector(ct, ph)
+    assert auto.use_packed and auto.vol_z2 is not None and auto.native_layout == 1
+    clean0, _ = auto.project(sp)
+    clean3, _ = projector(ct, ph, kernel=3).project(sp)
+    assert torch.equal(clean0, clean3)
+    n0, _ = auto.project(sp, noise=True, seed=5)
+    n3, _ = projector(ct, ph, kernel=3).project(sp, noise=True, seed=5)
+    assert torch.equal(n0, n3) and not torch.equal(n0, clean0)
+    ct2, ph2 = small_scan(n=40, nz=96, n_views=6, n_channels=40, n_rows=96)          # 96 rows: byte-volume kernel
+    assert not projector(ct2, ph2).use_packed
