@@ -568,3 +568,39 @@ def test_packed_volume_is_the_default_and_noise_falls_back(hip):
     assert torch.equal(n0, n3) and not torch.equal(n0, clean0)
     ct2, ph2 = small_scan(n=40, nz=96, n_views=6, n_channels=40, n_rows=96)          # 96 rows: byte-volume kernel
     assert not projector(ct2, ph2).use_packed
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_packed_volume_scans(hip, seed):
+    """Randomised stacked fans through RANDOM volumes (a material boundary in nearly every crossing slab and every
+    row: the correction path of rows16_kernel runs all the time), anisotropic non-square grids, fans wider than the
+    grid, 256 / 512 / 1024 rows, 2 or 3 materials: bit-identical path lengths and counts to rows4_kernel, and the
+    last rows against the oracle mirror."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    from dex_ct_sim_amd.system import AIR, BONE, WATER
+    rng = np.random.default_rng(7000 + seed)
+    nx, ny = int(rng.integers(9, 70)), int(rng.integers(9, 70))
+    n_rows = int(rng.choice([256, 256, 512, 1024]))
+    dxv, dyv, dzv = (float(v) for v in rng.uniform(0.1, 0.5, 3))
+    half_diag = 0.5 * np.hypot(nx * dxv, ny * dyv)
+    sid = float(half_diag * rng.uniform(1.2, 4.0))
+    sdd = float(sid + half_diag * rng.uniform(1.05, 3.0))
+    n_views, n_ch = int(rng.integers(2, 9)), int(rng.integers(3, 70))
+    n_mat = int(rng.integers(2, 4))
+    vol = rng.integers(0, n_mat, (n_rows, ny, nx), dtype=np.uint8)
+    vol[rng.random(vol.shape) < 0.3] = 0
+    ph = dx.VoxelPhantom.from_array('rnd', vol, [AIR, WATER, BONE][:n_mat], dx=dxv, dy=dyv, dz=dzv)
+    ct = dx.FanBeamGeometry(N_channels=n_ch, N_proj=n_views, gamma_fan=float(rng.uniform(0.2, 1.8)), SID=sid, SDD=sdd,
+                            N_rows=n_rows)
+    sp = spectra()
+    (c3, p3), _ = projector(ct, ph, kernel=3).project(sp, want_pathlen=True)
+    pj = projector(ct, ph)
+    assert pj.use_packed
+    (c7, p7), _ = pj.project(sp, want_pathlen=True)
+    assert torch.equal(p7, p3), seed
+    assert torch.equal(c7, c3), seed
+    E, mu, w = fp.merged_tables(ct, ph, sp)
+    sub = co.make_geom(n_views, n_ch, 8, n_rows - 8, nx, ny, n_rows, dxv, dyv, dzv, sid, sdd)
+    _, rpl = co.project_dda(sub, ct.view_cs(), ct.chan_cs(), 0, n_views, vol, mu, w, True, n_threads=8)
+    assert np.array_equal(p7[:, n_rows - 8:].cpu().numpy(), rpl), seed
