@@ -111,7 +111,9 @@ def launch_ranks(args):
         time.sleep(0.2)
     codes = [p.wait() for p in procs]
     reader.join(timeout=10)
-    sys.stdout.write(b''.join(buf).decode())
+    # rank 0's JSON line goes to stdout; anything else a library printed there (gloo's connection banner) to stderr
+    for ln in b''.join(buf).decode().splitlines():
+        print(ln, file=sys.stdout if ln.startswith('{') else sys.stderr)
     sys.stdout.flush()
     if failed or any(codes):
         print(f'bench.py: rank exit codes {codes}', file=sys.stderr)
