@@ -427,7 +427,9 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
 // wave owns a contiguous run of 64 * chunk pixels and every lane whose pixel has finished takes the next one of
 // the run, so all 64 lanes keep iterating until the run is used up.  The energy loops stay wave-uniform (scalar
 // table loads) because the tables do not depend on the pixel.  Results are bit-identical to gn_kernel's.
-template <int MINW, bool IEXP>      // MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
+// HLDS (A/B variant): the four older states of the history live in an LDS ring (one 16-B slot per lane and state, written
+// when a state leaves the registers) instead of 16 VGPRs.
+template <int MINW, bool IEXP, bool HLDS = false>      // MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, int chunk,
@@ -436,6 +438,8 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
                                                              double* __restrict__ out_a,
                                                              unsigned long long* __restrict__ executed) {
   __shared__ double lds_pow[kPowN];
+  __shared__ longlong2 lds_hist[HLDS ? 4 : 1][HLDS ? kGnBlock : 1];
+  constexpr int kR = HLDS ? 4 : kGnHistory;       // states kept in registers
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
@@ -450,9 +454,9 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   unsigned n_exec = 0;                    // Newton steps this wave executed (< 2^32: 64 lanes x chunk x n_iters)
   double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
   int it = 0;
-  long long h0[kGnHistory], h1[kGnHistory];
+  long long h0[kR], h1[kR];
 #pragma unroll
-  for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
+  for (int k = 0; k < kR; ++k) { h0[k] = 0; h1[k] = 0; }
 
   for (;;) {
     const unsigned long long want = __ballot(p < 0);
@@ -489,8 +493,16 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     if (exact_exit) {
       const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
       if (b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1)) hit = -1;
+      if (HLDS) {
+        // hist[k] = s_{it-1-k} for k >= 4 sits in ring slot (it - 1 - k) & 3 (written when it left the registers)
 #pragma unroll
-      for (int k = kGnHistory - 1; k >= 0; --k)
+        for (int k = kGnHistory - 1; k >= kR; --k) {
+          const longlong2 hs = lds_hist[(it - 1 - k) & 3][threadIdx.x];
+          if (k < it && b0 == hs.x && b1 == hs.y && hit != -1) hit = k;
+        }
+      }
+#pragma unroll
+      for (int k = kR - 1; k >= 0; --k)
         if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
     }
     // opt-in (DEXCT_GN_STOP_TOL, off by default): also stop when the step no longer moves the pixel by more than
@@ -520,11 +532,17 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     double f0 = converged ? n0 : a0, f1 = converged ? n1 : a1;
     if (__ballot(slot >= 0) != 0ull) {
 #pragma unroll
-      for (int k = 0; k < kGnHistory; ++k)
+      for (int k = 0; k < kR; ++k)
         if (slot == k) { f0 = __longlong_as_double(h0[k]); f1 = __longlong_as_double(h1[k]); }
+      if (HLDS && slot >= kR) {
+        const longlong2 hs = lds_hist[(it - 1 - slot) & 3][threadIdx.x];
+        f0 = __longlong_as_double(hs.x);
+        f1 = __longlong_as_double(hs.y);
+      }
     }
+    if (HLDS && advance) lds_hist[(it - 4) & 3][threadIdx.x] = longlong2{h0[kR - 1], h1[kR - 1]};   // s_{it-4} leaves the registers
 #pragma unroll
-    for (int k = kGnHistory - 1; k > 0; --k) {
+    for (int k = kR - 1; k > 0; --k) {
       h0[k] = advance ? h0[k - 1] : h0[k];
       h1[k] = advance ? h1[k - 1] : h1[k];
     }
@@ -642,6 +660,8 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     // for a spill-free register allocation, DEXCT_GN_IEXP=1 scales by 2^k with integer adds instead of v_ldexp_f64
     const char* ve = getenv("DEXCT_GN_MINW");
     const char* ie = getenv("DEXCT_GN_IEXP");
+    const char* he = getenv("DEXCT_GN_HLDS");
+    const int hlds = (he && atoi(he) == 1) ? 1 : 0;
     const int minw = (ve && atoi(ve) == 4) ? 4 : 5;
     const int iexp = (ie && atoi(ie) == 1) ? 1 : 0;
     unsigned long long* stat = reinterpret_cast<unsigned long long*>(ws) + 9;
@@ -649,7 +669,10 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
 #define DEXCT_GN_LAUNCH(MW, IE)                                                                                         \
   hipLaunchKernelGGL((gn_refill_kernel<MW, IE>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,            \
                      (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat)
-    if (minw == 4 && iexp) DEXCT_GN_LAUNCH(4, true);
+    if (hlds)
+      hipLaunchKernelGGL((gn_refill_kernel<5, false, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,
+                         (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
+    else if (minw == 4 && iexp) DEXCT_GN_LAUNCH(4, true);
     else if (minw == 4) DEXCT_GN_LAUNCH(4, false);
     else if (iexp) DEXCT_GN_LAUNCH(5, true);
     else DEXCT_GN_LAUNCH(5, false);

@@ -27,7 +27,7 @@ ref = torch.empty_like(a)
 
 
 def run(out, env):
-    for k in ('DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_FULL_LOOP'):
+    for k in ('DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HLDS'):
         os.environ.pop(k, None)
     os.environ.update(env)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,8 +39,8 @@ def run(out, env):
 
 
 run(ref, {})
-variants = [{}, {'DEXCT_GN_IEXP': '1'}, {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_MINW': '4', 'DEXCT_GN_IEXP': '1'},
-            {'DEXCT_GN_FULL_LOOP': '1'}, {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_IEXP': '1'}]
+variants = [{}, {'DEXCT_GN_HLDS': '1'}, {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_FULL_LOOP': '1'},
+            {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_HLDS': '1'}]
 times = {i: [] for i in range(len(variants))}
 same = {}
 for rep in range(3):
