@@ -306,9 +306,10 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   if (n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
   if (n_materials < 2 || n_materials > 3 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;     // ids 0..2
   if (geom->z_first < 0 || geom->z_first + geom->n_rows > geom->nz) return DEXCT_EINVAL;
-  if (geom->nz % 16 != 0 || geom->z_first % 16 != 0 || geom->n_rows % 16 != 0) return DEXCT_EINVAL;
-  const int lanes = geom->n_rows / 16;
-  if (lanes != 16 && lanes != 32 && lanes % 64 != 0) return DEXCT_EINVAL;
+  if (geom->nz % 16 != 0 || geom->z_first % 16 != 0) return DEXCT_EINVAL;
+  // a (view, channel) pair takes ceil(n_rows / 16) lanes: 16 or 32 lanes per pair (4 or 2 pairs per wave) or whole
+  // waves; lanes past the last row idle (the caller decides whether that is still worth it)
+  const int lanes = (geom->n_rows + 15) / 16;
   if ((uint64_t)geom->nx * geom->ny * (geom->nz / 4) > 0xEFFF0000ull) return DEXCT_ERANGE;     // below kOob
   if (geom->nx > 2047 || geom->ny > 2047) return DEXCT_ERANGE;             // 11-bit sliced counters: one count per slab
   if (layout != 0 && layout != 1) return DEXCT_EINVAL;
@@ -332,8 +333,8 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   a.layout = layout;
   a.view_tile = 8;
   pa.vol_z2 = vol_z2;
-  pa.lanes_per_pair = lanes >= 64 ? 64 : lanes;
-  pa.n_zchunks = lanes >= 64 ? lanes / 64 : 1;
+  pa.lanes_per_pair = lanes > 32 ? 64 : (lanes > 16 ? 32 : 16);
+  pa.n_zchunks = lanes > 64 ? (lanes + 63) / 64 : 1;
   pa.view_tile = 8;
   if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) pa.view_tile = t; }
   const int n_pairs = 64 / pa.lanes_per_pair;

@@ -53,7 +53,7 @@ class Projector:
     picks for stacked fans of >= 256 rows; same bits as kernel 3), 6 one wavefront per ray (lanes over
     dominant-axis slabs, shuffle reductions, tables in LDS: the mapping BASELINE.json's north star names; <= 4
     materials), 7 the stacked fan on a 2-bit packed volume with bit-sliced counters (rows16_kernel: 16 rows per
-    lane; <= 3 materials, rows a multiple of 256 or 512 or of 1024).
+    lane; <= 3 materials; what kernel 0 picks from 192 rows on when a pair fills 3/4 of its lane group).
     """
 
     def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
@@ -87,13 +87,14 @@ class Projector:
         # the in-plane geometry does not change).
         packed_wanted = kernel in (3, 4, 5, 7) or (kernel == 0 and ct.N_rows >= 64)
         # the 2-bit packed volume with bit-sliced counters (rows16_kernel): what kernel 0 picks where it applies
-        lanes16 = ct.N_rows // 16
-        packed2_ok = (not self.cone and 2 <= phantom.n_materials <= 3 and ct.N_rows % 16 == 0
-                      and (lanes16 in (16, 32) or (lanes16 >= 64 and lanes16 % 64 == 0))
-                      and max(phantom.Nx, phantom.Ny) <= 2047)
-        self.use_packed = (kernel == 7) or (kernel == 0 and packed2_ok)
+        lanes16 = -(-ct.N_rows // 16)
+        group16 = 64 * (-(-lanes16 // 64)) if lanes16 > 32 else (32 if lanes16 > 16 else 16)     # lanes the pair occupies
+        packed2_ok = (not self.cone and 2 <= phantom.n_materials <= 3 and max(phantom.Nx, phantom.Ny) <= 2047)
+        # kernel 0 picks it when at least 3/4 of the pair's lane group carry rows (>= 192 rows)
+        self.use_packed = (kernel == 7 and packed2_ok) or (kernel == 0 and packed2_ok and ct.N_rows >= 192
+                                                           and 4 * lanes16 >= 3 * group16)
         if kernel == 7 and not packed2_ok:
-            raise ValueError('kernel 7 (2-bit packed volume) needs 2..3 materials and 256, 512 or a multiple of 1024 rows')
+            raise ValueError('kernel 7 (2-bit packed volume) needs a stacked fan, 2..3 materials and nx, ny <= 2047')
         align = 16 if self.use_packed else 4
         if not self.cone and packed_wanted and (nz % align or z_first % align):
             lead = (-z_first) % align

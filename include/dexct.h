@@ -131,8 +131,10 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
  * bits, one dword load serves 16 detector rows, the per-row material counts are kept bit-sliced (carry-save adders).
  * dexct_volume_pack2: vol_zf [ny][nx][nz] bytes -> vol_z2 [ny][nx][nz/4] bytes (row z of a column in bits
  *   2(z%4).. of byte z/4); n_voxels = nx*ny*nz, a multiple of 4.
- * dexct_siddon_project_packed: same outputs and layouts as dexct_siddon_project; nz, z_first and n_rows multiples of
- *   16 and n_rows/16 one of 16, 32 or a multiple of 64; nx, ny <= 2047.  Bit-identical per-material path lengths. */
+ * dexct_siddon_project_packed: same outputs and layouts as dexct_siddon_project; nz and z_first multiples of 16;
+ *   nx, ny <= 2047.  A (view, channel) pair occupies ceil(n_rows/16) lanes of a 16-, 32- or 64-lane group (lanes past
+ *   the last row idle: efficient for n_rows near 256, 512 or a multiple of 1024).  Bit-identical per-material path
+ *   lengths. */
 int dexct_volume_pack2(const uint8_t* vol_zf, int64_t n_voxels, uint8_t* vol_z2, void* stream);
 int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                                 int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,

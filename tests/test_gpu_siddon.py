@@ -512,7 +512,8 @@ def test_degenerate_shapes_through_the_public_calls(hip):
                 assert img.shape == ((8, 8) if rows == 1 else (rows, 8, 8))
 
 
-@pytest.mark.parametrize('n_rows,nz,z_index', [(256, 256, 0), (256, 270, 2), (512, 512, 0), (1024, 1024, 0), (2048, 2048, 0)])
+@pytest.mark.parametrize('n_rows,nz,z_index', [(256, 256, 0), (256, 270, 2), (512, 512, 0), (1024, 1024, 0), (2048, 2048, 0),
+                                               (200, 203, 1), (320, 320, 0), (768, 768, 0), (1100, 1100, 0), (50, 64, 3)])
 @pytest.mark.parametrize('n_mat', [2, 3])
 def test_packed_volume_kernel_bit_identical(hip, n_rows, nz, z_index, n_mat):
     """rows16_kernel (kernel 7): 2 bits per voxel, 16 rows per lane, bit-sliced counters.  4, 2 or 1 (view, channel)
@@ -543,14 +544,19 @@ def test_packed_volume_kernel_bit_identical(hip, n_rows, nz, z_index, n_mat):
     assert np.max(np.abs(c7[:, :, n_rows - 16:].cpu().numpy() - cls) / cls) < REL_TOL
 
 
+def dx_cone(ct):
+    import dex_ct_sim_amd as dx
+    return dx.FanBeamGeometry(N_channels=ct.N_channels, N_proj=ct.N_proj, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=0.1,
+                              N_rows=8, cone=True)
+
+
 def test_packed_volume_kernel_refuses_what_it_cannot_do(hip):
-    from dex_ct_sim_amd._native import DexctError
     ct, ph = small_scan(n=40, nz=256, n_views=4, n_channels=16, n_rows=256)
     with pytest.raises(ValueError):
         projector(ct, ph_many(ph, 5), kernel=7)                      # ids above 2
-    ct2, ph2 = small_scan(n=40, nz=96, n_views=4, n_channels=16, n_rows=96)
+    cone = dx_cone(ct)
     with pytest.raises(ValueError):
-        projector(ct2, ph2, kernel=7)                                # 96 rows: not 256, 512 or a multiple of 1024
+        projector(cone, ph, kernel=7)                                # not a stacked fan
 
 
 def test_packed_volume_is_the_default_and_noise_falls_back(hip):
@@ -566,8 +572,12 @@ def test_packed_volume_is_the_default_and_noise_falls_back(hip):
     n0, _ = auto.project(sp, noise=True, seed=5)
     n3, _ = projector(ct, ph, kernel=3).project(sp, noise=True, seed=5)
     assert torch.equal(n0, n3) and not torch.equal(n0, clean0)
-    ct2, ph2 = small_scan(n=40, nz=96, n_views=6, n_channels=40, n_rows=96)          # 96 rows: byte-volume kernel
+    ct2, ph2 = small_scan(n=40, nz=96, n_views=6, n_channels=40, n_rows=96)          # 96 rows: 6 of 16 lanes: byte-volume kernel
     assert not projector(ct2, ph2).use_packed
+    ct3, ph3 = small_scan(n=40, nz=320, n_views=6, n_channels=40, n_rows=320)        # 320 rows: 20 of 32 lanes: byte-volume kernel
+    assert not projector(ct3, ph3).use_packed
+    ct4, ph4 = small_scan(n=40, nz=768, n_views=6, n_channels=40, n_rows=768)        # 768 rows: 48 of 64 lanes: packed
+    assert projector(ct4, ph4).use_packed
 
 
 @pytest.mark.parametrize('seed', range(8))
