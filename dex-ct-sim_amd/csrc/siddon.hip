@@ -414,6 +414,8 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
   // slab).  They are kept out of the crossing list, whose records then need no validity masks.
   __shared__ CrossRec edge_rec[2];       // [0] entering, [1] leaving; offset ~0u: absent in this pass
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  BlockMasks bm{{~0ull, ~0ull}, false};
+  if (!GROUPED) bm = detect_block_masks(w, a.n_energies, a.n_spectra);       // every lane of every wave is here
   const BlockRay br = block_to_ray(a.n_local_views, a.g.n_channels, n_chunks, a.view_tile);
   const int chunk = br.chunk, c = br.c, v = br.v;
   const int r0 = (chunk * BLOCK + tid) * 4;          // first of this lane's 4 rows
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void rows4_kernel(ProjArgs a, const float* _
 #pragma unroll
     for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
   }
-  detect_store<NM, 4>(L, a, mu, w, w2, rays, valid);
+  detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,6 +681,8 @@ __global__ __launch_bounds__(NPAIR * 64) void rows4t_kernel(ProjArgs a, const fl
   __shared__ CrossRec edge_rec[NPAIR][2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  BlockMasks bm{{~0ull, ~0ull}, false};
+  if (!GROUPED) bm = detect_block_masks(w, a.n_energies, a.n_spectra);       // every lane of every wave is here
   const int tile_c = NPAIR / tile_v;
   // block -> (z-chunk fastest, then view tile, then channel tile), a contiguous range of logical ids per XCD
   const uint32_t nblk = gridDim.x, b = blockIdx.x, per = nblk >> 3;
@@ -913,7 +917,7 @@ __global__ __launch_bounds__(NPAIR * 64) void rows4t_kernel(ProjArgs a, const fl
 #pragma unroll
     for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
   }
-  detect_store<NM, 4>(L, a, mu, w, w2, rays, valid);
+  detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm);
 }
 
 // ---------------------------------------------------------------------------------------------

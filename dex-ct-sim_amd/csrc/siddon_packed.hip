@@ -34,6 +34,7 @@ struct PackedArgs {
   int lanes_per_pair;      // n_rows / 16 (16, 32 or 64)
   int n_zchunks;           // ceil(n_rows / 1024)
   int view_tile;
+  int det_masks;           // skip detection FMAs of spectrum slots with zero weights (blocks of four energies)
 };
 
 // carry-save adder on 32 one-bit lanes: (h, l) = a + b + c
@@ -113,6 +114,8 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   extern __shared__ uint32_t lds_lists[];          // per pair: kP16Super crossing records (16 B), then kP16Super offsets
   const ProjArgs& a = pa.a;
   const int lane = threadIdx.x;
+  BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // all 64 lanes are here
+  bm.use = bm.use && pa.det_masks;
   const int lpp = pa.lanes_per_pair, n_pairs = 64 / lpp;
   CrossRec (*list_cross)[kP16Super] = reinterpret_cast<CrossRec (*)[kP16Super]>(lds_lists);
   uint32_t (*list_full)[kP16Super] = reinterpret_cast<uint32_t (*)[kP16Super]>(lds_lists + (size_t)n_pairs * kP16Super * 4);
@@ -243,32 +246,37 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   }
   cnt.finish();
   if (!pair_live || r0 >= a.g.n_rows) return;
-  // ---- un-slice the counters, form the lengths, detect 4 rows at a time
+  // ---- un-slice the counters (in place of the corrections), then detect 4 rows at a time.  The rounds are a real
+  // loop with ONE copy of the detection code (rows move down the register array between rounds): four inlined copies
+  // made the kernel as large as the instruction cache two CUs share.
 #pragma unroll
+  for (int row = 0; row < 16; ++row) {
+    corr[0][row] += (float)(int32_t)cnt.value(2 * row);
+    if (NM > 2) corr[1][row] += (float)(int32_t)cnt.value(2 * row + 1);
+  }
+#pragma unroll 1
   for (int q4 = 0; q4 < 4; ++q4) {
-    __builtin_amdgcn_sched_barrier(0);       // one round of 4 rows at a time: keeps the un-sliced values of later rounds out of registers
+    if (r0 + 4 * q4 >= a.g.n_rows) break;
     float L[4][NM];
     size_t rays[4];
     bool valid[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int row = 4 * q4 + rr, r = r0 + row;
+      const int r = r0 + 4 * q4 + rr;
       valid[rr] = r < a.g.n_rows;
       rays[rr] = ray_index(a, v, valid[rr] ? r : 0, c);
-      L[rr][1] = (float)(int32_t)cnt.value(2 * row) + corr[0][row];
-      if (NM > 2) L[rr][NM - 1] = (float)(int32_t)cnt.value(2 * row + 1) + corr[1][row];
-    }
-    if (!valid[0]) break;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
       float others = 0.0f;
 #pragma unroll
-      for (int m = 1; m < NM; ++m) others += L[rr][m];
+      for (int m = 1; m < NM; ++m) others += corr[m - 1][rr];
       L[rr][0] = (p.chord_u - others) * p.len_per_u;
 #pragma unroll
-      for (int m = 1; m < NM; ++m) L[rr][m] *= p.len_per_u;
+      for (int m = 1; m < NM; ++m) L[rr][m] = corr[m - 1][rr] * p.len_per_u;
     }
-    detect_store<NM, 4>(L, a, mu, w, w2, rays, valid);
+    detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm);
+#pragma unroll
+    for (int m = 0; m < NM - 1; ++m)
+#pragma unroll
+      for (int row = 0; row < 12; ++row) corr[m][row] = corr[m][row + 4];
   }
 }
 
@@ -336,6 +344,8 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   pa.lanes_per_pair = lanes > 32 ? 64 : (lanes > 16 ? 32 : 16);
   pa.n_zchunks = lanes > 64 ? (lanes + 63) / 64 : 1;
   pa.view_tile = 8;
+  pa.det_masks = 1;
+  if (const char* e = getenv("DEXCT_DET_MASKS")) pa.det_masks = atoi(e) != 0;
   if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) pa.view_tile = t; }
   const int n_pairs = 64 / pa.lanes_per_pair;
   const size_t nblk = (size_t)a.n_local_views * ((geom->n_channels + n_pairs - 1) / n_pairs) * pa.n_zchunks;

@@ -614,3 +614,38 @@ def test_random_packed_volume_scans(hip, seed):
     sub = co.make_geom(n_views, n_ch, 8, n_rows - 8, nx, ny, n_rows, dxv, dyv, dzv, sid, sdd)
     _, rpl = co.project_dda(sub, ct.view_cs(), ct.chan_cs(), 0, n_views, vol, mu, w, True, n_threads=8)
     assert np.array_equal(p7[:, n_rows - 8:].cpu().numpy(), rpl), seed
+
+
+@pytest.mark.parametrize('n_e,n_s', [(140, 2), (139, 2), (300, 2), (64, 1), (7, 2), (3, 1)])
+def test_detection_skips_only_exact_zeros(hip, n_e, n_s):
+    """The row-parallel kernels skip the accumulations of a spectrum slot over blocks of four energies it does not
+    weight (the 80 kVp spectrum above 80 keV; the absent second slot of a single-spectrum scan).  Arbitrary zero
+    patterns (isolated blocks, a slot that weights nothing, -0.0, more than 256 energies, energy counts that are not
+    multiples of 4): counts bit-identical to rays_kernel, which has no such shortcut, and equal to the float64 sum."""
+    from dex_ct_sim_amd import forward_project as fp
+    ct, ph = small_scan(n=40, nz=256, n_views=5, n_channels=37, n_rows=256)
+    rng = np.random.default_rng(n_e * 10 + n_s)
+    mu = rng.uniform(0.01, 0.4, (3, n_e)).astype(np.float32)
+    mu[0] *= 1e-3
+    w = rng.uniform(0.5, 2.0, (n_s, n_e)).astype(np.float32)
+    for s in range(n_s):
+        for b in range(0, n_e, 4):
+            r = rng.random()
+            if r < 0.35:
+                w[s, b:b + 4] = 0.0                                   # a whole block
+            elif r < 0.45:
+                w[s, b:b + 2] = 0.0                                   # part of a block: not skippable
+            elif r < 0.5:
+                w[s, b:b + 4] = -0.0                                  # sign bit set: runs, adds nothing
+    if n_s == 2 and n_e >= 64:
+        w[1, 32:] = 0.0                                               # a slot that ends early
+    dev = torch.device('cuda:0')
+    mu_d, w_d = torch.from_numpy(mu).to(dev), torch.from_numpy(w).to(dev)
+    ref, pl = projector(ct, ph, kernel=1).project_tables(mu_d, w_d, want_pathlen=True)
+    for kernel in (3, 5, 7):
+        got = projector(ct, ph, kernel=kernel).project_tables(mu_d, w_d)
+        assert torch.equal(got, ref), kernel
+    exact = np.einsum('se,...e->s...', w.astype(np.float64),
+                      np.exp(-np.einsum('...m,me->...e', pl.cpu().numpy().astype(np.float64), mu.astype(np.float64))))
+    scale = np.abs(w).sum(axis=1).reshape(-1, 1, 1, 1)
+    assert np.max(np.abs(ref.cpu().numpy() - exact) / scale) < REL_TOL
