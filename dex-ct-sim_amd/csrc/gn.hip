@@ -83,10 +83,15 @@ __device__ __forceinline__ double rcp_f64(double x) {
 // term of the reference's sums - only their order.
 template <int KSEL, bool CLIP, bool IEXP = false>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip
 __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
-                                                int e0, int e1, double a0, double a1, double (&nu)[2], double (&G0)[2],
-                                                double (&G1)[2], double (&H00)[2], double (&H01)[2], double (&H11)[2]) {
-#pragma unroll 2
-  for (int e = e0; e < e1; ++e) {
+                                                int e0, int e1, double a0, double a1, double (&nu)[2], double (&nuo)[2],
+                                                double (&G0)[2], double (&G1)[2], double (&H00)[2], double (&H01)[2],
+                                                double (&H11)[2]) {
+  // The expected counts nu are summed in TWO partial sums (every other energy of a run into nuo, joined by the
+  // caller): the residual g / nu - 1 cancels to rounding level at the solution, so the rounding of nu is what moves the
+  // iterate in its last bits, and halving the length of each running sum shortens that wandering - the exact
+  // repeated-state exit then fires after 28.6 instead of 31.8 iterations on average (benchmark sinograms), at no
+  // instruction per energy.  (A compensated sum of nu was tried: no further gain, 25.3 vs 24.7 with the residual below.)
+  auto one = [&](int e, double (&nuk)[2]) {
     const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
     double y = fma(a1, t[1], a0 * t[0]);               // t[0], t[1] = -mu0, -mu1 times 2048/ln2
     if (CLIP) y = fmin(fmax(y, -kExpClip), kExpClip);
@@ -95,14 +100,20 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
     for (int k = 0; k < 2; ++k) {
       if ((KSEL == 1 && k == 1) || (KSEL == 2 && k == 0)) continue;
       const double* __restrict__ tk = t + 2 + 6 * k;
-      nu[k] = fma(tk[0], at, nu[k]);
+      nuk[k] = fma(tk[0], at, nuk[k]);
       G0[k] = fma(tk[1], at, G0[k]);
       G1[k] = fma(tk[2], at, G1[k]);
       H00[k] = fma(tk[3], at, H00[k]);
       H01[k] = fma(tk[4], at, H01[k]);
       H11[k] = fma(tk[5], at, H11[k]);
     }
+  };
+  int e = e0;
+  for (; e + 2 <= e1; e += 2) {
+    one(e, nu);
+    one(e + 1, nuo);
   }
+  if (e < e1) one(e, nu);
 }
 
 // Each class is stored as [energies that always need the clip (large mu) | energies whose exponent is provably
@@ -114,28 +125,35 @@ struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; }
 template <bool IEXP = false>
 __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
-  double nu[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
+  double nu[2] = {0, 0}, nuo[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
   const int bA = 0, bB = ec.nA, bC = ec.nA + ec.nB;
   // the always-clipped heads of the three classes
-  energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, G0, G1, H00, H01, H11);
-  energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, G0, G1, H00, H01, H11);
-  energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, G0, G1, H00, H01, H11);
+  energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
   if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 699.9) {
-    energy_sums_f64<0, false, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, false, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, false, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, false, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, false, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, false, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   } else {
-    energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   }
+  nu[0] += nuo[0];
+  nu[1] += nuo[1];
   const double g[2] = {g0, g1};
   double dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const double inv = rcp_f64(nu[k]), ratio = g[k] * inv;
-    const double c = ratio - 1.0, q = ratio * inv;             // g / nu - 1 and g / nu^2 (matdecomp.py:122-123)
+    // g / nu - 1 (matdecomp.py:122) as (g - nu) / nu: near the solution the subtraction is exact, so the residual
+    // carries the rounding of nu only, not an extra half ulp of 1 from the quotient - the last-bit wandering of the
+    // iterate is shorter again (mean executed iterations 28.6 -> 24.7).  An overflowed nu (inf) keeps the reference's
+    // value: g / inf - 1 = -1.
+    const double c = fabs(nu[k]) < __builtin_huge_val() ? (g[k] - nu[k]) * inv : ratio - 1.0;
+    const double q = ratio * inv;                              // g / nu^2 (matdecomp.py:123)
     dF0 += c * G0[k];
     dF1 += c * G1[k];
     h00 += q * (G0[k] * G0[k]) - c * H00[k];
@@ -429,7 +447,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
 // table loads) because the tables do not depend on the pixel.  Results are bit-identical to gn_kernel's.
 // HLDS (A/B variant): the four older states of the history live in an LDS ring (one 16-B slot per lane and state, written
 // when a state leaves the registers) instead of 16 VGPRs.
-template <int MINW, bool IEXP, bool HLDS = false>      // MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
+template <int MINW, bool IEXP, bool HLDS = false, int HIST = kGnHistory>      // HIST: states kept for the repeated-state exit; MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, int chunk,
@@ -439,7 +457,8 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
                                                              unsigned long long* __restrict__ executed) {
   __shared__ double lds_pow[kPowN];
   __shared__ longlong2 lds_hist[HLDS ? 4 : 1][HLDS ? kGnBlock : 1];
-  constexpr int kR = HLDS ? 4 : kGnHistory;       // states kept in registers
+  static_assert(!HLDS || HIST == kGnHistory, "the LDS ring holds the 4 older of 8 states");
+  constexpr int kR = HLDS ? 4 : HIST;       // states kept in registers
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
@@ -669,13 +688,28 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
 #define DEXCT_GN_LAUNCH(MW, IE)                                                                                         \
   hipLaunchKernelGGL((gn_refill_kernel<MW, IE>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,            \
                      (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat)
+#define DEXCT_GN_LAUNCH_H(MW, H)                                                                                        \
+  hipLaunchKernelGGL((gn_refill_kernel<MW, false, false, H>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, \
+                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat)
+    const char* hs = getenv("DEXCT_GN_HIST");
+    const int hist = hs ? atoi(hs) : kGnHistory;
+    const int mw = ve ? atoi(ve) : 5;
     if (hlds)
       hipLaunchKernelGGL((gn_refill_kernel<5, false, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,
                          (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
+    else if (hist == 4 && mw == 6) DEXCT_GN_LAUNCH_H(6, 4);
+    else if (hist == 6 && mw == 6) DEXCT_GN_LAUNCH_H(6, 6);
+    else if (hist == 4) DEXCT_GN_LAUNCH_H(5, 4);
+    else if (hist == 5) DEXCT_GN_LAUNCH_H(5, 5);
+    else if (hist == 6) DEXCT_GN_LAUNCH_H(5, 6);
+    else if (hist == 7) DEXCT_GN_LAUNCH_H(5, 7);
+    else if (hist == 10) DEXCT_GN_LAUNCH_H(5, 10);
+    else if (hist == 12) DEXCT_GN_LAUNCH_H(5, 12);
     else if (minw == 4 && iexp) DEXCT_GN_LAUNCH(4, true);
     else if (minw == 4) DEXCT_GN_LAUNCH(4, false);
     else if (iexp) DEXCT_GN_LAUNCH(5, true);
     else DEXCT_GN_LAUNCH(5, false);
+#undef DEXCT_GN_LAUNCH_H
 #undef DEXCT_GN_LAUNCH
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
