@@ -254,6 +254,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
     corr[0][row] += (float)(int32_t)cnt.value(2 * row);
     if (NM > 2) corr[1][row] += (float)(int32_t)cnt.value(2 * row + 1);
   }
+  AirCache air_cache{0.0f, {0.0f, 0.0f}, false};
 #pragma unroll 1
   for (int q4 = 0; q4 < 4; ++q4) {
     if (r0 + 4 * q4 >= a.g.n_rows) break;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
 #pragma unroll
       for (int m = 1; m < NM; ++m) L[rr][m] = corr[m - 1][rr] * p.len_per_u;
     }
-    detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm);
+    detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm, &air_cache);
 #pragma unroll
     for (int m = 0; m < NM - 1; ++m)
 #pragma unroll
