@@ -354,7 +354,10 @@ def main():
     # and, per 4 rays and energy bin that any spectrum weights, 6 v_pk_fma (3 materials x 2 ray pairs) + 4 v_exp_f32
     # (2 issue slots each) + 2 v_pk_fma per spectrum that weights the bin; one slot = 4 cycles of one of the 1024 SIMDs.
     n_e_any = int(((w_d != 0).any(dim=0)).sum().item())
-    lanes = n_rays / 4.0
+    # rays that crossed air only (they are the pixels the decomposition masks) are detected once per (view, channel)
+    # pair, not per row: they are left out of the floor (their one detection per pair is not counted either)
+    air_rays = float((counts_nat[0] >= 0.95 * gmax).float().mean().item())
+    lanes = n_rays * (1.0 - air_rays) / 4.0
     rows_per_dword, per_visit = (16.0, 3.0) if kname == 'rows16_kernel' else (4.0, 2.0)
     floor_slots = per_visit * seg_vc * rows / rows_per_dword + lanes * (14.0 * n_e_any + 2.0 * sum(n_e_spec))
     slots_per_s = 1024 * CLOCK_GHZ * 1e9 / 4.0                 # wave-instruction issue slots per second, whole chip
