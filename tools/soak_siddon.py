@@ -1,0 +1,111 @@
+"""Randomised differential soak of the stacked-fan traversal kernels on one MI355X (not part of the test suite: a
+one-off campaign whose log is kept under profiles/).  Every case draws a geometry (grid 9..90 voxels per side,
+anisotropic voxels, fan narrower or much wider than the grid, 16..1400 rows with an arbitrary first slice), a volume
+(blobs in air so that whole waves of rays see nothing but air, or dense random voxels so that every crossing slab
+corrects) and detection tables (1 or 2 spectra, random runs of zero weights, 1..300 energies) and demands
+
+  * per-material path lengths and counts of kernels 3 (rows4), 5 (tiled) and 7 (rows16, 2-bit volume) bit-identical to
+    kernel 1 (one thread per ray: no shared lists, no packed counters, no detection shortcuts);
+  * the path lengths of a random block of rows bit-identical to the oracle's mirror (CPU).
+
+    python tools/soak_siddon.py [n_cases] [first_seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dex_ct_sim_amd as dx
+from dex_ct_sim_amd import forward_project as fp
+from dex_ct_sim_amd.system import AIR, BONE, WATER
+from oracle import c_oracle as co
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device('cuda:0')
+t0 = time.time()
+fails = 0
+stats = {'packed_auto': 0, 'air_cases': 0, 'rays': 0, 'hit': 0, 'counts_sum': 0.0}
+for case in range(n_cases):
+    seed = seed0 + case
+    rng = np.random.default_rng(910000 + seed)
+    nx, ny = int(rng.integers(9, 90)), int(rng.integers(9, 90))
+    n_rows = int(rng.choice([16, 48, 64, 100, 192, 256, 256, 320, 512, 512, 700, 768, 1024, 1100, 1400]))
+    z_index = int(rng.integers(0, 6))
+    nz = n_rows + z_index + int(rng.integers(0, 5))
+    dxv, dyv, dzv = (float(v) for v in rng.uniform(0.1, 0.5, 3))
+    half_diag = 0.5 * np.hypot(nx * dxv, ny * dyv)
+    sid = float(half_diag * rng.uniform(1.2, 4.0))
+    sdd = float(sid + half_diag * rng.uniform(1.05, 3.0))
+    n_views, n_ch = int(rng.integers(1, 10)), int(rng.integers(1, 200))
+    n_mat = int(rng.integers(2, 4))
+    style = rng.choice(['blob', 'dense', 'empty', 'slab'])
+    vol = np.zeros((nz, ny, nx), dtype=np.uint8)
+    if style == 'dense':
+        vol = rng.integers(0, n_mat, vol.shape, dtype=np.uint8)
+        vol[rng.random(vol.shape) < 0.3] = 0
+    elif style == 'blob':                      # a small object in a wide field: most rays miss it
+        cx, cy = rng.integers(0, nx), rng.integers(0, ny)
+        r = max(1, int(min(nx, ny) * rng.uniform(0.05, 0.3)))
+        yy, xx = np.ogrid[:ny, :nx]
+        disc = (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r
+        z0, z1 = sorted(rng.integers(0, nz, 2))
+        vol[z0:z1 + 1, disc] = 1
+        if n_mat > 2:
+            vol[z0:z1 + 1][:, disc & (rng.random((ny, nx)) < 0.3)] = 2
+        stats['air_cases'] += 1
+    elif style == 'slab':                      # z-invariant except a few slices
+        vol[:, ny // 4:3 * ny // 4, nx // 4:3 * nx // 4] = 1
+        vol[rng.integers(0, nz, 3)] = n_mat - 1
+    ph = dx.VoxelPhantom.from_array('soak', vol, [AIR, WATER, BONE][:n_mat], dx=dxv, dy=dyv, dz=dzv, z_index=z_index)
+    ct = dx.FanBeamGeometry(N_channels=n_ch, N_proj=n_views, gamma_fan=float(rng.uniform(0.1, 2.2)), SID=sid, SDD=sdd,
+                            N_rows=n_rows)
+    n_e, n_s = int(rng.choice([1, 3, 4, 7, 64, 140, 140, 141, 300])), int(rng.integers(1, 3))
+    mu = rng.uniform(0.01, 0.4, (n_mat, n_e)).astype(np.float32)
+    mu[0] *= 1e-3
+    w = rng.uniform(0.5, 2.0, (n_s, n_e)).astype(np.float32)
+    for s in range(n_s):
+        b = 0
+        while b < n_e:                          # runs of zero weights of random length
+            run = int(rng.integers(1, 40))
+            if rng.random() < 0.4:
+                w[s, b:b + run] = 0.0
+            b += run
+    mu_d, w_d = torch.from_numpy(mu).to(dev), torch.from_numpy(w).to(dev)
+    try:
+        ref, pl = fp.Projector(ct, ph, kernel=1).project_tables(mu_d, w_d, want_pathlen=True)
+        bad = []
+        stats['hit'] += int((pl[..., 1:].sum(dim=-1) > 0).sum())
+        stats['counts_sum'] += float(ref.double().sum())
+        for kernel in (3, 5, 7):
+            got, gpl = fp.Projector(ct, ph, kernel=kernel).project_tables(mu_d, w_d, want_pathlen=True)
+            if not torch.equal(gpl, pl):
+                bad.append(f'kernel {kernel}: path lengths differ ({int((gpl != pl).sum())} values)')
+            if not torch.equal(got, ref):
+                bad.append(f'kernel {kernel}: counts differ ({int((got != ref).sum())} values)')
+        auto = fp.Projector(ct, ph)
+        stats['packed_auto'] += int(bool(auto.use_packed))
+        if not torch.equal(auto.project_tables(mu_d, w_d), ref):
+            bad.append('kernel 0 (host choice): counts differ')
+        nsub = min(8, n_rows)
+        r0 = int(rng.integers(0, n_rows - nsub + 1))
+        sub = co.make_geom(n_views, n_ch, nsub, z_index + r0, nx, ny, nz, dxv, dyv, dzv, sid, sdd)
+        _, rpl = co.project_dda(sub, ct.view_cs(), ct.chan_cs(), 0, n_views, vol, mu, w, True, n_threads=8)
+        if not np.array_equal(pl[:, r0:r0 + nsub].cpu().numpy(), rpl):
+            bad.append('kernel 1 vs the oracle mirror: path lengths differ')
+    except Exception as exc:                    # a refusal is a finding too
+        bad = [f'{type(exc).__name__}: {exc}']
+    stats['rays'] += n_views * n_rows * n_ch
+    if bad:
+        fails += 1
+        print(f'FAIL seed {seed}: grid {nx}x{ny}x{nz}, rows {n_rows} from {z_index}, {n_views} views x {n_ch} ch, {n_mat} materials, '
+              f'{style}, {n_s} spectra x {n_e} energies: ' + '; '.join(bad), flush=True)
+    if case % 500 == 499 or case == n_cases - 1:
+        print(f'{case + 1} cases, {fails} failed, {stats["rays"]:.3g} rays ({stats["hit"] / max(stats["rays"], 1):.2f} of them through the '
+              f'object, sum of all counts {stats["counts_sum"]:.6g}), host picked the packed kernel in {stats["packed_auto"]}, '
+              f'{stats["air_cases"]} small-object cases, {time.time() - t0:.0f} s', flush=True)
+sys.exit(1 if fails else 0)
