@@ -11,8 +11,9 @@ and, as a sanity check of the arithmetic (a statistic, not an invariant), agreem
 the reference on the pixels where that one is finite and insensitive both to a 1e-13 perturbation of its input and to the
 order of its own sums.  The few pixels beyond 1e-9 that this screen lets through (about 1 in 1e5 here) are of two kinds,
 traced iteration by iteration: photon-starved pixels still crawling after 60 iterations along an ill-conditioned valley
-(differences of 1e-15 grow to 1e-6), and transients through float64 OVERFLOW of the Hessian (tables scaled x30: mu up to
-275 cm^2/g and a negative iterate), where the restatement takes a step of exactly 2^-9 and the kernel's reciprocal-based
+(differences of 1e-15 grow to 1e-6), and transients with a numerically SINGULAR Hessian (tables scaled x30, a negative
+iterate, expected counts 1e16 times the measured ones: h00 h11 - h01^2 cancels to a rounding residue or to exactly 0),
+where the restatement's residue yields a step of exactly 2^-9 and the kernel's closed-form
 solve returns inf - the class the unscreened reference golden documents (tests/test_gpu_gn.py).
 
     python tools/soak_gn.py [n_cases] [first_seed]
