@@ -12,7 +12,8 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_siddon_project', 'dexct_siddon_trace', 'dexct_gn_decompose', 'dexct_gn_apply_mask',
            'dexct_reduce_max', 'dexct_transpose_batched', 'dexct_fbp_filter', 'dexct_fbp_backproject',
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
-           'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather',
+           'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
+           'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather',
            'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
 
 
@@ -66,6 +67,7 @@ def load():
     lib.dexct_cone_project.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, vp, i32, i32, i32, vp, vp,
                                        vp, vp, vp]
     lib.dexct_volume_pack2.argtypes = [vp, i64, vp, vp]
+    lib.dexct_volume_groups_pack2.argtypes = [vp, i64, i32, vp, vp]
     lib.dexct_siddon_project_packed.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp]
     lib.dexct_cone_layout.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.dexct_cone_project_rows.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, i32, i32, i32, vp, vp, vp,
@@ -74,6 +76,7 @@ def load():
     lib.dexct_cone_layout_bytes.restype = i64
     lib.dexct_siddon_project_grouped.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp,
                                                  i32, vp, vp, vp]
+    lib.dexct_siddon_project_grouped_packed.argtypes = lib.dexct_siddon_project_grouped.argtypes
     lib.dexct_transpose_batched.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     lib.dexct_fbp_filter.argtypes = [vp, vp, vp, i64, i32, f64, vp, vp]
     lib.dexct_fbp_backproject.argtypes = [vp, vp, i32, i32, i32, f64, f64, f64, i32, f64, vp, vp]

@@ -1026,6 +1026,34 @@ static int launch_detect(const ProjArgs& a, const Tables& t, hipStream_t st) {
   return DEXCT_OK;
 }
 
+int launch_detect_any(const ProjArgs& a, const Tables& t, hipStream_t st) {
+  switch (a.n_materials) {
+    case 2: return launch_detect<2>(a, t, st);
+    case 3: return launch_detect<3>(a, t, st);
+    case 4: return launch_detect<4>(a, t, st);
+    case 5: return launch_detect<5>(a, t, st);
+    case 6: return launch_detect<6>(a, t, st);
+    case 7: return launch_detect<7>(a, t, st);
+    case 8: return launch_detect<8>(a, t, st);
+    case 9: return launch_detect<9>(a, t, st);
+    case 10: return launch_detect<10>(a, t, st);
+    case 11: return launch_detect<11>(a, t, st);
+    case 12: return launch_detect<12>(a, t, st);
+    case 13: return launch_detect<13>(a, t, st);
+    case 14: return launch_detect<14>(a, t, st);
+    case 15: return launch_detect<15>(a, t, st);
+    case 16: return launch_detect<16>(a, t, st);
+    default: break;
+  }
+  const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const size_t nblk = (n_rays + kLdsBlock - 1) / kLdsBlock;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(detect_kernel_lds, dim3((unsigned)nblk), dim3(kLdsBlock), (size_t)a.n_materials * kLdsBlock * sizeof(float),
+                     st, a, t.mu, t.w, t.w2);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Trace: the voxel-index sequence and float32 piece lengths of selected rays (parity tests).
 __global__ __launch_bounds__(64) void trace_kernel(dexct_fan_geom g, const dexct_ray_plan* __restrict__ plan,
@@ -1316,31 +1344,7 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
     else rc = launch_rows4<2>(a, t, st);
     if (rc != DEXCT_OK) return rc;
   }
-  switch (n_materials) {
-    case 2: return launch_detect<2>(a, t, st);
-    case 3: return launch_detect<3>(a, t, st);
-    case 4: return launch_detect<4>(a, t, st);
-    case 5: return launch_detect<5>(a, t, st);
-    case 6: return launch_detect<6>(a, t, st);
-    case 7: return launch_detect<7>(a, t, st);
-    case 8: return launch_detect<8>(a, t, st);
-    case 9: return launch_detect<9>(a, t, st);
-    case 10: return launch_detect<10>(a, t, st);
-    case 11: return launch_detect<11>(a, t, st);
-    case 12: return launch_detect<12>(a, t, st);
-    case 13: return launch_detect<13>(a, t, st);
-    case 14: return launch_detect<14>(a, t, st);
-    case 15: return launch_detect<15>(a, t, st);
-    case 16: return launch_detect<16>(a, t, st);
-    default: break;
-  }
-  const size_t n_rays = (size_t)a.n_local_views * geom->n_rows * geom->n_channels;
-  const size_t nblk = (n_rays + kLdsBlock - 1) / kLdsBlock;
-  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  hipLaunchKernelGGL(detect_kernel_lds, dim3((unsigned)nblk), dim3(kLdsBlock), (size_t)n_materials * kLdsBlock * sizeof(float),
-                     st, a, t.mu, t.w, t.w2);
-  DEXCT_LAUNCH_CHECK();
-  return DEXCT_OK;
+  return launch_detect_any(a, t, st);
 }
 
 int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const int32_t* ray_vrc, int32_t n_rays,

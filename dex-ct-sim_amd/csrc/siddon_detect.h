@@ -36,6 +36,16 @@ struct ProjArgs {
   int mat_base;
 };
 
+// launch arguments of rows16_kernel (siddon_packed.hip): the 2-bit packed volume
+struct PackedArgs {
+  ProjArgs a;
+  const uint8_t* vol_z2;   // [ny][nx][nz / 4]
+  int lanes_per_pair;      // lanes a (view, channel) pair occupies (16, 32 or 64)
+  int n_zchunks;           // ceil(n_rows / 1024)
+  int view_tile;
+  int det_masks;           // skip detection FMAs of spectrum slots with zero weights (blocks of four energies)
+};
+
 // The attenuation and weight tables are passed as DIRECT __restrict__ kernel arguments (not inside
 // ProjArgs): only then does the compiler know they are read-only and wave-uniform and fetch them with
 // s_load through the scalar cache; as struct members they were fetched with 670 vector loads per wave.
@@ -44,6 +54,9 @@ struct Tables {
   const float* __restrict__ w;    // [S][nE]
   const float* __restrict__ w2;   // [S][nE] w * signal per photon (variance weights), or null
 };
+
+// detection of the material-major accumulator planes a group pass leaves in a.acc_out (siddon.hip; any material count)
+int launch_detect_any(const ProjArgs& a, const Tables& t, hipStream_t st);
 
 __device__ __forceinline__ size_t ray_index(const ProjArgs& a, int v, int r, int c) {
   return a.layout == 0 ? ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c

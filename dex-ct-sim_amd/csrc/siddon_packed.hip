@@ -1,6 +1,6 @@
 // rows16_kernel: the stacked-fan traversal on a 2-BIT PACKED volume with bit-sliced counters (gfx950).
 //
-// Material ids of the fast path are < 3, so a voxel needs 2 bits, not 8.  dexct_volume_pack2 stores the z-fastest
+// Material ids of the fast path are < 4, so a voxel needs 2 bits, not 8.  dexct_volume_pack2 stores the z-fastest
 // volume with four voxels per byte: column (x, y) is nz / 4 bytes, row z in bits 2(z % 16), 2(z % 16) + 1 of dword
 // z / 16.  One dword load then serves SIXTEEN detector rows (rows4_kernel: four), the volume is a quarter of the bytes
 // (a 1024^3 phantom is 256 MiB: it fits the Infinity Cache) and a (view, channel) pair of 1024 rows is one wave.
@@ -8,6 +8,8 @@
 // Counting.  The loaded word x IS 32 one-bit flags: bit 2r = "row r sees id 1", bit 2r + 1 = "row r sees id 2" (ids
 // 0, 1, 2).  n_1 and n_2 per row are therefore per-bit-position population counts over the slabs of the ray.  They are
 // kept BIT-SLICED (Harley-Seal): words ones / twos / fours hold bits 0..2 of the 32 counters, hi[0..7] bits 3..10; eight
+// (Id 3 sets both flags: with 4 ids - a full material group, or a 4-material phantom - a second set of counters runs
+// on x & (x >> 1), the "both" flags at the even positions, and n_1 = n(bit 0) - n_3, n_2 = n(bit 1) - n_3.)  Eight
 // loaded words are folded by seven carry-save adders (3 logic instructions each: a ^ b, (a ^ b) ^ c, majority by bit
 // select); two of the resulting weight-8 words meet in an eighth adder and the carry ripples into hi[] once per 16
 // words: 30 instructions per 8 dwords = 0.23 per row and slab against 0.75 (+ a v_readfirstlane per 4 rows) in
@@ -27,15 +29,6 @@ namespace dexct {
 
 constexpr int kP16Super = 128;      // slabs staged per pass
 constexpr uint32_t kOob = 0xF0000000u;   // a list offset outside every buffer (< 3.75 GiB): the load returns 0 (air), no traffic
-
-struct PackedArgs {
-  ProjArgs a;
-  const uint8_t* vol_z2;   // [ny][nx][nz / 4]
-  int lanes_per_pair;      // n_rows / 16 (16, 32 or 64)
-  int n_zchunks;           // ceil(n_rows / 1024)
-  int view_tile;
-  int det_masks;           // skip detection FMAs of spectrum slots with zero weights (blocks of four energies)
-};
 
 // carry-save adder on 32 one-bit lanes: (h, l) = a + b + c
 __device__ __forceinline__ void csa(uint32_t& h, uint32_t& l, uint32_t a, uint32_t b, uint32_t c) {
@@ -107,15 +100,21 @@ struct Sliced {
   }
 };
 
-template <int NM, int MINW = 4>      // MINW: waves per SIMD the register allocation must allow
+// GROUPED: a material-group pass (ids = codes 0..3 of one group of three materials): raw accumulators (units of u) go to
+// acc_out[(mat_base + code) * n_rays + ray], no detection (dexct_siddon_project_grouped_packed).
+template <int NM, int MINW = 4, bool GROUPED = false>      // MINW: waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
                                                     const float* __restrict__ w2) {
-  static_assert(NM == 2 || NM == 3, "ids 0..2");
+  static_assert(NM >= 2 && NM <= 4, "ids 0..3");
+  constexpr bool BOTH = NM > 3;              // id 3 exists: count the "both flags" plane too
   extern __shared__ uint32_t lds_lists[];          // per pair: kP16Super crossing records (16 B), then kP16Super offsets
   const ProjArgs& a = pa.a;
   const int lane = threadIdx.x;
-  BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // all 64 lanes are here
-  bm.use = bm.use && pa.det_masks;
+  BlockMasks bm{{~0ull, ~0ull}, false};
+  if (!GROUPED) {
+    bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // all 64 lanes are here
+    bm.use = bm.use && pa.det_masks;
+  }
   const int lpp = pa.lanes_per_pair, n_pairs = 64 / lpp;
   CrossRec (*list_cross)[kP16Super] = reinterpret_cast<CrossRec (*)[kP16Super]>(lds_lists);
   uint32_t (*list_full)[kP16Super] = reinterpret_cast<uint32_t (*)[kP16Super]>(lds_lists + (size_t)n_pairs * kP16Super * 4);
@@ -149,10 +148,10 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   auto ld16 = [&](uint32_t off) {           // off + zoff beyond the buffer (list padding, edge pieces): 0, no access
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(off + zoff), 0, 0);
   };
-  Sliced cnt;
-  float corr[2][16];                         // [material - 1][row]
+  Sliced cnt, cnt3;                          // cnt3: flags of id 3 at the even bit positions (BOTH only)
+  float corr[NM - 1][16];                    // [material - 1][row]
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < NM - 1; ++m)
 #pragma unroll
     for (int q = 0; q < 16; ++q) corr[m][q] = 0.0f;
   auto correct = [&](uint32_t xa, uint32_t xb, float t) {
@@ -219,6 +218,12 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
       for (int q = 0; q < 8; ++q) x[q] = ld16(list_full[g][k + q]);
       __builtin_amdgcn_sched_barrier(0);
       cnt.add8(x);
+      if (BOTH) {
+        uint32_t b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b[q] = x[q] & (x[q] >> 1);
+        cnt3.add8(b);
+      }
     }
     // ---- crossing slabs (and the edge slabs): count the b voxel, correct where the two voxels differ
     for (int k = 0; k < n_cross; k += 4) {
@@ -233,6 +238,12 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
       }
       __builtin_amdgcn_sched_barrier(0);
       cnt.add4(xb);
+      if (BOTH) {
+        uint32_t b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = xb[j] & (xb[j] >> 1);
+        cnt3.add4(b);
+      }
       uint32_t any = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) any |= xa[j] ^ xb[j];
@@ -245,14 +256,45 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
     __builtin_amdgcn_wave_barrier();
   }
   cnt.finish();
+  if (BOTH) cnt3.finish();
   if (!pair_live || r0 >= a.g.n_rows) return;
   // ---- un-slice the counters (in place of the corrections), then detect 4 rows at a time.  The rounds are a real
   // loop with ONE copy of the detection code (rows move down the register array between rounds): four inlined copies
   // made the kernel as large as the instruction cache two CUs share.
 #pragma unroll
   for (int row = 0; row < 16; ++row) {
-    corr[0][row] += (float)(int32_t)cnt.value(2 * row);
-    if (NM > 2) corr[1][row] += (float)(int32_t)cnt.value(2 * row + 1);
+    // the sums are formed exactly as in rows4_kernel: (float) count + corrections
+    if (BOTH) {
+      const uint32_t n3 = cnt3.value(2 * row);
+      corr[0][row] = (float)(int32_t)(cnt.value(2 * row) - n3) + corr[0][row];
+      corr[1][row] = (float)(int32_t)(cnt.value(2 * row + 1) - n3) + corr[1][row];
+      corr[2][row] = (float)(int32_t)n3 + corr[2][row];
+    } else {
+      corr[0][row] = (float)(int32_t)cnt.value(2 * row) + corr[0][row];
+      if (NM > 2) corr[1][row] = (float)(int32_t)cnt.value(2 * row + 1) + corr[1][row];
+    }
+  }
+  if (GROUPED) {         // hand the raw accumulators to the detection kernel, one plane per material of the group
+    const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int r = r0 + 4 * q4;
+      if (r >= a.g.n_rows) break;
+      const bool vec4 = a.layout == 1 && (a.g.n_rows & 3) == 0;
+#pragma unroll
+      for (int m = 1; m < NM; ++m) {
+        float* plane = a.acc_out + (size_t)(a.mat_base + m) * n_rays;
+        if (vec4) {
+          *reinterpret_cast<float4*>(plane + ray_index(a, v, r, c)) =
+              make_float4(corr[m - 1][4 * q4], corr[m - 1][4 * q4 + 1], corr[m - 1][4 * q4 + 2], corr[m - 1][4 * q4 + 3]);
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            if (r + rr < a.g.n_rows) plane[ray_index(a, v, r + rr, c)] = corr[m - 1][4 * q4 + rr];
+        }
+      }
+    }
+    return;
   }
   AirCache air_cache{0.0f, {0.0f, 0.0f}, false};
 #pragma unroll 1
@@ -290,6 +332,51 @@ __global__ __launch_bounds__(256) void pack2_kernel(const uint8_t* __restrict__ 
   out[i] = (uint8_t)((x & 3u) | (((x >> 8) & 3u) << 2) | (((x >> 16) & 3u) << 4) | (((x >> 24) & 3u) << 6));
 }
 
+// Material groups on the packed volume: ids 3g+1..3g+3 -> codes 1..3, everything else 0 (group_codes_kernel of
+// siddon.hip), packed four voxels per byte: out [n_groups][n_voxels / 4]
+__global__ __launch_bounds__(256) void group_codes_pack2_kernel(const uint8_t* __restrict__ vol_zf, size_t n_bytes_out,
+                                                                int n_groups, uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_bytes_out) return;
+  const uint32_t x = *reinterpret_cast<const uint32_t*>(vol_zf + 4 * i);
+  for (int g = 0; g < n_groups; ++g) {
+    uint32_t y = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t rel = ((x >> (8 * b)) & 0xFFu) - 3u * g;      // 1..3 inside the group
+      y |= ((rel >= 1u && rel <= 3u) ? rel : 0u) << (2 * b);
+    }
+    out[(size_t)g * n_bytes_out + i] = (uint8_t)y;
+  }
+}
+
+// what both entry points check; fills the launch shape
+static int packed_shape(const dexct_fan_geom* geom, int32_t view_begin, int32_t view_end, int32_t layout, PackedArgs& pa,
+                        size_t& nblk, size_t& lds) {
+  if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
+  if (geom->n_rows < 1) return DEXCT_EINVAL;
+  if (geom->z_first < 0 || geom->z_first + geom->n_rows > geom->nz) return DEXCT_EINVAL;
+  if (geom->nz % 16 != 0 || geom->z_first % 16 != 0) return DEXCT_EINVAL;
+  if ((uint64_t)geom->nx * geom->ny * (geom->nz / 4) > 0xEFFF0000ull) return DEXCT_ERANGE;     // below kOob
+  if (geom->nx > 2047 || geom->ny > 2047) return DEXCT_ERANGE;             // 11-bit sliced counters: one count per slab
+  if (layout != 0 && layout != 1) return DEXCT_EINVAL;
+  if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
+  // a (view, channel) pair takes ceil(n_rows / 16) lanes: 16 or 32 lanes per pair (4 or 2 pairs per wave) or whole
+  // waves; lanes past the last row idle (the caller decides whether that is still worth it)
+  const int lanes = (geom->n_rows + 15) / 16;
+  pa.lanes_per_pair = lanes > 32 ? 64 : (lanes > 16 ? 32 : 16);
+  pa.n_zchunks = lanes > 64 ? (lanes + 63) / 64 : 1;
+  pa.view_tile = 8;
+  pa.det_masks = 1;
+  if (const char* e = getenv("DEXCT_DET_MASKS")) pa.det_masks = atoi(e) != 0;
+  if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) pa.view_tile = t; }
+  const int n_pairs = 64 / pa.lanes_per_pair;
+  nblk = (size_t)(view_end - view_begin) * ((geom->n_channels + n_pairs - 1) / n_pairs) * pa.n_zchunks;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  lds = (size_t)n_pairs * kP16Super * (sizeof(CrossRec) + sizeof(uint32_t));
+  return DEXCT_OK;
+}
+
 }  // namespace dexct
 
 using namespace dexct;
@@ -306,24 +393,30 @@ int dexct_volume_pack2(const uint8_t* vol_zf, int64_t n_voxels, uint8_t* vol_z2,
   return DEXCT_OK;
 }
 
+int dexct_volume_groups_pack2(const uint8_t* vol_zf, int64_t n_voxels, int32_t n_materials, uint8_t* codes2, void* stream) {
+  if (!vol_zf || !codes2 || n_voxels <= 0 || (n_voxels & 3)) return DEXCT_EINVAL;
+  if (n_materials < 2 || n_materials > DEXCT_MAX_MATERIALS) return DEXCT_ERANGE;
+  const int n_groups = (n_materials - 1 + 2) / 3;
+  const size_t nb = (size_t)n_voxels / 4;
+  const size_t nblk = (nb + 255) / 256;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(group_codes_pack2_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vol_zf, nb, n_groups,
+                     codes2);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
 int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                                 int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
                                 int32_t n_spectra, const float* mu, const float* weights, float* counts, float* pathlen,
                                 int32_t layout, void* stream) {
   if (!geom || !plan || !vol_z2 || !mu || !weights || !counts) return DEXCT_EINVAL;
-  if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
-  if (n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
-  if (n_materials < 2 || n_materials > 3 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;     // ids 0..2
-  if (geom->z_first < 0 || geom->z_first + geom->n_rows > geom->nz) return DEXCT_EINVAL;
-  if (geom->nz % 16 != 0 || geom->z_first % 16 != 0) return DEXCT_EINVAL;
-  // a (view, channel) pair takes ceil(n_rows / 16) lanes: 16 or 32 lanes per pair (4 or 2 pairs per wave) or whole
-  // waves; lanes past the last row idle (the caller decides whether that is still worth it)
-  const int lanes = (geom->n_rows + 15) / 16;
-  if ((uint64_t)geom->nx * geom->ny * (geom->nz / 4) > 0xEFFF0000ull) return DEXCT_ERANGE;     // below kOob
-  if (geom->nx > 2047 || geom->ny > 2047) return DEXCT_ERANGE;             // 11-bit sliced counters: one count per slab
-  if (layout != 0 && layout != 1) return DEXCT_EINVAL;
-  if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
+  if (n_energies < 1 || n_spectra < 1) return DEXCT_EINVAL;
+  if (n_materials < 2 || n_materials > 4 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;     // ids 0..3
   PackedArgs pa;
+  size_t nblk, lds;
+  const int rc = packed_shape(geom, view_begin, view_end, layout, pa, nblk, lds);
+  if (rc != DEXCT_OK) return rc;
   ProjArgs& a = pa.a;
   a.g = *geom;
   a.plan = plan;
@@ -340,33 +433,76 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   a.acc_out = nullptr;
   a.mat_base = 0;
   a.layout = layout;
-  a.view_tile = 8;
+  a.view_tile = pa.view_tile;
   pa.vol_z2 = vol_z2;
-  pa.lanes_per_pair = lanes > 32 ? 64 : (lanes > 16 ? 32 : 16);
-  pa.n_zchunks = lanes > 64 ? (lanes + 63) / 64 : 1;
-  pa.view_tile = 8;
-  pa.det_masks = 1;
-  if (const char* e = getenv("DEXCT_DET_MASKS")) pa.det_masks = atoi(e) != 0;
-  if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) pa.view_tile = t; }
-  const int n_pairs = 64 / pa.lanes_per_pair;
-  const size_t nblk = (size_t)a.n_local_views * ((geom->n_channels + n_pairs - 1) / n_pairs) * pa.n_zchunks;
-  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   hipStream_t st = as_stream(stream);
-  const size_t lds = (size_t)n_pairs * kP16Super * (sizeof(CrossRec) + sizeof(uint32_t));
   int minw = 4;
   if (const char* e = getenv("DEXCT_P16_MINW")) minw = atoi(e);      // tuning knob
+  const float* none = nullptr;
   if (n_materials == 2)
-    hipLaunchKernelGGL((rows16_kernel<2>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<2>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
+  else if (n_materials == 4)
+    hipLaunchKernelGGL((rows16_kernel<4, 3>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (minw == 5)
-    hipLaunchKernelGGL((rows16_kernel<3, 5>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3, 5>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (minw == 6)
-    hipLaunchKernelGGL((rows16_kernel<3, 6>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3, 6>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (minw == 8)
-    hipLaunchKernelGGL((rows16_kernel<3, 8>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3, 8>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else
-    hipLaunchKernelGGL((rows16_kernel<3>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, (const float*)nullptr);
+    hipLaunchKernelGGL((rows16_kernel<3>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
+}
+
+int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
+                                        int32_t view_end, const uint8_t* codes2, int32_t n_materials, int32_t n_energies,
+                                        int32_t n_spectra, const float* mu, const float* weights, float* counts,
+                                        float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
+                                        float* variance, void* stream) {
+  if (!geom || !plan || !codes2 || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
+  if (n_materials < 2 || n_energies < 1 || n_spectra < 1) return DEXCT_EINVAL;
+  if (n_materials > DEXCT_MAX_MATERIALS || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
+  if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
+  PackedArgs pa;
+  size_t nblk, lds;
+  const int rc = packed_shape(geom, view_begin, view_end, layout, pa, nblk, lds);
+  if (rc != DEXCT_OK) return rc;
+  ProjArgs& a = pa.a;
+  a.g = *geom;
+  a.plan = plan;
+  a.vol_yx = nullptr;
+  a.vol_xy = nullptr;
+  a.vol_zf = nullptr;
+  a.n_local_views = view_end - view_begin;
+  a.n_materials = n_materials;
+  a.n_energies = n_energies;
+  a.n_spectra = n_spectra;
+  a.counts = counts;
+  a.pathlen = pathlen;
+  a.variance = variance;
+  a.acc_out = acc_scratch;
+  a.mat_base = 0;
+  a.layout = layout;
+  a.view_tile = pa.view_tile;
+  hipStream_t st = as_stream(stream);
+  const size_t group_bytes = (size_t)geom->nx * geom->ny * (geom->nz / 4);
+  const int n_groups = (n_materials - 1 + 2) / 3;
+  const float* none = nullptr;
+  for (int g = 0; g < n_groups; ++g) {
+    pa.vol_z2 = codes2 + (size_t)g * group_bytes;
+    a.mat_base = 3 * g;
+    const int left = n_materials - 1 - 3 * g;           // materials in this group: 1..3
+    if (left >= 3)
+      hipLaunchKernelGGL((rows16_kernel<4, 3, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, none, none, none);
+    else if (left == 2)
+      hipLaunchKernelGGL((rows16_kernel<3, 4, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, none, none, none);
+    else
+      hipLaunchKernelGGL((rows16_kernel<2, 4, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, none, none, none);
+    DEXCT_LAUNCH_CHECK();
+  }
+  const Tables t{mu, weights, weights2};
+  return launch_detect_any(a, t, st);
 }
 
 }  // extern "C"

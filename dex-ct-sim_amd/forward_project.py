@@ -53,7 +53,9 @@ class Projector:
     picks for stacked fans of >= 256 rows; same bits as kernel 3), 6 one wavefront per ray (lanes over
     dominant-axis slabs, shuffle reductions, tables in LDS: the mapping BASELINE.json's north star names; <= 4
     materials), 7 the stacked fan on a 2-bit packed volume with bit-sliced counters (rows16_kernel: 16 rows per
-    lane; <= 3 materials; what kernel 0 picks from 192 rows on when a pair fills 3/4 of its lane group).
+    lane; <= 4 materials; what kernel 0 picks from 192 rows on when a pair fills 3/4 of its lane group), 8 the same
+    kernel run once per group of three materials on packed group codes (2..48 materials; what kernel 0 picks for more
+    than 4 materials under the same conditions).
     """
 
     def __init__(self, ct, phantom, view_range=None, kernel=0, dev=None):
@@ -85,17 +87,24 @@ class Projector:
         # The 4-rows-per-lane kernels read aligned dwords along z: pad the uploaded copy with empty slices so that
         # the first imaged slice and the slice count are multiples of 4 (stacked fans only see their own slices,
         # the in-plane geometry does not change).
-        packed_wanted = kernel in (3, 4, 5, 7) or (kernel == 0 and ct.N_rows >= 64)
+        packed_wanted = kernel in (3, 4, 5, 7, 8) or (kernel == 0 and ct.N_rows >= 64)
         # the 2-bit packed volume with bit-sliced counters (rows16_kernel): what kernel 0 picks where it applies
         lanes16 = -(-ct.N_rows // 16)
         group16 = 64 * (-(-lanes16 // 64)) if lanes16 > 32 else (32 if lanes16 > 16 else 16)     # lanes the pair occupies
-        packed2_ok = (not self.cone and 2 <= phantom.n_materials <= 3 and max(phantom.Nx, phantom.Ny) <= 2047)
+        M = phantom.n_materials
+        shape2_ok = not self.cone and max(phantom.Nx, phantom.Ny) <= 2047
         # kernel 0 picks it when at least 3/4 of the pair's lane group carry rows (>= 192 rows)
-        self.use_packed = (kernel == 7 and packed2_ok) or (kernel == 0 and packed2_ok and ct.N_rows >= 192
-                                                           and 4 * lanes16 >= 3 * group16)
+        fills = ct.N_rows >= 192 and 4 * lanes16 >= 3 * group16
+        packed2_ok = shape2_ok and 2 <= M <= 4                     # one fused pass: ids 0..3
+        self.use_packed = (kernel == 7 and packed2_ok) or (kernel == 0 and packed2_ok and fills)
         if kernel == 7 and not packed2_ok:
-            raise ValueError('kernel 7 (2-bit packed volume) needs a stacked fan, 2..3 materials and nx, ny <= 2047')
-        align = 16 if self.use_packed else 4
+            raise ValueError('kernel 7 (2-bit packed volume) needs a stacked fan, 2..4 materials and nx, ny <= 2047')
+        # material groups (5..48 materials) on packed group codes: kernel 8 forces it, kernel 0 picks it like kernel 7
+        self.grouped_packed = (kernel == 8 and shape2_ok and 2 <= M <= 48) or (kernel == 0 and shape2_ok and 4 < M <= 48 and fills)
+        if kernel == 8 and not self.grouped_packed:
+            raise ValueError('kernel 8 (material groups on the 2-bit packed volume) needs a stacked fan, 2..48 materials '
+                             'and nx, ny <= 2047')
+        align = 16 if (self.use_packed or self.grouped_packed) else 4
         if not self.cone and packed_wanted and (nz % align or z_first % align):
             lead = (-z_first) % align
             tail = (-(nz + lead)) % align
@@ -127,20 +136,24 @@ class Projector:
                 self.vol_zc = torch.empty(nb, dtype=torch.uint8, device=self.dev)
                 _native.check(self.lib.dexct_cone_layout(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz, ptr(self.vol_zc), st),
                               'dexct_cone_layout')
-        want_zf = kernel in (2, 3, 4, 5, 7) or (kernel == 0 and ct.N_rows >= 64)
+        want_zf = kernel in (2, 3, 4, 5, 7, 8) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz,
                                                     ptr(self.vol_xy), ptr(self.vol_zf), st), 'dexct_volume_layouts')
-        M = phantom.n_materials
         self.vol_z2 = None
         if self.use_packed:
             self.vol_z2 = torch.empty(self.vol_zf.numel() // 4, dtype=torch.uint8, device=self.dev)
             _native.check(self.lib.dexct_volume_pack2(ptr(self.vol_zf), self.vol_zf.numel(), ptr(self.vol_z2), st),
                           'dexct_volume_pack2')
         aligned = nz % 4 == 0 and z_first % 4 == 0
-        self.grouped = kernel == 4 or (kernel == 0 and want_zf and M > 4 and aligned)
+        self.grouped = not self.grouped_packed and (kernel == 4 or (kernel == 0 and want_zf and M > 4 and aligned))
         self.codes = None
-        if self.grouped:
+        if self.grouped_packed:
+            n_groups = (M - 1 + 2) // 3
+            self.codes = torch.empty((n_groups, self.vol_zf.numel() // 4), dtype=torch.uint8, device=self.dev)
+            _native.check(self.lib.dexct_volume_groups_pack2(ptr(self.vol_zf), self.vol_zf.numel(), M, ptr(self.codes), st),
+                          'dexct_volume_groups_pack2')
+        elif self.grouped:
             if not (2 <= M <= 48 and aligned):
                 raise ValueError('kernel 4 needs 2..48 materials')
             n_groups = (M - 1 + 2) // 3
@@ -159,7 +172,7 @@ class Projector:
     @property
     def native_layout(self):
         """1 (row fastest) when a row-parallel kernel will run, else 0 (channel fastest)."""
-        if self.kernel in (2, 3, 4, 5, 7):
+        if self.kernel in (2, 3, 4, 5, 7, 8):
             return 1
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 
@@ -209,6 +222,12 @@ class Projector:
             _native.check(self.lib.dexct_siddon_project_packed(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_z2), M, nE, S,
                 ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, stream_ptr()), 'dexct_siddon_project_packed')
+        elif self.grouped_packed:                        # noise too: the detection pass carries the variance
+            scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
+            _native.check(self.lib.dexct_siddon_project_grouped_packed(
+                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
+                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
+                stream_ptr()), 'dexct_siddon_project_grouped_packed')
         elif self.grouped:
             scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
             _native.check(self.lib.dexct_siddon_project_grouped(
@@ -219,7 +238,7 @@ class Projector:
             _native.check(self.lib.dexct_siddon_project(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx),
                 ptr(self.vol_xy), ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
-                3 if self.kernel == 7 else self.kernel, run_layout, ptr(w2_d), ptr(variance), stream_ptr()),
+                3 if self.kernel in (7, 8) else self.kernel, run_layout, ptr(w2_d), ptr(variance), stream_ptr()),
                 'dexct_siddon_project')
         if variance is not None:
             _native.check(self.lib.dexct_add_noise(ptr(counts), ptr(variance), S, nV, nR, nC, run_layout,

@@ -127,7 +127,7 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
                                  float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
                                  float* variance, void* stream);
 
-/* The stacked-fan projection on a 2-BIT PACKED volume (rows16_kernel; <= 3 materials, i.e. ids 0..2): a voxel is 2
+/* The stacked-fan projection on a 2-BIT PACKED volume (rows16_kernel; <= 4 materials, i.e. ids 0..3): a voxel is 2
  * bits, one dword load serves 16 detector rows, the per-row material counts are kept bit-sliced (carry-save adders).
  * dexct_volume_pack2: vol_zf [ny][nx][nz] bytes -> vol_z2 [ny][nx][nz/4] bytes (row z of a column in bits
  *   2(z%4).. of byte z/4); n_voxels = nx*ny*nz, a multiple of 4.
@@ -140,6 +140,18 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
                                 int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
                                 int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                 float* pathlen, int32_t layout, void* stream);
+
+/* Material groups on the packed volume (5..DEXCT_MAX_MATERIALS materials; the packed form of dexct_volume_groups /
+ * dexct_siddon_project_grouped, same arguments and outputs; preconditions of dexct_siddon_project_packed).
+ * dexct_volume_groups_pack2: codes2[g][n_voxels / 4]: the group codes 0..3 of dexct_volume_groups at 2 bits per voxel.
+ * dexct_siddon_project_grouped_packed: one rows16_kernel pass per group (no detection) into acc_scratch, then the
+ *   detection pass of dexct_siddon_project_grouped.  Bit-identical to it. */
+int dexct_volume_groups_pack2(const uint8_t* vol_zf, int64_t n_voxels, int32_t n_materials, uint8_t* codes2, void* stream);
+int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
+                                        int32_t view_end, const uint8_t* codes2, int32_t n_materials, int32_t n_energies,
+                                        int32_t n_spectra, const float* mu, const float* weights, float* counts,
+                                        float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
+                                        float* variance, void* stream);
 
 /* Cone-beam (3-D) projection, SURVEY 8f.4: the fan of dexct_fan_plan in the (x, y) plane, source at height
  * src_z, detector row r at height row_z[r] (device float64 [n_rows], cm, z = 0 at the centre of the grid;

@@ -87,12 +87,13 @@ def test_voxel_index_sequence_bit_exact(hip, n, nv, nc):
         assert np.array_equal(ln[k, :ns[k]], rl)
 
 
-@pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('kernel', [1, 2, 3, 4, 5, 6, 8])
 @pytest.mark.parametrize('n_mat', [2, 3, 4, 7, 13, 16, 29])
 def test_pathlen_bit_exact_and_counts(hip, kernel, n_mat):
     """Register accumulators (<= 4 materials), LDS accumulators (more), the packed-count 4-rows-per-lane
-    kernel and its material-group form (kernel 4, up to 16 materials); 66 rows from slice 2 of 70: neither a
-    multiple of 4, so the host pads the uploaded volume, and the last lane is ragged."""
+    kernel and its material-group form (kernel 4, up to 16 materials), the group passes on 2-bit packed codes (kernel
+    8); 66 rows from slice 2 of 70: neither a multiple of 4 (or 16), so the host pads the uploaded volume, and the last
+    lane is ragged."""
     from dex_ct_sim_amd._native import DexctError
     from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
     ct, ph = small_scan(n=48, nz=70, n_views=24, n_channels=80, n_rows=66, z_index=2)      # unaligned on purpose
@@ -514,7 +515,7 @@ def test_degenerate_shapes_through_the_public_calls(hip):
 
 @pytest.mark.parametrize('n_rows,nz,z_index', [(256, 256, 0), (256, 270, 2), (512, 512, 0), (1024, 1024, 0), (2048, 2048, 0),
                                                (200, 203, 1), (320, 320, 0), (768, 768, 0), (1100, 1100, 0), (50, 64, 3)])
-@pytest.mark.parametrize('n_mat', [2, 3])
+@pytest.mark.parametrize('n_mat', [2, 3, 4])
 def test_packed_volume_kernel_bit_identical(hip, n_rows, nz, z_index, n_mat):
     """rows16_kernel (kernel 7): 2 bits per voxel, 16 rows per lane, bit-sliced counters.  4, 2 or 1 (view, channel)
     pairs per wave (256 / 512 / >= 1024 rows), ragged channel groups (53 channels), an unaligned first slice (the host
@@ -526,6 +527,8 @@ def test_packed_volume_kernel_bit_identical(hip, n_rows, nz, z_index, n_mat):
     if n_mat == 2:
         ph.volume = np.minimum(ph.volume, 1).astype(np.uint8)
         ph.materials = [AIR, WATER]
+    if n_mat == 4:
+        ph = ph_many(ph, 4)                                          # id 3 sets both flags: the third set of counters
     rng = np.random.default_rng(nz + n_mat)
     speck = rng.random(ph.volume.shape) < 0.02                      # isolated voxels: corrections in many rows
     ph.volume[speck] = rng.integers(0, n_mat, int(speck.sum()), dtype=np.uint8)
@@ -649,3 +652,33 @@ def test_detection_skips_only_exact_zeros(hip, n_e, n_s):
                       np.exp(-np.einsum('...m,me->...e', pl.cpu().numpy().astype(np.float64), mu.astype(np.float64))))
     scale = np.abs(w).sum(axis=1).reshape(-1, 1, 1, 1)
     assert np.max(np.abs(ref.cpu().numpy() - exact) / scale) < REL_TOL
+
+
+@pytest.mark.parametrize('n_rows', [256, 512, 200])
+@pytest.mark.parametrize('n_mat', [4, 5, 7, 10, 13, 20])
+def test_material_groups_on_the_packed_volume(hip, n_rows, n_mat):
+    """Kernel 8: one rows16_kernel pass per group of three materials on 2-bit group codes (a full group uses all four
+    codes: the "both flags" counters), then the detection pass of the byte-volume group path.  Path lengths and counts
+    bit-identical to kernel 4 (byte codes) and kernel 1; the host picks it for more than 4 materials where it picks the
+    packed kernel for fewer; with noise it gives the sample kernel 4 gives."""
+    ct, ph = small_scan(n=40, nz=n_rows, n_views=6, n_channels=45, n_rows=n_rows)
+    ph = ph_many(ph, n_mat)
+    rng = np.random.default_rng(n_rows + n_mat)
+    speck = rng.random(ph.volume.shape) < 0.02
+    ph.volume[speck] = rng.integers(0, n_mat, int(speck.sum()), dtype=np.uint8)
+    sp = spectra()
+    (c1, p1), _ = projector(ct, ph, kernel=1).project(sp, want_pathlen=True)
+    (c4, p4), _ = projector(ct, ph, kernel=4).project(sp, want_pathlen=True)
+    pj8 = projector(ct, ph, kernel=8)
+    (c8, p8), _ = pj8.project(sp, want_pathlen=True)
+    assert pj8.grouped_packed and pj8.codes.shape == ((n_mat + 1) // 3, ph.Nx * ph.Ny * pj8.geom.nz // 4)
+    assert torch.equal(p8, p1) and torch.equal(p8, p4)
+    assert torch.equal(c8, c4)
+    assert float(((c8 - c1).abs() / c1).max()) < REL_TOL          # kernel 1 detects from LDS columns beyond 4 materials
+    auto = projector(ct, ph)
+    assert auto.grouped_packed == (n_mat > 4) and auto.use_packed == (n_mat <= 4)      # 200, 256, 512 rows fill their lane groups
+    ca = auto.project(sp)[0]
+    assert torch.equal(ca, c4) if n_mat > 4 else float(((ca - c4).abs() / c4).max()) < REL_TOL
+    n8, _ = pj8.project(sp, noise=True, seed=3)
+    n4, _ = projector(ct, ph, kernel=4).project(sp, noise=True, seed=3)
+    assert torch.equal(n8, n4) and not torch.equal(n8, c8)

@@ -1,5 +1,6 @@
-"""Traversal time vs number of materials (512^3, 1000 x 800 x 512 rays): 1-row-per-lane kernel (2) against the
-packed-count kernel, single pass (3, <= 4 materials) or per material group (4)."""
+"""Projection time vs number of materials (512^3, 1000 x 800 x 512 rays, both spectra): the byte-volume packed-count
+kernel in a single pass (3, <= 4 materials) or per material group (4) against the 2-bit-volume kernel, single pass (7,
+<= 4 materials) or per material group (8); results compared bit for bit."""
 import os
 import sys
 
@@ -30,17 +31,21 @@ for M in MS:
             blk = ph.volume[iz[0]:iz[-1] + 1, iy[0]:iy[-1] + 1, ix[0]:ix[-1] + 1]
             blk[sub] = 2 + k % (M - 2)
         ph.materials = [AIR, WATER, BONE] + [Material(f'm{i}', 1.0 + 0.05 * i, 'H(11.2)O(88.8)') for i in range(3, M)]
-    for kernel in ((3, 4) if M <= 4 else (4,)):
+    ref = None
+    for kernel in ((3, 7, 4, 8) if M <= 4 else (4, 8)):
         pj = fp.Projector(ct, ph, kernel=kernel)
         _, mu_d, w_d, _ = pj.upload_tables(specs)
         out = pj.project_tables(mu_d, w_d, layout=None)
         torch.cuda.synchronize()
+        same = '' if ref is None else f'   counts bit-identical to kernel 4: {bool(torch.equal(out, ref))}'
+        if kernel == 4:
+            ref = out.clone()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
             pj.project_tables(mu_d, w_d, out=out, layout=None)
         e1.record()
         torch.cuda.synchronize()
-        print(f'materials {M:2d} kernel {kernel}: {e0.elapsed_time(e1) / 3:.1f} ms', flush=True)
+        print(f'materials {M:2d} kernel {kernel}: {e0.elapsed_time(e1) / 3:.1f} ms{same}', flush=True)
         del pj, out
         torch.cuda.empty_cache()
