@@ -950,7 +950,7 @@ constexpr int kMaxGrouped = DEXCT_MAX_MATERIALS;   // register detect kernels up
 
 // One thread per ray, in memory order of the chosen layout; NMAT = exact number of materials (fully unrolled:
 // a version with 16 predicated material slots spent its time in scalar branches).
-template <int NMAT, int R>   // R rays per thread: 4 consecutive rows (layout 1, n_rows % 4 == 0) or 1
+template <int NMAT, int R>   // R rays per thread: 4 (or, beyond 16 materials, 2) consecutive rows (layout 1, n_rows % R == 0) or 1
 __global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __restrict__ mu, const float* __restrict__ w,
                                                      const float* __restrict__ w2) {
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
@@ -971,6 +971,9 @@ __global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __
     if (R == 4) {
       const float4 x = *reinterpret_cast<const float4*>(plane);
       L[0][m] = x.x; L[R > 1 ? 1 : 0][m] = x.y; L[R > 2 ? 2 : 0][m] = x.z; L[R > 3 ? 3 : 0][m] = x.w;
+    } else if (R == 2) {
+      const float2 x = *reinterpret_cast<const float2*>(plane);
+      L[0][m] = x.x; L[R > 1 ? 1 : 0][m] = x.y;
     } else {
       L[0][m] = plane[0];
     }
@@ -1013,14 +1016,16 @@ __global__ __launch_bounds__(kLdsBlock) void detect_kernel_lds(ProjArgs a, const
   detect_store_lds(lds_L, tid, kLdsBlock, a, mu, w, w2, ray);
 }
 
+// rays per thread: 4 up to 16 materials, 2 up to 32, 1 beyond (the lengths of all materials live in registers)
 template <int NMAT>
 static int launch_detect(const ProjArgs& a, const Tables& t, hipStream_t st) {
+  constexpr int RMAX = NMAT <= 16 ? 4 : (NMAT <= 32 ? 2 : 1);
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
-  const bool four = a.layout == 1 && (a.g.n_rows & 3) == 0;
-  const size_t n_thr = four ? n_rays / 4 : n_rays;
+  const bool wide = RMAX > 1 && a.layout == 1 && (a.g.n_rows % RMAX) == 0;
+  const size_t n_thr = wide ? n_rays / RMAX : n_rays;
   const size_t nblk = (n_thr + 255) / 256;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  if (four) hipLaunchKernelGGL((detect_kernel<NMAT, 4>), dim3((unsigned)nblk), dim3(256), 0, st, a, t.mu, t.w, t.w2);
+  if (wide) hipLaunchKernelGGL((detect_kernel<NMAT, RMAX>), dim3((unsigned)nblk), dim3(256), 0, st, a, t.mu, t.w, t.w2);
   else hipLaunchKernelGGL((detect_kernel<NMAT, 1>), dim3((unsigned)nblk), dim3(256), 0, st, a, t.mu, t.w, t.w2);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
@@ -1043,8 +1048,41 @@ int launch_detect_any(const ProjArgs& a, const Tables& t, hipStream_t st) {
     case 14: return launch_detect<14>(a, t, st);
     case 15: return launch_detect<15>(a, t, st);
     case 16: return launch_detect<16>(a, t, st);
+    case 17: return launch_detect<17>(a, t, st);
+    case 18: return launch_detect<18>(a, t, st);
+    case 19: return launch_detect<19>(a, t, st);
+    case 20: return launch_detect<20>(a, t, st);
+    case 21: return launch_detect<21>(a, t, st);
+    case 22: return launch_detect<22>(a, t, st);
+    case 23: return launch_detect<23>(a, t, st);
+    case 24: return launch_detect<24>(a, t, st);
+    case 25: return launch_detect<25>(a, t, st);
+    case 26: return launch_detect<26>(a, t, st);
+    case 27: return launch_detect<27>(a, t, st);
+    case 28: return launch_detect<28>(a, t, st);
+    case 29: return launch_detect<29>(a, t, st);
+    case 30: return launch_detect<30>(a, t, st);
+    case 31: return launch_detect<31>(a, t, st);
+    case 32: return launch_detect<32>(a, t, st);
+    case 33: return launch_detect<33>(a, t, st);
+    case 34: return launch_detect<34>(a, t, st);
+    case 35: return launch_detect<35>(a, t, st);
+    case 36: return launch_detect<36>(a, t, st);
+    case 37: return launch_detect<37>(a, t, st);
+    case 38: return launch_detect<38>(a, t, st);
+    case 39: return launch_detect<39>(a, t, st);
+    case 40: return launch_detect<40>(a, t, st);
+    case 41: return launch_detect<41>(a, t, st);
+    case 42: return launch_detect<42>(a, t, st);
+    case 43: return launch_detect<43>(a, t, st);
+    case 44: return launch_detect<44>(a, t, st);
+    case 45: return launch_detect<45>(a, t, st);
+    case 46: return launch_detect<46>(a, t, st);
+    case 47: return launch_detect<47>(a, t, st);
+    case 48: return launch_detect<48>(a, t, st);
     default: break;
   }
+  // (more than DEXCT_MAX_MATERIALS never gets here; kept for a library built with a larger limit)
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   const size_t nblk = (n_rays + kLdsBlock - 1) / kLdsBlock;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
