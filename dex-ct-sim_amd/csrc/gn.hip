@@ -664,13 +664,15 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   } else if (precision == 0) {
     // lane refill: each wave works through a run of 64 * chunk pixels.  Measured optimum (8e5 ... 4e8 pixels):
     // up to 8 pixels per lane while that still leaves ~12 500 waves (2.4 x the 5 120 resident ones), and beyond
-    // that as many as keep the grid near 100 000 waves; small inputs degenerate to one pixel per lane.
+    // that as many as keep the grid near 200 000 waves (re-measured after the late-r2 arithmetic changes, 4.1e8 pixels:
+    // 8 / 16 / 32 / 64 / 128 / 256 pixels per lane = 855 / 824 / 804 / 808 / 833 / 890 ms); small inputs degenerate to
+    // one pixel per lane.
     const char* ce = getenv("DEXCT_GN_CHUNK");
     int64_t chunk = n_pix / (kWave * 12500ll);
     if (chunk > 8) chunk = 8;
-    if (n_pix / (kWave * 100000ll) > chunk) chunk = n_pix / (kWave * 100000ll);
+    if (n_pix / (kWave * 200000ll) > chunk) chunk = n_pix / (kWave * 200000ll);
     if (ce) chunk = atoll(ce);
-    chunk = chunk < 1 ? 1 : (chunk > 64 ? 64 : chunk);
+    chunk = chunk < 1 ? 1 : (chunk > (ce ? 1024 : 64) ? (ce ? 1024 : 64) : chunk);
     const int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
     const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     const char* te = getenv("DEXCT_GN_STOP_TOL");

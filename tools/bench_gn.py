@@ -27,7 +27,7 @@ ref = torch.empty_like(a)
 
 
 def run(out, env):
-    for k in ('DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HLDS', 'DEXCT_GN_HIST'):
+    for k in ('DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HLDS', 'DEXCT_GN_HIST', 'DEXCT_GN_CHUNK'):
         os.environ.pop(k, None)
     os.environ.update(env)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,6 +41,8 @@ def run(out, env):
 run(ref, {})
 variants = [{}, {'DEXCT_GN_HLDS': '1'}, {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_FULL_LOOP': '1'},
             {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_HLDS': '1'}]
+if os.environ.get('GN_VARIANTS') == 'chunk':      # pixels per lane of a wave's run (default 64 at this size)
+    variants = [{}] + [{'DEXCT_GN_CHUNK': str(c)} for c in (8, 16, 32, 128, 256)]
 if os.environ.get('GN_VARIANTS') == 'hist':      # history length of the repeated-state exit (x occupancy)
     variants = [{}] + [{'DEXCT_GN_HIST': str(h)} for h in (4, 5, 6, 7, 10, 12)] + \
         [{'DEXCT_GN_HIST': '4', 'DEXCT_GN_MINW': '6'}, {'DEXCT_GN_HIST': '6', 'DEXCT_GN_MINW': '6'}]
