@@ -91,12 +91,26 @@ struct Sliced {
     fours ^= fa;
     add_eights(e);
   }
-  // counter of bit position p (after finish())
-  __device__ __forceinline__ uint32_t value(int p) const {
-    uint32_t n = ((ones >> p) & 1u) | (((twos >> p) & 1u) << 1) | (((fours >> p) & 1u) << 2) | (((eights >> p) & 1u) << 3);
+  // all 32 counters at once (after finish()): out[p] = counter of bit position p.  A 32 x 32 bit-matrix transpose
+  // (five rounds of masked swaps) of the 11 planes; the 21 zero rows fold away at compile time: about a third of
+  // extracting every bit of every counter on its own.
+  __device__ __forceinline__ void unslice(uint32_t (&out)[32]) const {
+    out[0] = ones; out[1] = twos; out[2] = fours; out[3] = eights;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) n |= ((hi[k] >> p) & 1u) << (4 + k);
-    return n;
+    for (int k = 0; k < 7; ++k) out[4 + k] = hi[k];
+#pragma unroll
+    for (int k = 11; k < 32; ++k) out[k] = 0u;
+    uint32_t m = 0x0000FFFFu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+        const uint32_t t = ((out[k] >> j) ^ out[k + j]) & m;
+        out[k] ^= t << j;
+        out[k + j] ^= t;
+      }
+      m ^= m << (j >> 1);
+    }
   }
 };
 
@@ -261,17 +275,21 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   // ---- un-slice the counters (in place of the corrections), then detect 4 rows at a time.  The rounds are a real
   // loop with ONE copy of the detection code (rows move down the register array between rounds): four inlined copies
   // made the kernel as large as the instruction cache two CUs share.
-#pragma unroll
-  for (int row = 0; row < 16; ++row) {
+  {
     // the sums are formed exactly as in rows4_kernel: (float) count + corrections
-    if (BOTH) {
-      const uint32_t n3 = cnt3.value(2 * row);
-      corr[0][row] = (float)(int32_t)(cnt.value(2 * row) - n3) + corr[0][row];
-      corr[1][row] = (float)(int32_t)(cnt.value(2 * row + 1) - n3) + corr[1][row];
-      corr[2][row] = (float)(int32_t)n3 + corr[2][row];
-    } else {
-      corr[0][row] = (float)(int32_t)cnt.value(2 * row) + corr[0][row];
-      if (NM > 2) corr[1][row] = (float)(int32_t)cnt.value(2 * row + 1) + corr[1][row];
+    uint32_t n[32], n3[32];
+    cnt.unslice(n);
+    if (BOTH) cnt3.unslice(n3);
+#pragma unroll
+    for (int row = 0; row < 16; ++row) {
+      if (BOTH) {
+        corr[0][row] = (float)(int32_t)(n[2 * row] - n3[2 * row]) + corr[0][row];
+        corr[1][row] = (float)(int32_t)(n[2 * row + 1] - n3[2 * row]) + corr[1][row];
+        corr[2][row] = (float)(int32_t)n3[2 * row] + corr[2][row];
+      } else {
+        corr[0][row] = (float)(int32_t)n[2 * row] + corr[0][row];
+        if (NM > 2) corr[1][row] = (float)(int32_t)n[2 * row + 1] + corr[1][row];
+      }
     }
   }
   if (GROUPED) {         // hand the raw accumulators to the detection kernel, one plane per material of the group
