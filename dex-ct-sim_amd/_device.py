@@ -28,3 +28,16 @@ def to_dev(a, dtype, dev):
     if isinstance(a, torch.Tensor):
         return a.to(device=dev, dtype=dtype).contiguous()
     return torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dtype)
+
+
+def to_host(t):
+    """Device tensor -> NumPy array through PAGE-LOCKED host memory (one DMA at PCIe rate instead of a staged copy
+    through pageable memory).  The pinned buffer comes from torch's caching host allocator and is referenced by the
+    returned array alone: the caller owns it like any fresh array, and the allocator reuses the pages once the array
+    is garbage, so repeated calls do not pin new memory."""
+    if not t.is_cuda:
+        return t.numpy()
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return host.numpy()

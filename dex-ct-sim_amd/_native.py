@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libdexct_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every entry point include/dexct.h declares
 SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
@@ -14,7 +14,7 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
            'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
            'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather',
-           'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
+           'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
 
 
 class FanGeom(C.Structure):
@@ -22,6 +22,22 @@ class FanGeom(C.Structure):
     _fields_ = [('n_views', C.c_int32), ('n_channels', C.c_int32), ('n_rows', C.c_int32), ('z_first', C.c_int32),
                 ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32), ('pad_', C.c_int32),
                 ('dx', C.c_double), ('dy', C.c_double), ('dz', C.c_double), ('sid', C.c_double), ('sdd', C.c_double)]
+
+
+class LogOut(C.Structure):
+    """dexct_log_out: the optional second output of get_sino, sino_log = ln(air / counts)"""
+    _fields_ = [('sino_log', C.c_void_p), ('air', C.c_float * 4)]
+
+
+def log_out(sino_log_ptr, air):
+    """byref-able dexct_log_out, or None when no log sinogram is wanted."""
+    if sino_log_ptr is None:
+        return None
+    lo = LogOut()
+    lo.sino_log = sino_log_ptr
+    for k in range(4):
+        lo.air[k] = float(air[k]) if k < len(air) else 1.0
+    return C.byref(lo)
 
 
 PLAN_BYTES = 40   # sizeof(dexct_ray_plan)
@@ -55,7 +71,8 @@ def load():
     lib.dexct_volume_layouts.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.dexct_fan_plan.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp]
     lib.dexct_siddon_project.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp,
-                                         vp, i32, i32, vp, vp, vp]
+                                         vp, i32, i32, vp, vp, vp, vp]
+    lib.dexct_sino_log.argtypes = [vp, C.POINTER(C.c_float), i32, i64, vp, vp]
     lib.dexct_add_noise.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, C.c_uint64, vp]
     lib.dexct_volume_groups.argtypes = [vp, i64, i32, vp, vp]
     lib.dexct_vmi.argtypes = [vp, vp, i64, f64, f64, f64, i32, vp, vp]
@@ -65,17 +82,17 @@ def load():
                                           f64, f64, vp, vp]
     lib.dexct_poisson_detect.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp]
     lib.dexct_cone_project.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, vp, i32, i32, i32, vp, vp,
-                                       vp, vp, vp]
+                                       vp, vp, vp, vp]
     lib.dexct_volume_pack2.argtypes = [vp, i64, vp, vp]
     lib.dexct_volume_groups_pack2.argtypes = [vp, i64, i32, vp, vp]
-    lib.dexct_siddon_project_packed.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp]
+    lib.dexct_siddon_project_packed.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.dexct_cone_layout.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.dexct_cone_project_rows.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, i32, i32, i32, vp, vp, vp,
-                                            vp, vp]
+                                            vp, vp, vp]
     lib.dexct_cone_layout_bytes.argtypes = [i32, i32, i32]
     lib.dexct_cone_layout_bytes.restype = i64
     lib.dexct_siddon_project_grouped.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp,
-                                                 i32, vp, vp, vp]
+                                                 i32, vp, vp, vp, vp]
     lib.dexct_siddon_project_grouped_packed.argtypes = lib.dexct_siddon_project_grouped.argtypes
     lib.dexct_transpose_batched.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     lib.dexct_fbp_filter.argtypes = [vp, vp, vp, i64, i32, f64, vp, vp]

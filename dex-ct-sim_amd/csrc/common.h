@@ -43,5 +43,10 @@ __device__ __forceinline__ SlabPieces dda_slab(long long Va, long long SV, uint3
   return s;
 }
 
+// The second output of get_sino (main.py:120-122): ln(air / counts) in float32, as np.log(np.float32(air) / raw)
+// computes it: v_rcp_f32 and v_log_f32 (1 ulp each); counts == 0 gives +inf like the NumPy expression.
+__device__ __forceinline__ float log_ratio(float air, float c) {
+  return __builtin_amdgcn_logf(air * __builtin_amdgcn_rcpf(c)) * 0.693147180559945309f;
+}
 
 }  // namespace dexct

@@ -64,6 +64,40 @@ extern "C" int dexct_add_noise(float* counts, const float* variance, int32_t n_s
   return DEXCT_OK;
 }
 
+// sino_log = ln(air / counts) as a pass of its own: for the noisy sinograms (their counts exist only after the sampling
+// above) and for callers that hold counts without having projected them here.
+namespace dexct {
+struct AirValues { float v[DEXCT_MAX_SPECTRA]; };
+__global__ __launch_bounds__(256) void sino_log_kernel(const float* __restrict__ counts, AirValues air, size_t n_rays,
+                                                       size_t n_total, float* __restrict__ out) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n_total) return;
+  if (i + 4 <= n_total && (n_rays & 3) == 0) {
+    const float a = air.v[i / n_rays];
+    const float4 c = *reinterpret_cast<const float4*>(counts + i);
+    *reinterpret_cast<float4*>(out + i) = make_float4(log_ratio(a, c.x), log_ratio(a, c.y), log_ratio(a, c.z), log_ratio(a, c.w));
+  } else {
+    for (size_t k = i; k < n_total && k < i + 4; ++k) out[k] = log_ratio(air.v[k / n_rays], counts[k]);
+  }
+}
+}  // namespace dexct
+
+extern "C" int dexct_sino_log(const float* counts, const float* air, int32_t n_spectra, int64_t n_rays, float* sino_log,
+                              void* stream) {
+  using namespace dexct;
+  if (!counts || !air || !sino_log || n_spectra < 1 || n_rays < 1) return DEXCT_EINVAL;
+  if (n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
+  AirValues av;
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) av.v[s] = s < n_spectra ? air[s] : 1.0f;
+  const size_t n_total = (size_t)n_spectra * (size_t)n_rays;
+  const size_t nblk = (n_total / 4 + 256) / 256;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(sino_log_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), counts, av, (size_t)n_rays,
+                     n_total, sino_log);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Exact model for photon-starved rays: per energy bin N_e ~ Poisson(lambda_e), lambda_e = photons[s][e] *
 // exp(-sum_m mu[m][e] L_m), signal = sum_e gain[e] * N_e.  One Philox block per (ray, spectrum, energy).

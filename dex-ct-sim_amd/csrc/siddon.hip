@@ -64,6 +64,7 @@ __device__ __forceinline__ void detect_store_lds(const float* lds_L, int tid, in
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
     if (s < a.n_spectra) {
       a.counts[ray + s * sstride] = acc[s];
+      if (a.sino_log) a.sino_log[ray + s * sstride] = log_ratio(a.air[s], acc[s]);
       if (a.variance) a.variance[ray + s * sstride] = var[s];
     }
 }
@@ -287,7 +288,10 @@ __global__ __launch_bounds__(256) void wave_ray_kernel(ProjArgs a, const float* 
       if (sI < n_s) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc[sI] += __shfl_xor(acc[sI], o, 64);
-        if (lane == 0) a.counts[ray + sI * sstride] = acc[sI];
+        if (lane == 0) {
+          a.counts[ray + sI * sstride] = acc[sI];
+          if (a.sino_log) a.sino_log[ray + sI * sstride] = log_ratio(a.air[sI], acc[sI]);
+        }
       }
   }
 }
@@ -1248,7 +1252,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
                          const uint8_t* vol_yx, const uint8_t* vol_xy, const uint8_t* vol_zf, int32_t n_materials,
                          int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights, float* counts,
                          float* pathlen, int32_t kernel, int32_t layout, const float* weights2, float* variance,
-                         void* stream) {
+                         const dexct_log_out* log_out, void* stream) {
   if (!geom || !plan || !mu || !weights || !counts) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
@@ -1281,6 +1285,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
   a.acc_out = nullptr;
   a.mat_base = 0;
   a.layout = layout;
+  if (set_log_out(a, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
   const Tables t{mu, weights, weights2};
   a.view_tile = kViewTileDefault;
   if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.view_tile = t; }   // tuning knob
@@ -1341,7 +1346,7 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
                                  int32_t view_end, const uint8_t* codes, int32_t n_materials, int32_t n_energies,
                                  int32_t n_spectra, const float* mu, const float* weights, float* counts, float* pathlen,
                                  float* acc_scratch, int32_t layout, const float* weights2, float* variance,
-                                 void* stream) {
+                                 const dexct_log_out* log_out, void* stream) {
   if (!geom || !plan || !codes || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 2 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
@@ -1366,6 +1371,7 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
   a.variance = variance;
   a.layout = layout;
   a.acc_out = acc_scratch;
+  if (set_log_out(a, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
   a.view_tile = kViewTileDefault;
   if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.view_tile = t; }
   const Tables t{mu, weights, weights2};

@@ -36,6 +36,8 @@ struct ConeArgs {
   int n_materials, n_energies, n_spectra;
   float* counts;           // [S][view][row][channel]
   float* pathlen;          // optional [ray][M]
+  float* sino_log;         // optional [S][view][row][channel]: ln(air[s] / counts)
+  float air[DEXCT_MAX_SPECTRA];
 };
 
 template <int NM>
@@ -169,7 +171,10 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
   }
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
-    if (s < a.n_spectra) a.counts[ray + s * sstride] = accs[s];
+    if (s < a.n_spectra) {
+      a.counts[ray + s * sstride] = accs[s];
+      if (a.sino_log) a.sino_log[ray + s * sstride] = log_ratio(a.air[s], accs[s]);
+    }
 }
 
 template <int NM>
@@ -393,7 +398,10 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   }
 #pragma unroll
   for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
-    if (sI < a.n_spectra) a.counts[ray + sI * sstride] = accs[sI];
+    if (sI < a.n_spectra) {
+      a.counts[ray + sI * sstride] = accs[sI];
+      if (a.sino_log) a.sino_log[ray + sI * sstride] = log_ratio(a.air[sI], accs[sI]);
+    }
 }
 
 // vol [nz][ny][nx] -> guarded z-fastest layout [(ny*nx + 1)][nz + 2]: guard slices and the extra column hold 3.
@@ -418,7 +426,8 @@ extern "C" int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_pl
                                   const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
                                   int32_t view_begin, int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
                                   int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
-                                  const float* weights, float* counts, float* pathlen, void* stream) {
+                                  const float* weights, float* counts, float* pathlen, const dexct_log_out* log_out,
+                                  void* stream) {
   if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_yx || !vol_xy || !mu || !weights || !counts)
     return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
@@ -447,6 +456,8 @@ extern "C" int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_pl
   a.n_spectra = n_spectra;
   a.counts = counts;
   a.pathlen = pathlen;
+  a.sino_log = log_out ? log_out->sino_log : nullptr;
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = log_out ? log_out->air[s] : 1.0f;
   hipStream_t st = as_stream(stream);
   switch (n_materials) {
     case 1: return launch_cone<1>(a, mu, weights, st);
@@ -477,7 +488,8 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
                                        const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
                                        int32_t view_begin, int32_t view_end, const uint8_t* vol_zc,
                                        int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
-                                       const float* weights, float* counts, float* pathlen, void* stream) {
+                                       const float* weights, float* counts, float* pathlen,
+                                       const dexct_log_out* log_out, void* stream) {
   if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_zc || !mu || !weights || !counts) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
@@ -502,6 +514,8 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
   a.n_spectra = n_spectra;
   a.counts = counts;
   a.pathlen = pathlen;
+  a.sino_log = log_out ? log_out->sino_log : nullptr;
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = log_out ? log_out->air[s] : 1.0f;
   const int n_chunks = (geom->n_rows + kConeRows - 1) / kConeRows;
   const size_t nblk = (size_t)a.n_local_views * geom->n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;

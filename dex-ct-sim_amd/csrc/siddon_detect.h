@@ -34,7 +34,23 @@ struct ProjArgs {
   // three materials; raw accumulators (units of u) go to acc_out[(mat_base + code)*n_rays + ray], no detection
   float* acc_out;
   int mat_base;
+  // second output of get_sino (main.py:120-122): sino_log[s][ray] = ln(air[s] / counts[s][ray]), same ray order as
+  // counts; null = not wanted.  air[s] = sum_e w[s][e] (the unattenuated signal), given by the caller.
+  float* sino_log;
+  float air[DEXCT_MAX_SPECTRA];
 };
+
+// log_out of the C ABI -> launch arguments (null: no log sinogram).  With a variance output the log belongs to the noisy
+// counts, which only exist after dexct_add_noise: the caller then uses dexct_sino_log.
+inline int set_log_out(ProjArgs& a, const dexct_log_out* lo, const float* variance) {
+  a.sino_log = nullptr;
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = 1.0f;
+  if (!lo || !lo->sino_log) return DEXCT_OK;
+  if (variance) return DEXCT_EINVAL;
+  a.sino_log = lo->sino_log;
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = lo->air[s];
+  return DEXCT_OK;
+}
 
 // launch arguments of rows16_kernel (siddon_packed.hip): the 2-bit packed volume
 struct PackedArgs {
@@ -44,6 +60,7 @@ struct PackedArgs {
   int n_zchunks;           // ceil(n_rows / 1024)
   int view_tile;
   int det_masks;           // skip detection FMAs of spectrum slots with zero weights (blocks of four energies)
+  int staged_store;        // store the results of a wave through LDS as whole lines (DEXCT_P16_STAGED=0: per-round 16-B stores)
 };
 
 // The attenuation and weight tables are passed as DIRECT __restrict__ kernel arguments (not inside
@@ -182,15 +199,16 @@ struct AirCache {
 // counts[s] = sum_e w[s][e] * exp(-sum_m mu[m][e] * L[m]) (v_exp_f32 on the log2(e)-scaled exponent)
 // for R rays at once (R = 4 in rows4_kernel: one scalar table load serves 4 rays and the FMAs pair up
 // into v_pk_fma_f32).  mu and w are wave-uniform (scalar loads); NM materials in registers.
-template <int NM, int R>
+// EXTRAS = false leaves out the optional path-length and variance outputs (the caller writes them or has none).
+template <int NM, int R, bool EXTRAS = true>
 __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const ProjArgs& a, const float* __restrict__ mu,
                                              const float* __restrict__ w, const float* __restrict__ w2,
                                              const size_t (&ray)[R], const bool (&valid)[R],
                                              const BlockMasks& bm = BlockMasks{{~0ull, ~0ull}, false},
-                                             AirCache* air_cache = nullptr) {
+                                             AirCache* air_cache = nullptr, float (*res_out)[2][R] = nullptr) {
   const int n_e = a.n_energies;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
-  if (a.pathlen) {
+  if (EXTRAS && a.pathlen) {
 #pragma unroll
     for (int q = 0; q < R; ++q)
       if (valid[q]) {
@@ -262,7 +280,7 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
     detect_energies<NM, R, 2>(Lp, mu, w, n_e, srow, bm, acc);
   else
     detect_energies<NM, R, DEXCT_MAX_SPECTRA>(Lp, mu, w, n_e, srow, bm, acc);
-  if (a.variance) {
+  if (EXTRAS && a.variance) {
     // second pass, only when noise is requested: var_s = sum_e w2[s][e] * exp(-P_e), w2 = w * (signal per photon)
     float var[DEXCT_MAX_SPECTRA][R];
 #pragma unroll
@@ -295,6 +313,13 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
           if (valid[q]) a.variance[ray[q] + s * sstride] = var[s][q];
       }
   }
+  if (res_out) {           // the caller stores (rows16_kernel: whole lines after its last round)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < R; ++q) (*res_out)[s][q] = acc[s][q];
+    return;
+  }
   // 4 consecutive rays (layout 1, rows4_kernel): one 16-byte store per spectrum
   const bool vec4 = R == 4 && a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[R - 1];
 #pragma unroll
@@ -303,10 +328,17 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
       if (vec4) {
         *reinterpret_cast<float4*>(a.counts + ray[0] + s * sstride) =
             make_float4(acc[s][0], acc[s][R > 1 ? 1 : 0], acc[s][R > 2 ? 2 : 0], acc[s][R > 3 ? 3 : 0]);
+        if (a.sino_log)
+          *reinterpret_cast<float4*>(a.sino_log + ray[0] + s * sstride) =
+              make_float4(log_ratio(a.air[s], acc[s][0]), log_ratio(a.air[s], acc[s][R > 1 ? 1 : 0]),
+                          log_ratio(a.air[s], acc[s][R > 2 ? 2 : 0]), log_ratio(a.air[s], acc[s][R > 3 ? 3 : 0]));
       } else {
 #pragma unroll
         for (int q = 0; q < R; ++q)
-          if (valid[q]) a.counts[ray[q] + s * sstride] = acc[s][q];
+          if (valid[q]) {
+            a.counts[ray[q] + s * sstride] = acc[s][q];
+            if (a.sino_log) a.sino_log[ray[q] + s * sstride] = log_ratio(a.air[s], acc[s][q]);
+          }
       }
     }
 }

@@ -116,7 +116,8 @@ struct Sliced {
 
 // GROUPED: a material-group pass (ids = codes 0..3 of one group of three materials): raw accumulators (units of u) go to
 // acc_out[(mat_base + code) * n_rays + ray], no detection (dexct_siddon_project_grouped_packed).
-template <int NM, int MINW = 4, bool GROUPED = false>      // MINW: waves per SIMD the register allocation must allow
+// STAGED: results leave through LDS as whole lines (see below); the host picks it whenever it applies.
+template <int NM, int MINW = 4, bool GROUPED = false, bool STAGED = false>      // MINW: waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
                                                     const float* __restrict__ w2) {
   static_assert(NM >= 2 && NM <= 4, "ids 0..3");
@@ -271,7 +272,17 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   }
   cnt.finish();
   if (BOTH) cnt3.finish();
-  if (!pair_live || r0 >= a.g.n_rows) return;
+  // STAGED (the usual case: row-fastest output, whole groups of 4 rows, no more spectra than correction arrays): the
+  // four detection rounds leave their results in registers and the wave stores them through LDS at the end, so that one
+  // store instruction writes 1 KiB of consecutive addresses (whole 64-byte lines) instead of 64 separate 16-byte pieces
+  // per round - every lane's 64 output bytes used to leave as four partial writes (WRITE_SIZE 2.1x the output bytes).
+  // All lanes then stay to the end, because a lane also stores pieces of other lanes.
+  constexpr int kResSlots = (NM - 1) < 2 ? (NM - 1) : 2;
+  static_assert(!(GROUPED && STAGED), "group passes hand over raw accumulators");
+  constexpr bool staged = STAGED;            // host: layout 1, n_rows % 4 == 0, n_spectra <= kResSlots
+  const bool lane_live = pair_live && r0 < a.g.n_rows;
+  if (!staged && !lane_live) return;
+  if (lane_live)
   // ---- un-slice the counters (in place of the corrections), then detect 4 rows at a time.  The rounds are a real
   // loop with ONE copy of the detection code (rows move down the register array between rounds): four inlined copies
   // made the kernel as large as the instruction cache two CUs share.
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
     }
   }
   if (GROUPED) {         // hand the raw accumulators to the detection kernel, one plane per material of the group
+    if (!lane_live) return;
     const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
@@ -317,27 +329,82 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   AirCache air_cache{0.0f, {0.0f, 0.0f}, false};
 #pragma unroll 1
   for (int q4 = 0; q4 < 4; ++q4) {
-    if (r0 + 4 * q4 >= a.g.n_rows) break;
-    float L[4][NM];
-    size_t rays[4];
-    bool valid[4];
+    const bool round_live = lane_live && r0 + 4 * q4 < a.g.n_rows;
+    if (!staged && !round_live) break;
+    float res[2][4];
+    if (round_live) {
+      float L[4][NM];
+      size_t rays[4];
+      bool valid[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int r = r0 + 4 * q4 + rr;
-      valid[rr] = r < a.g.n_rows;
-      rays[rr] = ray_index(a, v, valid[rr] ? r : 0, c);
-      float others = 0.0f;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = r0 + 4 * q4 + rr;
+        valid[rr] = r < a.g.n_rows;
+        rays[rr] = ray_index(a, v, valid[rr] ? r : 0, c);
+        float others = 0.0f;
 #pragma unroll
-      for (int m = 1; m < NM; ++m) others += corr[m - 1][rr];
-      L[rr][0] = (p.chord_u - others) * p.len_per_u;
+        for (int m = 1; m < NM; ++m) others += corr[m - 1][rr];
+        L[rr][0] = (p.chord_u - others) * p.len_per_u;
 #pragma unroll
-      for (int m = 1; m < NM; ++m) L[rr][m] = corr[m - 1][rr] * p.len_per_u;
+        for (int m = 1; m < NM; ++m) L[rr][m] = corr[m - 1][rr] * p.len_per_u;
+      }
+      if constexpr (staged) {
+        if (a.pathlen) {             // (test output) written here so that the detection holds no store addresses
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            if (valid[rr]) {
+#pragma unroll
+              for (int m = 0; m < NM; ++m) a.pathlen[rays[rr] * NM + m] = L[rr][m];
+            }
+        }
+        detect_store<NM, 4, false>(L, a, mu, w, w2, rays, valid, bm, &air_cache, &res);
+      } else {
+        detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm, &air_cache);
+      }
     }
-    detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm, &air_cache);
+    // the rows move down; the four rows just detected leave the array and, when staged, their results enter at its top:
+    // after the fourth round corr[s][row] holds the counts of spectrum s for the lane's row `row`
 #pragma unroll
     for (int m = 0; m < NM - 1; ++m)
 #pragma unroll
       for (int row = 0; row < 12; ++row) corr[m][row] = corr[m][row + 4];
+    if (staged) {
+#pragma unroll
+      for (int s = 0; s < kResSlots; ++s)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) corr[s][12 + rr] = res[s][rr];
+    }
+  }
+  if constexpr (!staged) return;
+  // ---- whole-line stores: lane l writes its four 16-byte pieces to LDS at 64 l + 16 c; store instruction k then takes
+  // piece 64 k + lane = (lane l' = piece / 4, c' = piece % 4) - consecutive lanes write consecutive 16 bytes
+  float4* stage = reinterpret_cast<float4*>(lds_lists);
+  const int lpp_shift = __builtin_ctz((unsigned)lpp);
+  const int c_base = c - g;                                    // first channel of the wave
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+#pragma unroll
+  for (int s = 0; s < kResSlots; ++s) {
+    if (s >= a.n_spectra) break;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      stage[lane * 4 + cc] = make_float4(corr[s][4 * cc], corr[s][4 * cc + 1], corr[s][4 * cc + 2], corr[s][4 * cc + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int piece = k * 64 + lane, l2 = piece >> 2, c2 = piece & 3;
+      const int g2 = l2 >> lpp_shift, li2 = l2 - (g2 << lpp_shift);
+      const int row = (zc * 64 + li2) * 16 + 4 * c2, chan = c_base + g2;
+      if (chan < a.g.n_channels && row < a.g.n_rows) {
+        const float4 x = stage[piece];
+        const size_t at = s * sstride + ((size_t)v * a.g.n_channels + chan) * a.g.n_rows + row;
+        *reinterpret_cast<float4*>(a.counts + at) = x;
+        if (a.sino_log)
+          *reinterpret_cast<float4*>(a.sino_log + at) = make_float4(log_ratio(a.air[s], x.x), log_ratio(a.air[s], x.y),
+                                                                    log_ratio(a.air[s], x.z), log_ratio(a.air[s], x.w));
+      }
+    }
   }
 }
 
@@ -387,11 +454,14 @@ static int packed_shape(const dexct_fan_geom* geom, int32_t view_begin, int32_t 
   pa.view_tile = 8;
   pa.det_masks = 1;
   if (const char* e = getenv("DEXCT_DET_MASKS")) pa.det_masks = atoi(e) != 0;
+  pa.staged_store = 1;
+  if (const char* e = getenv("DEXCT_P16_STAGED")) pa.staged_store = atoi(e) != 0;
   if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) pa.view_tile = t; }
   const int n_pairs = 64 / pa.lanes_per_pair;
   nblk = (size_t)(view_end - view_begin) * ((geom->n_channels + n_pairs - 1) / n_pairs) * pa.n_zchunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   lds = (size_t)n_pairs * kP16Super * (sizeof(CrossRec) + sizeof(uint32_t));
+  if (lds < 64 * 64) lds = 64 * 64;           // the staged store of the results: 64 bytes per lane
   return DEXCT_OK;
 }
 
@@ -427,7 +497,7 @@ int dexct_volume_groups_pack2(const uint8_t* vol_zf, int64_t n_voxels, int32_t n
 int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                                 int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
                                 int32_t n_spectra, const float* mu, const float* weights, float* counts, float* pathlen,
-                                int32_t layout, void* stream) {
+                                int32_t layout, const dexct_log_out* log_out, void* stream) {
   if (!geom || !plan || !vol_z2 || !mu || !weights || !counts) return DEXCT_EINVAL;
   if (n_energies < 1 || n_spectra < 1) return DEXCT_EINVAL;
   if (n_materials < 2 || n_materials > 4 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;     // ids 0..3
@@ -451,16 +521,27 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   a.acc_out = nullptr;
   a.mat_base = 0;
   a.layout = layout;
+  set_log_out(a, log_out, nullptr);
   a.view_tile = pa.view_tile;
   pa.vol_z2 = vol_z2;
   hipStream_t st = as_stream(stream);
   int minw = 4;
   if (const char* e = getenv("DEXCT_P16_MINW")) minw = atoi(e);      // tuning knob
   const float* none = nullptr;
-  if (n_materials == 2)
+  // whole-line stores through LDS (STAGED) wherever the output allows them: row-fastest layout, whole groups of 4 rows,
+  // and the results of all spectra fit the registers the corrections leave behind
+  const int res_slots = n_materials - 1 < 2 ? n_materials - 1 : 2;
+  const bool staged = pa.staged_store && layout == 1 && geom->n_rows % 4 == 0 && n_spectra <= res_slots;
+  if (n_materials == 2 && staged)
+    hipLaunchKernelGGL((rows16_kernel<2, 4, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
+  else if (n_materials == 2)
     hipLaunchKernelGGL((rows16_kernel<2>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
+  else if (n_materials == 4 && staged)
+    hipLaunchKernelGGL((rows16_kernel<4, 3, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (n_materials == 4)
     hipLaunchKernelGGL((rows16_kernel<4, 3>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
+  else if (staged && minw == 4)
+    hipLaunchKernelGGL((rows16_kernel<3, 4, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (minw == 5)
     hipLaunchKernelGGL((rows16_kernel<3, 5>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (minw == 6)
@@ -477,7 +558,7 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
                                         int32_t view_end, const uint8_t* codes2, int32_t n_materials, int32_t n_energies,
                                         int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                         float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
-                                        float* variance, void* stream) {
+                                        float* variance, const dexct_log_out* log_out, void* stream) {
   if (!geom || !plan || !codes2 || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
   if (n_materials < 2 || n_energies < 1 || n_spectra < 1) return DEXCT_EINVAL;
   if (n_materials > DEXCT_MAX_MATERIALS || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
@@ -502,6 +583,7 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
   a.acc_out = acc_scratch;
   a.mat_base = 0;
   a.layout = layout;
+  if (set_log_out(a, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
   a.view_tile = pa.view_tile;
   hipStream_t st = as_stream(stream);
   const size_t group_bytes = (size_t)geom->nx * geom->ny * (geom->nz / 4);

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _native, _shard
-from ._device import device, ptr, stream_ptr, to_dev
+from ._device import device, ptr, stream_ptr, to_dev, to_host
 
 
 def effective_weights(ct, spec):
@@ -49,8 +49,8 @@ class Projector:
     rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel (1 row per lane),
     3 row-parallel with 4 rows per lane (<= 4 materials, Nz and z_index multiples of 4), 4 the same kernel
     run once per group of three materials (5..48 materials), 5 the 4-rows-per-lane kernel with a tile of
-    neighbouring (view, channel) pairs per workgroup walking the volume in step (rows4t_kernel: what kernel 0
-    picks for stacked fans of >= 256 rows; same bits as kernel 3), 6 one wavefront per ray (lanes over
+    neighbouring (view, channel) pairs per workgroup walking the volume in step (rows4t_kernel: opt-in, kept for A/B
+    runs - kernel 0 never picks it; same bits as kernel 3), 6 one wavefront per ray (lanes over
     dominant-axis slabs, shuffle reductions, tables in LDS: the mapping BASELINE.json's north star names; <= 4
     materials), 7 the stacked fan on a 2-bit packed volume with bit-sliced counters (rows16_kernel: 16 rows per
     lane; <= 4 materials; what kernel 0 picks from 192 rows on when a pair fills 3/4 of its lane group), 8 the same
@@ -176,8 +176,13 @@ class Projector:
             return 1
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 
-    def project_tables(self, mu_d, w_d, want_pathlen=False, out=None, layout=0, w2_d=None, seed=0):
+    def project_tables(self, mu_d, w_d, want_pathlen=False, out=None, layout=0, w2_d=None, seed=0, air=None,
+                       log_out=None):
         """Device-side call: mu_d [M, nE], w_d [S, nE] float32 tensors -> counts.
+
+        ``air`` (S unattenuated signals, sum_e w[s][e]) asks for get_sino's second output as well, the log sinogram
+        ln(air / counts) (main.py:120-122), written by the projection kernel's own detection store (dexct_log_out) into
+        ``log_out`` or a new tensor of the counts' shape; the call then returns (counts[, pathlen], log).
 
         layout 0: counts [S, nV, rows, channels] (the reference's order); layout 1: [S, nV, channels, rows]
         (what the row-parallel kernels produce natively); ``layout=None`` returns the native one.  When
@@ -204,6 +209,12 @@ class Projector:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
         variance = torch.empty_like(counts) if w2_d is not None else None
+        log = None
+        if air is not None:
+            log = log_out if (log_out is not None and direct) else torch.empty(shape[run_layout], dtype=torch.float32,
+                                                                               device=self.dev)
+        # fused into the detection store, except for noisy sinograms (their counts exist after the sampling)
+        lo = _native.log_out(ptr(log), air) if (log is not None and w2_d is None) else None
         if self.cone:
             if w2_d is not None:
                 raise NotImplementedError('noise is not available for cone-beam scans')
@@ -212,59 +223,86 @@ class Projector:
                 _native.check(self.lib.dexct_cone_project_rows(
                     C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
                     self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
-                    ptr(w_d), ptr(counts), ptr(pathlen), stream_ptr()), 'dexct_cone_project_rows')
+                    ptr(w_d), ptr(counts), ptr(pathlen), lo, stream_ptr()), 'dexct_cone_project_rows')
             else:
                 _native.check(self.lib.dexct_cone_project(
                     C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
                     self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
-                    ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), stream_ptr()), 'dexct_cone_project')
+                    ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), lo, stream_ptr()), 'dexct_cone_project')
         elif self.use_packed and w2_d is None:           # (with noise the byte-volume kernel below runs: it carries the variance)
             _native.check(self.lib.dexct_siddon_project_packed(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_z2), M, nE, S,
-                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, stream_ptr()), 'dexct_siddon_project_packed')
+                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, lo, stream_ptr()), 'dexct_siddon_project_packed')
         elif self.grouped_packed:                        # noise too: the detection pass carries the variance
             scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
             _native.check(self.lib.dexct_siddon_project_grouped_packed(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
                 ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
-                stream_ptr()), 'dexct_siddon_project_grouped_packed')
+                lo, stream_ptr()), 'dexct_siddon_project_grouped_packed')
         elif self.grouped:
             scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
             _native.check(self.lib.dexct_siddon_project_grouped(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
                 ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
-                stream_ptr()), 'dexct_siddon_project_grouped')
+                lo, stream_ptr()), 'dexct_siddon_project_grouped')
         else:
             _native.check(self.lib.dexct_siddon_project(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx),
                 ptr(self.vol_xy), ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
-                3 if self.kernel in (7, 8) else self.kernel, run_layout, ptr(w2_d), ptr(variance), stream_ptr()),
+                3 if self.kernel in (7, 8) else self.kernel, run_layout, ptr(w2_d), ptr(variance), lo, stream_ptr()),
                 'dexct_siddon_project')
         if variance is not None:
             _native.check(self.lib.dexct_add_noise(ptr(counts), ptr(variance), S, nV, nR, nC, run_layout,
                                                    self.view_begin, int(seed) & (2 ** 64 - 1), stream_ptr()),
                           'dexct_add_noise')
+            if log is not None:
+                self.sino_log(counts, air, log)
         if not direct:
             dst = out if out is not None else torch.empty(shape[want], dtype=torch.float32, device=self.dev)
             r, c = (nC, nR) if run_layout == 1 else (nR, nC)
             _native.check(self.lib.dexct_transpose_batched(ptr(counts), ptr(dst), S * nV, r, c, 4, stream_ptr()),
                           'dexct_transpose_batched')
             counts = dst
+            if log is not None:
+                dst = log_out if log_out is not None else torch.empty(shape[want], dtype=torch.float32, device=self.dev)
+                _native.check(self.lib.dexct_transpose_batched(ptr(log), ptr(dst), S * nV, r, c, 4, stream_ptr()),
+                              'dexct_transpose_batched')
+                log = dst
             if pathlen is not None:
                 pathlen = pathlen.permute(0, 2, 1, 3).contiguous()      # test-only output
-        return (counts, pathlen) if want_pathlen else counts
+        res = (counts, pathlen) if want_pathlen else (counts,)
+        if log is not None:
+            res = res + (log,)
+        return res if len(res) > 1 else res[0]
 
-    def project(self, specs, want_pathlen=False, layout=0, noise=False, seed=0):
+    def sino_log(self, counts, air, out=None):
+        """ln(air[s] / counts[s]) as a pass of its own (dexct_sino_log): noisy and gathered sinograms."""
+        import ctypes as _C
+        S = counts.shape[0]
+        out = torch.empty_like(counts) if out is None else out
+        arr = (_C.c_float * S)(*[float(x) for x in air[:S]])
+        _native.check(self.lib.dexct_sino_log(ptr(counts), arr, S, counts[0].numel(), ptr(out), stream_ptr()),
+                      'dexct_sino_log')
+        return out
+
+    def project(self, specs, want_pathlen=False, layout=0, noise=False, seed=0, want_log=False):
         """noise: False (expectation), True / 'gaussian' (compound-Poisson variance, normal sample) or 'poisson'
-        (per-energy-bin Poisson photon counts: exact for photon-starved rays, ~5x the projection time)."""
+        (per-energy-bin Poisson photon counts: exact for photon-starved rays, ~5x the projection time).
+        ``want_log``: also the log sinogram ln(air / counts), from the device (appended to the projection's result)."""
         if not noise:
             _, mu_d, w_d, air = self.upload_tables(specs)
-            return self.project_tables(mu_d, w_d, want_pathlen, layout=layout), air
+            return self.project_tables(mu_d, w_d, want_pathlen, layout=layout, air=air if want_log else None), air
         if noise == 'poisson':
-            return self._project_poisson(specs, want_pathlen, layout, seed)
+            res, air = self._project_poisson(specs, want_pathlen, layout, seed)
+            if want_log:
+                res = (res if isinstance(res, tuple) else (res,))
+                res = res + (self.sino_log(res[0], air),)
+            return res, air
         _, mu, w, w2 = merged_tables(self.ct, self.phantom, specs, with_variance=True)
         mu_d, w_d, w2_d = (to_dev(x, torch.float32, self.dev) for x in (mu, w, w2))
-        return self.project_tables(mu_d, w_d, want_pathlen, layout=layout, w2_d=w2_d, seed=seed), w.sum(axis=1)
+        air = w.sum(axis=1)
+        return self.project_tables(mu_d, w_d, want_pathlen, layout=layout, w2_d=w2_d, seed=seed,
+                                   air=air if want_log else None), air
 
     def _project_poisson(self, specs, want_pathlen, layout, seed):
         E, mu, w = merged_tables(self.ct, self.phantom, specs)
@@ -302,29 +340,46 @@ class Projector:
 
 _cache = {}
 
+# True: checksum the whole volume on every call (64-bit; 16 ms per 128 MiB with xxhash, ~0.1 s without) - the round-2
+# behaviour.  Default: an O(1) key (below).  Also switched on by DEXCT_VERIFY_VOLUME=1.
+verify_volume = False
 
-def _checksum(a):
-    """64-bit checksum of an array's bytes: xxh3 where the xxhash module is present (16 ms per 128 MiB), else crc32
-    (0.13 s per 128 MiB)."""
+
+def _hash64(a):
+    """64-bit hash of an array's bytes: xxh3 where the xxhash module is present, else blake2b."""
     a = np.ascontiguousarray(a)
     try:
         import xxhash
         return xxhash.xxh3_64_intdigest(a.data)
     except ImportError:
-        import zlib
-        return zlib.crc32(a.data)
+        import hashlib
+        return int.from_bytes(hashlib.blake2b(a.data, digest_size=8).digest(), 'little')
+
+
+def _volume_key(phantom):
+    """What identifies the bytes of ``phantom.volume`` without reading them all: the phantom's version counter (bumped
+    whenever ``volume`` is assigned and by ``phantom.touch()``, which a caller who edits the array IN PLACE must call -
+    or ``invalidate()``), the identity and shape of the array, and a hash of 4096 evenly spaced voxels (cheap, and it
+    catches most in-place edits that forget ``touch()``).  ``verify_volume`` / DEXCT_VERIFY_VOLUME=1 hashes every byte."""
+    import os
+    v = phantom.volume
+    flat = v.reshape(-1)
+    step = max(1, flat.size // 4096)
+    key = (getattr(phantom, 'version', 0), id(v), v.shape, _hash64(flat[::step]))
+    if verify_volume or os.environ.get('DEXCT_VERIFY_VOLUME', '0') == '1':
+        key += (_hash64(v),)
+    return key
 
 
 def _fingerprint(ct, phantom, view_range):
     """Everything the device-resident state (volume layouts, ray plans) depends on.  The reference rebuilds its
     state on every get_sino call; here the state is reused only while the scanner numbers, the voxel sizes and
-    the volume's bytes (checksummed on the host at every call) are what they were when it was built - in-place
-    edits of ``phantom.volume`` or of ``ct.SID`` between two calls are therefore seen."""
+    the volume (see _volume_key: O(1), not a checksum of 128 MiB per call) are what they were when it was built."""
     return (id(ct), id(phantom), view_range, ct.N_proj, ct.N_channels, ct.N_rows, ct.SID, ct.SDD,
-            _checksum(ct.thetas), _checksum(ct.gammas),
+            _hash64(ct.thetas), _hash64(ct.gammas),
             ct.h_iso, bool(getattr(ct, 'cone', False)), float(getattr(ct, 'src_z', 0.0)),
             phantom.z_index, phantom.Nx, phantom.Ny, phantom.Nz, phantom.dx, phantom.dy, phantom.dz,
-            phantom.n_materials, np.shape(phantom.volume), _checksum(phantom.volume))
+            phantom.n_materials) + _volume_key(phantom)
 
 
 def invalidate():
@@ -350,22 +405,25 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0):
     noise-free expectation, which is what every parity test uses.
 
     Returns a list of (sino_raw, sino_log) float32 NumPy pairs, shaped [N_proj, N_channels]
-    (or [N_proj, N_rows, N_channels] for N_rows > 1).  Under torch.distributed the projection angles
-    are sharded over the ranks and every rank returns the full gathered sinograms.
+    (or [N_proj, N_rows, N_channels] for N_rows > 1).  Both come from the device (the log sinogram is written by
+    the projection kernel's detection store) through page-locked host memory: the arrays returned are views of a
+    pinned buffer that belongs to them alone (torch's caching host allocator hands it out again once they are
+    garbage).  Under torch.distributed the projection angles are sharded over the ranks and every rank returns the
+    full gathered sinograms.
     """
     vb, ve = _shard.my_views(ct.N_proj)
     pj = _projector(ct, phantom, (vb, ve))
-    counts, air = pj.project(specs, noise=noise, seed=seed)
-    counts = _shard.gather_views(counts, ct.N_proj, view_dim=1)
-    raw = counts.cpu().numpy()
+    sharded = _shard.world()[1] > 1
+    res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded)
+    if sharded:
+        counts = _shard.gather_views(res, ct.N_proj, view_dim=1)
+        log = pj.sino_log(counts, air)              # of the gathered sinogram: one collective instead of two
+    else:
+        counts, log = res
+    raw, lg = to_host(counts), to_host(log)
     if ct.N_rows == 1:
-        raw = raw[:, :, 0, :]
-    out = []
-    for k in range(len(specs)):
-        with np.errstate(divide='ignore'):
-            log = np.log(np.float32(air[k]) / raw[k])
-        out.append((raw[k], log.astype(np.float32)))
-    return out
+        raw, lg = raw[:, :, 0, :], lg[:, :, 0, :]
+    return [(raw[k], lg[k]) for k in range(len(specs))]
 
 
 def get_sino(ct, phantom, spec, noise=False, seed=0):

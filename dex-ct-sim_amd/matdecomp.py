@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _native, _shard, xcompy as xc
-from ._device import device, ptr, stream_ptr, to_dev
+from ._device import device, ptr, stream_ptr, to_dev, to_host
 
 # Basis materials, as data (matdecomp.py:11-17).
 mat1 = 'ICRU tissue'
@@ -53,6 +53,7 @@ def _as_device_counts(x, dev):
 
 
 _last_ws = None
+_last_zeroed = None
 
 
 def last_gn_stats():
@@ -89,6 +90,10 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
         precision = 'f64'               # mixed precision exists for the shared-spectrum fast path only
     a = out if out is not None else torch.empty(tuple(g1.shape) + (2,), dtype=torch.float64, device=dev)
     ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, n_bins), dtype=torch.uint8, device=dev)
+    ws[72:88].zero_()        # executed-iteration and finished-pixel counters: defined before anybody polls them
+    global _last_zeroed
+    _last_zeroed = torch.cuda.Event()
+    _last_zeroed.record()    # a progress poller on another stream waits for this (never reads uninitialised bytes)
     _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), int(g1.dtype == torch.float64), g1.numel(), ptr(i0_d),
                                          ptr(mus_d), n_e, n_bins, int(bin_div), int(n_iters),
                                          int(precision == 'mixed'), int(n_polish), ptr(mask_max), float(mask_frac), ptr(a),
@@ -104,15 +109,21 @@ def _progress_lines(ws, n_views, n_bins, done_event, t0, every=20, poll_s=0.05):
     kernel's own finished-pixel counter (workspace byte 80), read on a side stream while the kernel runs."""
     import time
     side = torch.cuda.Stream()
+    if _last_zeroed is not None:
+        side.wait_event(_last_zeroed)
     host = torch.zeros(1, dtype=torch.int64).pin_memory()
     counter = ws[80:88].view(torch.int64)
+    n_pix = n_views * max(n_bins, 1)
     next_view = 0
     while True:
         finished = done_event.query()
         with torch.cuda.stream(side):
             host.copy_(counter, non_blocking=True)
         side.synchronize()
-        views_done = n_views if finished else min(int(host.item()) // max(n_bins, 1), n_views)
+        done_pix = int(host.item())
+        if not 0 <= done_pix <= n_pix:      # never a value the kernel can have written: ignore
+            done_pix = 0
+        views_done = n_views if finished else min(done_pix // max(n_bins, 1), n_views)
         while next_view < n_views and next_view <= views_done:
             print(next_view, '/', n_views, f't={time.time() - t0:.2f}s')
             next_view += every
@@ -145,7 +156,7 @@ def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, preci
         done = torch.cuda.Event()
         done.record()
         _progress_lines(_last_ws, int(g.shape[1]), int(g[0].numel() // max(int(g.shape[1]), 1)), done, t0)
-    return a.cpu().numpy()
+    return to_host(a)
 
 
 optimize_sino_cpu = optimize_sino   # the reference's NumPy twin (:87); same engine here
@@ -171,7 +182,7 @@ def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None):
     g1 = _as_device_counts(sino1, dev)
     g2 = _as_device_counts(sino2, dev).to(g1.dtype)
     a = gn_device(g1, g2, i0, mus, n_iters, precision)
-    return a if isinstance(sino1, torch.Tensor) else a.cpu().numpy()
+    return a if isinstance(sino1, torch.Tensor) else to_host(a)
 
 
 def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None,
@@ -227,5 +238,5 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
         a = _shard.gather_views(a, n_views, view_dim=0)
     if isinstance(sino_raw_1, torch.Tensor):
         return a[..., 0], a[..., 1]
-    a = a.cpu().numpy()
+    a = to_host(a)          # page-locked: one DMA; the two results are views of this one buffer, like the reference's
     return a[..., 0], a[..., 1]

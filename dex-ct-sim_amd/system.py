@@ -159,6 +159,21 @@ class VoxelPhantom:
             raise ValueError('volume holds a material id without a table entry')
         return self
 
+    # The device-resident copy of the volume (forward_project._projector) is keyed on ``version``: assigning
+    # ``phantom.volume`` bumps it; after editing the array in place call ``touch()`` (or forward_project.invalidate()).
+    @property
+    def volume(self):
+        return self._volume
+
+    @volume.setter
+    def volume(self, v):
+        self._volume = v
+        self.version = getattr(self, 'version', 0) + 1
+
+    def touch(self):
+        """Tell the engine that ``volume`` was edited in place."""
+        self.version = getattr(self, 'version', 0) + 1
+
     @property
     def n_materials(self):
         return len(self.materials)

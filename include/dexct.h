@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DEXCT_ABI_VERSION 1
+#define DEXCT_ABI_VERSION 2   /* 2: log_out argument of the projection entry points, dexct_sino_log */
 
 #define DEXCT_OK 0
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
@@ -63,6 +63,16 @@ typedef struct dexct_ray_plan {
   float chord_u;     /* length of the ray inside the grid, in units of u */
   uint32_t flags;    /* bit0: dominant axis (0: u=x, v=y; 1: u=y, v=x); bit1: SV > 0 */
 } dexct_ray_plan;
+
+/* The second output of get_sino, `sino_raw, sino_log = get_sino(ct, phantom, spec)` (main.py:120-122; sino_log is what
+ * get_recon reconstructs, main.py:134): sino_log[s*n_rays + ray] = ln(air[s] / counts[s*n_rays + ray]) in float32, written
+ * by the projection's own detection store in the ray order of counts.  air[s] = sum_e weights[s*n_energies + e], the
+ * unattenuated signal.  Pass NULL (or a NULL sino_log) when the log sinogram is not wanted.  Not together with a
+ * variance output (DEXCT_EINVAL): the log of a noisy sinogram is taken after dexct_add_noise, by dexct_sino_log. */
+typedef struct dexct_log_out {
+  float* sino_log;              /* device, n_spectra * n_rays float32 */
+  float air[DEXCT_MAX_SPECTRA]; /* host values, copied into the launch arguments */
+} dexct_log_out;
 
 const char* dexct_strerror(int code);
 int dexct_abi_version(void);
@@ -111,7 +121,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
                          const uint8_t* vol_zf, int32_t n_materials, int32_t n_energies,
                          int32_t n_spectra, const float* mu, const float* weights, float* counts,
                          float* pathlen, int32_t kernel, int32_t layout, const float* weights2, float* variance,
-                         void* stream);
+                         const dexct_log_out* log_out, void* stream);
 
 /* Fast path for 5..DEXCT_MAX_MATERIALS materials (stacked fan, nz and z_first multiples of 4).
  * dexct_volume_groups: codes[g][voxel] for g < ceil((n_materials-1)/3): ids 3g+1..3g+3 of the z-fastest
@@ -125,7 +135,7 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
                                  int32_t view_end, const uint8_t* codes, int32_t n_materials, int32_t n_energies,
                                  int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                  float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
-                                 float* variance, void* stream);
+                                 float* variance, const dexct_log_out* log_out, void* stream);
 
 /* The stacked-fan projection on a 2-BIT PACKED volume (rows16_kernel; <= 4 materials, i.e. ids 0..3): a voxel is 2
  * bits, one dword load serves 16 detector rows, the per-row material counts are kept bit-sliced (carry-save adders).
@@ -139,7 +149,7 @@ int dexct_volume_pack2(const uint8_t* vol_zf, int64_t n_voxels, uint8_t* vol_z2,
 int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                                 int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
                                 int32_t n_spectra, const float* mu, const float* weights, float* counts,
-                                float* pathlen, int32_t layout, void* stream);
+                                float* pathlen, int32_t layout, const dexct_log_out* log_out, void* stream);
 
 /* Material groups on the packed volume (5..DEXCT_MAX_MATERIALS materials; the packed form of dexct_volume_groups /
  * dexct_siddon_project_grouped, same arguments and outputs; preconditions of dexct_siddon_project_packed).
@@ -151,7 +161,7 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
                                         int32_t view_end, const uint8_t* codes2, int32_t n_materials, int32_t n_energies,
                                         int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                         float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
-                                        float* variance, void* stream);
+                                        float* variance, const dexct_log_out* log_out, void* stream);
 
 /* Cone-beam (3-D) projection, SURVEY 8f.4: the fan of dexct_fan_plan in the (x, y) plane, source at height
  * src_z, detector row r at height row_z[r] (device float64 [n_rows], cm, z = 0 at the centre of the grid;
@@ -162,7 +172,7 @@ int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
                        const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
                        int32_t view_begin, int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
                        int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
-                       const float* weights, float* counts, float* pathlen, void* stream);
+                       const float* weights, float* counts, float* pathlen, const dexct_log_out* log_out, void* stream);
 
 /* The same projection with the ROWS of one (view, channel) pair as lanes (cone_rows_kernel): the in-plane slab
  * records are computed once per pair and shared by all its rows, a lane carries only its z DDA and reads one voxel
@@ -176,13 +186,18 @@ int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* pl
                             const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
                             int32_t view_begin, int32_t view_end, const uint8_t* vol_zc, int32_t n_materials,
                             int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights,
-                            float* counts, float* pathlen, void* stream);
+                            float* counts, float* pathlen, const dexct_log_out* log_out, void* stream);
 
 /* counts += sqrt(variance) * z, z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
  * channel, spectrum) and key seed: independent of view sharding and of the layout (0 / 1 as above).
  * Results are clipped at 1e-20 so that a log sinogram stays finite. */
 int dexct_add_noise(float* counts, const float* variance, int32_t n_spectra, int32_t n_views, int32_t n_rows,
                     int32_t n_channels, int32_t layout, int32_t view_offset, uint64_t seed, void* stream);
+
+/* sino_log[s*n_rays + ray] = ln(air[s] / counts[s*n_rays + ray]) as a pass of its own (air: n_spectra HOST floats): for
+ * noisy sinograms, whose counts exist only after dexct_add_noise / dexct_poisson_detect, and for counts that were not
+ * projected in this call.  Same arithmetic as the fused form (dexct_log_out). */
+int dexct_sino_log(const float* counts, const float* air, int32_t n_spectra, int64_t n_rays, float* sino_log, void* stream);
 
 /* Exact quantum noise: counts[s][ray] = sum_e gain[e] * Poisson(photons[s][e] * exp(-sum_m mu[m][e] * pathlen[ray][m])),
  * from the per-material path lengths a projection wrote (pathlen [ray][n_materials], cm, same ray order =

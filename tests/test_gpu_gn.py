@@ -179,7 +179,7 @@ def test_entry_points_are_graph_capturable(hip):
         _native.check(lib.dexct_fan_plan(C.byref(pj.geom), ptr(pj.view_cs), ptr(pj.chan_cs), 0, 10, ptr(pj.plan), st), 'plan')
         _native.check(lib.dexct_siddon_project(C.byref(pj.geom), ptr(pj.plan), 0, 10, ptr(pj.vol_yx), ptr(pj.vol_xy),
                                                ptr(pj.vol_zf), 3, mu_d.shape[1], 2, ptr(mu_d), ptr(w_d), ptr(counts),
-                                               None, 3, 1, None, None, st), 'project')
+                                               None, 3, 1, None, None, None, st), 'project')
         _native.check(lib.dexct_reduce_max(ptr(counts[0]), 0, counts[0].numel(), ptr(gmax), st), 'max')
         _native.check(lib.dexct_gn_decompose(ptr(counts[0]), ptr(counts[1]), 0, counts[0].numel(), ptr(i0_d), ptr(mus_d),
                                              i0.shape[1], 1, 1, 30, 0, 0, None, 0.0, ptr(a), ptr(ws), st), 'gn')

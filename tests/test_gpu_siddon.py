@@ -682,3 +682,116 @@ def test_material_groups_on_the_packed_volume(hip, n_rows, n_mat):
     n8, _ = pj8.project(sp, noise=True, seed=3)
     n4, _ = projector(ct, ph, kernel=4).project(sp, noise=True, seed=3)
     assert torch.equal(n8, n4) and not torch.equal(n8, c8)
+
+
+# ---- round 3: the second output of get_sino from the device, whole-line stores, the O(1) cache key
+def _np_log(air, counts):
+    """What the host did before round 3 (and what the reference's caller sees): float32 ln(air / raw)."""
+    with np.errstate(divide='ignore'):
+        return np.log(np.float32(air)[:, None] / counts.reshape(counts.shape[0], -1)).reshape(counts.shape)
+
+
+@pytest.mark.parametrize('kernel,n_rows,nz,n_mat', [(1, 1, 1, 3), (6, 1, 1, 3), (2, 66, 70, 3), (3, 64, 64, 3), (5, 64, 64, 4),
+                                                    (7, 256, 256, 3), (7, 512, 512, 2), (7, 200, 208, 4), (7, 50, 64, 3),
+                                                    (4, 64, 64, 7), (8, 256, 256, 7), (1, 8, 8, 6)])
+def test_log_sinogram_from_the_detection_store(hip, kernel, n_rows, nz, n_mat):
+    """sino_log = ln(air / counts) (main.py:120-122) is written by the projection kernels' own detection store
+    (dexct_log_out): same counts bit for bit as without it, the log within float32 rounding of the NumPy expression
+    the host used to evaluate, in the kernel's native layout and through the transpose."""
+    from dex_ct_sim_amd.system import AIR, WATER
+    ct, ph = small_scan(n=40, nz=nz, n_views=6, n_channels=37, n_rows=n_rows)
+    if n_mat == 2:
+        ph.volume = np.minimum(ph.volume, 1).astype(np.uint8)
+        ph.materials = [AIR, WATER]
+    elif n_mat > 3:
+        ph = ph_many(ph, n_mat)
+    pj = projector(ct, ph, kernel=kernel)
+    _, mu_d, w_d, air = pj.upload_tables(spectra())
+    for layout in (None, 0, 1):
+        plain = pj.project_tables(mu_d, w_d, layout=layout)
+        counts, log = pj.project_tables(mu_d, w_d, layout=layout, air=air)
+        assert torch.equal(counts, plain)
+        ref = _np_log(air, counts.cpu().numpy())
+        assert np.allclose(log.cpu().numpy(), ref, rtol=5e-6, atol=5e-7), np.abs(log.cpu().numpy() - ref).max()
+    alone = pj.sino_log(counts, air)                       # the pass of its own: same arithmetic
+    assert torch.equal(alone, log)
+
+
+def test_log_sinogram_of_noisy_and_cone_beam_scans(hip):
+    """With quantum noise the log belongs to the noisy counts (dexct_sino_log after the sampling); cone-beam kernels
+    write it from their detection like the fan kernels."""
+    ct, ph = small_scan(n=32, nz=64, n_views=10, n_channels=40, n_rows=64)
+    sp = spectra()
+    for s in sp:
+        s.rescale_counts(1e2)
+    pj = projector(ct, ph)
+    for noise in (True, 'poisson'):
+        (counts, log), air = pj.project(sp, noise=noise, seed=3, want_log=True)
+        clean, _ = pj.project(sp)
+        assert not torch.equal(counts, clean)
+        assert np.allclose(log.cpu().numpy(), _np_log(air, counts.cpu().numpy()), rtol=5e-6, atol=5e-7)
+    cone = dx_cone(ct)
+    for k in (1, 2):
+        pjc = projector(cone, ph, kernel=k)
+        (counts, log), air = pjc.project(sp, want_log=True)
+        plain, _ = pjc.project(sp)
+        assert torch.equal(counts, plain)
+        assert np.allclose(log.cpu().numpy(), _np_log(air, counts.cpu().numpy()), rtol=5e-6, atol=5e-7)
+
+
+@pytest.mark.parametrize('n_rows,n_channels,n_mat,n_spec', [(256, 53, 3, 2), (512, 7, 3, 2), (1024, 5, 3, 1), (200, 10, 3, 2),
+                                                            (320, 9, 2, 1), (2048, 3, 4, 2), (256, 6, 2, 2)])
+def test_whole_line_stores_change_no_bit(hip, n_rows, n_channels, n_mat, n_spec, monkeypatch):
+    """rows16_kernel hands its results over through LDS so that one store instruction writes consecutive addresses
+    (STAGED; DEXCT_P16_STAGED=0 restores the per-round 16-byte stores): same counts, same log sinogram, same path
+    lengths; 4 / 2 / 1 pairs per wave, ragged channel groups, idle lanes (200 and 320 rows), two z-chunks (2048 rows),
+    and the two-material / two-spectrum case that has no room for staged results and takes the old path by itself."""
+    from dex_ct_sim_amd.system import AIR, WATER
+    ct, ph = small_scan(n=40, nz=-(-n_rows // 16) * 16, n_views=5, n_channels=n_channels, n_rows=n_rows)
+    if n_mat == 2:
+        ph.volume = np.minimum(ph.volume, 1).astype(np.uint8)
+        ph.materials = [AIR, WATER]
+    elif n_mat == 4:
+        ph = ph_many(ph, 4)
+    pj = projector(ct, ph, kernel=7)
+    _, mu_d, w_d, air = pj.upload_tables(spectra()[:n_spec])
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('DEXCT_P16_STAGED', mode)
+        res[mode] = pj.project_tables(mu_d, w_d, layout=None, air=air, want_pathlen=True)
+    for a, b in zip(res['1'], res['0']):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res['1'][0]).all() and (res['1'][0] > 0).all()
+
+
+def test_get_sino_returns_page_locked_arrays_and_keys_the_cache_in_constant_time(hip, monkeypatch):
+    """Public boundary (NumPy in / NumPy out): results arrive through pinned memory that belongs to the
+    returned arrays; the device-resident state is keyed on the phantom's version counter + a 4096-voxel sample instead of
+    a checksum of the whole volume: assigning ``volume`` or ``touch()`` after an in-place edit rebuilds it."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    ct, ph = small_scan(n=48, nz=4, n_views=20, n_channels=48, n_rows=4)
+    sp = spectra()[0]
+    raw, log = dx.get_sino(ct, ph, sp)
+    assert raw.dtype == np.float32 and log.dtype == np.float32 and raw.shape == (20, 4, 48)
+    assert torch.from_numpy(raw).is_pinned()
+    raw2, _ = dx.get_sino(ct, ph, sp)
+    assert np.array_equal(raw, raw2) and not np.shares_memory(raw, raw2)       # each result owns its buffer
+    pj = fp._projector(ct, ph, (0, 20))
+    assert fp._projector(ct, ph, (0, 20)) is pj                                  # reused
+    calls = []
+    real = fp._hash64
+    monkeypatch.setattr(fp, '_hash64', lambda a: (calls.append(np.asarray(a).size), real(a))[1])
+    fp._projector(ct, ph, (0, 20))
+    assert max(calls) <= 4096                                                    # never the whole volume
+    ph.volume[:, 10:30, 10:30] = 2                                               # in-place edit, announced
+    ph.touch()
+    raw3, _ = dx.get_sino(ct, ph, sp)
+    assert fp._projector(ct, ph, (0, 20)) is not pj and not np.array_equal(raw3, raw)
+    ph.volume = np.zeros_like(ph.volume)                                         # assignment bumps the version by itself
+    raw4, log4 = dx.get_sino(ct, ph, sp)
+    assert np.allclose(log4, np.log(np.float32(fp.effective_weights(ct, sp).sum()) / raw4), atol=1e-6)
+    monkeypatch.setattr(fp, 'verify_volume', True)                               # opt-in: every byte hashed
+    calls.clear()
+    fp._projector(ct, ph, (0, 20))
+    assert max(calls) == ph.volume.size

@@ -111,7 +111,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.dexct_abi_version.restype = ctypes.c_int
-    assert lib.dexct_abi_version() == 1
+    assert lib.dexct_abi_version() == 2 == _native.ABI_VERSION
     lib.dexct_strerror.restype = ctypes.c_char_p
     assert lib.dexct_strerror(-2) == b'size out of supported range'
     # struct layouts the binding mirrors
@@ -165,12 +165,16 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_fan_plan(C.byref(big), one, one, 0, 10, one, None) == ERANGE       # fixed-point range
     assert lib.dexct_volume_layouts(one, 8, 8, 1, None, None, None) == EINVAL           # nothing to write
     args = [C.byref(g), one, 0, 10, one, one, None]
-    assert lib.dexct_siddon_project(*args, 0, 10, 2, one, one, one, None, 0, 0, None, None, None) == EINVAL   # no materials
-    assert lib.dexct_siddon_project(*args, 49, 10, 2, one, one, one, None, 0, 0, None, None, None) == ERANGE  # > DEXCT_MAX_MATERIALS
-    assert lib.dexct_siddon_project(*args, 3, 10, 5, one, one, one, None, 0, 0, None, None, None) == ERANGE   # > DEXCT_MAX_SPECTRA
-    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 3, 0, None, None, None) == EINVAL   # kernel 3 needs vol_zf
-    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 7, None, None, None) == EINVAL   # layout
-    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 0, one, None, None) == EINVAL   # weights2 without variance
+    assert lib.dexct_siddon_project(*args, 0, 10, 2, one, one, one, None, 0, 0, None, None, None, None) == EINVAL   # no materials
+    assert lib.dexct_siddon_project(*args, 49, 10, 2, one, one, one, None, 0, 0, None, None, None, None) == ERANGE  # > DEXCT_MAX_MATERIALS
+    assert lib.dexct_siddon_project(*args, 3, 10, 5, one, one, one, None, 0, 0, None, None, None, None) == ERANGE   # > DEXCT_MAX_SPECTRA
+    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 3, 0, None, None, None, None) == EINVAL   # kernel 3 needs vol_zf
+    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 7, None, None, None, None) == EINVAL   # layout
+    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 0, one, None, None, None) == EINVAL   # weights2 without variance
+    lo = _native.log_out(8, [1.0])                  # a log sinogram together with a variance output: the log of the noisy
+    assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 0, one, one, lo, None) == EINVAL   # counts comes from dexct_sino_log
+    assert lib.dexct_sino_log(one, None, 2, 16, one, None) == EINVAL and lib.dexct_sino_log(one, (C.c_float * 5)(), 5, 16, one, None) == ERANGE
+    assert C.sizeof(_native.LogOut) == 24
     assert lib.dexct_add_noise(one, one, 2, 4, 1, 8, 2, 0, 1, None) == EINVAL
     assert lib.dexct_gn_decompose(one, one, 1, 0, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == EINVAL    # no pixels
     assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 2, 0, None, 0.0, one, one, None) == EINVAL    # precision
