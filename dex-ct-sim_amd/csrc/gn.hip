@@ -17,6 +17,7 @@
 // HBM (8 B read + 16 B written per pixel); per energy-iteration it issues 25 FP64 instructions
 // (2 exponent, 2 clip, 9 exp, 12 accumulate).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -24,6 +25,7 @@ namespace dexct {
 
 // States kept for the exact repeated-state exit of the float64 Newton loop (cycles up to kGnHistory + 1).
 constexpr int kGnHistory = 8;
+constexpr int kGnRingDefault = 1;    // history of the lane-refill kernel as a ring (DEXCT_GN_RING=0: the shifting form)
 
 constexpr int kGnBlock = 256;
 constexpr int kTab = 14;  // -mu0 K, -mu1 K (K = 2048/ln2), then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2
@@ -144,7 +146,7 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
   nu[0] += nuo[0];
   nu[1] += nuo[1];
   const double g[2] = {g0, g1};
-  double dF0 = 0, dF1 = 0, h00 = 0, h01 = 0, h11 = 0;
+  double c[2], q[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const double inv = rcp_f64(nu[k]), ratio = g[k] * inv;
@@ -152,14 +154,16 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
     // carries the rounding of nu only, not an extra half ulp of 1 from the quotient - the last-bit wandering of the
     // iterate is shorter again (mean executed iterations 28.6 -> 24.7).  An overflowed nu (inf) keeps the reference's
     // value: g / inf - 1 = -1.
-    const double c = fabs(nu[k]) < __builtin_huge_val() ? (g[k] - nu[k]) * inv : ratio - 1.0;
-    const double q = ratio * inv;                              // g / nu^2 (matdecomp.py:123)
-    dF0 += c * G0[k];
-    dF1 += c * G1[k];
-    h00 += q * (G0[k] * G0[k]) - c * H00[k];
-    h01 += q * (G0[k] * G1[k]) - c * H01[k];
-    h11 += q * (G1[k] * G1[k]) - c * H11[k];
+    c[k] = fabs(nu[k]) < __builtin_huge_val() ? (g[k] - nu[k]) * inv : ratio - 1.0;
+    q[k] = ratio * inv;                                        // g / nu^2 (matdecomp.py:123)
   }
+  // the sums over the two measurements, first term + second term (a running sum started at 0 costs an addition of 0
+  // per sum that the compiler may not drop: 0 + (-0) is +0)
+  const double dF0 = c[0] * G0[0] + c[1] * G0[1];
+  const double dF1 = c[0] * G1[0] + c[1] * G1[1];
+  const double h00 = (q[0] * (G0[0] * G0[0]) - c[0] * H00[0]) + (q[1] * (G0[1] * G0[1]) - c[1] * H00[1]);
+  const double h01 = (q[0] * (G0[0] * G1[0]) - c[0] * H01[0]) + (q[1] * (G0[1] * G1[1]) - c[1] * H01[1]);
+  const double h11 = (q[0] * (G1[0] * G1[0]) - c[0] * H11[0]) + (q[1] * (G1[1] * G1[1]) - c[1] * H11[1]);
   const double inv_det = rcp_f64(h00 * h11 - h01 * h01);
   a0 -= (h11 * dF0 - h01 * dF1) * inv_det;
   a1 -= (h00 * dF1 - h01 * dF0) * inv_det;
@@ -440,6 +444,37 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   out_a[2 * p + 1] = a1;
 }
 
+
+// The history of the repeated-state exit as a RING whose write position is wave-uniform.  In the lane-refill kernel all
+// lanes of a wave take their Newton steps together, so "the state k + 1 steps ago" sits in the same ring slot for every
+// lane - (pos - 1 - k) mod 8 with pos = the wave's step counter mod 8 - whatever iteration each lane's own pixel is at
+// (entries older than the lane's pixel are excluded by k < it, as before).  With pos a template parameter every index
+// is static: the 32 selects that moved the history down one place per step (and the 32 copies back) become one
+// 4-register write.  Same states compared, same slot chosen: bit-identical results.
+template <int POS>
+struct GnRing {
+  static constexpr int slot_of(int k) { return ((POS - 1 - k) % kGnHistory + kGnHistory) % kGnHistory; }
+  // -2: no repeat, -1: fixed point, k >= 0: equal to the state k + 1 steps before the current one (smallest k)
+  static __device__ __forceinline__ int hit(const long long (&h0)[kGnHistory], const long long (&h1)[kGnHistory],
+                                            long long b0, long long b1, int it, bool fixed) {
+    int hit = fixed ? -1 : -2;
+#pragma unroll
+    for (int k = kGnHistory - 1; k >= 0; --k)
+      if (k < it && b0 == h0[slot_of(k)] && b1 == h1[slot_of(k)] && hit != -1) hit = k;
+    return hit;
+  }
+  static __device__ __forceinline__ void pick(const long long (&h0)[kGnHistory], const long long (&h1)[kGnHistory], int slot,
+                                              double& f0, double& f1) {
+#pragma unroll
+    for (int k = 0; k < kGnHistory; ++k)
+      if (slot == k) { f0 = __longlong_as_double(h0[slot_of(k)]); f1 = __longlong_as_double(h1[slot_of(k)]); }
+  }
+  static __device__ __forceinline__ void push(long long (&h0)[kGnHistory], long long (&h1)[kGnHistory], double a0, double a1) {
+    h0[POS] = __double_as_longlong(a0);
+    h1[POS] = __double_as_longlong(a1);
+  }
+};
+
 // float64, one shared spectrum - the benchmark's path - with lane refill.  The repeated-state exit ends pixels
 // at very different iterations (from 15 to all of n_iters), and a wave is as slow as its slowest lane.  Here a
 // wave owns a contiguous run of 64 * chunk pixels and every lane whose pixel has finished takes the next one of
@@ -447,7 +482,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
 // table loads) because the tables do not depend on the pixel.  Results are bit-identical to gn_kernel's.
 // HLDS (A/B variant): the four older states of the history live in an LDS ring (one 16-B slot per lane and state, written
 // when a state leaves the registers) instead of 16 VGPRs.
-template <int MINW, bool IEXP, bool HLDS = false, int HIST = kGnHistory>      // HIST: states kept for the repeated-state exit; MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
+template <int MINW, bool IEXP, bool HLDS = false, int HIST = kGnHistory, bool RING = false>      // RING: history as a ring with a wave-uniform write position (GnRing); HIST: states kept for the repeated-state exit; MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, int chunk,
@@ -458,6 +493,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   __shared__ double lds_pow[kPowN];
   __shared__ longlong2 lds_hist[HLDS ? 4 : 1][HLDS ? kGnBlock : 1];
   static_assert(!HLDS || HIST == kGnHistory, "the LDS ring holds the 4 older of 8 states");
+  static_assert(!RING || (HIST == kGnHistory && !HLDS), "the register ring has kGnHistory slots");
   constexpr int kR = HLDS ? 4 : HIST;       // states kept in registers
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
@@ -473,6 +509,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   unsigned n_exec = 0;                    // Newton steps this wave executed (< 2^32: 64 lanes x chunk x n_iters)
   double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
   int it = 0;
+  int ring_pos = 0;                       // RING: write position of this step, wave-uniform
   long long h0[kR], h1[kR];
 #pragma unroll
   for (int k = 0; k < kR; ++k) { h0[k] = 0; h1[k] = 0; }
@@ -505,6 +542,62 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     n_exec += (unsigned)__popcll(busy);                        // wave-uniform (scalar) count of Newton steps run
     double n0 = a0, n1 = a1;
     newton_step_f64<IEXP>(tab, lds_pow, ec, gd0, gd1, n0, n1);      // idle lanes repeat their last pixel's step; unused
+    if constexpr (RING) {
+      // ---- exit logic on the ring: one copy per write position, chosen by a scalar branch
+      const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
+      const bool fixed = exact_exit && b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1);
+      bool converged = false;
+      if (stop_tol > 0.0) {
+        const double size = fmax(fmax(fabs(n0), fabs(n1)), 1.0);
+        converged = fmax(fabs(n0 - a0), fabs(n1 - a1)) <= stop_tol * size;      // NaN compares false
+      }
+      int hit = fixed ? -1 : -2;
+      double f0 = converged ? n0 : a0, f1 = converged ? n1 : a1;
+      auto on_ring = [&](auto pos_tag) {
+        using R = GnRing<decltype(pos_tag)::value>;
+        if (exact_exit) hit = R::hit(h0, h1, b0, b1, it, fixed);
+        if (__ballot(hit >= 0) != 0ull) {
+          // the state a cycle holds at iteration n_iters (see the non-ring form below)
+          int slot = -1;
+          if (hit >= 0) {
+            const int period = hit + 2, x = n_iters - it - 1;
+            int r;
+            if (n_iters < (1 << 22)) {
+              const int q = (int)((float)x * __builtin_amdgcn_rcpf((float)period));
+              r = x - q * period;
+              r += r < 0 ? period : 0;
+              r -= r >= period ? period : 0;
+            } else {
+              r = x % period;
+            }
+            slot = hit - r;
+          }
+          R::pick(h0, h1, slot, f0, f1);
+        }
+        R::push(h0, h1, a0, a1);              // unconditional: a lane that ends its pixel here never reads the history again
+      };
+      switch (ring_pos) {
+        case 0: on_ring(std::integral_constant<int, 0>{}); break;
+        case 1: on_ring(std::integral_constant<int, 1>{}); break;
+        case 2: on_ring(std::integral_constant<int, 2>{}); break;
+        case 3: on_ring(std::integral_constant<int, 3>{}); break;
+        case 4: on_ring(std::integral_constant<int, 4>{}); break;
+        case 5: on_ring(std::integral_constant<int, 5>{}); break;
+        case 6: on_ring(std::integral_constant<int, 6>{}); break;
+        default: on_ring(std::integral_constant<int, 7>{}); break;
+      }
+      ring_pos = (ring_pos + 1) & (kGnHistory - 1);
+      const bool advance = hit == -2 && !converged;
+      a0 = advance ? n0 : f0;
+      a1 = advance ? n1 : f1;
+      it += advance ? 1 : 0;
+      if (p >= 0 && (!advance || it >= n_iters)) {
+        out_a[2 * p] = a0;
+        out_a[2 * p + 1] = a1;
+        p = -1;
+      }
+      continue;
+    }
     // same exit rule as gn_kernel: s_{it+1} equal to s_it (fixed point) or to hist[k] = s_{it-1-k} (cycle of
     // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
     // through it too and are ignored.
@@ -696,7 +789,15 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const char* hs = getenv("DEXCT_GN_HIST");
     const int hist = hs ? atoi(hs) : kGnHistory;
     const int mw = ve ? atoi(ve) : 5;
-    if (hlds)
+    const char* re = getenv("DEXCT_GN_RING");
+    const int ring = re ? atoi(re) : kGnRingDefault;
+    if (ring && !hlds && hist == kGnHistory && !iexp && mw == 5)
+      hipLaunchKernelGGL((gn_refill_kernel<5, false, false, kGnHistory, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64,
+                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
+    else if (ring && !hlds && hist == kGnHistory && !iexp && mw == 4)
+      hipLaunchKernelGGL((gn_refill_kernel<4, false, false, kGnHistory, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64,
+                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
+    else if (hlds)
       hipLaunchKernelGGL((gn_refill_kernel<5, false, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,
                          (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
     else if (hist == 4 && mw == 6) DEXCT_GN_LAUNCH_H(6, 4);

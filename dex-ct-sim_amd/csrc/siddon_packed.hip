@@ -272,17 +272,19 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   }
   cnt.finish();
   if (BOTH) cnt3.finish();
-  // STAGED (the usual case: row-fastest output, whole groups of 4 rows, no more spectra than correction arrays): the
-  // four detection rounds leave their results in registers and the wave stores them through LDS at the end, so that one
-  // store instruction writes 1 KiB of consecutive addresses (whole 64-byte lines) instead of 64 separate 16-byte pieces
-  // per round - every lane's 64 output bytes used to leave as four partial writes (WRITE_SIZE 2.1x the output bytes).
-  // All lanes then stay to the end, because a lane also stores pieces of other lanes.
-  constexpr int kResSlots = (NM - 1) < 2 ? (NM - 1) : 2;
+  // STAGED (the usual case: row-fastest output, whole groups of 4 rows, one or two spectra): each detection round leaves
+  // its results in LDS and the wave stores them at the end, so that one store instruction writes 1 KiB of consecutive
+  // addresses (whole lines) instead of 64 separate 16-byte pieces per round - every lane's 64 output bytes used to
+  // leave as four partial writes (WRITE_SIZE 2.1x the output bytes).  All lanes then stay to the end, because a lane
+  // also stores pieces of other lanes.
+  constexpr int kResSlots = 2;               // spectra whose results the stage holds
   static_assert(!(GROUPED && STAGED), "group passes hand over raw accumulators");
   constexpr bool staged = STAGED;            // host: layout 1, n_rows % 4 == 0, n_spectra <= kResSlots
   const bool lane_live = pair_live && r0 < a.g.n_rows;
   if (!staged && !lane_live) return;
-  if (lane_live)
+  // (STAGED: lanes without rows of their own run the code below too, on counters that saw nothing but air - branching
+  // around it per lane made the detection loops divergent in the compiler's eyes, and the tables then arrived by vector
+  // loads instead of through the scalar cache: +23 %)
   // ---- un-slice the counters (in place of the corrections), then detect 4 rows at a time.  The rounds are a real
   // loop with ONE copy of the detection code (rows move down the register array between rounds): four inlined copies
   // made the kernel as large as the instruction cache two CUs share.
@@ -331,8 +333,9 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   for (int q4 = 0; q4 < 4; ++q4) {
     const bool round_live = lane_live && r0 + 4 * q4 < a.g.n_rows;
     if (!staged && !round_live) break;
+    if (staged && __ballot(round_live) == 0ull) break;          // wave-uniform: nobody has rows left
     float res[2][4];
-    if (round_live) {
+    {
       float L[4][NM];
       size_t rays[4];
       bool valid[4];
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
         if (a.pathlen) {             // (test output) written here so that the detection holds no store addresses
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
-            if (valid[rr]) {
+            if (valid[rr] && round_live) {
 #pragma unroll
               for (int m = 0; m < NM; ++m) a.pathlen[rays[rr] * NM + m] = L[rr][m];
             }
@@ -362,42 +365,42 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
         detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm, &air_cache);
       }
     }
-    // the rows move down; the four rows just detected leave the array and, when staged, their results enter at its top:
-    // after the fourth round corr[s][row] holds the counts of spectrum s for the lane's row `row`
+    // STAGED: the round's results go to LDS right away (plane s, float index 16 lane + row): no registers are held for
+    // them, and the (corr[0][row], corr[1][row]) register pairs of the traversal's v_pk_add_f32 stay undisturbed
+    if constexpr (staged) {
+      if (round_live) {
+        float* stage_w = reinterpret_cast<float*>(lds_lists) + lane * 16 + 4 * q4;
+#pragma unroll
+        for (int s = 0; s < kResSlots; ++s)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) stage_w[s * 1024 + rr] = res[s][rr];
+      }
+    }
 #pragma unroll
     for (int m = 0; m < NM - 1; ++m)
 #pragma unroll
       for (int row = 0; row < 12; ++row) corr[m][row] = corr[m][row + 4];
-    if (staged) {
-#pragma unroll
-      for (int s = 0; s < kResSlots; ++s)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) corr[s][12 + rr] = res[s][rr];
-    }
   }
   if constexpr (!staged) return;
-  // ---- whole-line stores: lane l writes its four 16-byte pieces to LDS at 64 l + 16 c; store instruction k then takes
-  // piece 64 k + lane = (lane l' = piece / 4, c' = piece % 4) - consecutive lanes write consecutive 16 bytes
-  float4* stage = reinterpret_cast<float4*>(lds_lists);
+  // ---- whole-line stores: the rounds left the 16 results of lane l and spectrum s in LDS at plane s, float index
+  // 16 l + row; store instruction k takes the 16-byte piece 64 k + lane = (lane l' = piece / 4, rows 4 (piece % 4) ...):
+  // consecutive lanes write consecutive 16 bytes
+  float* stage = reinterpret_cast<float*>(lds_lists);
   const int lpp_shift = __builtin_ctz((unsigned)lpp);
   const int c_base = c - g;                                    // first channel of the wave
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int s = 0; s < kResSlots; ++s) {
     if (s >= a.n_spectra) break;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-      stage[lane * 4 + cc] = make_float4(corr[s][4 * cc], corr[s][4 * cc + 1], corr[s][4 * cc + 2], corr[s][4 * cc + 3]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int piece = k * 64 + lane, l2 = piece >> 2, c2 = piece & 3;
       const int g2 = l2 >> lpp_shift, li2 = l2 - (g2 << lpp_shift);
       const int row = (zc * 64 + li2) * 16 + 4 * c2, chan = c_base + g2;
       if (chan < a.g.n_channels && row < a.g.n_rows) {
-        const float4 x = stage[piece];
+        const float4 x = *reinterpret_cast<const float4*>(stage + s * 1024 + piece * 4);
         const size_t at = s * sstride + ((size_t)v * a.g.n_channels + chan) * a.g.n_rows + row;
         *reinterpret_cast<float4*>(a.counts + at) = x;
         if (a.sino_log)
@@ -461,7 +464,7 @@ static int packed_shape(const dexct_fan_geom* geom, int32_t view_begin, int32_t 
   nblk = (size_t)(view_end - view_begin) * ((geom->n_channels + n_pairs - 1) / n_pairs) * pa.n_zchunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   lds = (size_t)n_pairs * kP16Super * (sizeof(CrossRec) + sizeof(uint32_t));
-  if (lds < 64 * 64) lds = 64 * 64;           // the staged store of the results: 64 bytes per lane
+  if (lds < 2 * 64 * 64) lds = 2 * 64 * 64;   // the staged store of the results: 64 bytes per lane and spectrum
   return DEXCT_OK;
 }
 
@@ -529,9 +532,8 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   if (const char* e = getenv("DEXCT_P16_MINW")) minw = atoi(e);      // tuning knob
   const float* none = nullptr;
   // whole-line stores through LDS (STAGED) wherever the output allows them: row-fastest layout, whole groups of 4 rows,
-  // and the results of all spectra fit the registers the corrections leave behind
-  const int res_slots = n_materials - 1 < 2 ? n_materials - 1 : 2;
-  const bool staged = pa.staged_store && layout == 1 && geom->n_rows % 4 == 0 && n_spectra <= res_slots;
+  // one or two spectra (what the stage holds)
+  const bool staged = pa.staged_store && layout == 1 && geom->n_rows % 4 == 0 && n_spectra <= 2;
   if (n_materials == 2 && staged)
     hipLaunchKernelGGL((rows16_kernel<2, 4, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (n_materials == 2)
@@ -542,6 +544,8 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
     hipLaunchKernelGGL((rows16_kernel<4, 3>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (staged && minw == 4)
     hipLaunchKernelGGL((rows16_kernel<3, 4, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
+  else if (staged && minw == 5)
+    hipLaunchKernelGGL((rows16_kernel<3, 5, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (minw == 5)
     hipLaunchKernelGGL((rows16_kernel<3, 5>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (minw == 6)

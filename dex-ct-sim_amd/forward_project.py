@@ -364,7 +364,7 @@ def _volume_key(phantom):
     import os
     v = phantom.volume
     flat = v.reshape(-1)
-    step = max(1, flat.size // 4096)
+    step = max(1, -(-flat.size // 4096))
     key = (getattr(phantom, 'version', 0), id(v), v.shape, _hash64(flat[::step]))
     if verify_volume or os.environ.get('DEXCT_VERIFY_VOLUME', '0') == '1':
         key += (_hash64(v),)
@@ -416,7 +416,7 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0):
     sharded = _shard.world()[1] > 1
     res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded)
     if sharded:
-        counts = _shard.gather_views(res, ct.N_proj, view_dim=1)
+        counts = _shard.gather_views(res, ct.N_proj, view_dim=1).contiguous()
         log = pj.sino_log(counts, air)              # of the gathered sinogram: one collective instead of two
     else:
         counts, log = res

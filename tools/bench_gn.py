@@ -27,7 +27,8 @@ ref = torch.empty_like(a)
 
 
 def run(out, env):
-    for k in ('DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HLDS', 'DEXCT_GN_HIST', 'DEXCT_GN_CHUNK'):
+    for k in ('DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HLDS', 'DEXCT_GN_HIST', 'DEXCT_GN_CHUNK', 'DEXCT_GN_RING',
+              'DEXCT_GN_VAR'):
         os.environ.pop(k, None)
     os.environ.update(env)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,8 +40,8 @@ def run(out, env):
 
 
 run(ref, {})
-variants = [{}, {'DEXCT_GN_HLDS': '1'}, {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_FULL_LOOP': '1'},
-            {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_HLDS': '1'}]
+variants = [{}, {'DEXCT_GN_RING': '0'}, {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_RING': '0', 'DEXCT_GN_MINW': '4'},
+            {'DEXCT_GN_FULL_LOOP': '1'}, {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_RING': '0'}]
 if os.environ.get('GN_VARIANTS') == 'chunk':      # pixels per lane of a wave's run (default 64 at this size)
     variants = [{}] + [{'DEXCT_GN_CHUNK': str(c)} for c in (8, 16, 32, 128, 256)]
 if os.environ.get('GN_VARIANTS') == 'hist':      # history length of the repeated-state exit (x occupancy)
