@@ -91,11 +91,17 @@ def launch_ranks(args):
             env['DEXCT_DIST_BACKEND'] = 'gloo'
             print(f'bench.py: {torch.cuda.device_count()} device(s) for {args.gpus} ranks - gloo rehearsal, ranks share '
                   f'devices (not an RCCL measurement)', file=sys.stderr)
-    procs = []
+    # every rank's stdout / stderr go to gpurun_out/rank<r>.log (rank 0's stdout carries the JSON line and is piped):
+    # the first real RCCL run must be able to say what went wrong on WHICH rank
+    log_dir = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(log_dir, exist_ok=True)
+    procs, logs = [], []
     for r in range(args.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        lf = open(os.path.join(log_dir, f'rank{r}.log'), 'wb')
+        logs.append(lf)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else lf, stderr=lf))
     import threading
     buf = []
     reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
@@ -114,12 +120,21 @@ def launch_ranks(args):
         time.sleep(0.2)
     codes = [p.wait() for p in procs]
     reader.join(timeout=10)
+    for lf in logs:
+        lf.close()
     # rank 0's JSON line goes to stdout; anything else a library printed there (gloo's connection banner) to stderr
     for ln in b''.join(buf).decode().splitlines():
         print(ln, file=sys.stdout if ln.startswith('{') else sys.stderr)
     sys.stdout.flush()
     if failed or any(codes):
         print(f'bench.py: rank exit codes {codes}', file=sys.stderr)
+        first_bad = [r for r, c in enumerate(codes) if c not in (0, -9)] or [r for r, c in enumerate(codes) if c]
+        for r in first_bad[:2]:                 # the rank(s) that failed by themselves (-9: killed by this launcher afterwards)
+            try:
+                tail = open(os.path.join(log_dir, f'rank{r}.log'), 'rb').read()[-3000:].decode(errors='replace')
+            except OSError:
+                tail = '(no log)'
+            print(f'---- tail of gpurun_out/rank{r}.log (exit code {codes[r]}) ----\n{tail}', file=sys.stderr)
         return 1
     return 0
 
@@ -205,10 +220,26 @@ def main():
         # RCCL ("nccl") over xGMI; DEXCT_DIST_BACKEND=gloo only for rehearsing the N > 1 control flow on a
         # single-GPU box (ranks then share one device and collectives are staged through the host)
         backend = os.environ.get('DEXCT_DIST_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(backend)
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get('DEXCT_DIST_TIMEOUT_S', '300')))
+        where = (f'rank {rank}/{world} local_rank {local_rank} device {torch.cuda.current_device()} of '
+                 f'{torch.cuda.device_count()} backend {backend} rendezvous {os.environ.get("MASTER_ADDR")}:'
+                 f'{os.environ.get("MASTER_PORT")}')
+        try:
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+            probe = torch.ones(1, device='cuda' if backend == 'nccl' else 'cpu')
+            dist.all_reduce(probe)                    # the communicator really works before anything is timed
+            if float(probe.item()) != world:
+                raise RuntimeError(f'all_reduce probe returned {float(probe.item())}, expected {world}')
+        except Exception as exc:
+            print(f'bench.py: process group did not come up within {tmo.total_seconds():.0f} s ({where}): {exc!r}\n'
+                  f'  check: one process per GPU, HSA_ENABLE_IPC_MODE_LEGACY=0 (is {os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")!r}), '
+                  f'MASTER_ADDR=127.0.0.1, a free MASTER_PORT, DEXCT_DIST_TIMEOUT_S to wait longer', file=sys.stderr, flush=True)
+            raise
+        print(f'bench.py: process group up ({where})', file=sys.stderr, flush=True)
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher sets WORLD_SIZE; plain '
                          f'`python bench.py --gpus N` starts its own ranks)')
@@ -338,11 +369,13 @@ def main():
         _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows, 4,
                                                   stream_ptr()), 'transpose counts')
         barrier()
+        n_alloc0 = torch.cuda.memory_stats().get('allocation.all.allocated', 0)
         g0 = time.perf_counter()
         for _ in range(3):
             _shard.gather_views(counts, total_views, view_dim=1)
             torch.cuda.synchronize()
         gather_alone_ms = 1e3 * (time.perf_counter() - g0) / 3
+        gather_allocs = (torch.cuda.memory_stats().get('allocation.all.allocated', 0) - n_alloc0) / 3
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {'rank': rank, 'views': [vb, ve], 'siddon_ms': sid_ms, 'gn_ms': gn_ms,
                                           'gather_exposed_ms': float(np.mean(t_exposed)),
@@ -355,6 +388,7 @@ def main():
                  'gathered_bytes_per_rank_per_step': gathered_bytes,
                  'gather_ms': max(r['gather_alone_ms'] for r in per_rank),
                  'gather_exposed_ms': max(r['gather_exposed_ms'] for r in per_rank),
+                 'gather_device_allocations_per_call': gather_allocs,     # buffers are allocated once (_shard._buffers)
                  'gather_GBps_per_rank': gathered_bytes * (world - 1) / world / (max(r['gather_alone_ms'] for r in per_rank) * 1e-3) / 1e9,
                  'per_rank': per_rank,
                  'note': 'gather_ms: the all-gather alone; gather_exposed_ms: what the step still waits for after the '

@@ -32,33 +32,82 @@ def _needs_cpu_staging(t):
     return t.is_cuda and dist.get_backend() == 'gloo'
 
 
-def gather_views(local, n_views, view_dim=0, async_op=False):
+# Buffers of the gather, allocated once per (shape, dtype, device, scan) and reused by every later step: the result
+# tensor, and for ragged shards / the gloo rehearsal the padded send and receive buffers.
+_buffers = {}
+
+
+def _buffer(kind, shape, dtype, device, pin=False):
+    key = (kind, tuple(shape), dtype, str(device))
+    t = _buffers.get(key)
+    if t is None:
+        t = torch.empty(tuple(shape), dtype=dtype, device=device, pin_memory=bool(pin and str(device) == 'cpu' and torch.cuda.is_available()))
+        _buffers[key] = t
+    return t
+
+
+def release_buffers():
+    """Drop the cached gather buffers (they are sized like the full sinogram)."""
+    _buffers.clear()
+
+
+def gather_views(local, n_views, view_dim=0, async_op=False, out=None):
     """All-gather view shards (possibly of unequal size) into the full tensor on every rank.
 
-    With ``async_op=True`` returns ``finish`` - call it to wait and get the tensor (lets the caller
-    overlap the collective with compute; on the nccl/RCCL backend the transfer runs on the process
-    group's own stream)."""
+    ``local`` is this rank's contiguous shard with the views on ``view_dim`` (0, or 1 with a leading "spectrum"
+    dimension: ``[S, views, ...]``, the layout the projection writes).  The shards go straight from that buffer into
+    the result, one collective per leading index (each a contiguous block of views on both sides): no transposed copy,
+    no concatenation, and no allocation after the first call - the result lives in a buffer that is reused by the
+    next gather of the same shape (pass ``out=`` to own it; consume or copy the result before gathering again).
+    Ragged shards (n_views not a multiple of the world size) are padded through a preallocated send buffer and
+    compacted with in-place copies.  With ``async_op=True`` returns ``finish`` - call it to wait and get the tensor
+    (on the nccl/RCCL backend the transfers run on the process group's own stream and overlap the caller's kernels)."""
     r, w = world()
     if w == 1:
         return (lambda: local) if async_op else local
-    local = local.movedim(view_dim, 0).contiguous()
+    if view_dim not in (0, 1) or view_dim >= local.dim():
+        raise ValueError('views must be dimension 0, or 1 behind one leading dimension')
+    if not local.is_contiguous():
+        local = local.contiguous()
+    lead = local.shape[0] if view_dim == 1 else 1
+    tail = tuple(local.shape[view_dim + 1:])
     sizes = [split(n_views, k, w) for k in range(w)]
+    n_mine = sizes[r][1] - sizes[r][0]
+    if local.shape[view_dim] != n_mine:
+        raise ValueError(f'rank {r} holds {local.shape[view_dim]} views, its share of {n_views} is {n_mine}')
     n_max = max(e - b for b, e in sizes)
-    pad = n_max - local.shape[0]
-    if pad:
-        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], dim=0)
+    ragged = n_max * w != n_views
     dev = local.device
-    staged = _needs_cpu_staging(local)
-    src = local.cpu() if staged else local
-    out = src.new_empty((w * n_max,) + tuple(src.shape[1:]))
-    work = dist.all_gather_into_tensor(out, src, async_op=async_op)
+    staged = _needs_cpu_staging(local)                     # gloo rehearsal: collectives on host copies
+    cdev = torch.device('cpu') if staged else dev
+    full_shape = ((lead,) if view_dim == 1 else ()) + (n_views,) + tail
+    if out is None:
+        out = _buffer('out', full_shape, local.dtype, dev)
+    elif tuple(out.shape) != full_shape or not out.is_contiguous():
+        raise ValueError(f'out must be a contiguous tensor of shape {full_shape}')
+    loc3 = local.view((lead, n_mine) + tail)
+    out3 = out.view((lead, n_views) + tail)
+    direct = not ragged and not staged                     # shards land in the result as they arrive
+    works, recvs = [], []
+    for s in range(lead):
+        if direct:
+            src, dst = loc3[s], out3[s]
+        else:
+            src = _buffer(('send', s), (n_max,) + tail, local.dtype, cdev, pin=True)
+            src[:n_mine].copy_(loc3[s], non_blocking=not staged)
+            dst = _buffer(('recv', s), (w * n_max,) + tail, local.dtype, cdev, pin=True)
+        works.append(dist.all_gather_into_tensor(dst, src, async_op=async_op))
+        recvs.append(dst)
 
     def finish():
-        if async_op:
-            work.wait()
-        parts = [out[k * n_max:k * n_max + (e - b)] for k, (b, e) in enumerate(sizes)]
-        full = torch.cat(parts, dim=0) if pad or w * n_max != n_views else out
-        return full.to(dev).movedim(0, view_dim)
+        for wk in works:
+            if async_op and wk is not None:
+                wk.wait()
+        if not direct:
+            for s in range(lead):
+                for k, (b, e) in enumerate(sizes):
+                    out3[s, b:e].copy_(recvs[s][k * n_max:k * n_max + (e - b)], non_blocking=not staged)
+        return out
 
     return finish if async_op else finish()
 

@@ -416,7 +416,7 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0):
     sharded = _shard.world()[1] > 1
     res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded)
     if sharded:
-        counts = _shard.gather_views(res, ct.N_proj, view_dim=1).contiguous()
+        counts = _shard.gather_views(res, ct.N_proj, view_dim=1)
         log = pj.sino_log(counts, air)              # of the gathered sinogram: one collective instead of two
     else:
         counts, log = res

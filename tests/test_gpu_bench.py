@@ -32,6 +32,11 @@ def test_plain_command_single_gpu(hip):
     assert out['roofline']['kernel'] == 'gn_refill_kernel' and 'roofline_siddon' in out
     for r in (out['roofline'], out['roofline_siddon']):
         assert r['frac'] is None or 0 < r['frac'] <= 1.0, r
+    e2e = out['dropin_e2e']                      # the public NumPy boundary, timed (get_sino x 2 + get_basismat_sinos)
+    assert len(e2e) == 2
+    for case in e2e.values():
+        assert case['cold']['ok'] and case['warm']['ok'] and case['warm']['total_s'] > 0
+        assert case['bytes']['d2h_per_get_sino'] == 8 * case['rays']
 
 
 @pytest.mark.parametrize('scaling', ['strong', 'weak'])
@@ -42,6 +47,7 @@ def test_plain_command_two_ranks(hip, scaling):
     assert out['n_gpus'] == 2 and out['scaling'] == scaling
     m = out['multi_gpu']
     assert len(m['per_rank']) == 2 and m['gather_ms'] > 0
+    assert m['gather_device_allocations_per_call'] == 0          # preallocated send / receive / result buffers
     views = [r['views'] for r in sorted(m['per_rank'], key=lambda r: r['rank'])]
     total = 48 if scaling == 'strong' else 96
     assert views[0][0] == 0 and views[0][1] == views[1][0] and views[1][1] == total
@@ -57,6 +63,9 @@ def test_plain_command_four_ranks_ragged(hip):
     assert out['n_gpus'] == 4 and out['config']['rays_total'] == 50 * 64 * 96
     views = [r['views'] for r in sorted(out['multi_gpu']['per_rank'], key=lambda r: r['rank'])]
     assert views == [[0, 13], [13, 26], [26, 38], [38, 50]]
+    assert out['multi_gpu']['gather_device_allocations_per_call'] == 0       # the ragged path too
+    for r in range(4):                                                        # every rank leaves a log behind
+        assert os.path.exists(os.path.join(ROOT, 'gpurun_out', f'rank{r}.log'))
 
 
 def test_world_size_mismatch_is_an_error(hip):
