@@ -42,37 +42,18 @@ def load_plots_functions(ref_md, xc):
     return ns['make_vmi'], ns['measure_roi']
 
 
-def main():
-    ref = load_reference()
-    xc = load_pkg_module('xcompy')
-    ref.xc.mixatten = xc.mixatten
-    out = {}
+# The screening criterion is FROZEN at this version (round-2 review, item 2): a pixel is left out of the parity
+# comparison if (1) a change of its counts by a few ulps moves the reference's own answer by more than 1e-6 or makes it
+# raise, or (2) its trajectory in the reference passes a 2x2 Hessian of condition number > 1e13.  Both are computed
+# from the reference alone.  No further screen may be added; a later arithmetic change of the kernel must pass the
+# fixtures as committed (tests/test_gn_oracle.py::test_committed_screen_is_what_the_generator_produces).
+CRITERION_VERSION = 2
 
-    # ---- tables of the live default pair, captured from do_matdecomp_gn
-    captured = {}
-    real_opt = ref.optimize_sino_cpu
 
-    def spy(Sino_gg, ee, i0, mus, n_iters, verbose=True):
-        captured.update(ee=np.array(ee), i0=np.array(i0), mus=np.array(mus))
-        return real_opt(Sino_gg, ee, i0, mus, n_iters, verbose=False)
-
-    ref.optimize_sino_cpu = spy
-    det = half_split(f'{REF}/input/detector/eta_eid_mv.bin')
-    s1, s2 = half_split(f'{REF}/input/spectrum/detunedMV_1mGy_float32.bin'), half_split(
-        f'{REF}/input/spectrum/80kV_1mGy_float32.bin')
-    ct = types.SimpleNamespace(det_E=det[0], det_eta_E=det[1], eid=True)
-    sp1 = types.SimpleNamespace(E=s1[0], I0=s1[1] * 9.0 * 1e-4)
-    sp2 = types.SimpleNamespace(E=s2[0], I0=s2[1] * 1.0 * 1e-4)
-    ref.do_matdecomp_gn(ct, np.ones((1, 2)), np.ones((1, 2)), sp1, sp2, 1)
-    ref.optimize_sino_cpu = real_opt
-    ee, i0, mus = captured['ee'], captured['i0'][:, 0, :], captured['mus']
-
-    # ---- (a) unscreened pixels
-    rng = np.random.default_rng(20261004)
-    nV, nB, n_iters = 6, 32, 50
-    a_true = np.stack([rng.uniform(0.0, 35.0, (nV, nB)), rng.uniform(0.0, 6.0, (nV, nB))], axis=-1)
-    a_true[:, :2] = 0.0                                   # two air channels per view
-    g = forward_counts(a_true, i0, mus)                   # [2, nV, nB]
+def screen(real_opt, g, ee, i0, mus, n_iters):
+    """Per pixel of g [2, nV, nB]: did the reference raise (and at which iteration), its result after n_iters
+    iterations, the ill-conditioning flag of CRITERION_VERSION and the worst Hessian condition number on the way."""
+    _, nV, nB = g.shape
     raised = np.zeros((nV, nB), dtype=bool)
     raised_at = np.full((nV, nB), -1, dtype=np.int32)
     a50 = np.full((nV, nB, 2), np.nan)
@@ -134,7 +115,43 @@ def main():
                     a = real_opt(gp, ee, i0_1, mus, it + 1, verbose=False)[0, 0]
                 cond[j, b] = worst
     ill |= ~raised & ~(cond <= 1e13)
+    return raised, raised_at, a50, ill, cond
+
+
+def main():
+    ref = load_reference()
+    xc = load_pkg_module('xcompy')
+    ref.xc.mixatten = xc.mixatten
+    out = {}
+
+    # ---- tables of the live default pair, captured from do_matdecomp_gn
+    captured = {}
+    real_opt = ref.optimize_sino_cpu
+
+    def spy(Sino_gg, ee, i0, mus, n_iters, verbose=True):
+        captured.update(ee=np.array(ee), i0=np.array(i0), mus=np.array(mus))
+        return real_opt(Sino_gg, ee, i0, mus, n_iters, verbose=False)
+
+    ref.optimize_sino_cpu = spy
+    det = half_split(f'{REF}/input/detector/eta_eid_mv.bin')
+    s1, s2 = half_split(f'{REF}/input/spectrum/detunedMV_1mGy_float32.bin'), half_split(
+        f'{REF}/input/spectrum/80kV_1mGy_float32.bin')
+    ct = types.SimpleNamespace(det_E=det[0], det_eta_E=det[1], eid=True)
+    sp1 = types.SimpleNamespace(E=s1[0], I0=s1[1] * 9.0 * 1e-4)
+    sp2 = types.SimpleNamespace(E=s2[0], I0=s2[1] * 1.0 * 1e-4)
+    ref.do_matdecomp_gn(ct, np.ones((1, 2)), np.ones((1, 2)), sp1, sp2, 1)
+    ref.optimize_sino_cpu = real_opt
+    ee, i0, mus = captured['ee'], captured['i0'][:, 0, :], captured['mus']
+
+    # ---- (a) unscreened pixels
+    rng = np.random.default_rng(20261004)
+    nV, nB, n_iters = 6, 32, 50
+    a_true = np.stack([rng.uniform(0.0, 35.0, (nV, nB)), rng.uniform(0.0, 6.0, (nV, nB))], axis=-1)
+    a_true[:, :2] = 0.0                                   # two air channels per view
+    g = forward_counts(a_true, i0, mus)                   # [2, nV, nB]
+    raised, raised_at, a50, ill, cond = screen(real_opt, g, ee, i0, mus, n_iters)
     out['uns_cond'] = cond
+    out['uns_criterion_version'] = np.array(CRITERION_VERSION)
     out.update(uns_ee=ee, uns_i0=i0, uns_mus=mus, uns_a_true=a_true, uns_g=g, uns_raised=raised,
                uns_raised_at=raised_at, uns_a50=a50, uns_ill=ill, uns_n_iters=np.array(n_iters),
                uns_spec1_E=sp1.E, uns_spec1_I0=sp1.I0, uns_spec2_E=sp2.E, uns_spec2_I0=sp2.I0,

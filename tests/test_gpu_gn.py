@@ -422,6 +422,48 @@ def test_unscreened_live_default_pair(hip, extra):
         assert np.array_equal(s[0], p[0]) and np.array_equal(s[1], p[1])
 
 
+def test_excluded_live_pair_pixels_stay_visible(hip, extra):
+    """The 16 live-pair pixels the frozen screen leaves out (8 where the reference raises, 8 ill conditioned): what the
+    kernel returns on each of them next to the reference, written to gpurun_out/r03_live_pair_excluded.txt (and printed)
+    so that the cost of the exclusion stays visible.  Nothing is asserted about their values beyond 'never a trap'."""
+    import os
+    e = extra
+    a = run(e['uns_g'], e['uns_i0'], e['uns_mus'], int(e['uns_n_iters']), 'f64')
+    lines = ['view ch | reference a50 (tissue, bone)  raised@ | kernel (tissue, bone) | rel diff | worst Hessian cond | truth']
+    for j, b in zip(*np.nonzero(e['uns_raised'] | e['uns_ill'])):
+        r, k = e['uns_a50'][j, b], a[j, b]
+        d = np.max(np.abs(k - r) / np.maximum(np.abs(r), 1.0)) if np.isfinite(r).all() and np.isfinite(k).all() else np.nan
+        lines.append(f'{j:4d} {b:2d} | {r[0]: .6e} {r[1]: .6e}  {int(e["uns_raised_at"][j, b]):3d} | {k[0]: .6e} {k[1]: .6e} | '
+                     f'{d:.2e} | {e["uns_cond"][j, b]:.2e} | {e["uns_a_true"][j, b][0]:.2f} {e["uns_a_true"][j, b][1]:.2f}')
+    text = '\n'.join(lines)
+    print(text)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    open(os.path.join(out, 'r03_live_pair_excluded.txt'), 'w').write(text + '\n')
+    assert len(lines) == 17 and int(e['uns_criterion_version']) == 2
+
+
+@pytest.mark.parametrize('precision,tol', [('f64', TOL_F64), ('mixed', 1e-5)])
+def test_poisson_noisy_goldens(hip, precision, tol):
+    """Round 3: 140 / 80 kVp at the reference's default dose scaling (main.py:68) with per-bin Poisson noise
+    (tests/golden/make_goldens_r3.py; the frozen screen flags none of the 192 pixels): trajectories after 1, 2 and 50
+    iterations and the public call with the mask from the noisy maximum."""
+    import os
+    from conftest import GOLDEN
+    from dex_ct_sim_amd import matdecomp as md
+    e = np.load(os.path.join(GOLDEN, 'ref_noisy.npz'))
+    for n_iters, key in ((1, 'noisy_a1'), (2, 'noisy_a2'), (50, 'noisy_a50')):
+        a = run(e['noisy_g'], e['noisy_i0'], e['noisy_mus'], n_iters, precision)
+        assert err(a, e[key]) < (tol if n_iters == 50 or precision == 'f64' else 1e-4), (n_iters, err(a, e[key]))
+    ct = types.SimpleNamespace(det_E=e['noisy_det_E'], det_eta_E=e['noisy_det_eta'], eid=True)
+    s1 = types.SimpleNamespace(E=e['noisy_spec1_E'], I0=e['noisy_spec1_I0'])
+    s2 = types.SimpleNamespace(E=e['noisy_spec2_E'], I0=e['noisy_spec2_I0'])
+    m1, m2 = md.get_basismat_sinos(ct, e['noisy_g'][0].copy(), e['noisy_g'][1].copy(), s1, s2, n_iters=50, precision=precision,
+                                   strict=True)
+    assert np.array_equal(m1 == 0, e['noisy_mat1'] == 0) and np.array_equal(m2 == 0, e['noisy_mat2'] == 0)
+    assert err(np.stack([m1, m2], -1), np.stack([e['noisy_mat1'], e['noisy_mat2']], -1)) < tol
+
+
 def test_nan_count_masks_nothing_like_np_max(hip, golden, extra):
     """np.max propagates a NaN (matdecomp.py:195-196): with one NaN in sinogram 1 the reference masks NOTHING
     (air pixels keep their iterated values) and the NaN pixel stays NaN.  dexct_reduce_max propagates it too."""

@@ -1,0 +1,64 @@
+"""profiles/r03_shard_of.md: what ONE rank of a K-GPU strong-scaling run does, measured alone on one GPU
+(`bench.py --shard-of K`), for K = 1, 2, 4, 8 on BASELINE configs[2] (1000 x 800) and configs[3] (2000 x 1024) - the
+prediction the driver's first N-rank RCCL line is to be compared with.
+
+    python tools/shard_of_table.py > profiles/r03_shard_of.md
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LINK_GBS = 50.0          # assumed achievable per-link xGMI rate, one direction (nominal 7 x ~153 GB/s per GPU, both directions)
+
+rows = []
+for workload, views, chans in (('config2', 1000, 800), ('config3', 2000, 1024)):
+    for K in (1, 2, 4, 8):
+        for rank in sorted({0, K // 2}):
+            cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--shard-of', str(K), '--shard-rank',
+                   str(rank), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--skip-single-row', '--skip-gn-full-loop',
+                   '--skip-dropin']
+            if K == 1:
+                cmd = [c for c in cmd if c not in ('--shard-of', '--shard-rank')][:]
+                cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--steps', '3', '--warmup', '1',
+                       '--no-cpu-baseline', '--skip-single-row', '--skip-gn-full-loop', '--skip-dropin']
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            if p.returncode != 0:
+                print(p.stderr[-2000:], file=sys.stderr)
+                raise SystemExit(1)
+            j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][0])
+            n_e = 134 + 74
+            total_bytes = 2 * views * 512 * chans * 4                   # both raw sinograms of the whole scan, float32
+            recv = total_bytes * (K - 1) / K
+            rows.append(dict(workload=workload, K=K, rank=rank, views=j['config']['rays_per_gpu'] // (512 * chans),
+                             step_ms=j['ms_per_step'], sid_ms=j['kernel_ms']['siddon_project'], gn_ms=j['kernel_ms']['gn_decompose'],
+                             recv_gb=recv / 1e9, ring_ms=1e3 * recv / (LINK_GBS * 1e9),
+                             direct_ms=1e3 * (total_bytes / K) / (LINK_GBS * 1e9) if K > 1 else 0.0,
+                             integrals=views * 512 * chans * n_e))
+            print(f'{workload} K={K} rank={rank}: step {j["ms_per_step"]:.1f} ms', file=sys.stderr, flush=True)
+
+print('# One rank\'s share of a K-GPU strong-scaling run, measured alone on one MI355X (`bench.py --shard-of K`)\n')
+print('Step = plan + fused dual-spectrum projection (sino_raw + sino_log) + global max + 50-iteration Newton + transposes, on the')
+print('rank\'s contiguous views of the FIXED scan; no collective runs here.  `gather` = bytes the rank RECEIVES in the one')
+print('all-gather of the raw sinograms (both spectra, float32, reference order).  The collective is started right after the')
+print('projection and overlaps the Newton kernel, so only `max(0, gather - Newton)` is exposed.  Two gather estimates at an')
+print(f'assumed {LINK_GBS:.0f} GB/s per xGMI link and direction: `ring` = (K-1)/K x total / link (a ring is per-link bound),')
+print('`direct` = one shard per peer link in parallel.  Predicted value = ray-energy integrals of the whole scan / (slowest')
+print('measured rank step + exposed ring gather).\n')
+print('| workload | K | rank | views | step ms | projection ms | Newton ms | gather GB / rank | ring ms | direct ms | exposed (ring) ms |')
+print('|---|---|---|---|---|---|---|---|---|---|---|')
+for r in rows:
+    exposed = max(0.0, r['ring_ms'] - r['gn_ms'])
+    print(f"| {r['workload']} | {r['K']} | {r['rank']} | {r['views']} | {r['step_ms']:.1f} | {r['sid_ms']:.2f} | {r['gn_ms']:.1f} | "
+          f"{r['recv_gb']:.2f} | {r['ring_ms']:.1f} | {r['direct_ms']:.1f} | {exposed:.1f} |")
+print('\n| workload | K | slowest rank step ms | predicted integrals/s | speed-up vs K = 1 |')
+print('|---|---|---|---|---|')
+base = {}
+for wl in ('config2', 'config3'):
+    for K in (1, 2, 4, 8):
+        rr = [r for r in rows if r['workload'] == wl and r['K'] == K]
+        t = max(r['step_ms'] + max(0.0, r['ring_ms'] - r['gn_ms']) for r in rr)
+        val = rr[0]['integrals'] / (t * 1e-3)
+        base.setdefault(wl, val)
+        print(f'| {wl} | {K} | {t:.1f} | {val:.3e} | {val / base[wl]:.2f} |')
