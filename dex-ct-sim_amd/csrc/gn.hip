@@ -25,7 +25,7 @@ namespace dexct {
 
 // States kept for the exact repeated-state exit of the float64 Newton loop (cycles up to kGnHistory + 1).
 constexpr int kGnHistory = 8;
-constexpr int kGnRingDefault = 1;    // history of the lane-refill kernel as a ring (DEXCT_GN_RING=0: the shifting form)
+constexpr int kGnRingDefault = 0;    // DEXCT_GN_RING=1: history of the lane-refill kernel as a ring (fewer vector instructions, more spills: measured equal, profiles/r03_gn_isa.md)
 
 constexpr int kGnBlock = 256;
 constexpr int kTab = 14;  // -mu0 K, -mu1 K (K = 2048/ln2), then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2

@@ -145,7 +145,7 @@ constexpr int kLdsBlock = 128;   // block size of the LDS-accumulator instantiat
 
 // ---------------------------------------------------------------------------------------------
 // rays_kernel: one thread per ray.  NM > 0: materials in registers; NM == 0: LDS accumulators.
-template <int NM, int BLOCK>
+template <int NM, int BLOCK, int BATCH = 1>
 __global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a, const float* __restrict__ mu,
                                                       const float* __restrict__ w, const float* __restrict__ w2) {
   extern __shared__ float lds_dyn[];
@@ -165,14 +165,63 @@ __global__ __launch_bounds__(BLOCK) void rays_kernel(ProjArgs a, const float* __
   if (NM > 0) ra.clear(); else la.clear();
   long long V = p.V0 + (long long)p.i_first * p.SV;
   uint32_t off = (uint32_t)p.i_first * (uint32_t)nv;
-  for (int s = 0; s < p.n_slabs; ++s) {
-    const SlabPieces sp = dda_slab(V, p.SV, smask, p.kf);
-    const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
-    const uint32_t ida = ina ? base[off + (uint32_t)sp.ja] : 0u;
-    const uint32_t idb = inb ? base[off + (uint32_t)sp.jb] : 0u;
-    if (NM > 0) ra.slab(ida, idb, sp.t); else la.slab(ida, idb, sp.t);
-    V += p.SV;
-    off += (uint32_t)nv;
+  if constexpr (NM > 0 && BATCH > 1) {
+    // BATCH slabs at a time: all 2 x BATCH byte loads are issued before the first id is used (a lane's slabs form a
+    // serial chain otherwise: one L2 round trip per slab).  The slab geometry is integer arithmetic on V, independent of
+    // the loaded ids, so it runs ahead; the accumulation keeps slab order (corrections are order dependent) and uses the
+    // branch-free form (adding +0 changes no sum).  A piece outside the grid - or past the ray's last slab - reads byte 0
+    // of the slice and is then given id 0, which counts nothing.
+    for (int s0 = 0; s0 < p.n_slabs; s0 += BATCH) {
+      uint32_t xa[BATCH], xb[BATCH];
+      uint32_t in_mask = 0;
+      const long long Vb = V;
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const bool on = s0 + k < p.n_slabs;
+        const int32_t ja = (int32_t)(V >> DEXCT_FIX_FRAC), jb = (int32_t)((V + p.SV) >> DEXCT_FIX_FRAC);
+        const bool ina = on && (uint32_t)ja < (uint32_t)nv, inb = on && (uint32_t)jb < (uint32_t)nv;
+        xa[k] = base[ina ? off + (uint32_t)ja : 0u];
+        xb[k] = base[inb ? off + (uint32_t)jb : 0u];
+        in_mask |= (ina ? 1u : 0u) << (2 * k) | (inb ? 2u : 0u) << (2 * k);
+        V += p.SV;
+        off += (uint32_t)nv;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // counts: integer, order independent, no branch.  Corrections (float32, slab order) only where a crossing separates
+      // two different ids - rare (material boundaries), so the crossing parameter t is not even computed otherwise.
+      uint32_t differ = 0;
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        xa[k] = (in_mask >> (2 * k)) & 1u ? xa[k] : 0u;
+        xb[k] = (in_mask >> (2 * k + 1)) & 1u ? xb[k] : 0u;
+#pragma unroll
+        for (int m = 1; m < NM; ++m) ra.cnt[m] += (xb[k] == (uint32_t)m) ? 1 : 0;
+        differ |= xa[k] ^ xb[k];
+      }
+      if (__ballot(differ != 0u) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+          if (xa[k] != xb[k]) {
+            const float t = dda_slab(Vb + (long long)k * p.SV, p.SV, smask, p.kf).t;
+#pragma unroll
+            for (int m = 1; m < NM; ++m) {
+              ra.corr[m] += (xa[k] == (uint32_t)m) ? t : 0.0f;
+              ra.corr[m] -= (xb[k] == (uint32_t)m) ? t : 0.0f;
+            }
+          }
+        }
+      }
+    }
+  } else {
+    for (int s = 0; s < p.n_slabs; ++s) {
+      const SlabPieces sp = dda_slab(V, p.SV, smask, p.kf);
+      const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
+      const uint32_t ida = ina ? base[off + (uint32_t)sp.ja] : 0u;
+      const uint32_t idb = inb ? base[off + (uint32_t)sp.jb] : 0u;
+      if (NM > 0) ra.slab(ida, idb, sp.t); else la.slab(ida, idb, sp.t);
+      V += p.SV;
+      off += (uint32_t)nv;
+    }
   }
   if (!live) return;
   const size_t ray = ray_index(a, v, r, c);
@@ -1134,9 +1183,25 @@ __global__ __launch_bounds__(64) void trace_kernel(dexct_fan_geom g, const dexct
 template <int NM>
 static int launch_rays(const ProjArgs& a, const Tables& t, hipStream_t st) {
   constexpr int B = NM > 0 ? kBlock : kLdsBlock;
-  dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
   size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
-  hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w, t.w2);
+  if constexpr (NM > 0) {
+    // register accumulators: one wave per workgroup (no lanes idle beyond the last partial wave of a view: 800 channels
+    // are 12.5 waves, not 4 x 256 threads) and batches of slabs with all their loads in flight (DEXCT_RAYS_BATCH=1/4/8/16;
+    // measured on the reference's 1000 x 800 single-row scan: 0.620 / 0.440 / 0.450 / 0.457 ms, profiles/r03_kernels.md)
+    int batch = 4;
+    if (const char* e = getenv("DEXCT_RAYS_BATCH")) batch = atoi(e);
+    dim3 grid1((a.g.n_channels + 63) / 64, a.g.n_rows, a.n_local_views);
+    if (batch == 8) hipLaunchKernelGGL((rays_kernel<NM, 64, 8>), grid1, dim3(64), 0, st, a, t.mu, t.w, t.w2);
+    else if (batch == 4) hipLaunchKernelGGL((rays_kernel<NM, 64, 4>), grid1, dim3(64), 0, st, a, t.mu, t.w, t.w2);
+    else if (batch == 16) hipLaunchKernelGGL((rays_kernel<NM, 64, 16>), grid1, dim3(64), 0, st, a, t.mu, t.w, t.w2);
+    else {
+      dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
+      hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w, t.w2);
+    }
+  } else {
+    dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
+    hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w, t.w2);
+  }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

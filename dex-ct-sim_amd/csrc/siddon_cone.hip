@@ -214,12 +214,21 @@ struct ConeRec {
 
 constexpr int kConeRows = 256;
 
-template <int NM, int kB = 4>      // kB: slabs per batch
+// LDSC: the float32 corrections are accumulated in per-lane LDS cells, one row per id (4 ds_add_f32 per boundary slab
+// instead of 12 selects + 12 adds + 9 compares in registers: the exact path was 55 of the kernel's 21.6 vector
+// instructions per wave and slab).  Same additions in the same order per material - corrections of different
+// materials commute - so the path lengths stay bit-identical.
+template <int NM, int kB = 4, bool LDSC = true>      // kB: slabs per batch
 __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
                                                                const float* __restrict__ mu, const float* __restrict__ w,
                                                                int n_chunks, int view_tile) {
   __shared__ ConeRec rec[kConeRows];
+  __shared__ float lds_corr[LDSC ? 4 : 1][kConeRows];     // [id][lane]; id 3 = outside the grid: a cell nobody reads
   const int tid = threadIdx.x;
+  if (LDSC) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) lds_corr[m][tid] = 0.0f;  // each lane only ever touches its own cells: no barrier needed
+  }
   // block -> (view, channel, row chunk): contiguous logical ids per XCD, views fastest inside a tile of view_tile
   const uint32_t nblk = gridDim.x, bid = blockIdx.x, per = nblk >> 3;
   const uint32_t logical = (bid < (per << 3)) ? (bid & 7u) * per + (bid >> 3) : bid;
@@ -347,12 +356,21 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
             const uint32_t idm = vx[j] ? (v_first ? c1[j] : c2[j]) : (v_first ? xa[j] : x[j]);
             const uint32_t ida = xa[j], idb = x[j];
             if (ida != idm || idm != idb) {
+              if constexpr (LDSC) {
+                // the oracle's four terms, each added to the cell of the id it belongs to, in the oracle's order
+                float* cell = &lds_corr[0][tid];
+                __hip_atomic_fetch_add(cell + idm * kConeRows, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + idb * kConeRows, -t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + ida * kConeRows, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + idm * kConeRows, -t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              } else {
 #pragma unroll
-              for (int m = 0; m < NM; ++m) {
-                corr[m] += (idm == (uint32_t)m) ? t2 : 0.0f;
-                corr[m] -= (idb == (uint32_t)m) ? t2 : 0.0f;
-                corr[m] += (ida == (uint32_t)m) ? t1 : 0.0f;
-                corr[m] -= (idm == (uint32_t)m) ? t1 : 0.0f;
+                for (int m = 0; m < NM; ++m) {
+                  corr[m] += (idm == (uint32_t)m) ? t2 : 0.0f;
+                  corr[m] -= (idb == (uint32_t)m) ? t2 : 0.0f;
+                  corr[m] += (ida == (uint32_t)m) ? t1 : 0.0f;
+                  corr[m] -= (idm == (uint32_t)m) ? t1 : 0.0f;
+                }
               }
             }
           }
@@ -370,6 +388,10 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   }
 #pragma unroll
   for (int m = 0; m < NM; ++m) cnt[m] += (acc >> (8 * m)) & 0xFFu;
+  if (LDSC) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) corr[m] = lds_corr[m][tid];
+  }
   if (!live) return;
   // ---- detection (same weighting as the other kernels)
   const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
@@ -527,7 +549,9 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
     default: {
       const char* e = getenv("DEXCT_CONE_BATCH");         // tuning knob
       const int kb = e ? atoi(e) : 4;
-      if (kb == 8) hipLaunchKernelGGL((cone_rows_kernel<3, 8>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
+      const char* le = getenv("DEXCT_CONE_LDSC");         // 0: corrections in registers (the round-2 form), for A/B
+      if (le && atoi(le) == 0) hipLaunchKernelGGL((cone_rows_kernel<3, 4, false>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
+      else if (kb == 8) hipLaunchKernelGGL((cone_rows_kernel<3, 8>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
       else if (kb == 2) hipLaunchKernelGGL((cone_rows_kernel<3, 2>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
       else hipLaunchKernelGGL((cone_rows_kernel<3, 4>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
       break;
