@@ -434,16 +434,16 @@ def main():
     seg_vc, _ = segment_count(co, geom, ct.view_cs(), ct.chan_cs(), total_views, vb, ve)
     # algorithmic bytes: S_ray x bytes per stored voxel + outputs; the packed volume stores a voxel in 2 bits
     b_vox = 0.25 if getattr(pj, 'use_packed', False) else 1.0
-    alg_bytes = seg_vc * rows * b_vox + 4 * 2 * n_rays
+    alg_bytes = seg_vc * rows * b_vox + 4 * 4 * n_rays          # 4 floats out per ray: sino_raw and sino_log of both spectra
     alg_gbps = alg_bytes / (sid_ms * 1e-3) / 1e9
     kname = 'rows16_kernel' if getattr(pj, 'use_packed', False) else \
         {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel', 5: 'rows4t_kernel', 6: 'wave_ray_kernel'}[args.kernel or (3 if native == 1 else 1)]
     traffic = traffic_src = None
     prof = {}
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), key=os.path.getmtime):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):     # r01a < ... < r03a: the last match wins
         j = json.load(open(f))         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_gpu.sh)
         if j.get('rays_per_gpu') == n_rays and kname in j.get('siddon_kernel', '') and j.get('n', 512) == n:
-            prof, traffic_src = j, 'profiles/' + os.path.basename(f)        # same workload and kernel only; newest wins
+            prof, traffic_src = j, 'profiles/' + os.path.basename(f)        # same workload and kernel only
     traffic = prof.get('siddon_hbm_bytes_per_launch')
     vol_bytes = int(n * n * n * b_vox)
     cache_resident = vol_bytes <= 256 * 2 ** 20
@@ -610,6 +610,27 @@ def main():
         ms1 = e0.elapsed_time(e1) / 10
         out['single_row'] = {'rays': args.views * args.channels, 'siddon_ms': ms1, 'kernel': 'rays_kernel (lanes = channels)',
                              'integrals_per_s': args.views * args.channels * sum(n_e_spec) / (ms1 * 1e-3)}
+        # roofline of the reference's own geometry (one row, input/params.txt:12,18): vector issue.  Floor per slab and
+        # lane of this formulation: fixed-point step 1, two slices 2, two range tests 2, two offsets + their selects 4,
+        # two id selects 2, two counts (compare + add-with-carry) 4, id difference 2 = 17 vector instructions (the compiled
+        # loop issues 20.5, profiles/r03_kernels.md), 2 byte loads; detection per ray and weighted energy 3 FMA + v_exp_f32
+        # (2 slots) + 1 FMA per weighting spectrum.  Slabs from the oracle's plan of the same scan.
+        geom1 = co.make_geom(ct1.N_proj, ct1.N_channels, 1, 0, n, n, 1, ph1.dx, ph1.dy, ph1.dz, ct1.SID, ct1.SDD)
+        plan1 = co.plan(geom1, ct1.view_cs(), ct1.chan_cs(), 0, ct1.N_proj)
+        slabs1 = float(plan1['n_slabs'].sum())
+        floor1 = (17.0 * slabs1 + args.views * args.channels * (5.0 * n_e_any + sum(n_e_spec))) / 64.0
+        floor1_ms = floor1 / slots_per_s * 1e3
+        o1 = (prof.get('other_kernels') or {}).get('single_row', {})
+        out['single_row']['roofline'] = {
+            'kernel': 'rays_kernel<3, 64, 4>', 'bound': 'valu_issue', 'unit': 'G wave-instructions/s', 'peak': slots_per_s / 1e9,
+            'achieved': floor1 / (ms1 * 1e-3) / 1e9, 'frac': floor1_ms / ms1, 'floor_wave_instructions': floor1,
+            'floor_ms_at_%.1f_GHz' % CLOCK_GHZ: floor1_ms, 'slabs_per_launch': slabs1,
+            'algorithmic_bytes_per_launch': 2.0 * slabs1 + 8.0 * args.views * args.channels,
+            'measured_valu_instructions': o1.get('valu_insts'), 'measured_valu_busy': o1.get('valu_busy'),
+            'measured_wait_any_share': o1.get('wait_any_share'), 'traffic': (o1.get('fetch_bytes_raw', 0) + o1.get('write_bytes', 0)) or None,
+            'counters_source': traffic_src if o1 else None,
+            'note': 'one %d x %d slice is L2 resident (%.0f KiB): not an HBM-bound kernel; frac = instruction floor / time' %
+                    (n, n, n * n / 1024.0)}
         # the same scan with ONE WAVEFRONT PER RAY (the north star's mapping): A/B of DESIGN.md section 4.1
         pj6 = fp.Projector(ct1, ph1, kernel=6)
         pj6.project_tables(mu_d, w_d, out=c1)
@@ -646,6 +667,25 @@ def main():
         out['cone_beam'] = {'rays': cv * rows * args.channels, **res['cone_rows_kernel'],
                             'kernel': 'cone_rows_kernel (rows of a (view, channel) pair as lanes)',
                             'thread_per_ray': res['cone_kernel']}
+        # roofline: vector issue.  Floor per slab and lane (= detector row) of this formulation: 64-bit z step 1, slice
+        # (shift + clamp) 2, count the b voxel 2, id difference 1 = 6, plus 2 v_readfirstlane of the shared column offsets
+        # = 8 (the compiled fast path issues 16, profiles/r03_kernels.md), 2 byte loads; exact corrections only at material
+        # boundaries; detection as above.  In-plane slabs are shared by the rows of a (view, channel) pair.
+        geomc = co.make_geom(ctc.N_proj, ctc.N_channels, 1, 0, n, n, n, ph.dx, ph.dy, ph.dz, ctc.SID, ctc.SDD)
+        planc = co.plan(geomc, ctc.view_cs(), ctc.chan_cs(), 0, ctc.N_proj)
+        slabsc = float(planc['n_slabs'].sum()) * rows
+        floorc = (8.0 * slabsc + cv * rows * args.channels * (5.0 * n_e_any + sum(n_e_spec))) / 64.0
+        floorc_ms = floorc / slots_per_s * 1e3
+        oc = (prof.get('other_kernels') or {}).get('cone_rows', {})
+        msc = res['cone_rows_kernel']['siddon_ms']
+        out['cone_beam']['roofline'] = {
+            'kernel': 'cone_rows_kernel<3, 4>', 'bound': 'valu_issue', 'unit': 'G wave-instructions/s', 'peak': slots_per_s / 1e9,
+            'achieved': floorc / (msc * 1e-3) / 1e9, 'frac': floorc_ms / msc, 'floor_wave_instructions': floorc,
+            'floor_ms_at_%.1f_GHz' % CLOCK_GHZ: floorc_ms, 'lane_slabs_per_launch': slabsc,
+            'algorithmic_bytes_per_launch': 2.0 * slabsc + 8.0 * cv * rows * args.channels,
+            'measured_valu_instructions': oc.get('valu_insts'), 'measured_valu_busy': oc.get('valu_busy'),
+            'measured_wait_any_share': oc.get('wait_any_share'), 'traffic': (oc.get('fetch_bytes_raw', 0) + oc.get('write_bytes', 0)) or None,
+            'counters_source': traffic_src if oc else None}
         del cc
 
     # ---- the PUBLIC boundary (NumPy in / NumPy out): get_sino x 2 + get_basismat_sinos(n_iters=50) as

@@ -1270,10 +1270,12 @@ static int launch_rows4t_s(const ProjArgs& a, const Tables& t, hipStream_t st, i
 }
 
 // Tile shape of rows4t_kernel: NPAIR pairs = tile_v views x (NPAIR / tile_v) channels, barrier every SUB slabs.
-// Defaults are the measured optimum; DEXCT_TILE_PAIRS / DEXCT_TILE_V / DEXCT_TILE_SUB override.
+// Defaults = the FASTEST tile of profiles/r02_tiled_1024.md (8 pairs = 2 views x 4 channels, barrier every 64 slabs: 21.8 ms
+// on the 1024^3 share; 16 : 4 : 16 has the lowest fabric traffic, 61-66 GB, but takes 40.6 ms).  The kernel is opt-in
+// (kernel = 5, A/B only): DEXCT_TILE_PAIRS / DEXCT_TILE_V / DEXCT_TILE_SUB override.
 template <int NM>
 static int launch_rows4t(const ProjArgs& a, const Tables& t, hipStream_t st) {
-  int pairs = 16, tile_v = 4, sub = 16;
+  int pairs = 8, tile_v = 2, sub = 64;
   if (const char* e = getenv("DEXCT_TILE_PAIRS")) pairs = atoi(e);
   if (const char* e = getenv("DEXCT_TILE_V")) tile_v = atoi(e);
   if (const char* e = getenv("DEXCT_TILE_SUB")) sub = atoi(e);

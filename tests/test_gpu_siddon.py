@@ -795,3 +795,24 @@ def test_get_sino_returns_page_locked_arrays_and_keys_the_cache_in_constant_time
     calls.clear()
     fp._projector(ct, ph, (0, 20))
     assert max(calls) == ph.volume.size
+
+
+def test_integration_md_get_sino_stub_runs(hip):
+    """The reference-side get_sino binding shown in INTEGRATION.md, executed as written: same counts as the package's
+    get_sino bit for bit (same kernel), log sinogram within float32 rounding."""
+    import os
+    import re
+    import dex_ct_sim_amd as dx
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    blocks = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'def get_sino' in b]
+    assert len(blocks) == 1
+    code = blocks[0].replace("C.CDLL('dex-ct-sim_amd/libdexct_hip.so')",
+                             f"C.CDLL({os.path.join(root, 'dex-ct-sim_amd', 'libdexct_hip.so')!r})")
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    ct, ph = small_scan(n=48, n_views=40, n_channels=64)
+    sp = spectra()[0]
+    raw, log = ns['get_sino'](ct, ph, sp)
+    raw0, log0 = dx.get_sino(ct, ph, sp)
+    assert np.array_equal(raw, raw0) and np.allclose(log, log0, rtol=0, atol=1e-6)

@@ -9,11 +9,11 @@ REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-gn-full-loop"
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/clk -- python3 $REPO/bench.py $ARGS "$@" > $OUT/clk.json 2> $OUT/clk.err
-echo "clk rc=$?"
+rc=$?; echo "clk rc=$rc"; if [ $rc -ne 0 ]; then echo "rocprofv3 pass failed: stopping (no summary from partial CSVs)"; exit $rc; fi
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/a -- python3 $REPO/bench.py $ARGS "$@" > $OUT/a.json 2> $OUT/a.err
-echo "a rc=$?"
+rc=$?; echo "a rc=$rc"; if [ $rc -ne 0 ]; then echo "rocprofv3 pass failed: stopping (no summary from partial CSVs)"; exit $rc; fi
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/b -- python3 $REPO/bench.py $ARGS "$@" > $OUT/b.json 2> $OUT/b.err
-echo "b rc=$?"
+rc=$?; echo "b rc=$rc"; if [ $rc -ne 0 ]; then echo "rocprofv3 pass failed: stopping (no summary from partial CSVs)"; exit $rc; fi
 python3 - <<PY
 import csv, glob, collections
 dur = {}

@@ -7,7 +7,7 @@ mkdir -p $OUT
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $REPO/tools/bench_tiled.py --reps 1 "$@" > $OUT/run.txt 2> $OUT/run.err
-echo "rc=$?"
+rc=$?; echo "rc=$rc"; if [ $rc -ne 0 ]; then echo "rocprofv3 pass failed: stopping (no summary from partial CSVs)"; exit $rc; fi
 python3 - <<PY
 import csv, glob
 for f in glob.glob('$OUT/fetch/*/*_counter_collection.csv'):

@@ -73,7 +73,7 @@ if cal:
         if 'dexct' in k:
             lines.append(f'| `{k[:60]}` | {fetch[k] / 1e9:.3f} | {write.get(k, 0) / 1e9:.3f} |')
     for k in fetch:
-        if 'rows' in k and 'kernel' in k and 'siddon_kernel' not in traffic:
+        if 'rows' in k and 'kernel' in k and 'cone_' not in k and 'siddon_kernel' not in traffic:
             traffic['siddon_kernel'] = k
             # 4-B-per-lane dword loads (rows4) are tallied at half, like gn_kernel's float32 input stream
             corr = 2.0 if ('rows4' in k or 'rows16' in k) else 1.0
@@ -85,13 +85,54 @@ if cal:
             traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
             traffic['gn_write_bytes'] = write.get(k, 0.0)
     for k, d in sq.items():
-        if ('rows' in k and 'kernel' in k) or 'gn_refill_kernel' in k:
+        if ('rows' in k and 'kernel' in k and 'cone_' not in k) or 'gn_refill_kernel' in k:
             tag2 = 'siddon' if 'rows' in k else 'gn'
             traffic[f'{tag2}_valu_insts'] = d.get('SQ_INSTS_VALU')
             if d.get('GRBM_GUI_ACTIVE'):
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's waves; GRBM_GUI_ACTIVE sums the 8 XCDs
                 traffic[f'{tag2}_valu_busy'] = d.get('SQ_ACTIVE_INST_VALU', 0) * 4.0 / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0)
                 traffic[f'{tag2}_wait_any_share'] = (d.get('SQ_WAIT_ANY', 0) / d['SQ_WAVE_CYCLES']) if d.get('SQ_WAVE_CYCLES') else None
+    # the other kernels of the bench line (single-row scan, cone beam): raw counters per launch.  FETCH_SIZE is NOT
+    # corrected for these access shapes (byte loads per lane: uncalibrated, MI355X_MICROARCH.md section HBM)
+    sq2 = pmc_raw('sq2')
+    extra = {}
+    for key, pat in (('single_row', 'rays_kernel'), ('wave_per_ray', 'wave_ray_kernel'), ('cone_rows', 'cone_rows_kernel'),
+                     ('cone_thread_per_ray', 'cone_kernel')):
+        for k in fetch:
+            if pat + '<' in k and 'layout' not in k:
+                d, d2 = sq.get(k, {}), sq2.get(k, {})
+                e = {'kernel': k.split('(')[0].replace('void dexct::', ''), 'fetch_bytes_raw': fetch[k], 'write_bytes': write.get(k, 0.0),
+                     'valu_insts': d.get('SQ_INSTS_VALU'), 'vmem_rd_insts': d2.get('SQ_INSTS_VMEM_RD'),
+                     'salu_insts': d2.get('SQ_INSTS_SALU'), 'lds_insts': d2.get('SQ_INSTS_LDS'), 'waves': d2.get('SQ_WAVES')}
+                if d.get('GRBM_GUI_ACTIVE'):
+                    e['valu_busy'] = d.get('SQ_ACTIVE_INST_VALU', 0) * 4.0 / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0)
+                    e['wait_any_share'] = (d.get('SQ_WAIT_ANY', 0) / d['SQ_WAVE_CYCLES']) if d.get('SQ_WAVE_CYCLES') else None
+                extra[key] = e
+    for r in rows:
+        for key, e in extra.items():
+            if r['Name'].split('(')[0].replace('void dexct::', '') == e['kernel']:
+                e['avg_ms_kernel_trace'] = float(r['AverageNs']) / 1e6
+    traffic['other_kernels'] = extra
+    # calibration of the dword-per-lane correction IN THIS RUN: pack2_kernel reads the byte volume once with one dword per
+    # lane (256 contiguous bytes per wave instruction) - the access shape of rows16_kernel / rows4_kernel
+    for k in fetch:
+        if 'pack2_kernel' in k and 'groups' not in k:
+            nvox = float(bench['config'].get('n', 512)) ** 3
+            traffic['dword_load_calibration'] = {'kernel': 'pack2_kernel', 'bytes_read': nvox, 'FETCH_SIZE': fetch[k],
+                                                 'ratio': fetch[k] / nvox}
+            lines += ['', f'dword-per-lane calibration: pack2_kernel reads {nvox / 1e9:.3f} GB, FETCH_SIZE reports '
+                          f'{fetch[k] / 1e9:.3f} GB (ratio {fetch[k] / nvox:.3f}): such loads are doubled (`siddon_fetch_correction`)']
+    if 'siddon_hbm_bytes_per_launch' in traffic:
+        ms = bench['kernel_ms']['siddon_project']
+        tb = traffic['siddon_hbm_bytes_per_launch'] / (ms * 1e-3) / 1e12
+        alg = bench.get('roofline_siddon', {}).get('algorithmic_bytes_per_launch')
+        traffic['siddon_traffic_TBps'] = tb
+        traffic['siddon_traffic_frac_of_hbm_peak'] = tb / 8.0
+        lines += ['', f'traversal kernel: {ms:.2f} ms, fabric traffic {traffic["siddon_hbm_bytes_per_launch"] / 1e9:.2f} GB per launch '
+                      f'(fetch x {traffic["siddon_fetch_correction"]:.0f} + write) = {tb:.2f} TB/s = {tb / 8.0:.2f} of the 8 TB/s HBM peak'
+                      + (f'; algorithmic bytes {alg / 1e9:.2f} GB = {alg / (ms * 1e-3) / 1e12:.2f} TB/s' if alg else '')
+                      + f'; vector pipe {100 * (traffic.get("siddon_valu_busy") or 0):.0f} % busy, waves waiting '
+                        f'{100 * (traffic.get("siddon_wait_any_share") or 0):.0f} %']
     traffic['transpose_xy_fetch_bytes'] = vol_bytes
     traffic['rays_per_gpu'] = bench['config']['rays_per_gpu']
     traffic['n'] = bench['config'].get('n', 512)
