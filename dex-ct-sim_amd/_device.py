@@ -37,7 +37,16 @@ def to_host(t):
     is garbage, so repeated calls do not pin new memory."""
     if not t.is_cuda:
         return t.numpy()
-    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host = pinned_empty(t.shape, t.dtype)
     host.copy_(t, non_blocking=True)
     torch.cuda.current_stream().synchronize()
     return host.numpy()
+
+
+def pinned_empty(shape, dtype):
+    """Page-locked host tensor; pageable if the host refuses to lock that much memory (the copy is then staged by the
+    runtime: slower, same result)."""
+    try:
+        return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+    except RuntimeError:
+        return torch.empty(tuple(shape), dtype=dtype)

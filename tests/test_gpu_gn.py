@@ -534,3 +534,31 @@ def test_verbose_progress_lines(hip, golden, capsys):
     s2 = types.SimpleNamespace(E=g['gn0_spec2_E'], I0=g['gn0_spec2_I0'])
     md.get_basismat_sinos(ct, gg[0].copy(), gg[1].copy(), s1, s2, n_iters=5, verbose=True)
     assert [ln.split(' / ')[0] for ln in capsys.readouterr().out.splitlines() if ' / 45 ' in ln] == ['0', '20', '40']
+
+
+def test_pipelined_host_boundary_changes_no_bit(hip, golden, monkeypatch):
+    """Round 3: for large NumPy sinograms get_basismat_sinos overlaps the copies with the Newton kernel in view chunks
+    (matdecomp._basismat_sinos_pipelined).  Same kernels, same pixels: bit-identical to the plain sequence, for float32
+    and float64 inputs, page-locked and pageable ones, with the global maximum of the WHOLE sinogram in the mask."""
+    from dex_ct_sim_amd import matdecomp as md
+    from dex_ct_sim_amd._device import to_host
+    g = golden
+    ct = types.SimpleNamespace(det_E=g['gn0_det_E'], det_eta_E=g['gn0_det_eta'], eid=bool(g['gn0_eid']))
+    s1 = types.SimpleNamespace(E=g['gn0_spec1_E'], I0=g['gn0_spec1_I0'])
+    s2 = types.SimpleNamespace(E=g['gn0_spec2_E'], I0=g['gn0_spec2_I0'])
+    rng = np.random.default_rng(3)
+    base = np.tile(g['gn0_g'], (1, 12, 3))                          # [2, 48, 96]: 48 views
+    base = base * rng.uniform(0.7, 1.0, base.shape)
+    base[0, 40, 5] = base[0].max() * 1.02                           # the global maximum sits in the LAST chunk
+    for dtype in (np.float32, np.float64):
+        a1, a2 = base[0].astype(dtype), base[1].astype(dtype)
+        plain = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+        monkeypatch.setattr(md, '_PIPE_MIN_PIXELS', 1)
+        piped = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+        pinned = md.get_basismat_sinos(ct, to_host(torch.tensor(a1, device='cuda')), to_host(torch.tensor(a2, device='cuda')), s1, s2,
+                                       n_iters=30)
+        monkeypatch.setattr(md, '_PIPE_MIN_PIXELS', 1 << 24)
+        for got in (piped, pinned):
+            assert np.array_equal(got[0].view(np.int64), plain[0].view(np.int64))
+            assert np.array_equal(got[1].view(np.int64), plain[1].view(np.int64))
+        assert (plain[0] == 0).sum() < plain[0].size // 2 and np.isfinite(plain[0]).all()

@@ -107,7 +107,12 @@ for case in range(n_cases):
                     bad.append('kernel 8: counts differ from kernel 4')
         auto = fp.Projector(ct, ph)
         stats['packed_auto'] += int(bool(auto.use_packed or auto.grouped_packed))
-        got0 = auto.project_tables(mu_d, w_d)
+        air = w.astype(np.float64).sum(axis=1)
+        got0, log0 = auto.project_tables(mu_d, w_d, air=air)          # round 3: the log sinogram from the detection store
+        want_log = torch.log(torch.tensor(air, dtype=torch.float32, device=dev)[:, None, None, None] / got0)
+        live = (got0 > 0) & torch.isfinite(want_log)
+        if not torch.allclose(log0[live], want_log[live], rtol=5e-6, atol=5e-7):
+            bad.append(f'kernel 0: log sinogram off by {float((log0[live] - want_log[live]).abs().max()):.2e}')
         if n_mat <= 4:
             same0 = torch.equal(got0, ref)
         elif auto.grouped or auto.grouped_packed:
