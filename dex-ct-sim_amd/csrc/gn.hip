@@ -500,7 +500,14 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
   const double* __restrict__ tab = ws + kWsHeader;
   const int64_t run = (int64_t)kWave * chunk;
-  int64_t next = ((int64_t)blockIdx.x * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;   // wave-uniform
+  // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).  A sinogram is periodic in the view
+  // length (air at both ends of every fan: pixels that end at once), so with "block b takes run b" an unlucky run length
+  // hands some XCDs nothing but air and others nothing but object: 2.67 instead of 2.0 ns/pixel on the 2000 x 1024 scan
+  // at 64 pixels per lane, +10 % on the benchmark scan at 20 or 40 (profiles/r03_kernels.md).  Each XCD therefore works
+  // through a CONTIGUOUS eighth of the runs: the same mix of views for every XCD, whatever the run length.
+  const uint32_t nblk_x = gridDim.x, per_x = nblk_x >> 3;
+  const uint32_t lblk = (blockIdx.x < (per_x << 3)) ? (blockIdx.x & 7u) * per_x + (blockIdx.x >> 3) : blockIdx.x;
+  int64_t next = ((int64_t)lblk * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;   // wave-uniform
   const int64_t end = next + run < n_pix ? next + run : n_pix;
   const bool has_mask = mask_max != nullptr;
   const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   }
   if (executed && (threadIdx.x & 63) == 0) {
     atomicAdd(executed, (unsigned long long)n_exec);            // one atomic per wave
-    const int64_t first = ((int64_t)blockIdx.x * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;
+    const int64_t first = ((int64_t)lblk * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;
     if (end > first) atomicAdd(executed + 1, (unsigned long long)(end - first));    // this wave's run of pixels is done
   }
 }

@@ -43,7 +43,7 @@ run(ref, {})
 variants = [{}, {'DEXCT_GN_RING': '0'}, {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_RING': '0', 'DEXCT_GN_MINW': '4'},
             {'DEXCT_GN_FULL_LOOP': '1'}, {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_RING': '0'}]
 if os.environ.get('GN_VARIANTS') == 'chunk':      # pixels per lane of a wave's run (default 64 at this size)
-    variants = [{}] + [{'DEXCT_GN_CHUNK': str(c)} for c in (8, 16, 32, 128, 256)]
+    variants = [{}] + [{'DEXCT_GN_CHUNK': c} for c in os.environ.get('CHUNKS', '8,16,32,128,256').split(',')]
 if os.environ.get('GN_VARIANTS') == 'hist':      # history length of the repeated-state exit (x occupancy)
     variants = [{}] + [{'DEXCT_GN_HIST': str(h)} for h in (4, 5, 6, 7, 10, 12)] + \
         [{'DEXCT_GN_HIST': '4', 'DEXCT_GN_MINW': '6'}, {'DEXCT_GN_HIST': '6', 'DEXCT_GN_MINW': '6'}]
