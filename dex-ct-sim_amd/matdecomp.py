@@ -185,7 +185,9 @@ def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None):
     return a if isinstance(sino1, torch.Tensor) else to_host(a)
 
 
-_PIPE_CHUNKS = 8                 # view chunks of the pipelined host boundary
+_PIPE_CHUNKS = 3                 # view chunks of the pipelined host boundary (tools/probes/boundary_gn.py at configs[2] size:
+                                 # 2 / 3 / 4 / 6 chunks 0.931 / 0.916 / 0.932 / 0.932 s, the plain sequence 1.038 s; short launches
+                                 # cost the Newton kernel efficiency, tools/probes/overlap.py)
 _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinogram) the plain sequence is as fast
 
 
@@ -219,9 +221,27 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
             ev = torch.cuda.Event()
             ev.record(copy)
             arrived.append(ev)
+    # Stacked fans arrive as [view][row][channel].  The kernel is ~8 % faster on [view][channel][row] (z-neighbours are
+    # nearly the same problem, so the lanes of a wave end together; tools/probes/overlap.py: 0.87 vs 0.80 s), which is also
+    # the order the projection writes: transpose in (2 x 1.7 ms), solve, transpose the result back (2.3 ms).
+    row_fastest = g1.dim() == 3 and g1.shape[1] >= 8
+    if row_fastest:
+        nR, nC = int(g1.shape[1]), int(g1.shape[2])
+        t1 = torch.empty((n_views, nC, nR), dtype=dt, device=dev)
+        t2 = torch.empty_like(t1)
+        at = torch.empty((n_views, nC, nR, 2), dtype=torch.float64, device=dev)
+        eb = 4 if dt == torch.float32 else 8
     for (b, e), ev in zip(bounds, arrived):
         main.wait_event(ev)
-        gn_device(g1[b:e], g2[b:e], i0, mus, n_iters, precision, out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh))
+        if row_fastest:
+            for src, dst in ((g1, t1), (g2, t2)):
+                _native.check(lib.dexct_transpose_batched(ptr(src[b:e]), ptr(dst[b:e]), e - b, nR, nC, eb, stream_ptr()),
+                              'dexct_transpose_batched')
+            gn_device(t1[b:e], t2[b:e], i0, mus, n_iters, precision, out=at[b:e], mask_max=gmax, mask_frac=float(mask_thresh))
+            _native.check(lib.dexct_transpose_batched(ptr(at[b:e]), ptr(a[b:e]), e - b, nC, nR, 16, stream_ptr()),
+                          'dexct_transpose_batched')
+        else:
+            gn_device(g1[b:e], g2[b:e], i0, mus, n_iters, precision, out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh))
         done = torch.cuda.Event()
         done.record(main)
         with torch.cuda.stream(copy):

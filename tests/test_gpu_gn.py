@@ -561,4 +561,13 @@ def test_pipelined_host_boundary_changes_no_bit(hip, golden, monkeypatch):
         for got in (piped, pinned):
             assert np.array_equal(got[0].view(np.int64), plain[0].view(np.int64))
             assert np.array_equal(got[1].view(np.int64), plain[1].view(np.int64))
+        # a stacked fan [view][row][channel]: solved in [view][channel][row] order and transposed back
+        b1 = np.ascontiguousarray(a1.reshape(48, 8, 12))
+        b2 = np.ascontiguousarray(a2.reshape(48, 8, 12))
+        monkeypatch.setattr(md, '_PIPE_MIN_PIXELS', 1)
+        stacked = md.get_basismat_sinos(ct, b1, b2, s1, s2, n_iters=30)
+        monkeypatch.setattr(md, '_PIPE_MIN_PIXELS', 1 << 24)
+        assert stacked[0].shape == (48, 8, 12)
+        assert np.array_equal(stacked[0].reshape(48, 96).view(np.int64), plain[0].view(np.int64))
+        assert np.array_equal(stacked[1].reshape(48, 96).view(np.int64), plain[1].view(np.int64))
         assert 0 < (plain[0] == 0).sum() < plain[0].size // 2 and np.isfinite(plain[0]).mean() > 0.9      # (NaN payloads compared above too)
