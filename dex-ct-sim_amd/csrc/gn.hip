@@ -762,17 +762,18 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, out_a);
   } else if (precision == 0) {
-    // lane refill: each wave works through a run of 64 * chunk pixels.  Measured optimum (8e5 ... 4e8 pixels):
-    // up to 8 pixels per lane while that still leaves ~12 500 waves (2.4 x the 5 120 resident ones), and beyond
-    // that as many as keep the grid near 200 000 waves (re-measured after the late-r2 arithmetic changes, 4.1e8 pixels:
-    // 8 / 16 / 32 / 64 / 128 / 256 pixels per lane = 855 / 824 / 804 / 808 / 833 / 890 ms); small inputs degenerate to
-    // one pixel per lane.
+    // lane refill: each wave works through a run of 64 * chunk pixels.  Measured optimum (8e5 ... 1e9 pixels; round 3, after
+    // the XCD-contiguous run assignment, tools/bench_gn.py GN_VARIANTS=chunk): up to 6 pixels per lane while that still
+    // leaves ~12 500 waves (2.4 x the 5 120 resident ones), beyond that as many as keep the grid near 133 000 waves, at
+    // most 32 - 5.1e7 pixels (one GPU's share of an 8-GPU scan): 4 / 6 / 8 / 12 / 16 = 108 / 107 / 111 / 108 / 110 ms;
+    // 1.0e8: 8 / 12 / 16 / 24 = 216 / 209 / 211 / 211; 2.0e8: 16 / 24 / 32 = 413 / 406 / 410; 4.1e8: 24 / 32 / 48 / 64 = 802 / 801
+    // / 804 / 801; 1.05e9: 24 / 32 / 64 = 2036 / 2026 / 2058.  Small inputs degenerate to one pixel per lane.
     const char* ce = getenv("DEXCT_GN_CHUNK");
     int64_t chunk = n_pix / (kWave * 12500ll);
-    if (chunk > 8) chunk = 8;
-    if (n_pix / (kWave * 200000ll) > chunk) chunk = n_pix / (kWave * 200000ll);
+    if (chunk > 6) chunk = 6;
+    if (n_pix / (kWave * 133000ll) > chunk) chunk = n_pix / (kWave * 133000ll);
     if (ce) chunk = atoll(ce);
-    chunk = chunk < 1 ? 1 : (chunk > (ce ? 1024 : 64) ? (ce ? 1024 : 64) : chunk);
+    chunk = chunk < 1 ? 1 : (chunk > (ce ? 1024 : 32) ? (ce ? 1024 : 32) : chunk);
     const int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
     const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     const char* te = getenv("DEXCT_GN_STOP_TOL");

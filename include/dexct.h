@@ -261,7 +261,7 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  * kernel stops a pixel at the first state that repeats bit for bit (fixed point or cycle of up to 9 states) and
  * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly.
  * Environment (read per call, for checking and tuning only): DEXCT_GN_FULL_LOOP=1 executes every iteration;
- * DEXCT_GN_CHUNK=<1..64> pixels per lane of a wave's run in the float64 shared-spectrum kernel;
+ * DEXCT_GN_CHUNK=<1..1024> pixels per lane of a wave's run in the float64 shared-spectrum kernel;
  * DEXCT_GN_STOP_TOL=<t> (opt-in, not the reference's fixed count): a float64 shared-spectrum pixel also stops when a
  * step moves it by no more than t * max(|a|, 1). */
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
