@@ -217,7 +217,8 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, E
 // Workspace layout (doubles): [0] = scale of the float32 tables, [1..3] = nA, nB, nC (energy classes), [4..6] =
 // how many of each class come first and always need the clip, [7..8] = max mu0 / mu1 over the clip-free parts,
 // [9] = (uint64, diagnostic) pixel-iterations the last gn_refill_kernel launch on this workspace executed,
-// [10] = (uint64, progress) pixels that launch has finished so far (added wave by wave while it runs),
+// [10] = (uint64, progress) pixels that launch has finished so far (added wave by wave while it runs; with the run queue:
+// pixels handed out so far), [11] = (uint64) head of the run queue,
 // pad to 16, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
 constexpr int kWsHeader = 16;
 
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
       ws[8] = m1f;
       reinterpret_cast<unsigned long long*>(ws)[9] = 0ull;      // executed pixel-iterations, counted by gn_refill_kernel
       reinterpret_cast<unsigned long long*>(ws)[10] = 0ull;     // finished pixels (progress of the running launch)
+      reinterpret_cast<unsigned long long*>(ws)[11] = 0ull;     // head of the pixel-run queue of gn_refill_kernel
     }
   }
   __syncthreads();
@@ -489,7 +491,8 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
                                                              const double* __restrict__ mask_max, double mask_frac,
                                                              int exact_exit, double stop_tol,
                                                              double* __restrict__ out_a,
-                                                             unsigned long long* __restrict__ executed) {
+                                                             unsigned long long* __restrict__ executed,
+                                                             unsigned long long* __restrict__ queue) {
   __shared__ double lds_pow[kPowN];
   __shared__ longlong2 lds_hist[HLDS ? 4 : 1][HLDS ? kGnBlock : 1];
   static_assert(!HLDS || HIST == kGnHistory, "the LDS ring holds the 4 older of 8 states");
@@ -508,7 +511,13 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   const uint32_t nblk_x = gridDim.x, per_x = nblk_x >> 3;
   const uint32_t lblk = (blockIdx.x < (per_x << 3)) ? (blockIdx.x & 7u) * per_x + (blockIdx.x >> 3) : blockIdx.x;
   int64_t next = ((int64_t)lblk * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;   // wave-uniform
-  const int64_t end = next + run < n_pix ? next + run : n_pix;
+  int64_t end = next + run < n_pix ? next + run : n_pix;
+  // QUEUE (the default, `queue` != null): runs are not assigned but FETCHED - a wave whose run is used up takes the next
+  // one from a global counter at once, while its other lanes are still iterating.  No lane waits for the slowest pixel of
+  // "its" run any more (lanes idle only when the whole sinogram is used up), the load balances itself over CUs and XCDs,
+  // and the run length stops mattering.  Pixels are independent problems: bit-identical results in any order.
+  bool exhausted = false;
+  if (queue) { next = 0; end = 0; }
   const bool has_mask = mask_max != nullptr;
   const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
 
@@ -522,8 +531,19 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   for (int k = 0; k < kR; ++k) { h0[k] = 0; h1[k] = 0; }
 
   for (;;) {
-    const unsigned long long want = __ballot(p < 0);
-    if (want != 0ull && next < end) {
+    unsigned long long want = __ballot(p < 0);
+    while (want != 0ull) {
+      if (next >= end) {
+        if (!queue || exhausted) break;
+        long long base = 0;
+        if ((threadIdx.x & 63) == 0) base = (long long)atomicAdd(queue, (unsigned long long)run);
+        base = ((long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+               (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n_pix) { exhausted = true; break; }
+        next = base;
+        end = base + run < n_pix ? base + run : n_pix;
+        if (executed && (threadIdx.x & 63) == 0) atomicAdd(executed + 1, (unsigned long long)(end - base));   // progress: handed out
+      }
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
       const int64_t np = next + rank;
       if (p < 0 && np < end) {
@@ -540,10 +560,12 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
         }
       }
       next += __popcll(want);
+      if (!queue) break;                           // static runs: one serving per step, as in rounds 1-2
+      want = __ballot(p < 0);                      // air pixels leave their lane wanting: it is served again at once
     }
     const unsigned long long busy = __ballot(p >= 0);
     if (busy == 0ull) {
-      if (next >= end) break;
+      if (next >= end && (!queue || exhausted)) break;
       continue;
     }
     n_exec += (unsigned)__popcll(busy);                        // wave-uniform (scalar) count of Newton steps run
@@ -679,7 +701,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   if (executed && (threadIdx.x & 63) == 0) {
     atomicAdd(executed, (unsigned long long)n_exec);            // one atomic per wave
     const int64_t first = ((int64_t)lblk * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;
-    if (end > first) atomicAdd(executed + 1, (unsigned long long)(end - first));    // this wave's run of pixels is done
+    if (!queue && end > first) atomicAdd(executed + 1, (unsigned long long)(end - first));    // this wave's run of pixels is done
   }
 }
 
@@ -774,8 +796,28 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     if (n_pix / (kWave * 133000ll) > chunk) chunk = n_pix / (kWave * 133000ll);
     if (ce) chunk = atoll(ce);
     chunk = chunk < 1 ? 1 : (chunk > (ce ? 1024 : 32) ? (ce ? 1024 : 32) : chunk);
-    const int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
-    const int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
+    // run queue (default; DEXCT_GN_QUEUE=0 restores the static runs above): 2 pixels per lane and fetch (benchmark
+    // sinograms: 1 / 2 / 4 / 8 / 16 = 766 / 764 / 769 / 771 / 773 ms against 811 ms with static runs; an 8-GPU share, 5.1e7
+    // pixels: 98 / 97 / 99 / 102 / 106 against 108), and no more workgroups than could ever be resident
+    const char* qe = getenv("DEXCT_GN_QUEUE");
+    const bool use_queue = !(qe && atoi(qe) == 0);
+    if (use_queue && !ce) chunk = 2;
+    int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
+    int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
+    if (use_queue) {
+      static const int n_cu = [] {             // queried once per process (one GPU per process)
+        int dev_id = 0, n = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n <= 0)
+          n = 256;
+        return n;
+      }();
+      const char* be = getenv("DEXCT_GN_BLOCKS_PER_CU");          // tuning knob
+      const int64_t cap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : 8);       // 8 waves per SIMD is the hardware's most: whatever this instantiation's
+                                                   // occupancy, every resident slot gets a workgroup; the rest find the queue empty
+      if (nb > cap) nb = cap;
+    }
+    unsigned long long* queue = use_queue ? reinterpret_cast<unsigned long long*>(ws) + 11 : nullptr;
     const char* te = getenv("DEXCT_GN_STOP_TOL");
     const double stop_tol = te ? atof(te) : 0.0;
     // tuning knobs for A/B runs (defaults are the measured optimum): DEXCT_GN_MINW=4 trades occupancy
@@ -790,10 +832,10 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const double tol = stop_tol > 0.0 ? stop_tol : 0.0;
 #define DEXCT_GN_LAUNCH(MW, IE)                                                                                         \
   hipLaunchKernelGGL((gn_refill_kernel<MW, IE>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,            \
-                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat)
+                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue)
 #define DEXCT_GN_LAUNCH_H(MW, H)                                                                                        \
   hipLaunchKernelGGL((gn_refill_kernel<MW, false, false, H>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, \
-                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat)
+                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue)
     const char* hs = getenv("DEXCT_GN_HIST");
     const int hist = hs ? atoi(hs) : kGnHistory;
     const int mw = ve ? atoi(ve) : 5;
@@ -801,13 +843,13 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const int ring = re ? atoi(re) : kGnRingDefault;
     if (ring && !hlds && hist == kGnHistory && !iexp && mw == 5)
       hipLaunchKernelGGL((gn_refill_kernel<5, false, false, kGnHistory, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64,
-                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
+                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
     else if (ring && !hlds && hist == kGnHistory && !iexp && mw == 4)
       hipLaunchKernelGGL((gn_refill_kernel<4, false, false, kGnHistory, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64,
-                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
+                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
     else if (hlds)
       hipLaunchKernelGGL((gn_refill_kernel<5, false, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,
-                         (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat);
+                         (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
     else if (hist == 4 && mw == 6) DEXCT_GN_LAUNCH_H(6, 4);
     else if (hist == 6 && mw == 6) DEXCT_GN_LAUNCH_H(6, 6);
     else if (hist == 4) DEXCT_GN_LAUNCH_H(5, 4);

@@ -227,7 +227,8 @@ def test_repeated_state_exit_changes_no_bit(hip, golden):
 
 
 def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
-    """gn_refill_kernel: every pixel is solved exactly once whatever the run length per wave (DEXCT_GN_CHUNK),
+    """gn_refill_kernel: every pixel is solved exactly once whether the waves fetch their runs of pixels from the global
+    queue (round 3, the default) or own one static run each (DEXCT_GN_QUEUE=0), whatever the run length (DEXCT_GN_CHUNK),
     for pixel counts around the wave and run boundaries, with and without the fused air mask, and for 0 and 1
     iterations.  All run lengths give the same bits; the result matches the C oracle."""
     import os
@@ -248,15 +249,18 @@ def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
             air = cnt[0] >= 0.95 * cnt[0].max()                # what the mask rule selects (at least the maximum itself)
             ref = co.gn_decompose(cnt[0], cnt[1], i0, mus, 30, n_threads=8)
             results = {}
-            for chunk in ('1', '2', '7', '64'):
-                os.environ['DEXCT_GN_CHUNK'] = chunk
-                for masked in (False, True):
-                    out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
-                    md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None)
-                    results[(chunk, masked)] = out.cpu().numpy()
-            base_m, base_u = results[('1', True)], results[('1', False)]
-            for (chunk, masked), r in results.items():
-                assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, chunk)
+            for queue in ('1', '0'):                           # runs fetched from the global queue (default) / static runs
+                os.environ['DEXCT_GN_QUEUE'] = queue
+                for chunk in ('1', '2', '7', '64'):
+                    os.environ['DEXCT_GN_CHUNK'] = chunk
+                    for masked in (False, True):
+                        out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+                        md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None)
+                        results[(queue, chunk, masked)] = out.cpu().numpy()
+            os.environ.pop('DEXCT_GN_QUEUE')
+            base_m, base_u = results[('1', '1', True)], results[('1', '1', False)]
+            for (queue, chunk, masked), r in results.items():
+                assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, queue, chunk)
             assert not np.isnan(base_m[air]).any() and np.all(base_m[air] == 0.0)
             assert np.array_equal(base_m[~air].view(np.int64), base_u[~air].view(np.int64))
             live_u = np.isfinite(ref).all(-1)                  # without the mask every pixel is solved
@@ -274,6 +278,7 @@ def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
                     assert err(o[ok], one[ok]) < TOL_F64
     finally:
         os.environ.pop('DEXCT_GN_CHUNK', None)
+        os.environ.pop('DEXCT_GN_QUEUE', None)
 
 
 @pytest.mark.parametrize('seed', range(10))

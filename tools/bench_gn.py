@@ -28,7 +28,7 @@ ref = torch.empty_like(a)
 
 def run(out, env):
     for k in ('DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HLDS', 'DEXCT_GN_HIST', 'DEXCT_GN_CHUNK', 'DEXCT_GN_RING',
-              'DEXCT_GN_VAR'):
+              'DEXCT_GN_VAR', 'DEXCT_GN_QUEUE', 'DEXCT_GN_BLOCKS_PER_CU'):
         os.environ.pop(k, None)
     os.environ.update(env)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,11 +42,16 @@ def run(out, env):
 run(ref, {})
 variants = [{}, {'DEXCT_GN_RING': '0'}, {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_RING': '0', 'DEXCT_GN_MINW': '4'},
             {'DEXCT_GN_FULL_LOOP': '1'}, {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_RING': '0'}]
+if os.environ.get('GN_VARIANTS') == 'queue':      # run queue (default) against static runs, and pixels per lane and fetch
+    variants = [{}, {'DEXCT_GN_QUEUE': '0'}] + [{'DEXCT_GN_CHUNK': c} for c in ('1', '2', '8', '16')] + [{'DEXCT_GN_FULL_LOOP': '1'}, {'DEXCT_GN_FULL_LOOP': '1', 'DEXCT_GN_QUEUE': '0'}]
+if os.environ.get('GN_VARIANTS') == 'cap':        # workgroups launched per CU in run-queue mode
+    variants = [{}, {'DEXCT_GN_QUEUE': '0'}] + [{'DEXCT_GN_BLOCKS_PER_CU': c} for c in ('4', '5', '6', '8', '16')] + [{'DEXCT_GN_BLOCKS_PER_CU': '5', 'DEXCT_GN_CHUNK': '4'}]
 if os.environ.get('GN_VARIANTS') == 'chunk':      # pixels per lane of a wave's run (default 64 at this size)
     variants = [{}] + [{'DEXCT_GN_CHUNK': c} for c in os.environ.get('CHUNKS', '8,16,32,128,256').split(',')]
 if os.environ.get('GN_VARIANTS') == 'hist':      # history length of the repeated-state exit (x occupancy)
     variants = [{}] + [{'DEXCT_GN_HIST': str(h)} for h in (4, 5, 6, 7, 10, 12)] + \
-        [{'DEXCT_GN_HIST': '4', 'DEXCT_GN_MINW': '6'}, {'DEXCT_GN_HIST': '6', 'DEXCT_GN_MINW': '6'}]
+        [{'DEXCT_GN_HIST': '4', 'DEXCT_GN_MINW': '6'}, {'DEXCT_GN_HIST': '6', 'DEXCT_GN_MINW': '6'}, {'DEXCT_GN_RING': '1'},
+         {'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_RING': '1', 'DEXCT_GN_MINW': '4'}]
 times = {i: [] for i in range(len(variants))}
 same = {}
 for rep in range(3):

@@ -6,7 +6,7 @@ count 0..80, and demands, BIT FOR BIT including the NaN payloads:
   * the repeated-state exit returns what the full loop returns (DEXCT_GN_FULL_LOOP=1);
   * every history length of the exit (DEXCT_GN_HIST 4..12) returns the same;
   * the register-allocation / exponent / history variants (DEXCT_GN_MINW=4, DEXCT_GN_IEXP=1, DEXCT_GN_HLDS=1, DEXCT_GN_RING=1)
-    return the same;
+    return the same, and so do static pixel runs (DEXCT_GN_QUEUE=0) against the run queue and other run lengths;
   * with the air mask: masked pixels are exactly 0 and the others unchanged;
 and, as a sanity check of the arithmetic (a statistic, not an invariant), agreement to 1e-9 with the NumPy restatement of
 the reference on the pixels where that one is finite and insensitive both to a 1e-13 perturbation of its input and to the
@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 from dex_ct_sim_amd import matdecomp as md
 from oracle import gn_oracle
 
-KNOBS = ('DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HIST', 'DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_HLDS', 'DEXCT_GN_RING')
+KNOBS = ('DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HIST', 'DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_HLDS', 'DEXCT_GN_RING', 'DEXCT_GN_QUEUE',
+         'DEXCT_GN_CHUNK')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device('cuda:0')
@@ -107,7 +108,8 @@ for case in range(n_cases):
         bits = base.view(torch.int64)
         for env in ([{'DEXCT_GN_FULL_LOOP': '1'}] + [{'DEXCT_GN_HIST': str(h)} for h in (4, 5, 6, 7, 10, 12)] +
                     [{'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_IEXP': '1'}, {'DEXCT_GN_HLDS': '1'},
-                     {'DEXCT_GN_MINW': '6', 'DEXCT_GN_HIST': '4'}, {'DEXCT_GN_RING': '1'}, {'DEXCT_GN_RING': '1', 'DEXCT_GN_MINW': '4'}]):
+                     {'DEXCT_GN_MINW': '6', 'DEXCT_GN_HIST': '4'}, {'DEXCT_GN_RING': '1'}, {'DEXCT_GN_RING': '1', 'DEXCT_GN_MINW': '4'},
+                     {'DEXCT_GN_QUEUE': '0'}, {'DEXCT_GN_QUEUE': '0', 'DEXCT_GN_CHUNK': '3'}, {'DEXCT_GN_CHUNK': '1'}, {'DEXCT_GN_CHUNK': '7'}]):
             got = run(g_d, i0, mus, n_iters, env)
             if not torch.equal(got.view(torch.int64), bits):
                 bad.append(f'{env}: {int((got.view(torch.int64) != bits).sum())} values differ')
@@ -155,7 +157,7 @@ for case in range(n_cases):
         fails += 1
         print(f'FAIL seed {seed}: {n_e} energies, {n_v} x {n_c} pixels, {kind}, {n_iters} iterations: ' + '; '.join(bad), flush=True)
     if case % 100 == 99 or case == n_cases - 1:
-        print(f'{case + 1} cases, {fails} failed, {n_pix:.3g} pixels x 15 kernel variants, {n_cmp:.3g} stable pixels compared with the '
+        print(f'{case + 1} cases, {fails} failed, {n_pix:.3g} pixels x 19 kernel variants, {n_cmp:.3g} stable pixels compared with the '
               f'NumPy restatement ({n_off} beyond 1e-9 with >= 3 energies; with 1-2 energies {n_few} beyond 1e-9, the best '
               f'conditioned of them has Hessian cond {min_cond_few:.1e}), {time.time() - t0:.0f} s', flush=True)
 sys.exit(1 if fails else 0)
