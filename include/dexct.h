@@ -254,14 +254,18 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *              the kernel reads through the scalar cache); owned by the caller, no hidden state.  After the call
  *              the uint64 at byte offset 72 holds, as a diagnostic, the number of pixel-iterations the float64
  *              shared-spectrum kernel executed (what bench.py's executed-flop rate is computed from; 0 for the
- *              other kernels), and the uint64 at byte offset 80 the number of pixels it has finished - updated wave
- *              by wave WHILE the kernel runs, so a host thread may read it (on another stream) as a progress
- *              indicator: the reference prints a line every 20 views, matdecomp.py:111-112
+ *              other kernels), and the uint64 at byte offset 80 the number of pixels it has taken from its run queue
+ *              (runs handed to waves; with DEXCT_GN_QUEUE=0, runs finished) - updated run by run WHILE the kernel
+ *              runs, so a host thread may read it (on another stream) as a progress indicator: the reference prints
+ *              a line every 20 views, matdecomp.py:111-112.  The uint64 at byte offset 88 is the queue head (the
+ *              next pixel no wave owns yet); the library zeroes all three words at the start of every call
  * n_iters is the reference's fixed iteration count.  The update is a pure function of the two doubles, so the
  * kernel stops a pixel at the first state that repeats bit for bit (fixed point or cycle of up to 9 states) and
  * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly.
  * Environment (read per call, for checking and tuning only): DEXCT_GN_FULL_LOOP=1 executes every iteration;
- * DEXCT_GN_CHUNK=<1..1024> pixels per lane of a wave's run in the float64 shared-spectrum kernel;
+ * DEXCT_GN_CHUNK=<1..1024> pixels per lane in one run of pixels (default 2: a wave fetches 128 pixels at a time from
+ * the queue); DEXCT_GN_QUEUE=0 gives every wave one static run instead; DEXCT_GN_BLOCKS_PER_CU=<n> caps the grid of
+ * the queue kernel at n blocks per CU (default 8);
  * DEXCT_GN_STOP_TOL=<t> (opt-in, not the reference's fixed count): a float64 shared-spectrum pixel also stops when a
  * step moves it by no more than t * max(|a|, 1). */
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
