@@ -195,8 +195,8 @@ static int launch_cone(const ConeArgs& a, const float* mu, const float* w, hipSt
 // k = W >> 40.  Lanes (neighbouring rows) read neighbouring bytes of one voxel column of a z-fastest volume.
 //
 // The volume is the GUARDED z-fastest layout of dexct_cone_layout: column (x, y) holds nz + 2 bytes
-// [3, id(z=0), ..., id(z=nz-1), 3] and one extra column of all 3 stands for every (x, y) outside the grid, so a
-// voxel outside the grid reads as code 3 = "no material" without a bounds test (ids < 3: at most 3 materials).
+// [24, 8 id(z=0), ..., 8 id(z=nz-1), 24] and one extra column of all 24 stands for every (x, y) outside the grid, so a
+// voxel outside the grid reads as id 3 = "no material" without a bounds test (ids < 3: at most 3 materials).
 //
 // Per slab and lane the oracle's sum (orc_cone_pathlen)
 //     [idb] + t2 ([idm] - [idb]) + t1 ([ida] - [idm])
@@ -270,13 +270,10 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   const float len3d = (float)((1.0 / fabs(eu)) * sqrt(1.0 + tz * tz));
   const uint32_t wpos = SW > 0 ? 0xFFFFFFFFu : 0u;
 
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(vol_zc), 0, (int)(col_out + zs), 0x00020000);
   const int nz = a.g.nz;
   uint32_t acc = 0;                       // four byte counters: codes 0..3 of the b voxels since the last flush
   uint32_t cnt[3] = {0, 0, 0};
   float corr[3] = {0.0f, 0.0f, 0.0f};
-  int since_flush = 0;
   // W carries a bias of one slice: (W >> 40) is then k + 1, the byte index inside a guarded column
   long long W = W0 + (long long)p.i_first * SW + (1ll << DEXCT_FIX_FRAC);
   const int k_hi = nz + 1;
@@ -285,9 +282,15 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(kq) : "v"((int)(Wx >> DEXCT_FIX_FRAC)), "s"(k_hi));
     return kq;
   };
-  auto ldk = [&](int col_s, int kc) {                          // col_s: the column's byte offset, already a scalar
-    return (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, kc, col_s, 0);
-  };
+  // Voxel bytes through buffer_load_ubyte with the column's byte offset as the SCALAR offset and the slice as the vector
+  // offset.  Round 3: issued from inline assembly - the compiler widened the i8 of __builtin_amdgcn_raw_buffer_load_b8 (and
+  // of a plain byte load) with a v_and per load (2 of the 16 vector instructions per slab), although the instruction
+  // zero-extends.  The compiler does not count these loads: the batch ends with an explicit s_waitcnt vmcnt(0) that takes
+  // every loaded register as an in/out operand, so no use can be scheduled above it; "s_nop 4" = the wait states between
+  // the v_readfirstlane that produced a scalar offset and the load reading it.
+  typedef int rsrc4 __attribute__((ext_vector_type(4)));
+  const uint64_t vbase = (uint64_t)vol_zc;
+  const rsrc4 rs = {(int)(uint32_t)vbase, (int)(uint32_t)(vbase >> 32), (int)(col_out + zs), 0x00020000};
   for (int s0 = 0; s0 < p.n_slabs; s0 += kConeRows) {
     const int n_here = min(kConeRows, p.n_slabs - s0);
     const int n_pad = (n_here + kB - 1) / kB * kB;      // the last batch is filled with null records (all "outside")
@@ -305,14 +308,17 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
       rec[tid] = q;
     }
     __syncthreads();
-    for (int s = 0; s < n_pad; s += kB) {
+    // two levels so that the flush of the byte counters (they hold at most 128 slabs) needs no test inside the batch loop
+    for (int s1 = 0; s1 < n_pad; s1 += 128) {
+    const int s_end = min(n_pad, s1 + 128);
+    for (int s = s1; s < s_end; s += kB) {
       // ---- all voxel bytes of kB slabs first (no data-dependent branch in between): b = (jb, kb), a = (ja, ka) and,
       // in a slab with a v-crossing, the two possible middle voxels (jb, ka) and (ja, kb).  Without a crossing these
       // are the same byte again (an L1 hit); what differs is found by comparing the ids afterwards.
       ConeRec q[kB];
       int kc[kB + 1];
       uint32_t x[kB], xa[kB], c1[kB], c2[kB];
-      bool vx[kB];
+      uint32_t vx[kB];                                           // scalar: non-zero = the slab has a v-crossing
       const long long Wb = W;
       kc[0] = slice(W);
 #pragma unroll
@@ -322,30 +328,41 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
         W += SW;
         kc[j + 1] = slice(W);
         const int sb = __builtin_amdgcn_readfirstlane((int)q[j].colb), sa = __builtin_amdgcn_readfirstlane((int)q[j].cola);
-        x[j] = ldk(sb, kc[j + 1]);
-        xa[j] = ldk(sa, kc[j]);
-        // a v-crossing slab has two different columns (two outside pieces share the all-3 column: nothing to tell apart)
-        vx[j] = sb != sa;
-        if (vx[j]) {                                             // uniform; c1 / c2 are only ever read under vx[j]
-          c1[j] = ldk(sb, kc[j]);
-          c2[j] = ldk(sa, kc[j + 1]);
+        asm volatile("s_nop 4\n\tbuffer_load_ubyte %0, %2, %4, %5 offen\n\tbuffer_load_ubyte %1, %3, %4, %6 offen"
+                     : "=&v"(x[j]), "=&v"(xa[j])
+                     : "v"(kc[j + 1]), "v"(kc[j]), "s"(rs), "s"(sb), "s"(sa));
+        // a v-crossing slab has two different columns (two outside pieces share the all-24 column: nothing to tell apart)
+        vx[j] = (uint32_t)(sb ^ sa);
+        if (vx[j] != 0u) {                                           // uniform; c1 / c2 are only ever read under vx[j]
+          asm volatile("buffer_load_ubyte %0, %2, %4, %5 offen\n\tbuffer_load_ubyte %1, %3, %4, %6 offen"
+                       : "=&v"(c1[j]), "=&v"(c2[j])
+                       : "v"(kc[j]), "v"(kc[j + 1]), "s"(rs), "s"(sb), "s"(sa));
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      uint32_t dif[kB];                                          // non-zero: the slab's ids differ for this lane
-      uint32_t any = 0;
+#pragma unroll
+      for (int j = 0; j < kB; ++j)                               // the first one waits, the others find the counter at 0
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[j]), "+v"(xa[j]));
+      // ---- fast path: count the b voxel (the layout stores 8 * id: one v_lshl_add), compare the ids into LANE MASKS
+      // (v_cmp writing an SGPR pair; every OR below is scalar)
+      unsigned long long dm[kB], any = 0ull;
 #pragma unroll
       for (int j = 0; j < kB; ++j) {
-        acc = (1u << (x[j] << 3)) + acc;                         // count the b voxel: v_lshlrev + v_lshl_add
+        acc = (1u << x[j]) + acc;
         // with a single crossing (c1, c2) is (x, xa) or (xa, x): nothing new; with both, the middle voxel is one of them
-        dif[j] = xa[j] ^ x[j];
-        if (vx[j]) dif[j] |= (c1[j] ^ x[j]) | (c2[j] ^ x[j]);    // uniform branch
-        any |= dif[j];
+        dm[j] = __builtin_amdgcn_ballot_w64(xa[j] != x[j]);
+        // the flag is made opaque before each further test: every test is then its own s_cmp + branch (merged, the
+        // compiler keeps two 64-bit masks per slab alive - 6 scalar instructions per slab instead of 3)
+        asm volatile("" : "+s"(vx[j]));
+        if (vx[j] != 0u) {                                       // uniform; c1 / c2 exist only here (defined under the same test)
+          asm volatile("" : "+v"(c1[j]), "+v"(c2[j]));           // ordered behind the waits above
+          dm[j] |= __builtin_amdgcn_ballot_w64(c1[j] != x[j]) | __builtin_amdgcn_ballot_w64(c2[j] != x[j]);
+        }
+        any |= dm[j];
       }
-      if (__ballot(any != 0u) != 0ull) {
+      if (any != 0ull) {
 #pragma unroll
         for (int j = 0; j < kB; ++j) {
-          if (dif[j] != 0u) {
+          if (dm[j] != 0ull && __builtin_amdgcn_inverse_ballot_w64(dm[j])) {
             // the oracle's slab, operation for operation (orc_cone_pathlen); W of the slab's entry face without the bias
             const long long Wj = Wb + (long long)j * SW - (1ll << DEXCT_FIX_FRAC);
             const float tv = q[j].tv;
@@ -353,41 +370,39 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
             const float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
             const bool v_first = tv <= tw;
             // middle voxel (jm, km) = v_first ? (jb, ka) : (ja, kb)
-            const uint32_t idm = vx[j] ? (v_first ? c1[j] : c2[j]) : (v_first ? xa[j] : x[j]);
+            uint32_t vxc = vx[j];
+            asm volatile("" : "+s"(vxc));
+            const uint32_t idm = vxc != 0u ? (v_first ? c1[j] : c2[j]) : (v_first ? xa[j] : x[j]);
             const uint32_t ida = xa[j], idb = x[j];
             if (ida != idm || idm != idb) {
               if constexpr (LDSC) {
                 // the oracle's four terms, each added to the cell of the id it belongs to, in the oracle's order
-                float* cell = &lds_corr[0][tid];
-                __hip_atomic_fetch_add(cell + idm * kConeRows, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(cell + idb * kConeRows, -t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(cell + ida * kConeRows, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(cell + idm * kConeRows, -t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                float* cell = &lds_corr[0][tid];                 // ids are stored as 8 * id: row id = cell + (8 id) * 32
+                static_assert(kConeRows == 8 * 32, "cell offset of a stored id");
+                __hip_atomic_fetch_add(cell + idm * 32u, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + idb * 32u, -t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + ida * 32u, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + idm * 32u, -t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               } else {
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
-                  corr[m] += (idm == (uint32_t)m) ? t2 : 0.0f;
-                  corr[m] -= (idb == (uint32_t)m) ? t2 : 0.0f;
-                  corr[m] += (ida == (uint32_t)m) ? t1 : 0.0f;
-                  corr[m] -= (idm == (uint32_t)m) ? t1 : 0.0f;
+                  corr[m] += (idm == (uint32_t)(8 * m)) ? t2 : 0.0f;
+                  corr[m] -= (idb == (uint32_t)(8 * m)) ? t2 : 0.0f;
+                  corr[m] += (ida == (uint32_t)(8 * m)) ? t1 : 0.0f;
+                  corr[m] -= (idm == (uint32_t)(8 * m)) ? t1 : 0.0f;
                 }
               }
             }
           }
         }
       }
-      since_flush += kB;
-      if (since_flush > 255 - kB) {                              // uniform
+    }
 #pragma unroll
-        for (int m = 0; m < NM; ++m) cnt[m] += (acc >> (8 * m)) & 0xFFu;
-        acc = 0;
-        since_flush = 0;
-      }
+    for (int m = 0; m < NM; ++m) cnt[m] += (acc >> (8 * m)) & 0xFFu;
+    acc = 0;
     }
     __syncthreads();
   }
-#pragma unroll
-  for (int m = 0; m < NM; ++m) cnt[m] += (acc >> (8 * m)) & 0xFFu;
   if (LDSC) {
 #pragma unroll
     for (int m = 0; m < NM; ++m) corr[m] = lds_corr[m][tid];
@@ -426,7 +441,8 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
     }
 }
 
-// vol [nz][ny][nx] -> guarded z-fastest layout [(ny*nx + 1)][nz + 2]: guard slices and the extra column hold 3.
+// vol [nz][ny][nx] -> guarded z-fastest layout [(ny*nx + 1)][nz + 2] of 8 * id (the shift of the packed byte counter the
+// traversal adds with one v_lshl_add; round 3): guard slices and the extra column hold 24 = "outside", id 3.
 __global__ __launch_bounds__(256) void cone_layout_kernel(const uint8_t* __restrict__ vol, int nx, int ny, int nz,
                                                           uint8_t* __restrict__ out) {
   const size_t zs = (size_t)nz + 2;
@@ -435,8 +451,8 @@ __global__ __launch_bounds__(256) void cone_layout_kernel(const uint8_t* __restr
   if (i >= total) return;
   const size_t col = i / zs;
   const int kz = (int)(i - col * zs) - 1;
-  uint8_t val = 3;
-  if (col < (size_t)nx * ny && kz >= 0 && kz < nz) val = vol[(size_t)kz * nx * ny + col];      // col = y*nx + x
+  uint8_t val = 24;
+  if (col < (size_t)nx * ny && kz >= 0 && kz < nz) val = (uint8_t)(vol[(size_t)kz * nx * ny + col] << 3);      // col = y*nx + x
   out[i] = val;
 }
 
