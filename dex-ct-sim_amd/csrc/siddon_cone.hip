@@ -16,8 +16,10 @@
 // Mapping: one thread per ray, lanes over adjacent channels of one (view, row) - neighbouring rays visit
 // neighbouring voxels of the same slices.  Accumulators in registers (<= 4 materials) or per-lane LDS columns.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
+#include "siddon_detect.h"
 
 namespace dexct {
 
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
   const int tid = threadIdx.x;
   const int c = blockIdx.x * kConeBlock + tid;
   const int r = blockIdx.y, v = blockIdx.z;
+  const BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // a ballot: before lanes leave
   if (c >= a.g.n_channels) return;
   const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];
   const int axis = p.flags & 1u;
@@ -147,13 +150,20 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
       if (a.pathlen) a.pathlen[ray * n_mat + m] = l;
       L2[m] = l * 1.44269504088896340736f;
     }
-    for (int e = 0; e < n_e; ++e) {
-      float pe = 0.0f;
+    if (a.n_spectra <= 2) {                    // the detection of the row kernels (energies in pairs): identical counts
+      float two[2];
+      detect_energy_pairs<(NM > 0 ? NM : 1)>(L2, mu, w, n_e, a.n_spectra, bm, two);
+      accs[0] = two[0];
+      accs[1] = two[1];
+    } else {
+      for (int e = 0; e < n_e; ++e) {
+        float pe = 0.0f;
 #pragma unroll
-      for (int m = 0; m < (NM > 0 ? NM : 1); ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
-      const float t = __builtin_amdgcn_exp2f(-pe);
+        for (int m = 0; m < (NM > 0 ? NM : 1); ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
+        const float t = __builtin_amdgcn_exp2f(-pe);
 #pragma unroll
-      for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = fmaf(w[srow[s] + e], t, accs[s]);
+        for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = fmaf(w[srow[s] + e], t, accs[s]);
+      }
     }
   } else {
     for (int m = 0; m < n_mat; ++m) {
@@ -194,9 +204,11 @@ static int launch_cone(const ConeArgs& a, const float* mu, const float* w, hipSt
 // once per workgroup into LDS (as in rows_kernel), and a lane carries only its z DDA: W += SW (exact 64-bit add),
 // k = W >> 40.  Lanes (neighbouring rows) read neighbouring bytes of one voxel column of a z-fastest volume.
 //
-// The volume is the GUARDED z-fastest layout of dexct_cone_layout: column (x, y) holds nz + 2 bytes
-// [24, 8 id(z=0), ..., 8 id(z=nz-1), 24] and one extra column of all 24 stands for every (x, y) outside the grid, so a
-// voxel outside the grid reads as id 3 = "no material" without a bounds test (ids < 3: at most 3 materials).
+// The volume is the GUARDED z-fastest layout of dexct_cone_layout: column (x, y) holds cone_zs(nz) bytes - 16 guard bytes
+// of 24, then 8 id(z=0), ..., 8 id(z=nz-1), then at least 16 guard bytes up to a multiple of 16 (so that a column is a
+// whole number of 16-byte pieces for cone_cols_kernel's staging) - and one extra column of all 24 stands for every (x, y)
+// outside the grid, so a voxel outside the grid reads as id 3 = "no material" without a bounds test (ids < 3: at most 3
+// materials).
 //
 // Per slab and lane the oracle's sum (orc_cone_pathlen)
 //     [idb] + t2 ([idm] - [idb]) + t1 ([ida] - [idm])
@@ -206,6 +218,9 @@ static int launch_cone(const ConeArgs& a, const float* mu, const float* w, hipSt
 // load the a voxel / the two possible corner voxels only for the lanes that have the crossing; only lanes that see
 // differing ids enter the exact path, which evaluates the oracle's formula operation for operation - per-material
 // path lengths are bit-identical to cone_kernel's.
+constexpr int kConeGuard = 16;                                  // guard bytes in front of a column
+__host__ __device__ inline uint32_t cone_zs(int nz) { return (((uint32_t)nz + 15u) & ~15u) + 32u; }   // bytes per column
+
 struct ConeRec {
   uint32_t colb, cola;   // byte offsets of the b / a voxel columns in the guarded layout (outside column if out of the grid)
   float tv;
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   const int axis = p.flags & 1u;
   const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
   const int nv = axis == 0 ? a.g.ny : a.g.nx;
-  const uint32_t zs = (uint32_t)a.g.nz + 2u;                             // bytes per column
+  const uint32_t zs = cone_zs(a.g.nz);                                   // bytes per column
   const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * zs;
   const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * zs;
   const uint32_t col_out = (uint32_t)a.g.nx * (uint32_t)a.g.ny * zs;    // the all-3 column
@@ -270,14 +285,13 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   const float len3d = (float)((1.0 / fabs(eu)) * sqrt(1.0 + tz * tz));
   const uint32_t wpos = SW > 0 ? 0xFFFFFFFFu : 0u;
 
-  const int nz = a.g.nz;
   uint32_t acc = 0;                       // four byte counters: codes 0..3 of the b voxels since the last flush
   uint32_t cnt[3] = {0, 0, 0};
   float corr[3] = {0.0f, 0.0f, 0.0f};
-  // W carries a bias of one slice: (W >> 40) is then k + 1, the byte index inside a guarded column
-  long long W = W0 + (long long)p.i_first * SW + (1ll << DEXCT_FIX_FRAC);
-  const int k_hi = nz + 1;
-  auto slice = [&](long long Wx) {                              // clamp((int)(Wx >> 40), 0, nz + 1): v_ashr + v_med3_i32
+  // W carries a bias of the guard: (W >> 40) is then k + 16, the byte index inside a guarded column
+  long long W = W0 + (long long)p.i_first * SW + ((long long)kConeGuard << DEXCT_FIX_FRAC);
+  const int k_hi = (int)zs - 1;
+  auto slice = [&](long long Wx) {                              // clamp((int)(Wx >> 40), 0, zs - 1): v_ashr + v_med3_i32
     int kq;
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(kq) : "v"((int)(Wx >> DEXCT_FIX_FRAC)), "s"(k_hi));
     return kq;
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
         for (int j = 0; j < kB; ++j) {
           if (dm[j] != 0ull && __builtin_amdgcn_inverse_ballot_w64(dm[j])) {
             // the oracle's slab, operation for operation (orc_cone_pathlen); W of the slab's entry face without the bias
-            const long long Wj = Wb + (long long)j * SW - (1ll << DEXCT_FIX_FRAC);
+            const long long Wj = Wb + (long long)j * SW - ((long long)kConeGuard << DEXCT_FIX_FRAC);
             const float tv = q[j].tv;
             const float tw = fminf((float)((uint32_t)((unsigned long long)Wj >> 8) ^ wpos) * kfw, 1.0f);
             const float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
@@ -407,6 +421,7 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
 #pragma unroll
     for (int m = 0; m < NM; ++m) corr[m] = lds_corr[m][tid];
   }
+  const BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // a ballot: before dead rows leave
   if (!live) return;
   // ---- detection (same weighting as the other kernels)
   const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
@@ -422,16 +437,23 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   float accs[DEXCT_MAX_SPECTRA];
 #pragma unroll
   for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = 0.0f;
-  int srow[DEXCT_MAX_SPECTRA];
+  if (a.n_spectra <= 2) {                      // round 3: energies in pairs through v_pk_fma_f32, zero-weight blocks skipped
+    float two[2];
+    detect_energy_pairs<NM>(L2, mu, w, n_e, a.n_spectra, bm, two);
+    accs[0] = two[0];
+    accs[1] = two[1];
+  } else {
+    int srow[DEXCT_MAX_SPECTRA];
 #pragma unroll
-  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) srow[sI] = (sI < a.n_spectra ? sI : 0) * n_e;
-  for (int e = 0; e < n_e; ++e) {
-    float pe = 0.0f;
+    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) srow[sI] = (sI < a.n_spectra ? sI : 0) * n_e;
+    for (int e = 0; e < n_e; ++e) {
+      float pe = 0.0f;
 #pragma unroll
-    for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
-    const float t = __builtin_amdgcn_exp2f(-pe);
+      for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
+      const float t = __builtin_amdgcn_exp2f(-pe);
 #pragma unroll
-    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = fmaf(w[srow[sI] + e], t, accs[sI]);
+      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = fmaf(w[srow[sI] + e], t, accs[sI]);
+    }
   }
 #pragma unroll
   for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
@@ -441,16 +463,280 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
     }
 }
 
-// vol [nz][ny][nx] -> guarded z-fastest layout [(ny*nx + 1)][nz + 2] of 8 * id (the shift of the packed byte counter the
+// ---------------------------------------------------------------------------------------------
+// cone_cols_kernel (round 3): cone_rows_kernel with the voxel columns of a batch of slabs STAGED IN LDS.
+//
+// What bounded cone_rows_kernel was not the vector pipe (halving its instructions moved nothing) but the byte loads: a
+// wave instruction that fetches one byte per lane keeps the CU's texture path busy for 5-10 cycles, and a slab needs 2
+// (4 with a v-crossing) per wave.  Here the workgroup copies the two voxel columns of each slab of a batch - whole
+// columns, cone_zs(nz) bytes, 16 bytes per lane and load - into LDS once (double buffered: the next batch's loads are in
+// flight while this one is consumed), and the lanes read their bytes with ds_read_u8 at a static offset per (slab,
+// column): 0.3 global loads per wave and slab instead of 2.8, no v_readfirstlane of the column offsets, the same ids in
+// the same order - path lengths stay bit-identical.  CB = bytes reserved per staged column (>= cone_zs(nz)).
+template <int NM, int kB, int CB>
+__global__ __launch_bounds__(kConeRows) void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
+                                                               const float* __restrict__ mu, const float* __restrict__ w,
+                                                               int n_chunks, int view_tile) {
+  constexpr int kBufB = 2 * kB * CB;                       // bytes of one staging buffer: [slab][b column, a column][CB]
+  constexpr int kItems = (2 * kB * (CB / 16) + kConeRows - 1) / kConeRows;      // 16-byte pieces per lane and batch
+  __shared__ ConeRec rec[kConeRows];
+  __shared__ float lds_corr[4][kConeRows];                 // [id][lane]; id 3 = outside the grid: a cell nobody reads
+  __shared__ __attribute__((aligned(16))) uint8_t cols[2 * kBufB];
+  __shared__ unsigned long long vxm[kConeRows / 64];       // bit s: slab record s has a v-crossing (two different columns)
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) lds_corr[m][tid] = 0.0f;     // each lane only ever touches its own cells
+  // block -> (view, channel, row chunk): as cone_rows_kernel
+  const uint32_t nblk = gridDim.x, bid = blockIdx.x, per = nblk >> 3;
+  const uint32_t logical = (bid < (per << 3)) ? (bid & 7u) * per + (bid >> 3) : bid;
+  const uint32_t group = (uint32_t)view_tile * a.g.n_channels * n_chunks;
+  const uint32_t gq = logical / group, rem = logical - gq * group;
+  const uint32_t views_here = min((uint32_t)view_tile, (uint32_t)a.n_local_views - gq * view_tile);
+  const int chunk = rem % n_chunks;
+  const uint32_t qq = rem / n_chunks;
+  const int v = gq * view_tile + qq % views_here, c = qq / views_here;
+  const int r = chunk * kConeRows + tid;
+  const bool live = r < a.g.n_rows;
+  const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];      // uniform
+  const int axis = p.flags & 1u;
+  const uint32_t smask = (p.flags & 2u) ? 0xFFFFFFFFu : 0u;
+  const int nv = axis == 0 ? a.g.ny : a.g.nx;
+  const uint32_t zs = cone_zs(a.g.nz);                                   // bytes per column (<= CB, checked by the host)
+  const uint32_t su = (axis == 0 ? 1u : (uint32_t)a.g.nx) * zs;
+  const uint32_t sv = (axis == 0 ? (uint32_t)a.g.nx : 1u) * zs;
+  const uint32_t col_out = (uint32_t)a.g.nx * (uint32_t)a.g.ny * zs;    // the all-24 column
+  // ---- z part of the plan, float64, operation for operation as cone_kernel / the oracle's cone_row_plan
+  const int view = a.view_begin + v;
+  const double cb = a.view_cs[2 * view], sb = a.view_cs[2 * view + 1];
+  const double cg = a.chan_cs[2 * c], sg = a.chan_cs[2 * c + 1];
+  const double sx = a.g.sid * cb, sy = a.g.sid * sb;
+  const double ex = -(cb * cg - sb * sg), ey = -(sb * cg + cb * sg);
+  const double su_d = axis == 0 ? sx / a.g.dx + 0.5 * a.g.nx : sy / a.g.dy + 0.5 * a.g.ny;
+  const double eu = axis == 0 ? ex / a.g.dx : ey / a.g.dy;
+  const double det_z = a.row_z[live ? r : 0];
+  const double kOne = 1099511627776.0;
+  const double ws = a.src_z / a.g.dz + 0.5 * a.g.nz;
+  const double sw = ((det_z - a.src_z) / a.g.dz) / (a.g.sdd * eu);
+  const double w0 = ws - su_d * sw;
+  const long long SW = llrint(sw * kOne);
+  const long long W0 = llrint(w0 * kOne);
+  double inv = 16777216.0;
+  if (SW != 0) inv = fmin(kOne / fabs((double)SW), 16777216.0);
+  const float kfw = (float)(inv * (1.0 / 4294967296.0));
+  const double tz = (det_z - a.src_z) / a.g.sdd;
+  const float len3d = (float)((1.0 / fabs(eu)) * sqrt(1.0 + tz * tz));
+  const uint32_t wpos = SW > 0 ? 0xFFFFFFFFu : 0u;
+
+  // ---- this lane's share of the staging: pieces tid, tid + 256, ... of the 2 kB columns x (zs / 16) pieces of a batch
+  const uint32_t n16 = zs >> 4, n_pieces = 2u * kB * n16;
+  uint32_t pc_rec[kItems], pc_src[kItems], pc_dst[kItems];
+  bool pc_on[kItems];
+#pragma unroll
+  for (int t = 0; t < kItems; ++t) {
+    const uint32_t piece = (uint32_t)tid + (uint32_t)t * kConeRows;
+    pc_on[t] = piece < n_pieces;
+    const uint32_t seg = pc_on[t] ? piece / n16 : 0u, q16 = pc_on[t] ? piece - seg * n16 : 0u;    // seg = 2 slab + (0: b column, 1: a column)
+    pc_rec[t] = (seg >> 1) * (uint32_t)sizeof(ConeRec) + (seg & 1u) * 4u;      // byte offset of colb / cola in rec[]
+    pc_src[t] = q16 * 16u;
+    pc_dst[t] = seg * (uint32_t)CB + q16 * 16u;
+  }
+  const uint8_t* rec_bytes = reinterpret_cast<const uint8_t*>(rec);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 keeps the array in scratch)
+  u32x4 staged[kItems];
+  auto stage_load = [&](int s) {                 // the global loads of the batch that starts at record s
+#pragma unroll
+    for (int t = 0; t < kItems; ++t) {           // a lane without a piece t loads piece 0 of the batch again and does not store it
+      const uint32_t col = *reinterpret_cast<const uint32_t*>(rec_bytes + pc_rec[t] + (uint32_t)s * (uint32_t)sizeof(ConeRec));
+      staged[t] = *reinterpret_cast<const u32x4*>(vol_zc + (size_t)(col + pc_src[t]));
+    }
+  };
+  auto stage_store = [&](uint32_t bufoff) {
+#pragma unroll
+    for (int t = 0; t < kItems; ++t)
+      if (pc_on[t]) *reinterpret_cast<u32x4*>(cols + bufoff + pc_dst[t]) = staged[t];
+  };
+
+  uint32_t acc = 0;                       // four byte counters: codes 0..3 of the b voxels since the last flush
+  uint32_t cnt[3] = {0, 0, 0};
+  // W carries the guard and the offset of the staging buffer in use: (W >> 40) is the LDS byte offset of the lane's
+  // voxel inside column 0 of that buffer.  Only the fraction bits enter the exact path below.
+  long long W = W0 + (long long)p.i_first * SW + ((long long)kConeGuard << DEXCT_FIX_FRAC);
+  uint32_t bufoff = 0;
+  for (int s0 = 0; s0 < p.n_slabs; s0 += kConeRows) {
+    const int n_here = min(kConeRows, p.n_slabs - s0);
+    const int n_pad = (n_here + kB - 1) / kB * kB;      // the last batch is filled with null records (all "outside")
+    {
+      ConeRec q{col_out, col_out, 0.0f, 0u};
+      if (tid < n_here) {
+        const int i = p.i_first + s0 + tid;
+        const SlabPieces sp = dda_slab(p.V0 + (long long)i * p.SV, p.SV, smask, p.kf);
+        const bool ina = (uint32_t)sp.ja < (uint32_t)nv, inb = (uint32_t)sp.jb < (uint32_t)nv;
+        q.cola = ina ? (uint32_t)i * su + (uint32_t)sp.ja * sv : col_out;
+        q.colb = inb ? (uint32_t)i * su + (uint32_t)sp.jb * sv : col_out;
+        q.tv = sp.t;
+      }
+      rec[tid] = q;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(q.cola != q.colb);
+      if ((tid & 63) == 0) vxm[tid >> 6] = m;
+    }
+    __syncthreads();
+    stage_load(0);
+    stage_store(bufoff);
+    __syncthreads();
+    const uint8_t* vx_bytes = reinterpret_cast<const uint8_t*>(vxm);
+    // two levels so that the flush of the byte counters (they hold at most 128 slabs) needs no test inside the batch loop
+    for (int s1 = 0; s1 < n_pad; s1 += 128) {
+      const int s_end = min(n_pad, s1 + 128);
+      for (int s = s1; s < s_end; s += kB) {
+        const bool more = s + kB < n_pad;                        // uniform
+        if (more) stage_load(s + kB);                            // in flight while this batch is consumed
+        static_assert(kB == 8, "one byte of the crossing mask per batch");
+        const uint32_t vxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)vx_bytes[s >> 3]);
+        const int hi = (int)(bufoff + zs - 1u);
+        int lo = (int)bufoff;
+        asm volatile("" : "+v"(lo));                             // a VGPR: v_med3_i32 takes one scalar operand only
+        auto slice = [&](long long Wx) {                         // clamp((int)(Wx >> 40), lo, hi): v_ashr + v_med3_i32
+          int kq;
+          asm("v_med3_i32 %0, %1, %2, %3" : "=v"(kq) : "v"((int)(Wx >> DEXCT_FIX_FRAC)), "v"(lo), "s"(hi));
+          return kq;
+        };
+        // ---- fast path, four slabs at a time (all LDS reads of the four first): count the b voxel (the layout stores
+        // 8 * id: one v_lshl_add) and compare the ids into LANE MASKS.  Nothing but the masks is kept: the rare exact path
+        // reads its bytes again.  The byte reads are issued from inline assembly (ds_read_u8 zero-extends; the compiler
+        // adds a v_and per byte) and waited for by an explicit s_waitcnt that takes the registers as in/out operands.
+        const long long Wb = W;
+        unsigned long long dm[kB], any = 0ull;
+        int k0 = slice(W);
+        uint32_t vxc = vxb;
+        asm volatile("" : "+s"(vxc));                            // opaque copy for the compare phase: tests stay s_bitcmp + branch
+        auto half = [&](auto hc) {
+          constexpr int h = decltype(hc)::value;
+          uint32_t x[4], xa[4], c1[4], c2[4];
+          auto slab = [&](auto jc) {
+            constexpr int jj = decltype(jc)::value, j = h + jj;
+            W += SW;
+            const int k1 = slice(W);
+            asm volatile("ds_read_u8 %0, %2 offset:%4\n\tds_read_u8 %1, %3 offset:%5"
+                         : "=&v"(x[jj]), "=&v"(xa[jj])
+                         : "v"(k1), "v"(k0), "n"((2 * j) * CB), "n"((2 * j + 1) * CB));       // b = (jb, kb), a = (ja, ka)
+            if ((vxb >> j) & 1u)                                 // uniform: the two possible middle voxels (jb, ka), (ja, kb)
+              asm volatile("ds_read_u8 %0, %2 offset:%4\n\tds_read_u8 %1, %3 offset:%5"
+                           : "=&v"(c1[jj]), "=&v"(c2[jj])
+                           : "v"(k0), "v"(k1), "n"((2 * j) * CB), "n"((2 * j + 1) * CB));
+            k0 = k1;
+          };
+          slab(std::integral_constant<int, 0>{});
+          slab(std::integral_constant<int, 1>{});
+          slab(std::integral_constant<int, 2>{});
+          slab(std::integral_constant<int, 3>{});
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(x[0]), "+v"(xa[0]), "+v"(x[1]), "+v"(xa[1]), "+v"(x[2]), "+v"(xa[2]), "+v"(x[3]), "+v"(xa[3]));
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = h + jj;
+            acc = (1u << x[jj]) + acc;
+            dm[j] = __builtin_amdgcn_ballot_w64(xa[jj] != x[jj]);
+            if ((vxc >> j) & 1u) {
+              asm volatile("" : "+v"(c1[jj]), "+v"(c2[jj]));     // ordered behind the wait above
+              dm[j] |= __builtin_amdgcn_ballot_w64(c1[jj] != x[jj]) | __builtin_amdgcn_ballot_w64(c2[jj] != x[jj]);
+            }
+            any |= dm[j];
+          }
+        };
+        static_assert(kB == 8, "two halves of four slabs");
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 4>{});
+        if (any != 0ull) {
+#pragma unroll
+          for (int j = 0; j < kB; ++j) {
+            if (dm[j] != 0ull && __builtin_amdgcn_inverse_ballot_w64(dm[j])) {
+              // the oracle's slab, operation for operation (orc_cone_pathlen); only bits 8..39 of W enter
+              const long long Wj = Wb + (long long)j * SW;
+              const int ka = slice(Wj), kb = slice(Wj + SW);
+              const uint32_t ida = cols[ka + (2 * j + 1) * CB], idb = cols[kb + (2 * j) * CB];
+              const float tv = rec[s + j].tv;
+              const float tw = fminf((float)((uint32_t)((unsigned long long)Wj >> 8) ^ wpos) * kfw, 1.0f);
+              const float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
+              const bool v_first = tv <= tw;
+              // middle voxel (jm, km) = v_first ? (jb, ka) : (ja, kb); without a v-crossing both columns are the same one
+              const uint32_t idm = v_first ? cols[ka + (2 * j) * CB] : cols[kb + (2 * j + 1) * CB];
+              if (ida != idm || idm != idb) {
+                float* cell = &lds_corr[0][tid];                 // ids are stored as 8 * id: row id = cell + (8 id) * 32
+                static_assert(kConeRows == 8 * 32, "cell offset of a stored id");
+                __hip_atomic_fetch_add(cell + idm * 32u, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + idb * 32u, -t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + ida * 32u, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cell + idm * 32u, -t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+          }
+        }
+        // ---- the next batch goes to the other buffer; the lane's W follows it
+        if (more) {
+          const uint32_t next = bufoff ^ (uint32_t)kBufB;        // 0 <-> kBufB
+          stage_store(next);
+          W += (long long)((int)next - (int)bufoff) << DEXCT_FIX_FRAC;
+          bufoff = next;
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int m = 0; m < NM; ++m) cnt[m] += (acc >> (8 * m)) & 0xFFu;
+      acc = 0;
+    }
+  }
+  const BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // a ballot: before dead rows leave
+  if (!live) return;
+  // ---- detection (same weighting as the other kernels)
+  const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const int n_e = a.n_energies;
+  float L2[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const float l = ((float)(int32_t)cnt[m] + lds_corr[m][tid]) * len3d;
+    if (a.pathlen) a.pathlen[ray * a.n_materials + m] = l;
+    L2[m] = l * 1.44269504088896340736f;
+  }
+  float accs[DEXCT_MAX_SPECTRA];
+#pragma unroll
+  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = 0.0f;
+  if (a.n_spectra <= 2) {                      // round 3: energies in pairs through v_pk_fma_f32, zero-weight blocks skipped
+    float two[2];
+    detect_energy_pairs<NM>(L2, mu, w, n_e, a.n_spectra, bm, two);
+    accs[0] = two[0];
+    accs[1] = two[1];
+  } else {
+    int srow[DEXCT_MAX_SPECTRA];
+#pragma unroll
+    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) srow[sI] = (sI < a.n_spectra ? sI : 0) * n_e;
+    for (int e = 0; e < n_e; ++e) {
+      float pe = 0.0f;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
+      const float t = __builtin_amdgcn_exp2f(-pe);
+#pragma unroll
+      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = fmaf(w[srow[sI] + e], t, accs[sI]);
+    }
+  }
+#pragma unroll
+  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
+    if (sI < a.n_spectra) {
+      a.counts[ray + sI * sstride] = accs[sI];
+      if (a.sino_log) a.sino_log[ray + sI * sstride] = log_ratio(a.air[sI], accs[sI]);
+    }
+}
+
+// vol [nz][ny][nx] -> guarded z-fastest layout [(ny*nx + 1)][cone_zs(nz)] of 8 * id (the shift of the packed byte counter the
 // traversal adds with one v_lshl_add; round 3): guard slices and the extra column hold 24 = "outside", id 3.
 __global__ __launch_bounds__(256) void cone_layout_kernel(const uint8_t* __restrict__ vol, int nx, int ny, int nz,
                                                           uint8_t* __restrict__ out) {
-  const size_t zs = (size_t)nz + 2;
+  const size_t zs = cone_zs(nz);
   const size_t total = ((size_t)nx * ny + 1) * zs;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const size_t col = i / zs;
-  const int kz = (int)(i - col * zs) - 1;
+  const int kz = (int)(i - col * zs) - kConeGuard;
   uint8_t val = 24;
   if (col < (size_t)nx * ny && kz >= 0 && kz < nz) val = (uint8_t)(vol[(size_t)kz * nx * ny + col] << 3);      // col = y*nx + x
   out[i] = val;
@@ -509,7 +795,7 @@ extern "C" int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_pl
 
 extern "C" int64_t dexct_cone_layout_bytes(int32_t nx, int32_t ny, int32_t nz) {
   if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
-  return ((int64_t)nx * ny + 1) * ((int64_t)nz + 2);
+  return ((int64_t)nx * ny + 1) * (int64_t)cone_zs(nz);
 }
 
 extern "C" int dexct_cone_layout(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, uint8_t* vol_zc, void* stream) {
@@ -559,6 +845,29 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   hipStream_t st = as_stream(stream);
   const int view_tile = 8;
+  // round 3: columns staged in LDS (cone_cols_kernel) whenever a column fits the reserved bytes; DEXCT_CONE_COLS=0 = A/B
+  const char* ce = getenv("DEXCT_CONE_COLS");
+  const uint32_t zs = cone_zs(geom->nz);
+  if (!(ce && atoi(ce) == 0) && zs <= 544u) {
+#define DEXCT_CONE_COLS_LAUNCH(NM_, CB_) \
+    hipLaunchKernelGGL((cone_cols_kernel<NM_, 8, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile)
+    if (zs <= 288u) {
+      switch (n_materials) {
+        case 1: DEXCT_CONE_COLS_LAUNCH(1, 288); break;
+        case 2: DEXCT_CONE_COLS_LAUNCH(2, 288); break;
+        default: DEXCT_CONE_COLS_LAUNCH(3, 288); break;
+      }
+    } else {
+      switch (n_materials) {
+        case 1: DEXCT_CONE_COLS_LAUNCH(1, 544); break;
+        case 2: DEXCT_CONE_COLS_LAUNCH(2, 544); break;
+        default: DEXCT_CONE_COLS_LAUNCH(3, 544); break;
+      }
+    }
+#undef DEXCT_CONE_COLS_LAUNCH
+    DEXCT_LAUNCH_CHECK();
+    return DEXCT_OK;
+  }
   switch (n_materials) {
     case 1: hipLaunchKernelGGL(cone_rows_kernel<1>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
     case 2: hipLaunchKernelGGL(cone_rows_kernel<2>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;

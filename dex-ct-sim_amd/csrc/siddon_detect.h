@@ -188,6 +188,65 @@ __device__ __forceinline__ void detect_energies(const f32x2 (&Lp)[(R + 1) / 2][N
     for (int q = 0; q < R; ++q) acc[s][q] = (q & 1) ? ap[s][q / 2].y : ap[s][q / 2].x;
 }
 
+// One ray per lane (the cone-beam kernels, whose lanes are the rows of a pair): the pairs that go through v_pk_fma_f32
+// are pairs of ENERGIES - exponent FMAs with (mu[m][e], mu[m][e+1]) from the scalar cache, two v_exp_f32, one FMA per
+// spectrum slot with (w[s][e], w[s][e+1]); even and odd energies are summed separately and added at the end (another
+// summation order than the one-energy loop's: 1e-7 relative).  3.5 vector instructions per energy instead of 6 and four
+// energies per trip (wide scalar loads); zero-weight blocks of a slot are skipped as in detect_energies.  L2 = path
+// lengths x log2(e).  <= 2 spectrum slots; acc[s] for s >= n_spectra comes back 0.
+template <int NM>
+__device__ __forceinline__ void detect_energy_pairs(const float (&L2)[NM], const float* __restrict__ mu,
+                                                    const float* __restrict__ w, int n_e, int n_spectra,
+                                                    const BlockMasks& bm, float (&acc)[2]) {
+  f32x2 ap[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+  const int row1 = (n_spectra > 1 ? 1 : 0) * n_e;
+  auto two = [&](int e, auto live_tag) {
+    constexpr uint32_t LIVE = decltype(live_tag)::value;
+    f32x2 pe = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+      pe = __builtin_elementwise_fma(f32x2{mu[m * n_e + e], mu[m * n_e + e + 1]}, f32x2{L2[m], L2[m]}, pe);
+    const f32x2 te = f32x2{__builtin_amdgcn_exp2f(-pe.x), __builtin_amdgcn_exp2f(-pe.y)};
+    if (LIVE & 1u) ap[0] = __builtin_elementwise_fma(f32x2{w[e], w[e + 1]}, te, ap[0]);
+    if (LIVE & 2u) ap[1] = __builtin_elementwise_fma(f32x2{w[row1 + e], w[row1 + e + 1]}, te, ap[1]);
+  };
+  auto four = [&](int e, auto live_tag) {
+    two(e, live_tag);
+    two(e + 2, live_tag);
+  };
+  int e = 0;
+  const int nblk = n_e >> 2;
+  int b = 0;
+  while (b < nblk) {                                 // runs of blocks of the same class (wave-uniform), as detect_energies
+    uint32_t cls = 3u;
+    int run = nblk - b;
+    if (b < 64) {
+      const unsigned long long s0 = bm.m[0] >> b, s1 = bm.m[1] >> b;
+      cls = (uint32_t)(s0 & 1ull) | ((uint32_t)(s1 & 1ull) << 1);
+      const unsigned long long d = (s0 ^ (0ull - (s0 & 1ull))) | (s1 ^ (0ull - (s1 & 1ull)));
+      const int same = d ? __builtin_ctzll(d) : 64;
+      run = min(run, min(same, 64 - b));
+    }
+    const int e_end = 4 * (b + run);
+    if (cls == 3u) for (; e < e_end; e += 4) four(e, std::integral_constant<uint32_t, 3u>{});
+    else if (cls == 1u) for (; e < e_end; e += 4) four(e, std::integral_constant<uint32_t, 1u>{});
+    else if (cls == 2u) for (; e < e_end; e += 4) four(e, std::integral_constant<uint32_t, 2u>{});
+    else e = e_end;
+    b += run;
+  }
+  float tail0 = 0.0f, tail1 = 0.0f;
+  for (; e < n_e; ++e) {                             // n_e not a multiple of 4: the last energies one at a time
+    float pe = 0.0f;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
+    const float t = __builtin_amdgcn_exp2f(-pe);
+    tail0 = fmaf(w[e], t, tail0);
+    tail1 = fmaf(w[row1 + e], t, tail1);
+  }
+  acc[0] = (ap[0].x + ap[0].y) + tail0;
+  acc[1] = n_spectra > 1 ? (ap[1].x + ap[1].y) + tail1 : 0.0f;
+}
+
 // The detected signal of a ray that meets nothing but material 0 (air) depends on its chord only: one value per
 // (view, channel) pair of a stacked fan.  Kept per lane by kernels that detect several groups of rows per lane.
 struct AirCache {
