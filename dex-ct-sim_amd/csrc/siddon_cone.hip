@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
 // column): 0.3 global loads per wave and slab instead of 2.8, no v_readfirstlane of the column offsets, the same ids in
 // the same order - path lengths stay bit-identical.  CB = bytes reserved per staged column (>= cone_zs(nz)).
 template <int NM, int kB, int CB>
-__global__ __launch_bounds__(kConeRows) void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
+__global__ __launch_bounds__(kConeRows) __attribute__((amdgpu_waves_per_eu(kB == 4 ? 8 : 5, 8))) void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
                                                                const float* __restrict__ mu, const float* __restrict__ w,
                                                                int n_chunks, int view_tile) {
   constexpr int kBufB = 2 * kB * CB;                       // bytes of one staging buffer: [slab][b column, a column][CB]
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(kConeRows) void cone_cols_kernel(ConeArgs a, const 
       for (int s = s1; s < s_end; s += kB) {
         const bool more = s + kB < n_pad;                        // uniform
         if (more) stage_load(s + kB);                            // in flight while this batch is consumed
-        static_assert(kB == 8, "one byte of the crossing mask per batch");
-        const uint32_t vxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)vx_bytes[s >> 3]);
+        static_assert(kB == 8 || kB == 4, "a byte or a nibble of the crossing mask per batch");
+        const uint32_t vxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)vx_bytes[s >> 3]) >> (kB == 4 ? (s & 4) : 0);
         const int hi = (int)(bufoff + zs - 1u);
         int lo = (int)bufoff;
         asm volatile("" : "+v"(lo));                             // a VGPR: v_med3_i32 takes one scalar operand only
@@ -615,10 +615,11 @@ __global__ __launch_bounds__(kConeRows) void cone_cols_kernel(ConeArgs a, const 
           auto slab = [&](auto jc) {
             constexpr int jj = decltype(jc)::value, j = h + jj;
             W += SW;
-            const int k1 = slice(W);
-            asm volatile("ds_read_u8 %0, %2 offset:%4\n\tds_read_u8 %1, %3 offset:%5"
-                         : "=&v"(x[jj]), "=&v"(xa[jj])
-                         : "v"(k1), "v"(k0), "n"((2 * j) * CB), "n"((2 * j + 1) * CB));       // b = (jb, kb), a = (ja, ka)
+            int k1;                                              // the clamp of the slice rides in the same statement: no pad between
+            asm volatile("v_med3_i32 %2, %3, %4, %5\n\tds_read_u8 %0, %2 offset:%7\n\tds_read_u8 %1, %6 offset:%8"
+                         : "=&v"(x[jj]), "=&v"(xa[jj]), "=&v"(k1)
+                         : "v"((int)(W >> DEXCT_FIX_FRAC)), "v"(lo), "s"(hi), "v"(k0), "n"((2 * j) * CB),
+                           "n"((2 * j + 1) * CB));                // b = (jb, kb), a = (ja, ka)
             if ((vxb >> j) & 1u)                                 // uniform: the two possible middle voxels (jb, ka), (ja, kb)
               asm volatile("ds_read_u8 %0, %2 offset:%4\n\tds_read_u8 %1, %3 offset:%5"
                            : "=&v"(c1[jj]), "=&v"(c2[jj])
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(kConeRows) void cone_cols_kernel(ConeArgs a, const 
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
             const int j = h + jj;
-            acc = (1u << x[jj]) + acc;
+            asm("v_lshl_add_u32 %0, 1, %1, %0" : "+v"(acc) : "v"(x[jj]));      // acc += 1 << x (left alone, the compiler shifts all four and adds them in a tree: 1.5 per slab)
             dm[j] = __builtin_amdgcn_ballot_w64(xa[jj] != x[jj]);
             if ((vxc >> j) & 1u) {
               asm volatile("" : "+v"(c1[jj]), "+v"(c2[jj]));     // ordered behind the wait above
@@ -643,9 +644,8 @@ __global__ __launch_bounds__(kConeRows) void cone_cols_kernel(ConeArgs a, const 
             any |= dm[j];
           }
         };
-        static_assert(kB == 8, "two halves of four slabs");
         half(std::integral_constant<int, 0>{});
-        half(std::integral_constant<int, 4>{});
+        if constexpr (kB == 8) half(std::integral_constant<int, 4>{});
         if (any != 0ull) {
 #pragma unroll
           for (int j = 0; j < kB; ++j) {
@@ -844,13 +844,23 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
   const size_t nblk = (size_t)a.n_local_views * geom->n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   hipStream_t st = as_stream(stream);
-  const int view_tile = 8;
+  // views per tile of the block order: 1 = all channels of a view before the next view (round 3: 9.6 -> 9.2 ms on a
+  // 100-view scan, whose views 3.6 degrees apart share no columns; no difference at 0.36 degrees)
+  int view_tile = 1;
+  if (const char* te = getenv("DEXCT_CONE_VIEW_TILE")) view_tile = atoi(te) > 0 ? atoi(te) : 1;      // tuning knob
   // round 3: columns staged in LDS (cone_cols_kernel) whenever a column fits the reserved bytes; DEXCT_CONE_COLS=0 = A/B
   const char* ce = getenv("DEXCT_CONE_COLS");
   const uint32_t zs = cone_zs(geom->nz);
   if (!(ce && atoi(ce) == 0) && zs <= 544u) {
+    // slabs per staged batch: 4 (default: 64 VGPRs and 17 KB of LDS = 8 waves per SIMD; 9.6 ms) or 8 (92 VGPRs, 26 KB:
+    // 5 waves; 10.4 ms) - the loop waits for the staged loads of the next batch, so waves in flight are what counts
+    const char* ke = getenv("DEXCT_CONE_KB");
+    const bool kb4 = !(ke && atoi(ke) == 8);
 #define DEXCT_CONE_COLS_LAUNCH(NM_, CB_) \
-    hipLaunchKernelGGL((cone_cols_kernel<NM_, 8, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile)
+    do { \
+      if (kb4) hipLaunchKernelGGL((cone_cols_kernel<NM_, 4, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); \
+      else hipLaunchKernelGGL((cone_cols_kernel<NM_, 8, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); \
+    } while (0)
     if (zs <= 288u) {
       switch (n_materials) {
         case 1: DEXCT_CONE_COLS_LAUNCH(1, 288); break;
