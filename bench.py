@@ -665,21 +665,28 @@ def main():
                          'integrals_per_s': cv * rows * args.channels * sum(n_e_spec) / (msc * 1e-3)}
             del pjc
         out['cone_beam'] = {'rays': cv * rows * args.channels, **res['cone_rows_kernel'],
-                            'kernel': 'cone_rows_kernel (rows of a (view, channel) pair as lanes)',
+                            'kernel': 'cone_cols_kernel (rows of a (view, channel) pair as lanes, voxel columns of 4 slabs staged in LDS)',
                             'thread_per_ray': res['cone_kernel']}
         # roofline: vector issue.  Floor per slab and lane (= detector row) of this formulation: 64-bit z step 1, slice
-        # (shift + clamp) 2, count the b voxel 2, id difference 1 = 6, plus 2 v_readfirstlane of the shared column offsets
-        # = 8 (the compiled fast path issues 16, profiles/r03_kernels.md), 2 byte loads; exact corrections only at material
-        # boundaries; detection as above.  In-plane slabs are shared by the rows of a (view, channel) pair.
+        # (shift + clamp) 2, count the b voxel 1, id comparison 1 = 5 (the compiled loop issues 6.3 with the two middle
+        # voxels of a v-crossing slab), plus the staging of the two voxel columns of a slab by the 256 lanes of the
+        # workgroup (4 instructions per 16-byte piece); exact corrections only at material boundaries; detection with the
+        # energies in pairs: 1.5 exponent FMAs + 1 v_exp per energy, 0.5 per energy and weighting spectrum.  What the kernel
+        # measures against this floor is latency, not issue: each batch of 4 slabs waits for its staged loads, and waves in
+        # flight (8 per SIMD) are what hides it (profiles/r03_kernels.md).
         geomc = co.make_geom(ctc.N_proj, ctc.N_channels, 1, 0, n, n, n, ph.dx, ph.dy, ph.dz, ctc.SID, ctc.SDD)
         planc = co.plan(geomc, ctc.view_cs(), ctc.chan_cs(), 0, ctc.N_proj)
-        slabsc = float(planc['n_slabs'].sum()) * rows
-        floorc = (8.0 * slabsc + cv * rows * args.channels * (5.0 * n_e_any + sum(n_e_spec))) / 64.0
+        slabs_pair = float(planc['n_slabs'].sum())              # in-plane slabs, shared by the rows of a pair
+        slabsc = slabs_pair * rows
+        zs_col = ((n + 15) // 16) * 16 + 32                     # bytes per guarded voxel column (cone_zs)
+        chunks = (rows + 255) // 256
+        staging = slabs_pair * chunks * 2 * (zs_col / 16) * 4.0
+        floorc = (5.0 * slabsc + staging + cv * rows * args.channels * (2.5 * n_e_any + 0.5 * sum(n_e_spec))) / 64.0
         floorc_ms = floorc / slots_per_s * 1e3
         oc = (prof.get('other_kernels') or {}).get('cone_rows', {})
         msc = res['cone_rows_kernel']['siddon_ms']
         out['cone_beam']['roofline'] = {
-            'kernel': 'cone_rows_kernel<3, 4>', 'bound': 'valu_issue', 'unit': 'G wave-instructions/s', 'peak': slots_per_s / 1e9,
+            'kernel': 'cone_cols_kernel<3, 4, 544>', 'bound': 'valu_issue', 'unit': 'G wave-instructions/s', 'peak': slots_per_s / 1e9,
             'achieved': floorc / (msc * 1e-3) / 1e9, 'frac': floorc_ms / msc, 'floor_wave_instructions': floorc,
             'floor_ms_at_%.1f_GHz' % CLOCK_GHZ: floorc_ms, 'lane_slabs_per_launch': slabsc,
             'algorithmic_bytes_per_launch': 2.0 * slabsc + 8.0 * cv * rows * args.channels,

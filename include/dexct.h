@@ -174,12 +174,15 @@ int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
                        int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
                        const float* weights, float* counts, float* pathlen, const dexct_log_out* log_out, void* stream);
 
-/* The same projection with the ROWS of one (view, channel) pair as lanes (cone_rows_kernel): the in-plane slab
- * records are computed once per pair and shared by all its rows, a lane carries only its z DDA and reads one voxel
- * byte per slab (the a voxel of a slab is the previous slab's b voxel).  <= 3 materials.  It reads the guarded
- * z-fastest layout written by dexct_cone_layout: vol_zc[(y*nx + x)*(nz + 2) + 1 + z] = id, guard slices and one
- * extra column hold 3 ("outside the grid"); dexct_cone_layout_bytes gives its size.  Same outputs, bit-identical
- * per-material path lengths. */
+/* The same projection with the ROWS of one (view, channel) pair as lanes: the in-plane slab records are computed once
+ * per pair and shared by all its rows, a lane carries only its z DDA.  <= 3 materials.  Round 3 (cone_cols_kernel): the
+ * workgroup stages the two voxel columns of each slab of a batch in LDS and the lanes read their bytes from there
+ * (volumes of up to 512 slices; cone_rows_kernel, one byte load per lane and voxel, beyond that and with
+ * DEXCT_CONE_COLS=0).  It reads the guarded z-fastest layout written by dexct_cone_layout: a column is
+ * zs = ((nz + 15) & ~15) + 32 bytes, vol_zc[(y*nx + x)*zs + 16 + z] = 8 * id, every guard byte and one extra column
+ * hold 24 (id 3 = "outside the grid"); dexct_cone_layout_bytes gives its size.  Same outputs, bit-identical
+ * per-material path lengths.  Tuning / A-B knobs (environment, read per call): DEXCT_CONE_KB=8 (slabs per staged
+ * batch, default 4), DEXCT_CONE_VIEW_TILE (views per tile of the block order, default 1). */
 int64_t dexct_cone_layout_bytes(int32_t nx, int32_t ny, int32_t nz);
 int dexct_cone_layout(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, uint8_t* vol_zc, void* stream);
 int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,

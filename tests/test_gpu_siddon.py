@@ -459,6 +459,45 @@ def test_random_cone_beam_scans(hip, seed):
         assert rel.max() < REL_TOL, (seed, kernel, rel.max())
 
 
+@pytest.mark.parametrize('nz,n_rows', [(300, 300), (520, 40), (130, 257)])
+def test_cone_row_kernels_on_tall_volumes(hip, nz, n_rows, monkeypatch):
+    """The row-parallel cone kernels on volumes and detectors the random scans above do not reach: columns of more
+    than 288 bytes (cone_cols_kernel<.., 544>), more than 512 slices (falls back to cone_rows_kernel), more than one
+    chunk of 256 rows; and the A/B forms (DEXCT_CONE_COLS=0, DEXCT_CONE_KB=8, a view tile) - path lengths equal the
+    oracle's mirror bit for bit in every form, counts identical between the forms."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    from dex_ct_sim_amd.system import AIR, BONE, WATER
+    rng = np.random.default_rng(nz * 1000 + n_rows)
+    nx, ny = 20, 17
+    dxv, dyv, dzv = 0.2, 0.25, 0.05
+    vol = rng.integers(0, 3, (nz, ny, nx), dtype=np.uint8)
+    vol[rng.random(vol.shape) < 0.5] = 0
+    ph = dx.VoxelPhantom.from_array('tall', vol, [AIR, WATER, BONE], dx=dxv, dy=dyv, dz=dzv)
+    sid, sdd = 9.0, 16.0
+    reach = 0.6 * sdd * dzv / (max(dxv, dyv) * np.sqrt(2.0))
+    h_iso = float(reach / (0.5 * (n_rows - 1)) * sid / sdd * 0.9)
+    n_views, n_ch = 5, 11
+    cone = dx.FanBeamGeometry(N_channels=n_ch, N_proj=n_views, gamma_fan=0.9, SID=sid, SDD=sdd, h_iso=h_iso,
+                              N_rows=n_rows, cone=True, src_z=0.1 * reach)
+    g = co.make_geom(n_views, n_ch, n_rows, 0, nx, ny, nz, dxv, dyv, dzv, sid, sdd)
+    sp = spectra()
+    E, mu, w = fp.merged_tables(cone, ph, sp)
+    _, rpl = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), 0.1 * reach, vol, mu, w,
+                             dda=True, n_threads=8)
+    first = None
+    for env in ({}, {'DEXCT_CONE_COLS': '0'}, {'DEXCT_CONE_KB': '8'}, {'DEXCT_CONE_VIEW_TILE': '3'}):
+        for k in ('DEXCT_CONE_COLS', 'DEXCT_CONE_KB', 'DEXCT_CONE_VIEW_TILE'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        (counts, pl), _ = projector(cone, ph, kernel=2).project(sp, want_pathlen=True)
+        assert np.array_equal(pl.cpu().numpy(), rpl), env
+        if first is None:
+            first = counts.clone()
+        assert torch.equal(counts, first), env
+
+
 def test_sino_allgather_entry_point_single_rank(hip):
     """dexct_sino_allgather with a one-rank RCCL communicator created through the RCCL copy torch has loaded: the
     gathered buffer equals the shard, out of place and in place (the 8-rank use is the driver's; ranks > 1 are

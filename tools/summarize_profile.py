@@ -97,7 +97,7 @@ if cal:
     sq2 = pmc_raw('sq2')
     extra = {}
     for key, pat in (('single_row', 'rays_kernel'), ('wave_per_ray', 'wave_ray_kernel'), ('cone_rows', 'cone_rows_kernel'),
-                     ('cone_thread_per_ray', 'cone_kernel')):
+                     ('cone_rows', 'cone_cols_kernel'), ('cone_thread_per_ray', 'cone_kernel')):      # cone_rows = the row-parallel kernel the host picks (round 3: cone_cols_kernel)
         for k in fetch:
             if pat + '<' in k and 'layout' not in k:
                 d, d2 = sq.get(k, {}), sq2.get(k, {})
