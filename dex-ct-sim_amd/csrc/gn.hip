@@ -30,6 +30,14 @@ constexpr int kGnRingDefault = 0;    // DEXCT_GN_RING=1: history of the lane-ref
 constexpr int kGnBlock = 256;
 constexpr int kTab = 14;  // -mu0 K, -mu1 K (K = 2048/ln2), then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2
 
+// Results leave with the non-temporal hint (round 3): written once, never read by the kernel - left to the default policy
+// the 6.5 GB of them push the spill scratch of the resident waves out of the L2 (WRITE_SIZE 34 GB for 6.5 GB of results,
+// tools/probes/gn_write.py).  DEXCT_GN_NT=0 (A/B) is not needed: the bits written are the same.
+__device__ __forceinline__ void store_a(double* __restrict__ out_a, int64_t p, double a0, double a1) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store(d2{a0, a1}, reinterpret_cast<d2*>(out_a + 2 * p));
+}
+
 template <typename T>
 __device__ __forceinline__ T load_g(const void* p, int is_f64, int64_t i) {
   return is_f64 ? (T) reinterpret_cast<const double*>(p)[i] : (T) reinterpret_cast<const float*>(p)[i];
@@ -342,8 +350,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   // Fused air mask of get_basismat_sinos (matdecomp.py:195-196, :204-205): a pixel with g1 >= frac * max is set
   // to 0 afterwards whatever the iteration produced, so its iterations are not run at all.
   if (mask_max && gd0 >= mask_frac * mask_max[0]) {
-    out_a[2 * p] = 0.0;
-    out_a[2 * p + 1] = 0.0;
+    store_a(out_a, p, 0.0, 0.0);
     return;
   }
   double a0 = 1e-6, a1 = 1e-6;
@@ -442,8 +449,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
     for (int k = 0; k < kGnHistory; ++k)
       if (slot == k) { a0 = __longlong_as_double(h0[k]); a1 = __longlong_as_double(h1[k]); }
   }
-  out_a[2 * p] = a0;
-  out_a[2 * p + 1] = a1;
+  store_a(out_a, p, a0, a1);
 }
 
 
@@ -550,11 +556,9 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
         gd0 = load_g<double>(g1, g_is_f64, np);
         gd1 = load_g<double>(g2, g_is_f64, np);
         if (has_mask && gd0 >= thresh) {           // air (matdecomp.py:195-196, :204-205): 0, not iterated
-          out_a[2 * np] = 0.0;
-          out_a[2 * np + 1] = 0.0;
+          store_a(out_a, np, 0.0, 0.0);
         } else if (n_iters <= 0) {
-          out_a[2 * np] = 1e-6;
-          out_a[2 * np + 1] = 1e-6;
+          store_a(out_a, np, 1e-6, 1e-6);
         } else {
           p = np; a0 = 1e-6; a1 = 1e-6; it = 0;
         }
@@ -621,8 +625,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
       a1 = advance ? n1 : f1;
       it += advance ? 1 : 0;
       if (p >= 0 && (!advance || it >= n_iters)) {
-        out_a[2 * p] = a0;
-        out_a[2 * p + 1] = a1;
+        store_a(out_a, p, a0, a1);
         p = -1;
       }
       continue;
@@ -693,8 +696,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     a1 = advance ? n1 : f1;
     it += advance ? 1 : 0;
     if (p >= 0 && (!advance || it >= n_iters)) {
-      out_a[2 * p] = a0;
-      out_a[2 * p + 1] = a1;
+      store_a(out_a, p, a0, a1);
       p = -1;
     }
   }
@@ -710,8 +712,7 @@ __global__ __launch_bounds__(256) void mask_kernel(const void* __restrict__ g1, 
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n_pix) return;
   if (load_g<double>(g1, g_is_f64, p) >= thresh) {
-    out_a[2 * p] = 0.0;
-    out_a[2 * p + 1] = 0.0;
+    store_a(out_a, p, 0.0, 0.0);
   }
 }
 
@@ -769,6 +770,7 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   if (precision != 0 && precision != 1) return DEXCT_EINVAL;
   if (precision == 1 && n_bins > 1) return DEXCT_EINVAL;   // mixed precision only with one shared spectrum
   if (n_polish < 0) return DEXCT_EINVAL;
+  if (reinterpret_cast<uintptr_t>(out_a) & 15u) return DEXCT_EINVAL;      // a pixel's two doubles leave as one 16-byte store
   if (n_energies > 4096) return DEXCT_ERANGE;
   const int64_t nblk = (n_pix + kGnBlock - 1) / kGnBlock;
   if (nblk > 0x7FFFFFFFll) return DEXCT_ERANGE;

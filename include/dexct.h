@@ -245,7 +245,8 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *              n_bins > 1: pixel p uses row b = (p / bin_div) % n_bins (bin_div = 1 when the channel is
  *              the fastest pixel index, = n_rows for the row-fastest layout 1)
  *   mus[m*n_energies + e]  basis mass attenuation (float64), m = 0, 1
- *   out_a[2*p + m]         density line integrals (float64), initialised to 1e-6 inside
+ *   out_a[2*p + m]         density line integrals (float64), initialised to 1e-6 inside; 16-byte aligned (DEXCT_EINVAL
+ *                          otherwise): a pixel's pair is one non-temporal 16-byte store
  *   precision: 0 = float64 throughout (reference arithmetic);
  *              1 = float32 bulk iterations followed by float64 polish iterations; a pixel the
  *                  polish is still moving is redone in float64 from the start (n_bins == 1 only)
