@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
 // column): 0.3 global loads per wave and slab instead of 2.8, no v_readfirstlane of the column offsets, the same ids in
 // the same order - path lengths stay bit-identical.  CB = bytes reserved per staged column (>= cone_zs(nz)).
 template <int NM, int kB, int CB>
-__global__ __launch_bounds__(kConeRows) __attribute__((amdgpu_waves_per_eu(kB == 4 ? 8 : 5, 8))) void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
+__global__ __launch_bounds__(kConeRows) __attribute__((amdgpu_waves_per_eu(kB == 4 && CB <= 544 ? 8 : 5, 8))) void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
                                                                const float* __restrict__ mu, const float* __restrict__ w,
                                                                int n_chunks, int view_tile) {
   constexpr int kBufB = 2 * kB * CB;                       // bytes of one staging buffer: [slab][b column, a column][CB]
@@ -851,7 +851,7 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
   // round 3: columns staged in LDS (cone_cols_kernel) whenever a column fits the reserved bytes; DEXCT_CONE_COLS=0 = A/B
   const char* ce = getenv("DEXCT_CONE_COLS");
   const uint32_t zs = cone_zs(geom->nz);
-  if (!(ce && atoi(ce) == 0) && zs <= 544u) {
+  if (!(ce && atoi(ce) == 0) && zs <= 1056u) {
     // slabs per staged batch: 4 (default: 64 VGPRs and 17 KB of LDS = 8 waves per SIMD; 9.6 ms) or 8 (92 VGPRs, 26 KB:
     // 5 waves; 10.4 ms) - the loop waits for the staged loads of the next batch, so waves in flight are what counts
     const char* ke = getenv("DEXCT_CONE_KB");
@@ -867,11 +867,17 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
         case 2: DEXCT_CONE_COLS_LAUNCH(2, 288); break;
         default: DEXCT_CONE_COLS_LAUNCH(3, 288); break;
       }
-    } else {
+    } else if (zs <= 544u) {
       switch (n_materials) {
         case 1: DEXCT_CONE_COLS_LAUNCH(1, 544); break;
         case 2: DEXCT_CONE_COLS_LAUNCH(2, 544); break;
         default: DEXCT_CONE_COLS_LAUNCH(3, 544); break;
+      }
+    } else {                                   // up to 1024 slices: 4 slabs per batch only (17 KB of LDS per buffer)
+      switch (n_materials) {
+        case 1: hipLaunchKernelGGL((cone_cols_kernel<1, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
+        case 2: hipLaunchKernelGGL((cone_cols_kernel<2, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
+        default: hipLaunchKernelGGL((cone_cols_kernel<3, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
       }
     }
 #undef DEXCT_CONE_COLS_LAUNCH

@@ -177,7 +177,7 @@ int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
 /* The same projection with the ROWS of one (view, channel) pair as lanes: the in-plane slab records are computed once
  * per pair and shared by all its rows, a lane carries only its z DDA.  <= 3 materials.  Round 3 (cone_cols_kernel): the
  * workgroup stages the two voxel columns of each slab of a batch in LDS and the lanes read their bytes from there
- * (volumes of up to 512 slices; cone_rows_kernel, one byte load per lane and voxel, beyond that and with
+ * (volumes of up to 1024 slices; cone_rows_kernel, one byte load per lane and voxel, beyond that and with
  * DEXCT_CONE_COLS=0).  It reads the guarded z-fastest layout written by dexct_cone_layout: a column is
  * zs = ((nz + 15) & ~15) + 32 bytes, vol_zc[(y*nx + x)*zs + 16 + z] = 8 * id, every guard byte and one extra column
  * hold 24 (id 3 = "outside the grid"); dexct_cone_layout_bytes gives its size.  Same outputs, bit-identical

@@ -459,11 +459,11 @@ def test_random_cone_beam_scans(hip, seed):
         assert rel.max() < REL_TOL, (seed, kernel, rel.max())
 
 
-@pytest.mark.parametrize('nz,n_rows', [(300, 300), (520, 40), (130, 257)])
+@pytest.mark.parametrize('nz,n_rows', [(300, 300), (520, 40), (130, 257), (1030, 12)])
 def test_cone_row_kernels_on_tall_volumes(hip, nz, n_rows, monkeypatch):
     """The row-parallel cone kernels on volumes and detectors the random scans above do not reach: columns of more
-    than 288 bytes (cone_cols_kernel<.., 544>), more than 512 slices (falls back to cone_rows_kernel), more than one
-    chunk of 256 rows; and the A/B forms (DEXCT_CONE_COLS=0, DEXCT_CONE_KB=8, a view tile) - path lengths equal the
+    than 288 and than 544 bytes (cone_cols_kernel<.., 544>, <.., 1056>), more than 1024 slices (falls back to
+    cone_rows_kernel), more than one chunk of 256 rows; and the A/B forms (DEXCT_CONE_COLS=0, DEXCT_CONE_KB=8, a view tile) - path lengths equal the
     oracle's mirror bit for bit in every form, counts identical between the forms."""
     import dex_ct_sim_amd as dx
     from dex_ct_sim_amd import forward_project as fp
