@@ -32,7 +32,7 @@ constexpr int kTab = 14;  // -mu0 K, -mu1 K (K = 2048/ln2), then per k: i0, i0*m
 
 // Results leave with the non-temporal hint (round 3): written once, never read by the kernel - left to the default policy
 // the 6.5 GB of them push the spill scratch of the resident waves out of the L2 (WRITE_SIZE 34 GB for 6.5 GB of results,
-// tools/probes/gn_write.py).  DEXCT_GN_NT=0 (A/B) is not needed: the bits written are the same.
+// tools/probes/gn_write.py).  The bits written are the same.
 __device__ __forceinline__ void store_a(double* __restrict__ out_a, int64_t p, double a0, double a1) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   __builtin_nontemporal_store(d2{a0, a1}, reinterpret_cast<d2*>(out_a + 2 * p));
@@ -803,7 +803,10 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     // pixels: 98 / 97 / 99 / 102 / 106 against 108), and no more workgroups than could ever be resident
     const char* qe = getenv("DEXCT_GN_QUEUE");
     const bool use_queue = !(qe && atoi(qe) == 0);
-    if (use_queue && !ce) chunk = 2;
+    // Below ~1e8 pixels a fetch of 64 pixels is better (round 3, tools/probes/gn_small2.py: the reference's own 1200 x 800
+    // single-row sinogram 4.33 -> 3.61 ms, configs[1]'s 360 x 512: 2.06 -> 1.59, 5.1e6 pixels 11.6 -> 11.0, 2.6e7: 51.8 -> 51.5):
+    // the tail of a small launch is the last runs' slowest pixels, and halving a run halves what a wave can be left with.
+    if (use_queue && !ce) chunk = n_pix < 100000000ll ? 1 : 2;
     int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
     int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     if (use_queue) {
