@@ -63,6 +63,9 @@ def register_table(name, E_keV, mu_rho):
     _user_tables[name] = (E, m)
 
 
+_mix_cache = {}
+
+
 def _interp_loglog(E, tab):
     Et, mt = tab
     return np.exp(np.interp(np.log(E), np.log(Et), np.log(mt)))
@@ -99,9 +102,19 @@ def mixatten(formula, E_keV):
     (matdecomp.py:158).  Returns float64 with the shape of ``E_keV``.
     """
     E = np.asarray(E_keV, dtype=np.float64)
+    # the public calls ask for the same (material, energy grid) pairs on every call (0.3 ms of a 0.9 ms get_sino at the
+    # reference's own size): keep the last results; a registered table or another DEXCT_XCOM_DIR changes the key
+    key = (formula, E.shape, E.tobytes(), len(_user_tables), os.environ.get('DEXCT_XCOM_DIR'))
+    hit = _mix_cache.get(key)
+    if hit is not None:
+        return hit.copy()
     if formula in _user_tables:
-        return _interp_loglog(E, _user_tables[formula])
-    out = np.zeros_like(E)
-    for sym, w in parse_formula(formula):
-        out = out + w * _element(sym, E)
+        out = _interp_loglog(E, _user_tables[formula])
+    else:
+        out = np.zeros_like(E)
+        for sym, w in parse_formula(formula):
+            out = out + w * _element(sym, E)
+    if len(_mix_cache) >= 256:
+        _mix_cache.clear()
+    _mix_cache[key] = out.copy()
     return out

@@ -179,7 +179,9 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_gn_decompose(one, one, 1, 0, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == EINVAL    # no pixels
     assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 2, 0, None, 0.0, one, one, None) == EINVAL    # precision
     assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 8, 1, 5, 1, 0, None, 0.0, one, one, None) == EINVAL    # mixed + per-bin
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == ERANGE  # energies
+    al = C.c_void_p(16)      # out_a must be 16-byte aligned (a pixel's pair is one 16-byte store)
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, None, 0.0, al, one, None) == ERANGE   # energies
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == EINVAL    # out_a misaligned
     assert lib.dexct_gn_workspace_bytes(140, 1) > 140 * 14 * 12 and lib.dexct_gn_workspace_bytes(0, 1) == 0
     assert lib.dexct_transpose_batched(one, one, 1, 4, 4, 3, None) == EINVAL            # element size
     assert lib.dexct_fbp_filter(one, one, one, 1, 1, 0.01, one, None) == EINVAL
