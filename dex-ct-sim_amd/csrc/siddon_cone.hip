@@ -471,12 +471,15 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
 // (4 with a v-crossing) per wave.  Here the workgroup copies the two voxel columns of each slab of a batch - whole
 // columns, cone_zs(nz) bytes, 16 bytes per lane and load - into LDS once (double buffered: the next batch's loads are in
 // flight while this one is consumed), and the lanes read their bytes with ds_read_u8 at a static offset per (slab,
-// column): 0.3 global loads per wave and slab instead of 2.8, no v_readfirstlane of the column offsets, the same ids in
-// the same order - path lengths stay bit-identical.  CB = bytes reserved per staged column (>= cone_zs(nz)).
+// column): 0.23 global loads per wave and slab instead of 2.8, no v_readfirstlane of the column offsets, the same ids in
+// the same order - path lengths stay bit-identical.  CB = bytes reserved per staged column (>= cone_zs(nz)); kB = slabs
+// per batch.  What bounds THIS loop is the latency of the staged loads (a batch waits for the next batch's columns), so
+// waves in flight decide: kB = 4 with the register allocation capped at 64 VGPRs (8 waves per SIMD, 17 KB of LDS) runs
+// the benchmark scan in 9.6 ms, kB = 8 (92 VGPRs, 26 KB: 5 waves) in 10.4 (profiles/r03_kernels.md).
 template <int NM, int kB, int CB>
-__global__ __launch_bounds__(kConeRows) __attribute__((amdgpu_waves_per_eu(kB == 4 && CB <= 544 ? 8 : 5, 8))) void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
-                                                               const float* __restrict__ mu, const float* __restrict__ w,
-                                                               int n_chunks, int view_tile) {
+__global__ __launch_bounds__(kConeRows) __attribute__((amdgpu_waves_per_eu(kB == 4 && CB <= 544 ? 8 : 5, 8)))
+void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const float* __restrict__ mu,
+                      const float* __restrict__ w, int n_chunks, int view_tile) {
   constexpr int kBufB = 2 * kB * CB;                       // bytes of one staging buffer: [slab][b column, a column][CB]
   constexpr int kItems = (2 * kB * (CB / 16) + kConeRows - 1) / kConeRows;      // 16-byte pieces per lane and batch
   __shared__ ConeRec rec[kConeRows];
