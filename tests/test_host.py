@@ -183,6 +183,11 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, None, 0.0, al, one, None) == ERANGE   # energies
     assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == EINVAL    # out_a misaligned
     assert lib.dexct_gn_workspace_bytes(140, 1) > 140 * 14 * 12 and lib.dexct_gn_workspace_bytes(0, 1) == 0
+    # the guarded cone-beam layout (include/dexct.h): (nx ny + 1) columns of ((nz + 15) & ~15) + 32 bytes
+    for nx, ny, nz in ((3, 5, 1), (8, 8, 16), (20, 17, 300), (512, 512, 512)):
+        assert lib.dexct_cone_layout_bytes(nx, ny, nz) == (nx * ny + 1) * (((nz + 15) & ~15) + 32)
+    assert lib.dexct_cone_layout_bytes(0, 5, 5) == 0
+    assert lib.dexct_cone_layout(one, 8, 8, 0, one, None) == EINVAL
     assert lib.dexct_transpose_batched(one, one, 1, 4, 4, 3, None) == EINVAL            # element size
     assert lib.dexct_fbp_filter(one, one, one, 1, 1, 0.01, one, None) == EINVAL
     assert lib.dexct_fbp_backproject(one, one, 10, 16, 1, 60.0, 0.0, 0.1, 32, 20.0, one, None) == EINVAL
