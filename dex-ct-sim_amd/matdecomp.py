@@ -185,9 +185,10 @@ def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None):
     return a if isinstance(sino1, torch.Tensor) else to_host(a)
 
 
-_PIPE_CHUNKS = 3                 # view chunks of the pipelined host boundary (tools/probes/boundary_gn.py at configs[2] size:
-                                 # 2 / 3 / 4 / 6 chunks 0.931 / 0.916 / 0.932 / 0.932 s, the plain sequence 1.038 s; short launches
-                                 # cost the Newton kernel efficiency, tools/probes/overlap.py)
+_PIPE_CHUNKS = 8                 # view chunks of the pipelined host boundary (tools/probes/boundary_gn.py at configs[2] size,
+                                 # Newton kernel with its run queue: 2 / 3 / 4 / 6 / 8 / 12 / 16 chunks 0.878 / 0.856 / 0.848 /
+                                 # 0.834 / 0.832 / 0.832 / 0.836 s, the plain sequence 0.975 s.  With the static runs of rounds
+                                 # 1-2 short launches cost the kernel efficiency and 3 chunks were the optimum.)
 _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinogram) the plain sequence is as fast
 
 

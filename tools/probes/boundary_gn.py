@@ -19,7 +19,7 @@ specs = [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
 r1, _ = dx.get_sino(ct, ph, specs[0])
 r2, _ = dx.get_sino(ct, ph, specs[1])
 print('inputs pinned:', torch.from_numpy(r1).is_pinned(), r1.shape, r1.dtype)
-for label, chunks, minpix in (('pipelined 2', 2, 1), ('pipelined 3', 3, 1), ('pipelined 4', 4, 1), ('pipelined 5', 5, 1), ('pipelined 6', 6, 1), ('plain', 8, 1 << 62)):
+for label, chunks, minpix in (('pipelined 2', 2, 1), ('pipelined 3', 3, 1), ('pipelined 4', 4, 1), ('pipelined 5', 5, 1), ('pipelined 6', 6, 1), ('pipelined 8', 8, 1), ('pipelined 12', 12, 1), ('pipelined 16', 16, 1), ('plain', 8, 1 << 62)):
     md._PIPE_CHUNKS, md._PIPE_MIN_PIXELS = chunks, minpix
     for rep in range(2):
         torch.cuda.synchronize()
