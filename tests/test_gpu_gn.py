@@ -258,6 +258,13 @@ def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
                         md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None)
                         results[(queue, chunk, masked)] = out.cpu().numpy()
             os.environ.pop('DEXCT_GN_QUEUE')
+            os.environ['DEXCT_GN_CHUNK'] = '1'
+            for cap in ('1', '3'):                             # workgroups per CU of the run-queue grid
+                os.environ['DEXCT_GN_BLOCKS_PER_CU'] = cap
+                out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+                md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax)
+                results[('cap' + cap, '1', True)] = out.cpu().numpy()
+            os.environ.pop('DEXCT_GN_BLOCKS_PER_CU')
             base_m, base_u = results[('1', '1', True)], results[('1', '1', False)]
             for (queue, chunk, masked), r in results.items():
                 assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, queue, chunk)
@@ -279,6 +286,7 @@ def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
     finally:
         os.environ.pop('DEXCT_GN_CHUNK', None)
         os.environ.pop('DEXCT_GN_QUEUE', None)
+        os.environ.pop('DEXCT_GN_BLOCKS_PER_CU', None)
 
 
 @pytest.mark.parametrize('seed', range(10))
