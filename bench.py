@@ -169,7 +169,7 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
                 'ok': ok}, n
 
     def kernel_ms(ct_, ph_, s1):            # one single-spectrum projection with both outputs, device resident
-        pj = fp._projector(ct_, ph_, (0, ct_.N_proj))
+        pj = fp._projector(ct_, ph_, (0, ct_.N_proj))[0]
         _, mu_d, w_d, air = pj.upload_tables([s1])
         pj.project_tables(mu_d, w_d, air=air)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -278,11 +278,14 @@ def main():
     nat_shape = (nV, args.channels, rows) if native == 1 else (nV, rows, args.channels)
     counts_nat = torch.empty((2,) + nat_shape, dtype=torch.float32, device=dev)
     log_nat = torch.empty_like(counts_nat)          # get_sino's second output (main.py:120-122), from the same kernel
-    a_nat = torch.empty(nat_shape + (2,), dtype=torch.float64, device=dev)
-    # results in the reference's order ([view][row][channel]) are part of the step
+    # results in the reference's order ([view][row][channel]) are part of the step: the sinograms by a transpose pass, the
+    # decomposition directly from the Newton kernel (dexct_gn_options.out_rows / out_channels, ABI 3)
     counts = torch.empty((2, nV, rows, args.channels), dtype=torch.float32, device=dev) if native == 1 else counts_nat
     log_ref = torch.empty_like(counts) if native == 1 else log_nat
-    a_out = torch.empty((nV, rows, args.channels, 2), dtype=torch.float64, device=dev) if native == 1 else a_nat
+    a_out = torch.empty((nV, rows, args.channels, 2), dtype=torch.float64, device=dev)
+    out_rc = (rows, args.channels) if native == 1 else None
+    # None: the default of get_basismat_sinos / dexct_gn_decompose (tolerance stop, 1e-12); 0.0: the fixed count exactly
+    gn_tol = [None]
     gmax = torch.empty((), dtype=torch.float64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     precision = args.gn_precision or md.DEFAULT_PRECISION
@@ -305,22 +308,20 @@ def main():
             if native == 1:
                 _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
                                                           4, st), 'transpose counts')
-            finish_gather = _shard.gather_views(counts, total_views, view_dim=1, async_op=True)
+            finish_gather = _shard.gather_views(counts, total_views, view_dim=1, async_op=True, tag='bench', reuse_out=True)
         if timed:
             ev[2].record()
         # air mask fused into the Newton kernel: threshold = 0.95 * (all-reduced) max, read from the device scalar
-        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, precision, out=a_nat, mask_max=gm,
-                     mask_frac=0.95)
+        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, precision, out=a_out, out_rc=out_rc, mask_max=gm,
+                     mask_frac=0.95, stop_tol=gn_tol[0])
         if timed:
             ev[3].record()
-        if native == 1:       # hand the results over in the reference's [view][row][channel] order
+        if native == 1:       # hand the sinograms over in the reference's [view][row][channel] order
             if world == 1:
                 _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
                                                           4, st), 'transpose counts')
             _native.check(lib.dexct_transpose_batched(ptr(log_nat), ptr(log_ref), 2 * nV, args.channels, rows, 4, st),
                           'transpose log')
-            _native.check(lib.dexct_transpose_batched(ptr(a_nat), ptr(a_out), nV, args.channels, rows, 16, st),
-                          'transpose mats')
         if world > 1:
             # basis-material sinograms stay view-sharded (each rank owns its angles, as a view-sharded
             # back-projection would consume them); only the raw sinogram is assembled, as the north star says
@@ -372,7 +373,7 @@ def main():
         n_alloc0 = torch.cuda.memory_stats().get('allocation.all.allocated', 0)
         g0 = time.perf_counter()
         for _ in range(3):
-            _shard.gather_views(counts, total_views, view_dim=1)
+            _shard.gather_views(counts, total_views, view_dim=1, tag='bench', reuse_out=True)
             torch.cuda.synchronize()
         gather_alone_ms = 1e3 * (time.perf_counter() - g0) / 3
         gather_allocs = (torch.cuda.memory_stats().get('allocation.all.allocated', 0) - n_alloc0) / 3
@@ -495,8 +496,13 @@ def main():
     # 28 flops + 1 exp per energy-iteration
     flops_per_pixel_iter = i0.shape[1] * (28 + 1)
     gn_flops_all = (1.0 - masked) * n_rays * args.iters * flops_per_pixel_iter
+    # what the hardware issues of those: an energy only one spectrum weights takes 6 accumulations instead of 12 (17 of the
+    # 29 flop), an energy no spectrum weights is dropped
+    n_both = int(((i0[0] != 0) & (i0[1] != 0)).sum())
+    n_one = int(((i0[0] != 0) ^ (i0[1] != 0)).sum())
+    hw_share = (29.0 * n_both + 17.0 * n_one) / (29.0 * i0.shape[1])
     gn_name = 'gn_refill_kernel' if precision == 'f64' else 'gn_kernel<true,false>'
-    gstats = md.last_gn_stats() if hasattr(md, 'last_gn_stats') else None
+    gstats = md.last_gn_stats()            # of the last timed step's launch (the default mode)
     roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
             'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': gn_ms,
             'traffic': (prof.get('gn_fetch_bytes_x2_corrected', 0) + prof.get('gn_write_bytes', 0)) or None,
@@ -510,83 +516,91 @@ def main():
                      'executed_pixel_iterations': gstats['pixel_iterations'],
                      'mean_iterations_per_unmasked_pixel': gstats['pixel_iterations'] / max((1.0 - masked) * n_rays, 1.0),
                      'exit_saving': 1.0 - gstats['pixel_iterations'] / max((1.0 - masked) * n_rays * args.iters, 1.0),
+                     'stalled_lane_steps': gstats.get('stalled_lane_steps'),
+                     'hardware_fp64_flop_share': hw_share,
+                     'hardware_fp64_utilisation': hw_share * ex_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      'note': 'achieved = flops of the iterations the timed launch EXECUTED (counted by the kernel; SURVEY 8d: '
-                             '28 flops + 1 exp per energy and iteration, unmasked pixels) / its time.  exit_saving = share of '
-                             'the n_iters x pixels iterations the exact repeated-state exit proved unnecessary - reported '
-                             'separately, not as throughput'})
+                             '28 flops + 1 exp per energy and iteration, unmasked pixels) / its time.  The 29 flop per energy '
+                             'are ALGORITHMIC: of the %d energies of the union grid %d carry both spectra, %d only one '
+                             '(6 accumulations instead of 12) and %d none (dropped), so the FP64 flops the hardware issues are '
+                             'hardware_fp64_flop_share = %.2f of that and hardware_fp64_utilisation = share x frac; the rest of '
+                             'the fully busy vector pipe is integer / move work and the per-iteration 2x2 solve '
+                             '(profiles/r03_gn_isa.md).  exit_saving = share of the n_iters x pixels iterations the exits '
+                             '(repeated state, tolerance) made unnecessary - reported separately, not as throughput'
+                             % (i0.shape[1], n_both, n_one, i0.shape[1] - n_both - n_one, hw_share)})
     out['roofline'] = roof
     if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
+        # ---- the reference's fixed iteration count, EXACTLY (stop_tol = 0): the same step timed the same way -> value_exact;
+        # checked bit for bit against a launch that executes every iteration (DEXCT_GN_FULL_LOOP=1), and the default step's
+        # results checked against it on every pixel
+        a_default = a_out.clone()
+        gn_tol[0] = 0.0
+        step(False)
+        torch.cuda.synchronize()
+        t_gn_ex = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+            torch.cuda.synchronize()
+            t_gn_ex.append(ev[2].elapsed_time(ev[3]))
+        elapsed_ex = time.perf_counter() - t0
+        ex_stats = md.last_gn_stats()
+        a_exact = a_out.clone()
         os.environ['DEXCT_GN_FULL_LOOP'] = '1'
         try:
-            a_full = torch.empty_like(a_nat)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'f64', out=a_full, mask_max=gmax,
+            md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'f64', out=a_out, out_rc=out_rc, mask_max=gmax,
                          mask_frac=0.95)
             e1.record()
             torch.cuda.synchronize()
         finally:
             os.environ.pop('DEXCT_GN_FULL_LOOP', None)
         full_ms = e0.elapsed_time(e1)
-        roof.update({'full_loop_ms': full_ms, 'full_loop_achieved': gn_flops_all / (full_ms * 1e-3) / 1e12,
-                     'full_loop_frac': gn_flops_all / (full_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                     'full_loop_bit_identical': bool(torch.equal(a_full.view(torch.int64), a_nat.view(torch.int64))),
-                     'exit_speedup': full_ms / gn_ms})
-        if 'frac' not in roof:
-            roof.update({'achieved': roof['full_loop_achieved'], 'frac': roof['full_loop_frac'],
-                         'note': 'achieved = flops of ALL n_iters iterations / time of the launch that executes all of '
-                                 'them (DEXCT_GN_FULL_LOOP=1); the timed launch skips iterations proved unnecessary '
-                                 '(exit_speedup), which is not throughput'})
-        del a_full
+        exact_is_full = bool(torch.equal(a_out.view(torch.int64), a_exact.view(torch.int64)))
+        diff = float(torch.nan_to_num((a_default - a_exact).abs() / a_exact.abs().clamp(min=1.0), nan=0.0).max().item())
+        same_nan = bool(torch.equal(torch.isnan(a_default), torch.isnan(a_exact)))
+        if not exact_is_full:
+            raise SystemExit('bench.py: the exact launch (stop_tol = 0) differs from the full 50-iteration loop')
+        if not (diff <= 1e-12 and same_nan):
+            raise SystemExit(f'bench.py: the default tolerance stop moved a pixel by {diff:.3e} (> 1e-12) from the exact launch')
+        gn_ex_ms = float(np.mean(t_gn_ex))
+        out['value_exact'] = integrals_per_step / (elapsed_ex / args.steps)
+        out['gn_exact'] = {'stop_tol': 0.0, 'gn_ms': gn_ex_ms, 'ms_per_step': 1e3 * elapsed_ex / args.steps,
+                           'exact_bit_identical_to_full_loop': True, 'full_loop_ms': full_ms,
+                           'executed_pixel_iterations': ex_stats['pixel_iterations'],
+                           'mean_iterations_per_unmasked_pixel': ex_stats['pixel_iterations'] / max((1.0 - masked) * n_rays, 1.0),
+                           'achieved': ex_stats['pixel_iterations'] * flops_per_pixel_iter / (gn_ex_ms * 1e-3) / 1e12,
+                           'frac': ex_stats['pixel_iterations'] * flops_per_pixel_iter / (gn_ex_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                           'full_loop_achieved': gn_flops_all / (full_ms * 1e-3) / 1e12,
+                           'full_loop_frac': gn_flops_all / (full_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                           'default_max_diff_vs_exact': diff, 'pixels_compared': int(a_exact[..., 0].numel()),
+                           'default_within_1e-12_of_exact_on_every_pixel': True,
+                           'note': 'value_exact: the same step with stop_tol = 0 - the fixed iteration count of '
+                                   'matdecomp.py:114, every bit of it (checked here against a launch that executes all '
+                                   'iterations).  `value` is the default mode: a pixel also ends when a Newton step moves it by '
+                                   '<= 1e-12 * max(|a|, 1) and that step is at most half the previous one; its results are '
+                                   'compared with the exact ones on every pixel above'}
+        gn_tol[0] = None
+        step(False)                                                                  # the default results are back in place
+        torch.cuda.synchronize()
+        assert torch.equal(a_out.view(torch.int64), a_default.view(torch.int64))
+        del a_exact, a_default
     if 'frac' not in roof:
         roof.update({'achieved': None, 'frac': None, 'note': 'executed-iteration count not available in this mode'})
 
-    # ---- opt-in tolerance stop (float64, DEXCT_GN_STOP_TOL=1e-12), never `value`: the SAME step timed the same way, so
-    # that what the north star's 1e-5 tolerance would allow stands beside the headline as a measured number.  The
-    # headline stays the reference's fixed-count float64 iteration (matdecomp.py:114-125).
-    if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
-        a_exact = a_nat.clone()
-        os.environ['DEXCT_GN_STOP_TOL'] = '1e-12'
-        try:
-            step(False)
-            torch.cuda.synchronize()
-            t_gn_tol = []
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step(True)
-                torch.cuda.synchronize()
-                t_gn_tol.append(ev[2].elapsed_time(ev[3]))
-            elapsed_tol = time.perf_counter() - t0
-        finally:
-            os.environ.pop('DEXCT_GN_STOP_TOL', None)
-        diff = float(torch.nan_to_num((a_nat - a_exact).abs() / a_exact.abs().clamp(min=1.0), nan=0.0).max().item())
-        same_nan = bool(torch.equal(torch.isnan(a_nat), torch.isnan(a_exact)))
-        if not (diff <= 1e-12 and same_nan):
-            raise SystemExit(f'bench.py: DEXCT_GN_STOP_TOL=1e-12 moved a pixel by {diff:.3e} (> 1e-12) from the exact launch')
-        out['value_stop_tol'] = integrals_per_step / (elapsed_tol / args.steps)
-        out['gn_stop_tol'] = {'tol': 1e-12, 'gn_ms': float(np.mean(t_gn_tol)), 'ms_per_step': 1e3 * elapsed_tol / args.steps,
-                              'max_diff_vs_exact': diff, 'pixels_compared': int(a_exact[..., 0].numel()),
-                              'within_1e-12_of_the_exact_launch_on_every_pixel': True,
-                              'note': 'value_stop_tol: the same step, timed the same way, with DEXCT_GN_STOP_TOL=1e-12 '
-                                      '(float64; a pixel also stops when a step moves it by <= tol * max(|a|, 1)).  Opt-in: '
-                                      'not the fixed iteration count of the reference, never `value`'}
-        step(False)                                                                  # the exact results are back in place
-        torch.cuda.synchronize()
-        assert torch.equal(a_nat.view(torch.int64), a_exact.view(torch.int64))
-        del a_exact
-
     # ---- opt-in mixed-precision Newton (float32 bulk + float64 polish), never part of `value`
     if precision == 'f64' and world == 1:
-        a_mixed = torch.empty_like(a_nat)
-        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'mixed', out=a_mixed, mask_max=gmax,
+        a_mixed = torch.empty_like(a_out)
+        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'mixed', out=a_mixed, out_rc=out_rc, mask_max=gmax,
                      mask_frac=0.95)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'mixed', out=a_mixed, mask_max=gmax,
+        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'mixed', out=a_mixed, out_rc=out_rc, mask_max=gmax,
                      mask_frac=0.95)
         e1.record()
         torch.cuda.synchronize()
-        diff = ((a_mixed - a_nat).abs() / a_nat.abs().clamp(min=1.0))
+        diff = ((a_mixed - a_out).abs() / a_out.abs().clamp(min=1.0))
         out['gn_mixed_precision'] = {'gn_ms': e0.elapsed_time(e1),
                                      'max_diff_vs_f64': float(torch.nan_to_num(diff, nan=0.0).max().item()),
                                      'note': 'DEXCT_GN_PRECISION=mixed: first n-4 iterations float32, last 4 float64; '

@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libdexct_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every entry point include/dexct.h declares
 SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
@@ -38,6 +38,18 @@ def log_out(sino_log_ptr, air):
     for k in range(4):
         lo.air[k] = float(air[k]) if k < len(air) else 1.0
     return C.byref(lo)
+
+
+class GnOptions(C.Structure):
+    """dexct_gn_options (ABI 3)"""
+    _fields_ = [('stop_tol', C.c_double), ('out_rows', C.c_int32), ('out_channels', C.c_int32), ('kernel', C.c_int32),
+                ('reserved_', C.c_int32)]
+
+
+def gn_options(stop_tol=None, out_rows=0, out_channels=0, kernel=0):
+    """byref-able dexct_gn_options; ``stop_tol=None`` asks for the library default (a negative value in the struct)."""
+    o = GnOptions(-1.0 if stop_tol is None else float(stop_tol), int(out_rows), int(out_channels), int(kernel), 0)
+    return C.byref(o)
 
 
 PLAN_BYTES = 40   # sizeof(dexct_ray_plan)
@@ -98,7 +110,7 @@ def load():
     lib.dexct_fbp_filter.argtypes = [vp, vp, vp, i64, i32, f64, vp, vp]
     lib.dexct_fbp_backproject.argtypes = [vp, vp, i32, i32, i32, f64, f64, f64, i32, f64, vp, vp]
     lib.dexct_siddon_trace.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp, vp, vp]
-    lib.dexct_gn_decompose.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, f64, vp, vp, vp]
+    lib.dexct_gn_decompose.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, f64, vp, C.POINTER(GnOptions), vp, vp]
     lib.dexct_gn_workspace_bytes.argtypes = [i32, i32]
     lib.dexct_gn_workspace_bytes.restype = i64
     lib.dexct_gn_apply_mask.argtypes = [vp, i32, i64, f64, vp, vp]

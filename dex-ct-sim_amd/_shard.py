@@ -32,13 +32,14 @@ def _needs_cpu_staging(t):
     return t.is_cuda and dist.get_backend() == 'gloo'
 
 
-# Buffers of the gather, allocated once per (shape, dtype, device, scan) and reused by every later step: the result
-# tensor, and for ragged shards / the gloo rehearsal the padded send and receive buffers.
+# Buffers of the gather, allocated once per (caller tag, shape, dtype, device) and reused by every later call with the
+# same tag: the padded send and receive buffers of ragged shards / the gloo rehearsal, and - only for callers that ask
+# for it with ``reuse_out=True`` - the result tensor.
 _buffers = {}
 
 
-def _buffer(kind, shape, dtype, device, pin=False):
-    key = (kind, tuple(shape), dtype, str(device))
+def _buffer(kind, shape, dtype, device, pin=False, tag=None):
+    key = (tag, kind, tuple(shape), dtype, str(device))
     t = _buffers.get(key)
     if t is None:
         t = torch.empty(tuple(shape), dtype=dtype, device=device, pin_memory=bool(pin and str(device) == 'cpu' and torch.cuda.is_available()))
@@ -51,16 +52,18 @@ def release_buffers():
     _buffers.clear()
 
 
-def gather_views(local, n_views, view_dim=0, async_op=False, out=None):
+def gather_views(local, n_views, view_dim=0, async_op=False, out=None, tag=None, reuse_out=False):
     """All-gather view shards (possibly of unequal size) into the full tensor on every rank.
 
     ``local`` is this rank's contiguous shard with the views on ``view_dim`` (0, or 1 with a leading "spectrum"
     dimension: ``[S, views, ...]``, the layout the projection writes).  The shards go straight from that buffer into
     the result, one collective per leading index (each a contiguous block of views on both sides): no transposed copy,
-    no concatenation, and no allocation after the first call - the result lives in a buffer that is reused by the
-    next gather of the same shape (pass ``out=`` to own it; consume or copy the result before gathering again).
-    Ragged shards (n_views not a multiple of the world size) are padded through a preallocated send buffer and
-    compacted with in-place copies.  With ``async_op=True`` returns ``finish`` - call it to wait and get the tensor
+    no concatenation.  The result is a NEW tensor owned by the caller unless ``out=`` is given or ``reuse_out=True``
+    (then it lives in a buffer cached under ``tag`` and is overwritten by the next such gather of the same shape: for
+    step loops that consume the result at once, like bench.py - zero device allocations per call).
+    Ragged shards (n_views not a multiple of the world size) are padded through preallocated send / receive buffers
+    cached under ``tag`` and compacted with in-place copies: two gathers of the same shape that may be in flight at the
+    same time must use different tags.  With ``async_op=True`` returns ``finish`` - call it to wait and get the tensor
     (on the nccl/RCCL backend the transfers run on the process group's own stream and overlap the caller's kernels)."""
     r, w = world()
     if w == 1:
@@ -82,7 +85,8 @@ def gather_views(local, n_views, view_dim=0, async_op=False, out=None):
     cdev = torch.device('cpu') if staged else dev
     full_shape = ((lead,) if view_dim == 1 else ()) + (n_views,) + tail
     if out is None:
-        out = _buffer('out', full_shape, local.dtype, dev)
+        out = (_buffer('out', full_shape, local.dtype, dev, tag=tag) if reuse_out else
+               torch.empty(full_shape, dtype=local.dtype, device=dev))
     elif tuple(out.shape) != full_shape or not out.is_contiguous():
         raise ValueError(f'out must be a contiguous tensor of shape {full_shape}')
     loc3 = local.view((lead, n_mine) + tail)
@@ -93,9 +97,9 @@ def gather_views(local, n_views, view_dim=0, async_op=False, out=None):
         if direct:
             src, dst = loc3[s], out3[s]
         else:
-            src = _buffer(('send', s), (n_max,) + tail, local.dtype, cdev, pin=True)
+            src = _buffer(('send', s), (n_max,) + tail, local.dtype, cdev, pin=True, tag=tag)
             src[:n_mine].copy_(loc3[s], non_blocking=not staged)
-            dst = _buffer(('recv', s), (w * n_max,) + tail, local.dtype, cdev, pin=True)
+            dst = _buffer(('recv', s), (w * n_max,) + tail, local.dtype, cdev, pin=True, tag=tag)
         works.append(dist.all_gather_into_tensor(dst, src, async_op=async_op))
         recvs.append(dst)
 

@@ -25,7 +25,6 @@ namespace dexct {
 
 // States kept for the exact repeated-state exit of the float64 Newton loop (cycles up to kGnHistory + 1).
 constexpr int kGnHistory = 8;
-constexpr int kGnRingDefault = 0;    // DEXCT_GN_RING=1: history of the lane-refill kernel as a ring (fewer vector instructions, more spills: measured equal, profiles/r03_gn_isa.md)
 
 constexpr int kGnBlock = 256;
 constexpr int kTab = 14;  // -mu0 K, -mu1 K (K = 2048/ln2), then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2
@@ -52,7 +51,6 @@ constexpr int kPowBits = 11;
 constexpr int kPowN = 1 << kPowBits;
 constexpr double kExpScale = 0x1.71547652b82fep+11;          // 2048 / ln 2
 constexpr double kExpClip = 700.0 * kExpScale;               // the reference's clip of the exponent (matdecomp.py:116)
-template <bool IEXP = false>
 __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ lds_pow) {
   const double kMagic = 6755399441055744.0;   // 1.5 * 2^52
   constexpr double c1 = 0x1.62e42fefa39efp-12;               // ln2 / 2048
@@ -65,13 +63,7 @@ __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ l
   const double p = f * q;
   const double tj = lds_pow[ni & (kPowN - 1)];
   const double t = fma(tj, p, tj);
-  if (!IEXP) return ldexp(t, ni >> kPowBits);
-  // IEXP (A/B variant): 2^k by adding k to the exponent field - two 32-bit integer operations on the high dword
-  // instead of a shift and v_ldexp_f64.  Exact here: t = tj (1 + p) lies in [1, 2 + 4e-4) and |k| <= 1010 (the
-  // reference's clip at 700 bounds the exponent), so t 2^k is a normal number and ldexp performs the same exponent
-  // addition; a NaN argument has ni = 0 and stays the NaN it is.
-  const int hi = __double2hiint(t) + ((ni & ~(kPowN - 1)) << (20 - kPowBits));
-  return __hiloint2double(hi, __double2loint(t));
+  return ldexp(t, ni >> kPowBits);     // (2^k by integer adds on the exponent field was measured equal: profiles/r03_gn_isa.md)
 }
 
 // 1 / x by v_rcp_f64 and two Newton refinements (what a float64 division starts with, without its scaling and
@@ -91,7 +83,7 @@ __device__ __forceinline__ double rcp_f64(double x) {
 // (nB), only spectrum 1 (nC); energies no spectrum weights are dropped.  A zero weight contributes exactly
 // 0 to every sum (the attenuation factor is finite thanks to the clip), so skipping those FMAs changes no
 // term of the reference's sums - only their order.
-template <int KSEL, bool CLIP, bool IEXP = false>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip
+template <int KSEL, bool CLIP>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip
 __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 int e0, int e1, double a0, double a1, double (&nu)[2], double (&nuo)[2],
                                                 double (&G0)[2], double (&G1)[2], double (&H00)[2], double (&H01)[2],
@@ -105,7 +97,7 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
     const double* __restrict__ t = tab + e * kTab;   // wave-uniform: scalar loads
     double y = fma(a1, t[1], a0 * t[0]);               // t[0], t[1] = -mu0, -mu1 times 2048/ln2
     if (CLIP) y = fmin(fmax(y, -kExpClip), kExpClip);
-    const double at = exp_tab<IEXP>(y, lds_pow);
+    const double at = exp_tab(y, lds_pow);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if ((KSEL == 1 && k == 1) || (KSEL == 2 && k == 0)) continue;
@@ -132,24 +124,23 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
 // instructions per energy), bit for bit the same result.
 struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; };
 
-template <bool IEXP = false>
 __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
   double nu[2] = {0, 0}, nuo[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
   const int bA = 0, bB = ec.nA, bC = ec.nA + ec.nB;
   // the always-clipped heads of the three classes
-  energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<0, true>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<1, true>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<2, true>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
   if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 699.9) {
-    energy_sums_f64<0, false, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, false, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, false, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, false>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, false>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, false>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   } else {
-    energy_sums_f64<0, true, IEXP>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, true, IEXP>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, true, IEXP>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, true>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, true>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, true>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   }
   nu[0] += nuo[0];
   nu[1] += nuo[1];
@@ -225,8 +216,9 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, E
 // Workspace layout (doubles): [0] = scale of the float32 tables, [1..3] = nA, nB, nC (energy classes), [4..6] =
 // how many of each class come first and always need the clip, [7..8] = max mu0 / mu1 over the clip-free parts,
 // [9] = (uint64, diagnostic) pixel-iterations the last gn_refill_kernel launch on this workspace executed,
-// [10] = (uint64, progress) pixels that launch has finished so far (added wave by wave while it runs; with the run queue:
-// pixels handed out so far), [11] = (uint64) head of the run queue,
+// [10] = (uint64, progress) pixels that launch has handed to its waves so far (added tile by tile while it runs),
+// [11] = (uint64) head of the tile queue, [12] = (uint64, diagnostic) lane-steps spent without a pixel because all of a
+// wave's result slots were waiting for stragglers,
 // pad to 16, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
 constexpr int kWsHeader = 16;
 
@@ -291,7 +283,8 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
       ws[8] = m1f;
       reinterpret_cast<unsigned long long*>(ws)[9] = 0ull;      // executed pixel-iterations, counted by gn_refill_kernel
       reinterpret_cast<unsigned long long*>(ws)[10] = 0ull;     // finished pixels (progress of the running launch)
-      reinterpret_cast<unsigned long long*>(ws)[11] = 0ull;     // head of the pixel-run queue of gn_refill_kernel
+      reinterpret_cast<unsigned long long*>(ws)[11] = 0ull;     // head of the tile queue of gn_refill_kernel
+      reinterpret_cast<unsigned long long*>(ws)[12] = 0ull;     // lane-steps stalled on result slots
     }
   }
   __syncthreads();
@@ -328,6 +321,87 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
   }
 }
 
+// ---- pixel tiles, the run queue and the order of the results ---------------------------------------------------------
+// The lane-refill kernel hands pixels out in TILES of 64 (one per lane of a wave) that waves fetch from a global counter.
+// A tile is also the unit in which results leave: a wave collects the 64 (a0, a1) pairs of a tile in LDS and, when the last
+// one has arrived, writes the tile with one wave-wide store of whole 128-byte lines (round 3 stored every pair by itself
+// the moment its pixel ended: WRITE_SIZE 1.9 x the results, tools/probes/gn_write.py).
+//   plain:       tile t = pixels [64 t, 64 t + 64), results in the order of the pixels.
+//   transposed:  the sinograms are [view][channel][row] (row fastest - what the stacked-fan projection writes, layout 1 of
+//                dexct_siddon_project) and the results go out as [view][row][channel] (the reference's order,
+//                matdecomp.py:200-201): a tile is 4 channels x 16 rows of one view - on the input side 4 runs of 16
+//                consecutive floats (64 bytes), on the output side 16 runs of 4 consecutive (a0, a1) pairs = 64 bytes
+//                each.  This replaces the separate transpose pass over the 6.5 GB of results (2.3 ms and one more round
+//                trip through HBM in round 3).  Tile shape measured on the benchmark sinograms, exact mode, same box
+//                (profiles/r04_gn.md): 8 x 8: 770 ms, 4 x 16: 763, 2 x 32: 762, 1 x 64: 766; the plain order: 763.
+constexpr int kTilePix = kWave;
+#ifndef DEXCT_GN_SLOTS
+#define DEXCT_GN_SLOTS 3
+#endif
+#ifndef DEXCT_GN_TILE_CLOG2
+#define DEXCT_GN_TILE_CLOG2 2
+#endif
+constexpr int kSlots = DEXCT_GN_SLOTS;   // tiles a wave may have in flight: 3 x 64 x 16 B = 3 KB of LDS per wave (with 4 the 32 KB of a
+                                         // workgroup leave room for 4 workgroups per CU instead of 5: +2.5 %, profiles/r04_gn.md)
+constexpr int kTileCLog2 = DEXCT_GN_TILE_CLOG2, kTileC = 1 << kTileCLog2, kTileR = kTilePix / kTileC;   // transposed tiles: channels x rows
+
+struct GnTiling {
+  long long n_tiles;
+  int transposed;                    // 0 / 1
+  int rows, channels;                // transposed: R, C
+  int tiles_r, tiles_c;              // ceil(R / kTileR), ceil(C / kTileC)
+};
+
+struct GnTile {                      // wave-uniform description of one tile
+  long long in_base, out_base;       // pixel index of the tile's first pixel in the input / output order
+  int nr, nc;                        // valid rows / channels (edge tiles); plain: nr = 1, nc = valid pixels
+};
+
+__device__ __forceinline__ GnTile gn_decode_tile(const GnTiling& tl, long long n_pix, long long t) {
+  GnTile d;
+  if (!tl.transposed) {
+    d.in_base = d.out_base = t * kTilePix;
+    const long long left = n_pix - d.in_base;
+    d.nr = 1;
+    d.nc = left < kTilePix ? (int)left : kTilePix;
+  } else {
+    const unsigned tu = (unsigned)t;                                     // n_tiles < 2^31 (checked by the host)
+    const unsigned u = tu / (unsigned)tl.tiles_r, rb = tu - u * (unsigned)tl.tiles_r;
+    const unsigned v = u / (unsigned)tl.tiles_c, cb = u - v * (unsigned)tl.tiles_c;
+    const long long R = tl.rows, C = tl.channels;
+    d.in_base = ((long long)v * C + (long long)kTileC * cb) * R + (long long)kTileR * rb;
+    d.out_base = ((long long)v * R + (long long)kTileR * rb) * C + (long long)kTileC * cb;
+    d.nr = tl.rows - kTileR * (int)rb < kTileR ? tl.rows - kTileR * (int)rb : kTileR;
+    d.nc = tl.channels - kTileC * (int)cb < kTileC ? tl.channels - kTileC * (int)cb : kTileC;
+  }
+  return d;
+}
+
+// where pixel p of the input order goes in the output order (the kernels that store pixel by pixel)
+__device__ __forceinline__ long long gn_out_index(const GnTiling& tl, long long p) {
+  if (!tl.transposed) return p;
+  const long long R = tl.rows, C = tl.channels;
+  const long long u = p / R, r = p - u * R;
+  const long long v = u / C, c = u - v * C;
+  return (v * R + r) * C + c;
+}
+
+// The tolerance stop (the default since round 4; stop_tol = 0 keeps the reference's fixed count bit for bit): a pixel
+// also ends when a step moves it by no more than stop_tol * max(|a|, 1) AND that step is at most half the one before.
+// The second condition is what makes the first one a bound on the distance to the limit: a sequence whose steps at least
+// halve is within (last step) of where it is going.  A pixel that creeps (contraction worse than 1/2: a nearly singular
+// Hessian, a wild transient far from the solution, where steps are small only relative to a huge |a|) is NOT stopped and
+// runs on to the exact repeated-state exit or to n_iters, as in the reference.  prev0 / prev1: the state before (a0, a1)
+// (history slot 0), valid when it >= 1.
+__device__ __forceinline__ bool gn_converged(double stop_tol, double a0, double a1, double n0, double n1, double prev0,
+                                             double prev1, int it) {
+  if (!(stop_tol > 0.0)) return false;
+  const double dk = fmax(fabs(n0 - a0), fabs(n1 - a1));
+  const double size = fmax(fmax(fabs(n0), fabs(n1)), 1.0);
+  const double dprev = it >= 1 ? fmax(fabs(a0 - prev0), fabs(a1 - prev1)) : __builtin_huge_val();
+  return dk <= stop_tol * size && dk + dk <= dprev;                  // NaN compares false
+}
+
 // MIXED: n_iters - n_polish iterations in float32, then n_polish in float64.
 // PER_BIN: pixel p uses the tables of bin (p / bin_div) % n_bins (channel-dependent spectra, the general
 // signature of optimize_sino_cpu); the table pointer is then per lane and the values arrive by vector loads.
@@ -336,7 +410,8 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
                                                       int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
                                                       int n_e, int n_iters, int n_polish, int n_bins, int bin_div,
                                                       const double* __restrict__ mask_max, double mask_frac,
-                                                      int exact_exit, double* __restrict__ out_a) {
+                                                      int exact_exit, double stop_tol, GnTiling tl,
+                                                      double* __restrict__ out_a) {
   __shared__ double lds_pow[kPowN];     // 2^(j/2048), 16 KB
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();
@@ -349,8 +424,9 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   const double gd0 = load_g<double>(g1, g_is_f64, p), gd1 = load_g<double>(g2, g_is_f64, p);
   // Fused air mask of get_basismat_sinos (matdecomp.py:195-196, :204-205): a pixel with g1 >= frac * max is set
   // to 0 afterwards whatever the iteration produced, so its iterations are not run at all.
+  const long long po = gn_out_index(tl, p);              // where the result goes (a scattered 16-byte store either way)
   if (mask_max && gd0 >= mask_frac * mask_max[0]) {
-    store_a(out_a, p, 0.0, 0.0);
+    store_a(out_a, po, 0.0, 0.0);
     return;
   }
   double a0 = 1e-6, a1 = 1e-6;
@@ -433,6 +509,12 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
       for (int k = kGnHistory - 1; k >= 0; --k)              // descending, so the smallest period wins
         if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
       if (hit != -2) break;
+      // the tolerance stop (float64 loop only; see gn_converged)
+      if (gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it)) {
+        a0 = n0;
+        a1 = n1;
+        break;
+      }
 #pragma unroll
       for (int k = kGnHistory - 1; k > 0; --k) { h0[k] = h0[k - 1]; h1[k] = h1[k - 1]; }
       h0[0] = __double_as_longlong(a0);
@@ -449,187 +531,151 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
     for (int k = 0; k < kGnHistory; ++k)
       if (slot == k) { a0 = __longlong_as_double(h0[k]); a1 = __longlong_as_double(h1[k]); }
   }
-  store_a(out_a, p, a0, a1);
+  store_a(out_a, po, a0, a1);
 }
 
 
-// The history of the repeated-state exit as a RING whose write position is wave-uniform.  In the lane-refill kernel all
-// lanes of a wave take their Newton steps together, so "the state k + 1 steps ago" sits in the same ring slot for every
-// lane - (pos - 1 - k) mod 8 with pos = the wave's step counter mod 8 - whatever iteration each lane's own pixel is at
-// (entries older than the lane's pixel are excluded by k < it, as before).  With pos a template parameter every index
-// is static: the 32 selects that moved the history down one place per step (and the 32 copies back) become one
-// 4-register write.  Same states compared, same slot chosen: bit-identical results.
-template <int POS>
-struct GnRing {
-  static constexpr int slot_of(int k) { return ((POS - 1 - k) % kGnHistory + kGnHistory) % kGnHistory; }
-  // -2: no repeat, -1: fixed point, k >= 0: equal to the state k + 1 steps before the current one (smallest k)
-  static __device__ __forceinline__ int hit(const long long (&h0)[kGnHistory], const long long (&h1)[kGnHistory],
-                                            long long b0, long long b1, int it, bool fixed) {
-    int hit = fixed ? -1 : -2;
-#pragma unroll
-    for (int k = kGnHistory - 1; k >= 0; --k)
-      if (k < it && b0 == h0[slot_of(k)] && b1 == h1[slot_of(k)] && hit != -1) hit = k;
-    return hit;
-  }
-  static __device__ __forceinline__ void pick(const long long (&h0)[kGnHistory], const long long (&h1)[kGnHistory], int slot,
-                                              double& f0, double& f1) {
-#pragma unroll
-    for (int k = 0; k < kGnHistory; ++k)
-      if (slot == k) { f0 = __longlong_as_double(h0[slot_of(k)]); f1 = __longlong_as_double(h1[slot_of(k)]); }
-  }
-  static __device__ __forceinline__ void push(long long (&h0)[kGnHistory], long long (&h1)[kGnHistory], double a0, double a1) {
-    h0[POS] = __double_as_longlong(a0);
-    h1[POS] = __double_as_longlong(a1);
-  }
-};
-
-// float64, one shared spectrum - the benchmark's path - with lane refill.  The repeated-state exit ends pixels
-// at very different iterations (from 15 to all of n_iters), and a wave is as slow as its slowest lane.  Here a
-// wave owns a contiguous run of 64 * chunk pixels and every lane whose pixel has finished takes the next one of
-// the run, so all 64 lanes keep iterating until the run is used up.  The energy loops stay wave-uniform (scalar
-// table loads) because the tables do not depend on the pixel.  Results are bit-identical to gn_kernel's.
-// HLDS (A/B variant): the four older states of the history live in an LDS ring (one 16-B slot per lane and state, written
-// when a state leaves the registers) instead of 16 VGPRs.
-template <int MINW, bool IEXP, bool HLDS = false, int HIST = kGnHistory, bool RING = false>      // RING: history as a ring with a wave-uniform write position (GnRing); HIST: states kept for the repeated-state exit; MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128)
+// float64, one shared spectrum - the benchmark's path - with lane refill.  The exits end pixels at very different
+// iterations (from 10 to all of n_iters), and a wave is as slow as its slowest lane.  Here every lane whose pixel has ended
+// takes the next pixel of the wave's current tile, and a wave whose tile is handed out fetches the next tile from a global
+// counter at once, while its other lanes still iterate: all 64 lanes keep iterating until the sinogram is used up, the load
+// balances itself over CUs and XCDs.  The energy loops stay wave-uniform (scalar table loads) because the tables do not
+// depend on the pixel.  Pixels are independent problems: results are bit-identical to gn_kernel's in any order.
+// MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128).
+template <int MINW>
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
-                                                             int g_is_f64, int64_t n_pix, const double* __restrict__ ws,
-                                                             int n_e, int n_iters, int chunk,
+                                                             int g_is_f64, long long n_pix, const double* __restrict__ ws,
+                                                             int n_e, int n_iters, GnTiling tl,
                                                              const double* __restrict__ mask_max, double mask_frac,
                                                              int exact_exit, double stop_tol,
                                                              double* __restrict__ out_a,
                                                              unsigned long long* __restrict__ executed,
                                                              unsigned long long* __restrict__ queue) {
-  __shared__ double lds_pow[kPowN];
-  __shared__ longlong2 lds_hist[HLDS ? 4 : 1][HLDS ? kGnBlock : 1];
-  static_assert(!HLDS || HIST == kGnHistory, "the LDS ring holds the 4 older of 8 states");
-  static_assert(!RING || (HIST == kGnHistory && !HLDS), "the register ring has kGnHistory slots");
-  constexpr int kR = HLDS ? 4 : HIST;       // states kept in registers
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  __shared__ double lds_pow[kPowN];                                      // 16 KB
+  __shared__ d2 lds_out[kGnBlock / kWave][kSlots * kTilePix];            // 16 KB: with the table 32 KB = 5 workgroups per CU
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
   const double* __restrict__ tab = ws + kWsHeader;
-  const int64_t run = (int64_t)kWave * chunk;
-  // Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).  A sinogram is periodic in the view
-  // length (air at both ends of every fan: pixels that end at once), so with "block b takes run b" an unlucky run length
-  // hands some XCDs nothing but air and others nothing but object: 2.67 instead of 2.0 ns/pixel on the 2000 x 1024 scan
-  // at 64 pixels per lane, +10 % on the benchmark scan at 20 or 40 (profiles/r03_kernels.md).  Each XCD therefore works
-  // through a CONTIGUOUS eighth of the runs: the same mix of views for every XCD, whatever the run length.
-  const uint32_t nblk_x = gridDim.x, per_x = nblk_x >> 3;
-  const uint32_t lblk = (blockIdx.x < (per_x << 3)) ? (blockIdx.x & 7u) * per_x + (blockIdx.x >> 3) : blockIdx.x;
-  int64_t next = ((int64_t)lblk * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;   // wave-uniform
-  int64_t end = next + run < n_pix ? next + run : n_pix;
-  // QUEUE (the default, `queue` != null): runs are not assigned but FETCHED - a wave whose run is used up takes the next
-  // one from a global counter at once, while its other lanes are still iterating.  No lane waits for the slowest pixel of
-  // "its" run any more (lanes idle only when the whole sinogram is used up), the load balances itself over CUs and XCDs,
-  // and the run length stops mattering.  Pixels are independent problems: bit-identical results in any order.
-  bool exhausted = false;
-  if (queue) { next = 0; end = 0; }
+  d2* __restrict__ my_out = lds_out[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
   const bool has_mask = mask_max != nullptr;
   const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
+  const int in_stride = tl.transposed ? tl.rows : 1;                     // input distance of neighbouring channels of a tile
+  const int out_stride = tl.transposed ? tl.channels : 0;                // output distance of neighbouring rows of a tile
 
-  int64_t p = -1;                         // this lane's pixel, -1: none
-  unsigned n_exec = 0;                    // Newton steps this wave executed (< 2^32: 64 lanes x chunk x n_iters)
+  // wave-uniform state of the tiles in flight
+  int tid[kSlots];                        // tile held by a slot, -1: free
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) tid[k] = -1;
+  unsigned pend = 0u;                     // results a slot still waits for, one byte per slot (<= 64)
+  int cur = 0, next_j = kTilePix;         // the slot being handed out and its next rank; next_j >= 64: fetch a tile first
+  GnTile ct{0, 0, 0, 0};                  // the tile being handed out
+  bool exhausted = false;
+  unsigned n_exec = 0, n_stall = 0;       // Newton steps executed; lane-steps spent waiting for a free slot (diagnostic)
+
+  int ent = -1;                           // slot * 64 + place of this lane's result in the slot, -1: no pixel
   double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
   int it = 0;
-  int ring_pos = 0;                       // RING: write position of this step, wave-uniform
-  long long h0[kR], h1[kR];
+  long long h0[kGnHistory], h1[kGnHistory];
 #pragma unroll
-  for (int k = 0; k < kR; ++k) { h0[k] = 0; h1[k] = 0; }
+  for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
+
+  // `done_lanes` have just put their result into LDS (my_slot: the slot of this lane's result): count them off their
+  // slots; a slot whose last result has arrived is written - one wave-wide store of whole lines - and freed
+  auto settle = [&](unsigned long long done_lanes, int my_slot) {
+    unsigned complete = 0u;
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) {
+      const unsigned long long m = __ballot(my_slot == k) & done_lanes;
+      pend -= (unsigned)__popcll(m) << (8 * k);
+      complete |= (tid[k] >= 0 && ((pend >> (8 * k)) & 0xFFu) == 0u) ? (1u << k) : 0u;
+    }
+    while (complete != 0u) {                          // (wave-uniform; one copy of the store code for all slots)
+      const int k = __builtin_ctz(complete);
+      complete &= complete - 1u;
+      int tile = tid[0];
+#pragma unroll
+      for (int q = 1; q < kSlots; ++q) tile = k == q ? tid[q] : tile;
+#pragma unroll
+      for (int q = 0; q < kSlots; ++q) tid[q] = k == q ? -1 : tid[q];
+      if (k == cur) next_j = kTilePix;                // every valid pixel of the tile was handed out: the rest of its ranks is padding
+      __builtin_amdgcn_wave_barrier();
+      const GnTile d = gn_decode_tile(tl, n_pix, (long long)tile);
+      const int c_off = tl.transposed ? (lane & (kTileC - 1)) : lane, r_off = tl.transposed ? (lane >> kTileCLog2) : 0;
+#ifndef DEXCT_GN_DIRECT
+      if (c_off < d.nc && r_off < d.nr) {
+        const d2 v = my_out[k * kTilePix + lane];
+        __builtin_nontemporal_store(v, reinterpret_cast<d2*>(out_a) + (d.out_base + (long long)r_off * out_stride + c_off));
+      }
+#endif
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
 
   for (;;) {
-    unsigned long long want = __ballot(p < 0);
+    unsigned long long want = __ballot(ent < 0);
     while (want != 0ull) {
-      if (next >= end) {
-        if (!queue || exhausted) break;
-        long long base = 0;
-        if ((threadIdx.x & 63) == 0) base = (long long)atomicAdd(queue, (unsigned long long)run);
-        base = ((long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-               (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= n_pix) { exhausted = true; break; }
-        next = base;
-        end = base + run < n_pix ? base + run : n_pix;
-        if (executed && (threadIdx.x & 63) == 0) atomicAdd(executed + 1, (unsigned long long)(end - base));   // progress: handed out
+      if (next_j >= kTilePix) {
+        if (exhausted) break;
+        int s = -1;
+#pragma unroll
+        for (int k = kSlots - 1; k >= 0; --k) s = tid[k] < 0 ? k : s;
+        if (s < 0) { n_stall += (unsigned)__popcll(want); break; }     // every slot still waits for a straggler
+        long long t = 0;
+        if (lane == 0) t = (long long)atomicAdd(queue, 1ull);
+        t = ((long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+            (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= tl.n_tiles) { exhausted = true; break; }
+        ct = gn_decode_tile(tl, n_pix, t);
+        const int n_valid = ct.nr * ct.nc;
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) tid[k] = k == s ? (int)t : tid[k];
+        pend += (unsigned)n_valid << (8 * s);
+        cur = s;
+        next_j = 0;
+        if (executed && lane == 0) atomicAdd(executed + 1, (unsigned long long)n_valid);        // progress: handed to a wave
       }
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
-      const int64_t np = next + rank;
-      if (p < 0 && np < end) {
-        gd0 = load_g<double>(g1, g_is_f64, np);
-        gd1 = load_g<double>(g2, g_is_f64, np);
-        if (has_mask && gd0 >= thresh) {           // air (matdecomp.py:195-196, :204-205): 0, not iterated
-          store_a(out_a, np, 0.0, 0.0);
-        } else if (n_iters <= 0) {
-          store_a(out_a, np, 1e-6, 1e-6);
-        } else {
-          p = np; a0 = 1e-6; a1 = 1e-6; it = 0;
-        }
-      }
-      next += __popcll(want);
-      if (!queue) break;                           // static runs: one serving per step, as in rounds 1-2
-      want = __ballot(p < 0);                      // air pixels leave their lane wanting: it is served again at once
-    }
-    const unsigned long long busy = __ballot(p >= 0);
-    if (busy == 0ull) {
-      if (next >= end && (!queue || exhausted)) break;
-      continue;
-    }
-    n_exec += (unsigned)__popcll(busy);                        // wave-uniform (scalar) count of Newton steps run
-    double n0 = a0, n1 = a1;
-    newton_step_f64<IEXP>(tab, lds_pow, ec, gd0, gd1, n0, n1);      // idle lanes repeat their last pixel's step; unused
-    if constexpr (RING) {
-      // ---- exit logic on the ring: one copy per write position, chosen by a scalar branch
-      const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
-      const bool fixed = exact_exit && b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1);
-      bool converged = false;
-      if (stop_tol > 0.0) {
-        const double size = fmax(fmax(fabs(n0), fabs(n1)), 1.0);
-        converged = fmax(fabs(n0 - a0), fabs(n1 - a1)) <= stop_tol * size;      // NaN compares false
-      }
-      int hit = fixed ? -1 : -2;
-      double f0 = converged ? n0 : a0, f1 = converged ? n1 : a1;
-      auto on_ring = [&](auto pos_tag) {
-        using R = GnRing<decltype(pos_tag)::value>;
-        if (exact_exit) hit = R::hit(h0, h1, b0, b1, it, fixed);
-        if (__ballot(hit >= 0) != 0ull) {
-          // the state a cycle holds at iteration n_iters (see the non-ring form below)
-          int slot = -1;
-          if (hit >= 0) {
-            const int period = hit + 2, x = n_iters - it - 1;
-            int r;
-            if (n_iters < (1 << 22)) {
-              const int q = (int)((float)x * __builtin_amdgcn_rcpf((float)period));
-              r = x - q * period;
-              r += r < 0 ? period : 0;
-              r -= r >= period ? period : 0;
-            } else {
-              r = x % period;
-            }
-            slot = hit - r;
+      const int j = next_j + rank;
+      bool done_now = false;
+      if (ent < 0 && j < kTilePix) {
+        // consecutive lanes take consecutive rows of a channel (transposed) / consecutive pixels (plain)
+        const int c_off = tl.transposed ? j / kTileR : j, r_off = tl.transposed ? j % kTileR : 0;
+        if (c_off < ct.nc && r_off < ct.nr) {
+          const long long np = ct.in_base + (long long)c_off * in_stride + r_off;
+          const int place = cur * kTilePix + (tl.transposed ? r_off * kTileC + c_off : j);
+          gd0 = load_g<double>(g1, g_is_f64, np);
+          gd1 = load_g<double>(g2, g_is_f64, np);
+          if (has_mask && gd0 >= thresh) {             // air (matdecomp.py:195-196, :204-205): 0, not iterated
+#ifdef DEXCT_GN_DIRECT
+            store_a(out_a, np, 0.0, 0.0);
+#else
+            my_out[place] = d2{0.0, 0.0};
+#endif
+            done_now = true;
+          } else if (n_iters <= 0) {
+            my_out[place] = d2{1e-6, 1e-6};
+            done_now = true;
+          } else {
+            ent = place; a0 = 1e-6; a1 = 1e-6; it = 0;
           }
-          R::pick(h0, h1, slot, f0, f1);
         }
-        R::push(h0, h1, a0, a1);              // unconditional: a lane that ends its pixel here never reads the history again
-      };
-      switch (ring_pos) {
-        case 0: on_ring(std::integral_constant<int, 0>{}); break;
-        case 1: on_ring(std::integral_constant<int, 1>{}); break;
-        case 2: on_ring(std::integral_constant<int, 2>{}); break;
-        case 3: on_ring(std::integral_constant<int, 3>{}); break;
-        case 4: on_ring(std::integral_constant<int, 4>{}); break;
-        case 5: on_ring(std::integral_constant<int, 5>{}); break;
-        case 6: on_ring(std::integral_constant<int, 6>{}); break;
-        default: on_ring(std::integral_constant<int, 7>{}); break;
       }
-      ring_pos = (ring_pos + 1) & (kGnHistory - 1);
-      const bool advance = hit == -2 && !converged;
-      a0 = advance ? n0 : f0;
-      a1 = advance ? n1 : f1;
-      it += advance ? 1 : 0;
-      if (p >= 0 && (!advance || it >= n_iters)) {
-        store_a(out_a, p, a0, a1);
-        p = -1;
-      }
+      next_j += __popcll(want);
+      const unsigned long long dn = __ballot(done_now);
+      if (dn != 0ull) settle(dn, cur);
+      want = __ballot(ent < 0);                      // air pixels leave their lane wanting: it is served again at once
+    }
+    const unsigned long long busy = __ballot(ent >= 0);
+    if (busy == 0ull) {
+      if (exhausted) break;                          // (no busy lane and a tile to hand out or to fetch: around again)
       continue;
     }
+    n_exec += (unsigned)__popcll(busy);              // wave-uniform (scalar) count of Newton steps run
+    double n0 = a0, n1 = a1;
+    newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);      // idle lanes repeat their last pixel's step; unused
     // same exit rule as gn_kernel: s_{it+1} equal to s_it (fixed point) or to hist[k] = s_{it-1-k} (cycle of
     // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
     // through it too and are ignored.
@@ -637,25 +683,11 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     if (exact_exit) {
       const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
       if (b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1)) hit = -1;
-      if (HLDS) {
-        // hist[k] = s_{it-1-k} for k >= 4 sits in ring slot (it - 1 - k) & 3 (written when it left the registers)
 #pragma unroll
-        for (int k = kGnHistory - 1; k >= kR; --k) {
-          const longlong2 hs = lds_hist[(it - 1 - k) & 3][threadIdx.x];
-          if (k < it && b0 == hs.x && b1 == hs.y && hit != -1) hit = k;
-        }
-      }
-#pragma unroll
-      for (int k = kR - 1; k >= 0; --k)
+      for (int k = kGnHistory - 1; k >= 0; --k)
         if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
     }
-    // opt-in (DEXCT_GN_STOP_TOL, off by default): also stop when the step no longer moves the pixel by more than
-    // stop_tol relative to max(|a|, 1) - not the reference's fixed count any more, but within stop_tol of it
-    bool converged = false;
-    if (stop_tol > 0.0) {
-      const double size = fmax(fmax(fabs(n0), fabs(n1)), 1.0);
-      converged = fmax(fabs(n0 - a0), fabs(n1 - a1)) <= stop_tol * size;      // NaN compares false
-    }
+    const bool converged = gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it);
     const bool advance = hit == -2 && !converged;
     // the state a cycle holds at iteration n_iters: s_m = s_{base + (m - base) mod period} for m >= base = it-1-hit,
     // and (n_iters - base) = (n_iters - it - 1) mod period; s_{base+j} is hist[hit-j], s_it the current state (slot -1)
@@ -676,17 +708,11 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     double f0 = converged ? n0 : a0, f1 = converged ? n1 : a1;
     if (__ballot(slot >= 0) != 0ull) {
 #pragma unroll
-      for (int k = 0; k < kR; ++k)
+      for (int k = 0; k < kGnHistory; ++k)
         if (slot == k) { f0 = __longlong_as_double(h0[k]); f1 = __longlong_as_double(h1[k]); }
-      if (HLDS && slot >= kR) {
-        const longlong2 hs = lds_hist[(it - 1 - slot) & 3][threadIdx.x];
-        f0 = __longlong_as_double(hs.x);
-        f1 = __longlong_as_double(hs.y);
-      }
     }
-    if (HLDS && advance) lds_hist[(it - 4) & 3][threadIdx.x] = longlong2{h0[kR - 1], h1[kR - 1]};   // s_{it-4} leaves the registers
 #pragma unroll
-    for (int k = kR - 1; k > 0; --k) {
+    for (int k = kGnHistory - 1; k > 0; --k) {
       h0[k] = advance ? h0[k - 1] : h0[k];
       h1[k] = advance ? h1[k - 1] : h1[k];
     }
@@ -695,15 +721,27 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     a0 = advance ? n0 : f0;
     a1 = advance ? n1 : f1;
     it += advance ? 1 : 0;
-    if (p >= 0 && (!advance || it >= n_iters)) {
-      store_a(out_a, p, a0, a1);
-      p = -1;
+    const bool fin = ent >= 0 && (!advance || it >= n_iters);
+    const unsigned long long fb = __ballot(fin);
+    if (fb != 0ull) {
+#ifdef DEXCT_GN_DIRECT
+      if (fin) {                                     // experiment (plain order only): every result stored by itself
+        int tile = tid[0];
+#pragma unroll
+        for (int q = 1; q < kSlots; ++q) tile = (ent >> 6) == q ? tid[q] : tile;
+        store_a(out_a, (long long)tile * kTilePix + (ent & 63), a0, a1);
+      }
+#else
+      if (fin) my_out[ent] = d2{a0, a1};
+#endif
+      const int my_slot = ent >> 6;                  // (-1 for lanes without a pixel: matches no slot)
+      if (fin) ent = -1;
+      settle(fb, my_slot);
     }
   }
-  if (executed && (threadIdx.x & 63) == 0) {
+  if (executed && lane == 0) {
     atomicAdd(executed, (unsigned long long)n_exec);            // one atomic per wave
-    const int64_t first = ((int64_t)lblk * (kGnBlock / kWave) + (threadIdx.x >> 6)) * run;
-    if (!queue && end > first) atomicAdd(executed + 1, (unsigned long long)(end - first));    // this wave's run of pixels is done
+    if (n_stall) atomicAdd(executed + 3, (unsigned long long)n_stall);
   }
 }
 
@@ -763,7 +801,7 @@ int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins) {
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,
                        int32_t precision, int32_t n_polish, const double* mask_max, double mask_frac, double* out_a,
-                       void* workspace, void* stream) {
+                       const dexct_gn_options* options, void* workspace, void* stream) {
   if (!g1 || !g2 || !i0 || !mus || !out_a || !workspace || n_pix <= 0 || n_energies <= 0 || n_iters < 0)
     return DEXCT_EINVAL;
   if (n_bins < 1 || bin_div < 1 || n_bins > 65535) return DEXCT_EINVAL;
@@ -774,6 +812,20 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   if (n_energies > 4096) return DEXCT_ERANGE;
   const int64_t nblk = (n_pix + kGnBlock - 1) / kGnBlock;
   if (nblk > 0x7FFFFFFFll) return DEXCT_ERANGE;
+  // order of the results: the pixels' own, or [..][row][channel] for pixels given as [..][channel][row]
+  GnTiling tl{(n_pix + kTilePix - 1) / kTilePix, 0, 1, 1, 1, 1};
+  if (options && (options->out_rows != 0 || options->out_channels != 0)) {
+    const int64_t R = options->out_rows, C = options->out_channels;
+    if (R < 1 || C < 1 || n_pix % (R * C) != 0) return DEXCT_EINVAL;
+    tl.transposed = 1;
+    tl.rows = (int)R;
+    tl.channels = (int)C;
+    tl.tiles_r = (int)((R + kTileR - 1) / kTileR);
+    tl.tiles_c = (int)((C + kTileC - 1) / kTileC);
+    tl.n_tiles = (n_pix / (R * C)) * tl.tiles_r * tl.tiles_c;
+  }
+  if (tl.n_tiles > 0x7FFFFFFFll) return DEXCT_ERANGE;
+  if (options && (options->kernel < 0 || options->kernel > 2)) return DEXCT_EINVAL;
   hipStream_t st = as_stream(stream);
   double* ws = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(gn_tables_kernel, dim3(n_bins), dim3(256), 0, st, i0, mus, n_energies, n_bins, ws);
@@ -781,97 +833,49 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   // DEXCT_GN_FULL_LOOP=1 runs every iteration (to check that the repeated-state exit changes no bit)
   const char* full = getenv("DEXCT_GN_FULL_LOOP");
   const int exact_exit = (full && full[0] == '1') ? 0 : 1;
+  // The tolerance stop.  options->stop_tol >= 0 is taken as given (0 = the reference's fixed count, bit for bit);
+  // negative or no options = the library default: 1e-12, or DEXCT_GN_STOP_TOL, or 0 with DEXCT_GN_EXACT=1.
+  double tol = options ? options->stop_tol : -1.0;
+  if (!(tol >= 0.0)) {
+    const char* xe = getenv("DEXCT_GN_EXACT");
+    const char* te = getenv("DEXCT_GN_STOP_TOL");
+    tol = (xe && xe[0] == '1') ? 0.0 : (te ? atof(te) : DEXCT_GN_DEFAULT_STOP_TOL);
+    if (!(tol >= 0.0)) tol = 0.0;
+  }
+  if (!exact_exit) tol = 0.0;                         // the full loop is the full loop
   const dim3 grid((unsigned)nblk), block(kGnBlock);
   if (n_bins > 1) {
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, out_a);
+                       n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, tol, tl, out_a);
   } else if (precision == 0) {
-    // lane refill: each wave works through a run of 64 * chunk pixels.  Measured optimum (8e5 ... 1e9 pixels; round 3, after
-    // the XCD-contiguous run assignment, tools/bench_gn.py GN_VARIANTS=chunk): up to 6 pixels per lane while that still
-    // leaves ~12 500 waves (2.4 x the 5 120 resident ones), beyond that as many as keep the grid near 133 000 waves, at
-    // most 32 - 5.1e7 pixels (one GPU's share of an 8-GPU scan): 4 / 6 / 8 / 12 / 16 = 108 / 107 / 111 / 108 / 110 ms;
-    // 1.0e8: 8 / 12 / 16 / 24 = 216 / 209 / 211 / 211; 2.0e8: 16 / 24 / 32 = 413 / 406 / 410; 4.1e8: 24 / 32 / 48 / 64 = 802 / 801
-    // / 804 / 801; 1.05e9: 24 / 32 / 64 = 2036 / 2026 / 2058.  Small inputs degenerate to one pixel per lane.
-    const char* ce = getenv("DEXCT_GN_CHUNK");
-    int64_t chunk = n_pix / (kWave * 12500ll);
-    if (chunk > 6) chunk = 6;
-    if (n_pix / (kWave * 133000ll) > chunk) chunk = n_pix / (kWave * 133000ll);
-    if (ce) chunk = atoll(ce);
-    chunk = chunk < 1 ? 1 : (chunk > (ce ? 1024 : 32) ? (ce ? 1024 : 32) : chunk);
-    // run queue (default; DEXCT_GN_QUEUE=0 restores the static runs above): 2 pixels per lane and fetch (benchmark
-    // sinograms: 1 / 2 / 4 / 8 / 16 = 766 / 764 / 769 / 771 / 773 ms against 811 ms with static runs; an 8-GPU share, 5.1e7
-    // pixels: 98 / 97 / 99 / 102 / 106 against 108), and no more workgroups than could ever be resident
-    const char* qe = getenv("DEXCT_GN_QUEUE");
-    const bool use_queue = !(qe && atoi(qe) == 0);
-    // Below ~1e8 pixels a fetch of 64 pixels is better (round 3, tools/probes/gn_small2.py: the reference's own 1200 x 800
-    // single-row sinogram 4.33 -> 3.61 ms, configs[1]'s 360 x 512: 2.06 -> 1.59, 5.1e6 pixels 11.6 -> 11.0, 2.6e7: 51.8 -> 51.5):
-    // the tail of a small launch is the last runs' slowest pixels, and halving a run halves what a wave can be left with.
-    if (use_queue && !ce) chunk = n_pix < 100000000ll ? 1 : 2;
-    int64_t n_waves = (n_pix + kWave * chunk - 1) / (kWave * chunk);
-    int64_t nb = (n_waves + kGnBlock / kWave - 1) / (kGnBlock / kWave);
-    if (use_queue) {
-      static const int n_cu = [] {             // queried once per process (one GPU per process)
-        int dev_id = 0, n = 0;
-        if (hipGetDevice(&dev_id) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n <= 0)
-          n = 256;
-        return n;
-      }();
-      const char* be = getenv("DEXCT_GN_BLOCKS_PER_CU");          // tuning knob
-      const int64_t cap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : 8);       // 8 waves per SIMD is the hardware's most: whatever this instantiation's
-                                                   // occupancy, every resident slot gets a workgroup; the rest find the queue empty
-      if (nb > cap) nb = cap;
-    }
-    unsigned long long* queue = use_queue ? reinterpret_cast<unsigned long long*>(ws) + 11 : nullptr;
-    const char* te = getenv("DEXCT_GN_STOP_TOL");
-    const double stop_tol = te ? atof(te) : 0.0;
-    // tuning knobs for A/B runs (defaults are the measured optimum): DEXCT_GN_MINW=4 trades occupancy
-    // for a spill-free register allocation, DEXCT_GN_IEXP=1 scales by 2^k with integer adds instead of v_ldexp_f64
-    const char* ve = getenv("DEXCT_GN_MINW");
-    const char* ie = getenv("DEXCT_GN_IEXP");
-    const char* he = getenv("DEXCT_GN_HLDS");
-    const int hlds = (he && atoi(he) == 1) ? 1 : 0;
+    // Lane refill from a queue of 64-pixel tiles; no more workgroups than can be resident: 32 KB of LDS and 96 VGPRs allow 5 per CU
+    // (those beyond would start when the queue is already empty).  Round 3 measured the fetch size: 64 / 128 / 256 / 512 /
+    // 1024 pixels = 766 / 764 / 769 / 771 / 773 ms on the benchmark sinograms and 64 ahead below 1e8 pixels
+    // (tools/probes/gn_small2.py): the tail of a launch is the last fetches' slowest pixels.
+    static const int n_cu = [] {             // queried once per process (one GPU per process)
+      int dev_id = 0, n = 0;
+      if (hipGetDevice(&dev_id) != hipSuccess ||
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n <= 0)
+        n = 256;
+      return n;
+    }();
+    const char* be = getenv("DEXCT_GN_BLOCKS_PER_CU");          // tuning knob
+    const char* ve = getenv("DEXCT_GN_MINW");                   // 4: 128 VGPRs (no spills), 4 waves per SIMD
     const int minw = (ve && atoi(ve) == 4) ? 4 : 5;
-    const int iexp = (ie && atoi(ie) == 1) ? 1 : 0;
+    const int64_t cap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : minw);
+    int64_t nb = (tl.n_tiles + kGnBlock / kWave - 1) / (kGnBlock / kWave);
+    if (nb > cap) nb = cap;
     unsigned long long* stat = reinterpret_cast<unsigned long long*>(ws) + 9;
-    const double tol = stop_tol > 0.0 ? stop_tol : 0.0;
-#define DEXCT_GN_LAUNCH(MW, IE)                                                                                         \
-  hipLaunchKernelGGL((gn_refill_kernel<MW, IE>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,            \
-                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue)
-#define DEXCT_GN_LAUNCH_H(MW, H)                                                                                        \
-  hipLaunchKernelGGL((gn_refill_kernel<MW, false, false, H>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix, \
-                     (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue)
-    const char* hs = getenv("DEXCT_GN_HIST");
-    const int hist = hs ? atoi(hs) : kGnHistory;
-    const int mw = ve ? atoi(ve) : 5;
-    const char* re = getenv("DEXCT_GN_RING");
-    const int ring = re ? atoi(re) : kGnRingDefault;
-    if (ring && !hlds && hist == kGnHistory && !iexp && mw == 5)
-      hipLaunchKernelGGL((gn_refill_kernel<5, false, false, kGnHistory, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64,
-                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
-    else if (ring && !hlds && hist == kGnHistory && !iexp && mw == 4)
-      hipLaunchKernelGGL((gn_refill_kernel<4, false, false, kGnHistory, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64,
-                         n_pix, (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
-    else if (hlds)
-      hipLaunchKernelGGL((gn_refill_kernel<5, false, true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, n_pix,
-                         (const double*)ws, n_energies, n_iters, (int)chunk, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
-    else if (hist == 4 && mw == 6) DEXCT_GN_LAUNCH_H(6, 4);
-    else if (hist == 6 && mw == 6) DEXCT_GN_LAUNCH_H(6, 6);
-    else if (hist == 4) DEXCT_GN_LAUNCH_H(5, 4);
-    else if (hist == 5) DEXCT_GN_LAUNCH_H(5, 5);
-    else if (hist == 6) DEXCT_GN_LAUNCH_H(5, 6);
-    else if (hist == 7) DEXCT_GN_LAUNCH_H(5, 7);
-    else if (hist == 10) DEXCT_GN_LAUNCH_H(5, 10);
-    else if (hist == 12) DEXCT_GN_LAUNCH_H(5, 12);
-    else if (minw == 4 && iexp) DEXCT_GN_LAUNCH(4, true);
-    else if (minw == 4) DEXCT_GN_LAUNCH(4, false);
-    else if (iexp) DEXCT_GN_LAUNCH(5, true);
-    else DEXCT_GN_LAUNCH(5, false);
-#undef DEXCT_GN_LAUNCH_H
-#undef DEXCT_GN_LAUNCH
+    unsigned long long* queue = reinterpret_cast<unsigned long long*>(ws) + 11;
+    if (minw == 4)
+      hipLaunchKernelGGL((gn_refill_kernel<4>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
+    else
+      hipLaunchKernelGGL((gn_refill_kernel<5>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, out_a);
+                       n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, 0.0, tl, out_a);
   }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

@@ -69,10 +69,10 @@ extern "C" int dexct_add_noise(float* counts, const float* variance, int32_t n_s
 namespace dexct {
 struct AirValues { float v[DEXCT_MAX_SPECTRA]; };
 __global__ __launch_bounds__(256) void sino_log_kernel(const float* __restrict__ counts, AirValues air, size_t n_rays,
-                                                       size_t n_total, float* __restrict__ out) {
+                                                       size_t n_total, int vec_ok, float* __restrict__ out) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n_total) return;
-  if (i + 4 <= n_total && (n_rays & 3) == 0) {
+  if (i + 4 <= n_total && vec_ok) {
     const float a = air.v[i / n_rays];
     const float4 c = *reinterpret_cast<const float4*>(counts + i);
     *reinterpret_cast<float4*>(out + i) = make_float4(log_ratio(a, c.x), log_ratio(a, c.y), log_ratio(a, c.z), log_ratio(a, c.w));
@@ -92,8 +92,11 @@ extern "C" int dexct_sino_log(const float* counts, const float* air, int32_t n_s
   const size_t n_total = (size_t)n_spectra * (size_t)n_rays;
   const size_t nblk = (n_total / 4 + 256) / 256;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  // 16-byte loads and stores only when a spectrum's block starts on a multiple of 4 values AND both buffers are 16-byte
+  // aligned (a view into a larger tensor need not be); scalar otherwise, same values
+  const int vec_ok = (n_rays & 3) == 0 && ((reinterpret_cast<uintptr_t>(counts) | reinterpret_cast<uintptr_t>(sino_log)) & 15u) == 0;
   hipLaunchKernelGGL(sino_log_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), counts, av, (size_t)n_rays,
-                     n_total, sino_log);
+                     n_total, vec_ok, sino_log);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

@@ -340,9 +340,18 @@ class Projector:
 
 _cache = {}
 
-# True: checksum the whole volume on every call (64-bit; 16 ms per 128 MiB with xxhash, ~0.1 s without) - the round-2
-# behaviour.  Default: an O(1) key (below).  Also switched on by DEXCT_VERIFY_VOLUME=1.
-verify_volume = False
+# True (the default): every get_sino call checksums the WHOLE volume (xxh3, 64 bits; 15 ms per 128 MiB) and compares it with
+# the checksum of the bytes the device-resident state was built from - the reference rebuilds its state on every call, so
+# an in-place edit of ``phantom.volume`` must never return a stale sinogram.  The checksum runs on a helper thread WHILE
+# the projection kernel and the device-to-host copies are in flight (the calling thread waits for the GPU with the
+# interpreter lock released), so it costs the call no time; on a mismatch the state is rebuilt and the projection redone.
+# False / DEXCT_VERIFY_VOLUME=0 opts out: the O(1) key below alone (version counter + a strided sample).
+verify_volume = True
+
+
+def _verify_enabled():
+    import os
+    return verify_volume and os.environ.get('DEXCT_VERIFY_VOLUME', '1') != '0'
 
 
 def _hash64(a):
@@ -356,25 +365,49 @@ def _hash64(a):
         return int.from_bytes(hashlib.blake2b(a.data, digest_size=8).digest(), 'little')
 
 
+class _BackgroundHash:
+    """Checksum of an array on a helper thread; ``result()`` joins."""
+
+    def __init__(self, a):
+        import threading
+        self._out = None
+        self._t = threading.Thread(target=self._run, args=(a,), daemon=True)
+        self._t.start()
+
+    def _run(self, a):
+        self._out = _hash64(a)
+
+    def result(self):
+        self._t.join()
+        return self._out
+
+
+def _sample_step(shape, n_samples=4096):
+    """Stride of the O(1) sample: about size / n_samples and coprime to every dimension, so that the samples spread over
+    all rows, columns and slices (a stride that is a multiple of Nx - what size / 4096 is for every power-of-two volume -
+    only ever visits the x = 0 face, which is air for any centred phantom)."""
+    from math import gcd
+    size = int(np.prod(shape))
+    step = max(1, -(-size // n_samples)) | 1
+    while any(d > 1 and gcd(step, int(d)) != 1 for d in shape):
+        step += 2
+    return step
+
+
 def _volume_key(phantom):
     """What identifies the bytes of ``phantom.volume`` without reading them all: the phantom's version counter (bumped
-    whenever ``volume`` is assigned and by ``phantom.touch()``, which a caller who edits the array IN PLACE must call -
-    or ``invalidate()``), the identity and shape of the array, and a hash of 4096 evenly spaced voxels (cheap, and it
-    catches most in-place edits that forget ``touch()``).  ``verify_volume`` / DEXCT_VERIFY_VOLUME=1 hashes every byte."""
-    import os
+    whenever ``volume`` is assigned and by ``phantom.touch()``), the identity and shape of the array, and a hash of ~4096
+    voxels at a stride coprime to the dimensions.  This key only decides whether the cached state is a CANDIDATE; whether
+    its bytes are still the volume's is settled by the whole-volume checksum (``verify_volume``, on by default)."""
     v = phantom.volume
     flat = v.reshape(-1)
-    step = max(1, -(-flat.size // 4096))
-    key = (getattr(phantom, 'version', 0), id(v), v.shape, _hash64(flat[::step]))
-    if verify_volume or os.environ.get('DEXCT_VERIFY_VOLUME', '0') == '1':
-        key += (_hash64(v),)
-    return key
+    return (getattr(phantom, 'version', 0), id(v), v.shape, _hash64(flat[::_sample_step(v.shape)]))
 
 
 def _fingerprint(ct, phantom, view_range):
     """Everything the device-resident state (volume layouts, ray plans) depends on.  The reference rebuilds its
     state on every get_sino call; here the state is reused only while the scanner numbers, the voxel sizes and
-    the volume (see _volume_key: O(1), not a checksum of 128 MiB per call) are what they were when it was built."""
+    the volume (see _volume_key and verify_volume) are what they were when it was built."""
     return (id(ct), id(phantom), view_range, ct.N_proj, ct.N_channels, ct.N_rows, ct.SID, ct.SDD,
             _hash64(ct.thetas), _hash64(ct.gammas),
             ct.h_iso, bool(getattr(ct, 'cone', False)), float(getattr(ct, 'src_z', 0.0)),
@@ -388,12 +421,20 @@ def invalidate():
 
 
 def _projector(ct, phantom, view_range):
+    """The device-resident state for this (scanner, phantom, shard), and - when it was found in the cache and
+    verification is on - the running whole-volume checksum the caller must compare with ``pj.volume_hash`` before it
+    hands results out (None for a state built just now: its checksum is of the bytes it was built from)."""
     key = _fingerprint(ct, phantom, view_range)
     pj = _cache.get(key)
     if pj is None or pj.ct is not ct or pj.phantom is not phantom:
         _cache.clear()                      # keep one (scanner, phantom) pair resident
+        check = _BackgroundHash(phantom.volume) if _verify_enabled() else None      # beside the upload and the layouts
         pj = _cache[key] = Projector(ct, phantom, view_range)
-    return pj
+        pj.volume_hash = check.result() if check is not None else None
+        return pj, None
+    if _verify_enabled() and pj.volume_hash is not None:
+        return pj, _BackgroundHash(phantom.volume)
+    return pj, None
 
 
 def get_sinos(ct, phantom, specs, noise=False, seed=0):
@@ -412,15 +453,23 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0):
     full gathered sinograms.
     """
     vb, ve = _shard.my_views(ct.N_proj)
-    pj = _projector(ct, phantom, (vb, ve))
+    pj, check = _projector(ct, phantom, (vb, ve))
     sharded = _shard.world()[1] > 1
     res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded)
     if sharded:
-        counts = _shard.gather_views(res, ct.N_proj, view_dim=1)
+        counts = _shard.gather_views(res, ct.N_proj, view_dim=1, tag='get_sinos')
         log = pj.sino_log(counts, air)              # of the gathered sinogram: one collective instead of two
     else:
         counts, log = res
     raw, lg = to_host(counts), to_host(log)
+    if check is not None and check.result() != pj.volume_hash:
+        # phantom.volume was edited in place since the device state was built (no touch()): what was just computed is of
+        # the old bytes.  Rebuild from the current ones and project again - the result is what the reference, which
+        # builds its state on every call, returns.  (Under torch.distributed every rank holds the same phantom and
+        # takes the same branch.)
+        del raw, lg, counts, log, res
+        invalidate()
+        return get_sinos(ct, phantom, specs, noise=noise, seed=seed)
     if ct.N_rows == 1:
         raw, lg = raw[:, :, 0, :], lg[:, :, 0, :]
     return [(raw[k], lg[k]) for k in range(len(specs))]

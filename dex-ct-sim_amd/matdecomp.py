@@ -52,26 +52,37 @@ def _as_device_counts(x, dev):
     return to_dev(a.astype(np.float32 if dt == torch.float32 else np.float64, copy=False), dt, dev)
 
 
-_last_ws = None
+# Tolerance stop of the Newton iteration (include/dexct.h, dexct_gn_options).  None = the library default: 1e-12 unless the
+# environment says otherwise (DEXCT_GN_STOP_TOL=<t>, DEXCT_GN_EXACT=1).  0 = the reference's fixed count, bit for bit.
+DEFAULT_STOP_TOL = None
+
+_last_ws = []          # workspaces of the most recent call (one per view chunk of the pipelined boundary)
 _last_zeroed = None
 
 
 def last_gn_stats():
-    """Diagnostics of the most recent gn_device call (synchronises): ``pixel_iterations`` = Newton steps the float64
-    lane-refill kernel actually executed (the exact repeated-state exit ends pixels before n_iters; masked air
-    pixels run none).  0 for the mixed-precision and per-channel-spectrum kernels, which do not count."""
-    if _last_ws is None:
+    """Diagnostics of the most recent gn_device call - or of ALL the chunk launches of the most recent pipelined
+    get_basismat_sinos call - (synchronises): ``pixel_iterations`` = Newton steps the float64 shared-spectrum kernels
+    actually executed (the exits end pixels before n_iters; masked air pixels run none), ``stalled_lane_steps`` = lane-steps
+    a wave could not hand out because all its result slots waited for stragglers.  0 for the mixed-precision and
+    per-channel-spectrum kernels, which do not count."""
+    if not _last_ws:
         return None
-    return {'pixel_iterations': int(_last_ws[72:80].view(torch.int64).item())}
+    words = torch.stack([w[72:104].view(torch.int64) for w in _last_ws]).sum(dim=0).tolist()
+    return {'pixel_iterations': int(words[0]), 'stalled_lane_steps': int(words[3]), 'launches': len(_last_ws)}
 
 
 def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1, mask_max=None,
-              mask_frac=0.95):
+              mask_frac=0.95, stop_tol=None, out_rc=None, kernel=0, accumulate_stats=False):
     """g1, g2: device tensors of equal shape; mus: [2, nE] float64; i0: [2, nE] (one spectrum for all
     pixels) or [2, nBins, nE] (pixel p uses row (p // bin_div) % nBins: the reference's general layout).
     ``mask_max``: device float64 scalar (the global maximum of sinogram 1) - pixels with g1 >= mask_frac * max are
     the air pixels get_basismat_sinos zeroes (:204-205); they are written as 0 and not iterated.
-    Returns a device tensor of shape g1.shape + (2,) float64."""
+    ``stop_tol``: None = default (DEFAULT_STOP_TOL, else the library's 1e-12), 0 = the fixed iteration count exactly.
+    ``out_rc=(rows, channels)``: the sinograms are [..., channel, row] (row fastest) and the result is written as
+    [..., row, channel, 2], the reference's order, by the kernel itself.  ``kernel``: 0 choose, 1 lane per pixel,
+    2 cooperative (dexct_gn_options).
+    Returns a device tensor of shape g1.shape + (2,) float64 (with ``out_rc``: the last two sinogram dimensions swapped)."""
     lib = _native.load()
     dev = g1.device
     precision = precision or DEFAULT_PRECISION
@@ -88,19 +99,30 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     n_bins, n_e = i0_d.shape[1], i0_d.shape[2]
     if n_bins > 1 and precision == 'mixed':
         precision = 'f64'               # mixed precision exists for the shared-spectrum fast path only
-    a = out if out is not None else torch.empty(tuple(g1.shape) + (2,), dtype=torch.float64, device=dev)
+    shape = tuple(g1.shape)
+    rows = chans = 0
+    if out_rc is not None:
+        rows, chans = int(out_rc[0]), int(out_rc[1])
+        if shape[-2:] != (chans, rows):
+            raise ValueError(f'out_rc={out_rc}: the sinograms must end in [channel={chans}, row={rows}], got {shape}')
+        shape = shape[:-2] + (rows, chans)
+    a = out if out is not None else torch.empty(shape + (2,), dtype=torch.float64, device=dev)
+    if out is not None and (a.numel() != 2 * g1.numel() or a.dtype != torch.float64 or not a.is_contiguous()):
+        raise ValueError('out must be a contiguous float64 tensor with two values per pixel')
+    if stop_tol is None:
+        stop_tol = DEFAULT_STOP_TOL
     ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, n_bins), dtype=torch.uint8, device=dev)
-    ws[72:88].zero_()        # executed-iteration and finished-pixel counters: defined before anybody polls them
+    ws[72:104].zero_()       # executed-iteration, progress, queue and stall counters: defined before anybody polls them
     global _last_zeroed
     _last_zeroed = torch.cuda.Event()
     _last_zeroed.record()    # a progress poller on another stream waits for this (never reads uninitialised bytes)
     _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), int(g1.dtype == torch.float64), g1.numel(), ptr(i0_d),
                                          ptr(mus_d), n_e, n_bins, int(bin_div), int(n_iters),
                                          int(precision == 'mixed'), int(n_polish), ptr(mask_max), float(mask_frac), ptr(a),
-                                         ptr(ws), stream_ptr()),
+                                         _native.gn_options(stop_tol, rows, chans, kernel), ptr(ws), stream_ptr()),
                   'dexct_gn_decompose')
     global _last_ws
-    _last_ws = ws
+    _last_ws = (_last_ws + [ws]) if accumulate_stats else [ws]
     return a
 
 
@@ -132,7 +154,7 @@ def _progress_lines(ws, n_views, n_bins, done_event, t0, every=20, poll_s=0.05):
         time.sleep(poll_s)
 
 
-def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None):
+def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None, stop_tol=None):
     """Newton iterations for every pixel (signature of matdecomp.py:20 / :87).
     ``verbose`` prints the reference's progress line every 20 views (:111-112) from the kernel's finished-pixel
     counter; the drop-in callers below pass verbose=False unless asked (a benchmark should not print).
@@ -151,11 +173,11 @@ def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, preci
     g = _as_device_counts(np.asarray(Sino_gg), dev)
     import time
     t0 = time.time()
-    a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision)
+    a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision, stop_tol=stop_tol)
     if verbose:
         done = torch.cuda.Event()
         done.record()
-        _progress_lines(_last_ws, int(g.shape[1]), int(g[0].numel() // max(int(g.shape[1]), 1)), done, t0)
+        _progress_lines(_last_ws[-1], int(g.shape[1]), int(g[0].numel() // max(int(g.shape[1]), 1)), done, t0)
     return to_host(a)
 
 
@@ -175,13 +197,13 @@ def decomposition_tables(ct, spec1, spec2):
     return ee, i0, mus
 
 
-def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None):
+def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None, stop_tol=None):
     """[N_proj, N_channels, 2] density line integrals (matdecomp.py:130-164)."""
     _, i0, mus = decomposition_tables(ct, spec1, spec2)
     dev = device()
     g1 = _as_device_counts(sino1, dev)
     g2 = _as_device_counts(sino2, dev).to(g1.dtype)
-    a = gn_device(g1, g2, i0, mus, n_iters, precision)
+    a = gn_device(g1, g2, i0, mus, n_iters, precision, stop_tol=stop_tol)
     return a if isinstance(sino1, torch.Tensor) else to_host(a)
 
 
@@ -192,7 +214,7 @@ _PIPE_CHUNKS = 8                 # view chunks of the pipelined host boundary (t
 _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinogram) the plain sequence is as fast
 
 
-def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict):
+def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol):
     """get_basismat_sinos for NumPy sinograms of benchmark size: sinogram 1 goes to the device first (the mask needs its
     global maximum, matdecomp.py:195-196), then per view chunk: sinogram 2's chunk arrives on a copy stream, the Newton
     kernel runs on it, and the finished chunk leaves for page-locked host memory on the copy stream while the next chunk
@@ -224,25 +246,26 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
             arrived.append(ev)
     # Stacked fans arrive as [view][row][channel].  The kernel is ~8 % faster on [view][channel][row] (z-neighbours are
     # nearly the same problem, so the lanes of a wave end together; tools/probes/overlap.py: 0.87 vs 0.80 s), which is also
-    # the order the projection writes: transpose in (2 x 1.7 ms), solve, transpose the result back (2.3 ms).
+    # the order the projection writes: transpose in (2 x 1.7 ms) and solve; the kernel writes its results in the reference's
+    # order itself (out_rc: 4 x 16 tiles collected in LDS - round 3 needed a 2.3 ms transpose pass over 6.5 GB for it).
     row_fastest = g1.dim() == 3 and g1.shape[1] >= 8
     if row_fastest:
         nR, nC = int(g1.shape[1]), int(g1.shape[2])
         t1 = torch.empty((n_views, nC, nR), dtype=dt, device=dev)
         t2 = torch.empty_like(t1)
-        at = torch.empty((n_views, nC, nR, 2), dtype=torch.float64, device=dev)
         eb = 4 if dt == torch.float32 else 8
+    global _last_ws
+    _last_ws = []
     for (b, e), ev in zip(bounds, arrived):
         main.wait_event(ev)
+        kw = dict(out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol, accumulate_stats=True)
         if row_fastest:
             for src, dst in ((g1, t1), (g2, t2)):
                 _native.check(lib.dexct_transpose_batched(ptr(src[b:e]), ptr(dst[b:e]), e - b, nR, nC, eb, stream_ptr()),
                               'dexct_transpose_batched')
-            gn_device(t1[b:e], t2[b:e], i0, mus, n_iters, precision, out=at[b:e], mask_max=gmax, mask_frac=float(mask_thresh))
-            _native.check(lib.dexct_transpose_batched(ptr(at[b:e]), ptr(a[b:e]), e - b, nC, nR, 16, stream_ptr()),
-                          'dexct_transpose_batched')
+            gn_device(t1[b:e], t2[b:e], i0, mus, n_iters, precision, out_rc=(nR, nC), **kw)
         else:
-            gn_device(g1[b:e], g2[b:e], i0, mus, n_iters, precision, out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh))
+            gn_device(g1[b:e], g2[b:e], i0, mus, n_iters, precision, **kw)
         done = torch.cuda.Event()
         done.record(main)
         with torch.cuda.stream(copy):
@@ -263,7 +286,7 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
 
 
 def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None,
-                       strict=False, verbose=False):
+                       strict=False, verbose=False, stop_tol=None):
     """Basis-material sinograms (matdecomp.py:167-207): air mask from sinogram 1
     (``>= mask_thresh * max``), Newton decomposition, masked pixels set to exactly 0.
 
@@ -273,6 +296,9 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     is all-gathered); the mask threshold always uses the all-reduced global maximum.
     ``verbose=True`` prints the reference's progress line every 20 views (matdecomp.py:111-112; the reference always
     prints it) from the kernel's finished-pixel counter.
+    ``stop_tol``: None = the default tolerance stop (1e-12 relative step with a contraction check, include/dexct.h
+    dexct_gn_options; DEXCT_GN_EXACT=1 in the environment makes the default exact); 0 = the reference's fixed iteration
+    count bit for bit (matdecomp.py:114); the two agree to ~1e-14 on converging pixels and are identical on the others.
     ``strict=True``: raise ``SingularHessianError`` (a ``numpy.linalg.LinAlgError``, what :125 raises) if a pixel
     outside the air mask ends non-finite; the default returns the inf/NaN in place, as documented above.
     """
@@ -290,7 +316,7 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     if (world == 1 and not verbose and not isinstance(sino_raw_1, torch.Tensor) and np.ndim(sino_raw_1) >= 2
             and np.shape(sino_raw_1)[0] >= 2 * _PIPE_CHUNKS and np.size(sino_raw_1) >= _PIPE_MIN_PIXELS
             and np.shape(sino_raw_1) == np.shape(sino_raw_2)):
-        return _basismat_sinos_pipelined(lib, dev, sino_raw_1, sino_raw_2, i0, mus, n_iters, mask_thresh, precision, strict)
+        return _basismat_sinos_pipelined(lib, dev, sino_raw_1, sino_raw_2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol)
     g1 = _as_device_counts(sino_raw_1, dev)
     g2 = _as_device_counts(sino_raw_2, dev).to(g1.dtype)
     is64 = int(g1.dtype == torch.float64)
@@ -300,11 +326,11 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     # the mask is applied inside the kernel (threshold read from the device scalar: no host round trip)
     import time
     t0 = time.time()
-    a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh))
+    a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol)
     if verbose and rank == 0 and g1.dim() >= 2:
         done = torch.cuda.Event()
         done.record()
-        _progress_lines(_last_ws, int(g1.shape[0]), int(g1.numel() // max(int(g1.shape[0]), 1)), done, t0)
+        _progress_lines(_last_ws[-1], int(g1.shape[0]), int(g1.numel() // max(int(g1.shape[0]), 1)), done, t0)
     if strict:
         bad = ~torch.isfinite(a).all(dim=-1)          # masked pixels are exactly 0, hence finite
         n_bad = int(bad.sum().item())
@@ -318,7 +344,7 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
             raise SingularHessianError(f'Singular matrix: {n_bad} pixel(s) outside the air mask ended non-finite '
                                        f'after {n_iters} Newton iterations (first flat index on this rank: {first})')
     if full_in:
-        a = _shard.gather_views(a, n_views, view_dim=0)
+        a = _shard.gather_views(a, n_views, view_dim=0, tag='get_basismat_sinos')     # a new tensor: the caller owns it
     if isinstance(sino_raw_1, torch.Tensor):
         return a[..., 0], a[..., 1]
     a = to_host(a)          # page-locked: one DMA; the two results are views of this one buffer, like the reference's

@@ -42,6 +42,7 @@ _MEC2 = 510.99895          # electron rest energy [keV]
 _PE_K, _PE_N, _PE_P = 2.0e-23, 4.4, 3.1
 
 _user_tables = {}
+_mix_cache = {}
 
 
 def parse_formula(formula):
@@ -61,9 +62,8 @@ def register_table(name, E_keV, mu_rho):
     if E.ndim != 1 or E.shape != m.shape or np.any(np.diff(E) <= 0):
         raise ValueError('table needs increasing E and matching mu/rho')
     _user_tables[name] = (E, m)
+    _mix_cache.clear()          # a table replaced under an existing name must not leave old mixtures behind
 
-
-_mix_cache = {}
 
 
 def _interp_loglog(E, tab):
@@ -103,8 +103,8 @@ def mixatten(formula, E_keV):
     """
     E = np.asarray(E_keV, dtype=np.float64)
     # the public calls ask for the same (material, energy grid) pairs on every call (0.3 ms of a 0.9 ms get_sino at the
-    # reference's own size): keep the last results; a registered table or another DEXCT_XCOM_DIR changes the key
-    key = (formula, E.shape, E.tobytes(), len(_user_tables), os.environ.get('DEXCT_XCOM_DIR'))
+    # reference's own size): keep the last results; register_table() empties the cache, another DEXCT_XCOM_DIR changes the key
+    key = (formula, E.shape, E.tobytes(), os.environ.get('DEXCT_XCOM_DIR'))
     hit = _mix_cache.get(key)
     if hit is not None:
         return hit.copy()

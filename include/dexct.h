@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define DEXCT_ABI_VERSION 2   /* 2: log_out argument of the projection entry points, dexct_sino_log */
+#define DEXCT_ABI_VERSION 3   /* 2: log_out argument of the projection entry points, dexct_sino_log;
+                                 3: struct dexct_gn_options - tolerance stop, results in the reference's order; 256 material ids */
 
 #define DEXCT_OK 0
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
@@ -235,6 +236,32 @@ int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
  * torch.distributed (dex-ct-sim_amd/_shard.py). */
 int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_rank, void* rccl_comm, void* stream);
 
+/* Options of dexct_gn_decompose (ABI 3).  A NULL pointer = every default.
+ *   stop_tol    >= 0: taken as given.  0 = the reference's fixed iteration count, bit for bit (matdecomp.py:114: `for
+ *               i in range(n_iters)`).  > 0 = tolerance stop: a float64 pixel also ends when a Newton step moves it by no
+ *               more than stop_tol * max(|a0|, |a1|, 1) AND that step is at most half the previous one (so the remaining
+ *               distance to the limit is bounded by the last step; a creeping or wandering pixel is not stopped and runs
+ *               to n_iters as in the reference).
+ *               < 0: the library default = DEXCT_GN_DEFAULT_STOP_TOL (1e-12: seven orders inside the 1e-5 the results
+ *               are specified to, three inside the 1e-9 the kernel keeps to the reference's own outputs), or the value of
+ *               the environment variable DEXCT_GN_STOP_TOL, or 0 when DEXCT_GN_EXACT=1.
+ *   out_rows, out_channels   both 0: out_a[2*p + m] in the order of the pixels.  Both > 0 (n_pix a multiple of their
+ *               product): the pixels are given as [..][channel][row] (row fastest - layout 1 of dexct_siddon_project, what
+ *               the stacked-fan kernels write) and the results are written as [..][row][channel], the reference's order
+ *               (matdecomp.py:200-201): out_a[2*((v*out_rows + r)*out_channels + c) + m] for pixel (v*out_channels + c)*
+ *               out_rows + r.  The float64 shared-spectrum kernel collects 4 x 16 (channel, row) tiles in LDS and writes
+ *               them as 64-byte runs; no separate transpose pass over the results.
+ *   kernel      0 = choose by size; 1 = one lane per pixel (gn_refill_kernel); 2 = cooperative: the four waves of a
+ *               workgroup split the energies of 64 pixels (gn_coop_kernel, for sinograms too small to fill the chip with
+ *               one pixel per lane).  float64, n_bins == 1 only; ignored otherwise. */
+#define DEXCT_GN_DEFAULT_STOP_TOL 1e-12
+typedef struct dexct_gn_options {
+  double stop_tol;
+  int32_t out_rows, out_channels;
+  int32_t kernel;
+  int32_t reserved_;           /* 0 */
+} dexct_gn_options;
+
 /* Per-pixel Newton (Gauss-Newton) basis-material decomposition: replaces optimize_sino_cpu
  * (matdecomp.py:87-127).
  *   g1, g2     measured counts of the two spectra, n_pix values each; g_is_f64 selects
@@ -246,7 +273,7 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *              the fastest pixel index, = n_rows for the row-fastest layout 1)
  *   mus[m*n_energies + e]  basis mass attenuation (float64), m = 0, 1
  *   out_a[2*p + m]         density line integrals (float64), initialised to 1e-6 inside; 16-byte aligned (DEXCT_EINVAL
- *                          otherwise): a pixel's pair is one non-temporal 16-byte store
+ *                          otherwise): results leave as 16-byte pieces of whole-line stores; order: see dexct_gn_options
  *   precision: 0 = float64 throughout (reference arithmetic);
  *              1 = float32 bulk iterations followed by float64 polish iterations; a pixel the
  *                  polish is still moving is redone in float64 from the start (n_bins == 1 only)
@@ -254,29 +281,29 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *   mask_max   NULL, or a device float64 scalar (e.g. from dexct_reduce_max, all-reduced over ranks): pixels with
  *              g1 >= mask_frac * *mask_max are the air pixels get_basismat_sinos zeroes afterwards
  *              (matdecomp.py:195-196, :204-205); they get (0, 0) directly and their iterations are skipped
+ *   options    see dexct_gn_options; NULL = defaults
  *   workspace  device scratch of dexct_gn_workspace_bytes(n_energies, n_bins) bytes (the product tables
  *              the kernel reads through the scalar cache); owned by the caller, no hidden state.  After the call
  *              the uint64 at byte offset 72 holds, as a diagnostic, the number of pixel-iterations the float64
- *              shared-spectrum kernel executed (what bench.py's executed-flop rate is computed from; 0 for the
- *              other kernels), and the uint64 at byte offset 80 the number of pixels it has taken from its run queue
- *              (runs handed to waves; with DEXCT_GN_QUEUE=0, runs finished) - updated run by run WHILE the kernel
- *              runs, so a host thread may read it (on another stream) as a progress indicator: the reference prints
- *              a line every 20 views, matdecomp.py:111-112.  The uint64 at byte offset 88 is the queue head (the
- *              next pixel no wave owns yet); the library zeroes all three words at the start of every call
- * n_iters is the reference's fixed iteration count.  The update is a pure function of the two doubles, so the
+ *              shared-spectrum kernels executed (what bench.py's executed-flop rate is computed from; 0 for the
+ *              other kernels), and the uint64 at byte offset 80 the number of pixels handed to waves so far -
+ *              updated tile by tile WHILE the kernel runs, so a host thread may read it (on another stream) as a progress
+ *              indicator: the reference prints a line every 20 views, matdecomp.py:111-112.  The uint64 at byte offset 88
+ *              is the head of the tile queue, the one at 96 counts lane-steps that had to wait for a free result slot
+ *              (diagnostic); the library zeroes all four words at the start of every call
+ * n_iters is the reference's iteration count.  The update is a pure function of the two doubles, so the
  * kernel stops a pixel at the first state that repeats bit for bit (fixed point or cycle of up to 9 states) and
- * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly.
- * Environment (read per call, for checking and tuning only): DEXCT_GN_FULL_LOOP=1 executes every iteration;
- * DEXCT_GN_CHUNK=<1..1024> pixels per lane in one run of pixels (default 2: a wave fetches 128 pixels at a time from
- * the queue); DEXCT_GN_QUEUE=0 gives every wave one static run instead; DEXCT_GN_BLOCKS_PER_CU=<n> caps the grid of
- * the queue kernel at n blocks per CU (default 8);
- * DEXCT_GN_STOP_TOL=<t> (opt-in, not the reference's fixed count): a float64 shared-spectrum pixel also stops when a
- * step moves it by no more than t * max(|a|, 1). */
+ * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly; with a tolerance
+ * stop (the default, see dexct_gn_options) a converging pixel ends a few iterations earlier still.
+ * Environment (read per call, for checking and tuning only): DEXCT_GN_FULL_LOOP=1 executes every iteration (no exit of any
+ * kind); DEXCT_GN_EXACT=1 / DEXCT_GN_STOP_TOL=<t> change the DEFAULT tolerance (an explicit options->stop_tol >= 0 wins);
+ * DEXCT_GN_BLOCKS_PER_CU=<n> caps the grid of the queue kernel at n workgroups per CU (default 5 = what is resident);
+ * DEXCT_GN_MINW=4 selects the variant compiled for 128 registers per lane. */
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,
                        int32_t precision, int32_t n_polish, const double* mask_max, double mask_frac, double* out_a,
-                       void* workspace, void* stream);
+                       const dexct_gn_options* options, void* workspace, void* stream);
 
 /* Air mask of get_basismat_sinos (matdecomp.py:194-205): out_a[2p], out_a[2p+1] = 0 wherever
  * g1[p] >= thresh_value (thresh_value = mask_thresh * global max, computed by the caller so that a

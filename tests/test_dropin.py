@@ -223,7 +223,7 @@ def test_config1_default_params_full_size_relative_paths(tmp_path):
 @pytest.mark.gpu
 def test_get_sino_sees_in_place_changes():
     """The reference rebuilds its state on every get_sino call; the cached device state here is keyed on the geometry
-    numbers and a checksum of the volume, so an in-place edit of phantom.volume or of a scanner number is seen."""
+    numbers and a checksum of the whole volume (computed beside the GPU work), so an in-place edit of phantom.volume or of a scanner number is seen."""
     import dex_ct_sim_amd as dx
     from conftest import small_scan
     from dex_ct_sim_amd import synthetic

@@ -147,7 +147,7 @@ def _check_gn_sample(a_native, counts_native, native_layout, views_local, row0, 
     return float(err.max()), int(live.sum())
 
 
-def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at, n_iters=50):
+def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at, n_iters=50, compare_exact=False):
     """Fused dual-spectrum projection (140 / 80 kVp) + Newton decomposition of one view shard, as bench.py runs it."""
     from dex_ct_sim_amd import forward_project as fp, matdecomp as md, synthetic
     from dex_ct_sim_amd._device import ptr, stream_ptr
@@ -169,7 +169,29 @@ def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at
     gmax = torch.empty((), dtype=torch.float64, device='cuda')
     assert pj.lib.dexct_reduce_max(ptr(counts[0]), 0, counts[0].numel(), ptr(gmax), stream_ptr()) == 0
     assert float(gmax) == float(counts[0].max())
-    a = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95)
+    a = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95)     # the DEFAULT mode
+    if compare_exact:
+        # round 4: the default (tolerance stop) against the reference's fixed count (stop_tol = 0) on EVERY pixel of the
+        # scan: within 1e-12, identical where the exact run is not finite; and the results written in the reference's
+        # [view][row][channel] order by the kernel itself are the same bits
+        st_default = md.last_gn_stats()['pixel_iterations']
+        a_exact = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, stop_tol=0.0)
+        st_exact = md.last_gn_stats()['pixel_iterations']
+        worst, V = 0.0, a.shape[0]
+        for v0 in range(0, V, 100):
+            d, x = a[v0:v0 + 100], a_exact[v0:v0 + 100]
+            assert torch.equal(torch.isnan(d), torch.isnan(x))
+            worst = max(worst, float(torch.nan_to_num((d - x).abs() / x.abs().clamp(min=1.0), nan=0.0).max()))
+        assert worst <= 1e-12, worst
+        assert st_default < 0.8 * st_exact, (st_default, st_exact)
+        del a_exact
+        R, C = int(counts.shape[3]), int(counts.shape[2])
+        a_ref = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, out_rc=(R, C))
+        assert a_ref.shape == (V, R, C, 2)
+        for v0 in range(0, V, 100):
+            assert torch.equal(a_ref[v0:v0 + 100].view(torch.int64),
+                               a[v0:v0 + 100].permute(0, 2, 1, 3).contiguous().view(torch.int64))
+        del a_ref
     out = []
     for row0 in rows_at:
         out.append(_check_gn_sample(a, counts, 1, [v - vb for v in sample_views], row0, i0, mus, n_iters, float(gmax)))
@@ -217,7 +239,8 @@ def test_config2_256_cubed_120kvp_forward_only(hip):
 def test_config3_dual_energy_gn_full_size(hip):
     """BASELINE configs[2] - the benchmark's step at full size: 512^3, 1000 x 800 x 512 rows, fused 140 / 80 kVp
     projection, global max, 50-iteration Newton with the fused air mask (gn_refill_kernel)."""
-    res = _dual_energy_shard(512, 1000, 800, (0, 1000), sample_views=[0, 250, 333, 999], rows_at=(0, 252, 504))
+    res = _dual_energy_shard(512, 1000, 800, (0, 1000), sample_views=[0, 250, 333, 999], rows_at=(0, 252, 504),
+                             compare_exact=True)
     assert all(n_live > 1000 for _, n_live in res)
 
 

@@ -16,16 +16,25 @@ def err(a, b):
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))
 
 
-def run(g, i0, mus, n_iters, precision):
+def run(g, i0, mus, n_iters, precision, stop_tol=None):
+    """stop_tol=None: the DEFAULT mode (round 4: tolerance stop at 1e-12); 0: the fixed count, bit for bit"""
     from dex_ct_sim_amd import matdecomp as md
-    return md.optimize_sino(g, None, i0, mus, n_iters, verbose=False, precision=precision)
+    return md.optimize_sino(g, None, i0, mus, n_iters, verbose=False, precision=precision, stop_tol=stop_tol)
 
 
+@pytest.mark.parametrize('stop_tol', [None, 0.0])
 @pytest.mark.parametrize('ci', [0, 1, 2])
-@pytest.mark.parametrize('n_iters', [1, 2, 50])
-def test_f64_trajectory_matches_reference(hip, golden, ci, n_iters):
+@pytest.mark.parametrize('n_iters', [1, 2, 5, 50])
+def test_f64_trajectory_matches_reference(hip, golden, ci, n_iters, stop_tol):
+    """The reference's own trajectories (after 1 / 2 / 5 / 50 iterations, three spectrum / detector cases) at the unchanged
+    1e-9, in the DEFAULT mode (tolerance stop) and with the exact fixed count.  (Case 1 - the detunedMV pair - after 5
+    iterations is the one golden no restatement reproduces to 1e-9: a pixel passes a nearly singular Hessian on the way and
+    the step taken there is amplified rounding - the NumPy oracle itself is 2.7e-6 away from the reference there,
+    tests/test_gn_oracle.py::test_numpy_oracle_iter5 leaves it out for the same reason; by 50 iterations it has converged.)"""
+    if ci == 1 and n_iters == 5:
+        pytest.skip('ill-conditioned transient: not reproducible to 1e-9 by any arithmetic but the reference\'s own')
     g = golden
-    a = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], n_iters, 'f64')
+    a = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], n_iters, 'f64', stop_tol)
     assert a.shape == (4, 32, 2) and a.dtype == np.float64
     assert err(a, g[f'gn{ci}_a_iters{n_iters}']) < TOL_F64
 
@@ -173,6 +182,8 @@ def test_entry_points_are_graph_capturable(hip):
     a_ref_order = torch.zeros((10, 8, 40, 2), dtype=torch.float64, device='cuda')
     gmax = torch.zeros((), dtype=torch.float64, device='cuda')
     ws = torch.empty(lib.dexct_gn_workspace_bytes(i0.shape[1], 1), dtype=torch.uint8, device='cuda')
+    ws2 = torch.empty_like(ws)
+    a_direct = torch.zeros((10, 8, 40, 2), dtype=torch.float64, device='cuda')
 
     def run():
         st = stream_ptr()
@@ -182,14 +193,19 @@ def test_entry_points_are_graph_capturable(hip):
                                                None, 3, 1, None, None, None, st), 'project')
         _native.check(lib.dexct_reduce_max(ptr(counts[0]), 0, counts[0].numel(), ptr(gmax), st), 'max')
         _native.check(lib.dexct_gn_decompose(ptr(counts[0]), ptr(counts[1]), 0, counts[0].numel(), ptr(i0_d), ptr(mus_d),
-                                             i0.shape[1], 1, 1, 30, 0, 0, None, 0.0, ptr(a), ptr(ws), st), 'gn')
+                                             i0.shape[1], 1, 1, 30, 0, 0, None, 0.0, ptr(a), None, ptr(ws), st), 'gn')
         _native.check(lib.dexct_gn_apply_mask(ptr(counts[0]), 0, counts[0].numel(), 1e30, ptr(a), st), 'mask')
         _native.check(lib.dexct_transpose_batched(ptr(a), ptr(a_ref_order), 10, 40, 8, 16, st), 'transpose')
+        # ABI 3: the kernel writes the reference's [view][row][channel] order itself
+        _native.check(lib.dexct_gn_decompose(ptr(counts[0]), ptr(counts[1]), 0, counts[0].numel(), ptr(i0_d), ptr(mus_d),
+                                             i0.shape[1], 1, 1, 30, 0, 0, None, 0.0, ptr(a_direct),
+                                             _native.gn_options(None, 8, 40), ptr(ws2), st), 'gn direct')
 
     run()
     torch.cuda.synchronize()
+    assert torch.equal(a_direct.view(torch.int64), a_ref_order.view(torch.int64))      # same bits, no transpose pass
     eager = (counts.clone(), a_ref_order.clone(), gmax.clone())
-    counts.zero_(); a.zero_(); a_ref_order.zero_(); gmax.zero_()
+    counts.zero_(); a.zero_(); a_ref_order.zero_(); gmax.zero_(); a_direct.zero_()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         run()
@@ -197,6 +213,7 @@ def test_entry_points_are_graph_capturable(hip):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(counts, eager[0]) and torch.equal(a_ref_order, eager[1]) and torch.equal(gmax, eager[2])
+    assert torch.equal(a_direct, eager[1])
     assert torch.isfinite(a_ref_order).all()
 
 
@@ -218,64 +235,64 @@ def test_repeated_state_exit_changes_no_bit(hip, golden):
             for n_iters in (7, 23) + tuple(range(41, 52)):
                 for precision in ('f64', 'mixed'):       # mixed: the float32 bulk loop has the same exit
                     os.environ['DEXCT_GN_FULL_LOOP'] = '1'
-                    full = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision)
+                    full = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision, verbose=False)
                     os.environ['DEXCT_GN_FULL_LOOP'] = '0'
-                    fast = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision)
+                    fast = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision, verbose=False, stop_tol=0.0)
                     assert np.array_equal(full.view(np.int64), fast.view(np.int64)), (n_iters, precision)
     finally:
         os.environ.pop('DEXCT_GN_FULL_LOOP', None)
 
 
-def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
-    """gn_refill_kernel: every pixel is solved exactly once whether the waves fetch their runs of pixels from the global
-    queue (round 3, the default) or own one static run each (DEXCT_GN_QUEUE=0), whatever the run length (DEXCT_GN_CHUNK),
-    for pixel counts around the wave and run boundaries, with and without the fused air mask, and for 0 and 1
-    iterations.  All run lengths give the same bits; the result matches the C oracle."""
+def test_lane_refill_ragged_sizes_tiles_and_mask(hip, golden):
+    """gn_refill_kernel: every pixel is solved exactly once and lands in its place - pixel counts around the wave and
+    tile boundaries, with and without the fused air mask, 0 and 1 iterations, any cap on the grid of the tile queue, the
+    128-register variant; and with the results written in the reference's [view][row][channel] order from
+    [view][channel][row] input (4 x 16 tiles collected in LDS, ragged row / channel counts): the same bits as the plain
+    order transposed.  Exact mode (stop_tol = 0) for the bit comparisons; the result matches the C oracle."""
     import os
-    import torch
     from dex_ct_sim_amd import matdecomp as md
     g = golden
     i0, mus = g['gn0_i0'], g['gn0_mus']
     rng = np.random.default_rng(23)
+
+    def problem(n_pix):
+        a_true = np.stack([rng.uniform(0, 35, n_pix), rng.uniform(0, 6, n_pix)], -1)
+        ex = np.exp(-a_true @ mus)
+        cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, n_pix)))
+        cnt[0, rng.random(n_pix) < 0.3] = 2.0 * i0[0].sum()                    # above 0.95 * max: masked
+        return cnt
+
     try:
         for n_pix in (1, 63, 64, 65, 127, 1000, 4097, 64 * 64 * 3 + 5):
-            a_true = np.stack([rng.uniform(0, 35, n_pix), rng.uniform(0, 6, n_pix)], -1)
-            ex = np.exp(-a_true @ mus)
-            cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, n_pix)))
-            air = rng.random(n_pix) < 0.3
-            cnt[0, air] = 2.0 * i0[0].sum()                    # above 0.95 * max: masked
+            cnt = problem(n_pix)
             g1, g2 = (torch.tensor(cnt[k], device='cuda') for k in range(2))
             gmax = g1.max().double()
             air = cnt[0] >= 0.95 * cnt[0].max()                # what the mask rule selects (at least the maximum itself)
             ref = co.gn_decompose(cnt[0], cnt[1], i0, mus, 30, n_threads=8)
             results = {}
-            for queue in ('1', '0'):                           # runs fetched from the global queue (default) / static runs
-                os.environ['DEXCT_GN_QUEUE'] = queue
-                for chunk in ('1', '2', '7', '64'):
-                    os.environ['DEXCT_GN_CHUNK'] = chunk
-                    for masked in (False, True):
-                        out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
-                        md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None)
-                        results[(queue, chunk, masked)] = out.cpu().numpy()
-            os.environ.pop('DEXCT_GN_QUEUE')
-            os.environ['DEXCT_GN_CHUNK'] = '1'
-            for cap in ('1', '3'):                             # workgroups per CU of the run-queue grid
-                os.environ['DEXCT_GN_BLOCKS_PER_CU'] = cap
-                out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
-                md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax)
-                results[('cap' + cap, '1', True)] = out.cpu().numpy()
-            os.environ.pop('DEXCT_GN_BLOCKS_PER_CU')
-            base_m, base_u = results[('1', '1', True)], results[('1', '1', False)]
-            for (queue, chunk, masked), r in results.items():
-                assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, queue, chunk)
+            for masked in (False, True):
+                for env in ({}, {'DEXCT_GN_BLOCKS_PER_CU': '1'}, {'DEXCT_GN_BLOCKS_PER_CU': '3'}, {'DEXCT_GN_MINW': '4'}):
+                    os.environ.update(env)
+                    out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+                    md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None, stop_tol=0.0, kernel=1)
+                    for k in env:
+                        os.environ.pop(k)
+                    results[(masked, tuple(env.items()))] = out.cpu().numpy()
+            base_m, base_u = results[(True, ())], results[(False, ())]
+            for (masked, env), r in results.items():
+                assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, env)
             assert not np.isnan(base_m[air]).any() and np.all(base_m[air] == 0.0)
             assert np.array_equal(base_m[~air].view(np.int64), base_u[~air].view(np.int64))
             live_u = np.isfinite(ref).all(-1)                  # without the mask every pixel is solved
             assert err(base_u[live_u], ref[live_u]) < TOL_F64
-            os.environ['DEXCT_GN_CHUNK'] = '3'
+            # the default mode (tolerance stop): within 1e-11 of the exact result wherever that is finite
+            out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+            md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax, kernel=1)
+            fin = np.isfinite(base_m).all(-1)
+            assert err(out.cpu().numpy()[fin], base_m[fin]) < 1e-11
             for n_iters, expect in ((0, 1e-6), (1, None)):
                 out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
-                md.gn_device(g1, g2, i0, mus, n_iters, 'f64', out=out)
+                md.gn_device(g1, g2, i0, mus, n_iters, 'f64', out=out, kernel=1)
                 o = out.cpu().numpy()
                 if expect is not None:
                     assert np.all(o == expect)
@@ -283,10 +300,28 @@ def test_lane_refill_ragged_sizes_runs_and_mask(hip, golden):
                     one = co.gn_decompose(cnt[0], cnt[1], i0, mus, 1, n_threads=8)
                     ok = np.isfinite(one).all(-1)
                     assert err(o[ok], one[ok]) < TOL_F64
+        # results in the reference's order: [views][channels][rows] in, [views][rows][channels] out
+        for V, C, R in ((1, 1, 1), (2, 8, 8), (3, 5, 3), (2, 17, 9), (1, 64, 7), (5, 9, 70), (2, 40, 33)):
+            cnt = problem(V * C * R)
+            for dt in (torch.float64, torch.float32):
+                g1, g2 = (torch.tensor(cnt[k], device='cuda').to(dt).reshape(V, C, R) for k in range(2))
+                gmax = g1.max().double()
+                for masked in (False, True):
+                    plain = md.gn_device(g1, g2, i0, mus, 30, 'f64', mask_max=gmax if masked else None, stop_tol=0.0, kernel=1)
+                    out = torch.full((V, R, C, 2), float('nan'), dtype=torch.float64, device='cuda')
+                    got = md.gn_device(g1, g2, i0, mus, 30, 'f64', mask_max=gmax if masked else None, stop_tol=0.0,
+                                       out_rc=(R, C), out=out, kernel=1)
+                    assert got.shape == (V, R, C, 2)
+                    assert torch.equal(got.view(torch.int64), plain.permute(0, 2, 1, 3).contiguous().view(torch.int64)), (V, C, R)
+                    # the pixel-by-pixel kernels honour the same option (mixed precision: scattered stores)
+                    mix_p = md.gn_device(g1, g2, i0, mus, 30, 'mixed', mask_max=gmax if masked else None)
+                    mix_t = md.gn_device(g1, g2, i0, mus, 30, 'mixed', mask_max=gmax if masked else None, out_rc=(R, C))
+                    assert torch.equal(mix_t.view(torch.int64), mix_p.permute(0, 2, 1, 3).contiguous().view(torch.int64))
+        with pytest.raises(ValueError):
+            md.gn_device(g1, g2, i0, mus, 30, 'f64', out_rc=(C, R + 1))
     finally:
-        os.environ.pop('DEXCT_GN_CHUNK', None)
-        os.environ.pop('DEXCT_GN_QUEUE', None)
-        os.environ.pop('DEXCT_GN_BLOCKS_PER_CU', None)
+        for k in ('DEXCT_GN_BLOCKS_PER_CU', 'DEXCT_GN_MINW'):
+            os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize('seed', range(10))
@@ -337,10 +372,12 @@ def test_random_tables_against_numpy_oracle(hip, seed):
         assert err(got[ok], ref[ok]) < 1e-7, (seed, n_e, n_bins, n_iters, err(got[ok], ref[ok]))
 
 
-def test_opt_in_tolerance_stop(hip, golden):
-    """DEXCT_GN_STOP_TOL: off by default (bit-identical results with the variable unset or 0); when set, every
-    well-conditioned pixel ends within the tolerance of the 50-iteration result."""
-    import os
+def test_default_tolerance_stop_and_exact_switches(hip, golden, monkeypatch):
+    """Round 4: the tolerance stop (1e-12 relative step, contraction checked) is the DEFAULT of dexct_gn_decompose /
+    get_basismat_sinos; the reference's fixed count is one switch away and every way of asking for it gives the same bits
+    as the full loop: stop_tol=0, DEXCT_GN_EXACT=1, DEXCT_GN_STOP_TOL=0.  The default stays within 1e-12 of the exact
+    result on every finite pixel (measured ~1e-14); looser tolerances stay within a few tolerances; a pixel that never
+    converges (non-finite or wandering in the exact run) is not cut short: it is bit-identical to the exact run."""
     from dex_ct_sim_amd import matdecomp as md
     g = golden
     rng = np.random.default_rng(31)
@@ -348,17 +385,34 @@ def test_opt_in_tolerance_stop(hip, golden):
     a_true = np.stack([rng.uniform(0, 40, 50000), rng.uniform(0, 8, 50000)], -1)
     ex = np.exp(-a_true @ mus)
     cnt = (np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, 50000)))).reshape(2, 100, 500)
-    try:
-        exact = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64')
-        os.environ['DEXCT_GN_STOP_TOL'] = '0'
-        assert np.array_equal(md.optimize_sino(cnt, None, i0, mus, 50, precision='f64').view(np.int64), exact.view(np.int64))
-        for tol in (1e-12, 1e-8):
-            os.environ['DEXCT_GN_STOP_TOL'] = repr(tol)
-            fast = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64')
-            ok = np.isfinite(exact).all(-1)
-            assert err(fast[ok], exact[ok]) < 20 * tol
-    finally:
-        os.environ.pop('DEXCT_GN_STOP_TOL', None)
+    monkeypatch.setenv('DEXCT_GN_FULL_LOOP', '1')
+    full = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
+    monkeypatch.delenv('DEXCT_GN_FULL_LOOP')
+    exact = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=0.0)
+    assert np.array_equal(exact.view(np.int64), full.view(np.int64))
+    for var, val in (('DEXCT_GN_EXACT', '1'), ('DEXCT_GN_STOP_TOL', '0')):
+        monkeypatch.setenv(var, val)
+        assert np.array_equal(md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False).view(np.int64), exact.view(np.int64))
+        monkeypatch.delenv(var)
+    ok = np.isfinite(exact).all(-1)
+    default = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
+    st_default = md.last_gn_stats()['pixel_iterations']
+    assert err(default[ok], exact[ok]) < 1e-12
+    assert np.array_equal(default[~ok].view(np.int64), exact[~ok].view(np.int64))
+    md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=0.0)
+    st_exact = md.last_gn_stats()['pixel_iterations']
+    assert st_default < 0.95 * st_exact                                   # and it is what saves the iterations (15 % on this noisy data)
+    monkeypatch.setenv('DEXCT_GN_EXACT', '1')                             # an explicit tolerance wins over the environment
+    explicit = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=1e-12)
+    monkeypatch.delenv('DEXCT_GN_EXACT')
+    assert np.array_equal(explicit.view(np.int64), default.view(np.int64))
+    for tol in (1e-10, 1e-8):
+        fast = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=tol)
+        assert err(fast[ok], exact[ok]) < 20 * tol
+    # the ill-posed golden case (detunedMV pair: spurious roots, wandering pixels): default mode == the reference at 1e-9
+    for ci in range(3):
+        a = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], 50, 'f64')
+        assert err(a, g[f'gn{ci}_a_iters50']) < TOL_F64
 
 
 def test_integration_md_ctypes_stub_runs(hip, golden):
@@ -510,16 +564,13 @@ def test_nan_count_masks_nothing_like_np_max(hip, golden, extra):
 
 @pytest.mark.parametrize('ci', [0, 1, 2])
 def test_opt_in_modes_against_all_reference_cases(hip, golden, ci, monkeypatch):
-    """The two opt-in shortcuts (never the default, never the benchmark's value) against ALL THREE reference
-    golden cases at the north-star tolerance: DEXCT_GN_STOP_TOL=1e-12 (float64, stops a converged pixel early)
-    and the mixed-precision mode.  Where they diverge is recorded here: on the well-posed kV pairs (cases 0, 2)
+    """Two opt-in shortcuts against ALL THREE reference golden cases at the north-star tolerance: a LOOSE tolerance stop
+    (1e-8; the default 1e-12 is held to 1e-9 by test_f64_trajectory_matches_reference) and the mixed-precision mode.  Where they diverge is recorded here: on the well-posed kV pairs (cases 0, 2)
     every pixel is within 1e-5; on the detunedMV pair (case 1) the tolerance stop still agrees everywhere (it only
     ends pixels that stopped moving), the float32 bulk may land on a different stationary point for a few pixels."""
     g = golden
     ref = g[f'gn{ci}_a_iters50']
-    monkeypatch.setenv('DEXCT_GN_STOP_TOL', '1e-12')
-    a_tol = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], 50, 'f64')
-    monkeypatch.delenv('DEXCT_GN_STOP_TOL')
+    a_tol = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], 50, 'f64', stop_tol=1e-8)      # a much looser stop than the default
     assert err(a_tol, ref) < TOL_NS
     a_mix = run(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], 50, 'mixed')
     e = np.max(np.abs(a_mix - ref) / np.maximum(np.abs(ref), 1.0), axis=-1)

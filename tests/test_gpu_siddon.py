@@ -803,10 +803,10 @@ def test_whole_line_stores_change_no_bit(hip, n_rows, n_channels, n_mat, n_spec,
     assert torch.isfinite(res['1'][0]).all() and (res['1'][0] > 0).all()
 
 
-def test_get_sino_returns_page_locked_arrays_and_keys_the_cache_in_constant_time(hip, monkeypatch):
+def test_get_sino_returns_page_locked_arrays_and_verifies_the_cached_volume(hip, monkeypatch):
     """Public boundary (NumPy in / NumPy out): results arrive through pinned memory that belongs to the
-    returned arrays; the device-resident state is keyed on the phantom's version counter + a 4096-voxel sample instead of
-    a checksum of the whole volume: assigning ``volume`` or ``touch()`` after an in-place edit rebuilds it."""
+    returned arrays; the device-resident state is found by an O(1) key (version counter + a strided sample) and VERIFIED
+    by a whole-volume checksum that runs on a helper thread while the GPU works; DEXCT_VERIFY_VOLUME=0 opts out."""
     import dex_ct_sim_amd as dx
     from dex_ct_sim_amd import forward_project as fp
     ct, ph = small_scan(n=48, nz=4, n_views=20, n_channels=48, n_rows=4)
@@ -816,24 +816,49 @@ def test_get_sino_returns_page_locked_arrays_and_keys_the_cache_in_constant_time
     assert torch.from_numpy(raw).is_pinned()
     raw2, _ = dx.get_sino(ct, ph, sp)
     assert np.array_equal(raw, raw2) and not np.shares_memory(raw, raw2)       # each result owns its buffer
-    pj = fp._projector(ct, ph, (0, 20))
-    assert fp._projector(ct, ph, (0, 20)) is pj                                  # reused
-    calls = []
-    real = fp._hash64
-    monkeypatch.setattr(fp, '_hash64', lambda a: (calls.append(np.asarray(a).size), real(a))[1])
-    fp._projector(ct, ph, (0, 20))
-    assert max(calls) <= 4096                                                    # never the whole volume
+    pj, check = fp._projector(ct, ph, (0, 20))
+    assert check is not None and check.result() == pj.volume_hash              # found in the cache: checksum under way
+    assert fp._projector(ct, ph, (0, 20))[0] is pj                               # reused
     ph.volume[:, 10:30, 10:30] = 2                                               # in-place edit, announced
     ph.touch()
     raw3, _ = dx.get_sino(ct, ph, sp)
-    assert fp._projector(ct, ph, (0, 20)) is not pj and not np.array_equal(raw3, raw)
+    assert fp._projector(ct, ph, (0, 20))[0] is not pj and not np.array_equal(raw3, raw)
     ph.volume = np.zeros_like(ph.volume)                                         # assignment bumps the version by itself
     raw4, log4 = dx.get_sino(ct, ph, sp)
     assert np.allclose(log4, np.log(np.float32(fp.effective_weights(ct, sp).sum()) / raw4), atol=1e-6)
-    monkeypatch.setattr(fp, 'verify_volume', True)                               # opt-in: every byte hashed
-    calls.clear()
-    fp._projector(ct, ph, (0, 20))
-    assert max(calls) == ph.volume.size
+    # opt-out: the key alone, never more than the sample is hashed
+    monkeypatch.setenv('DEXCT_VERIFY_VOLUME', '0')
+    calls = []
+    real = fp._hash64
+    monkeypatch.setattr(fp, '_hash64', lambda a: (calls.append(np.asarray(a).size), real(a))[1])
+    assert fp._projector(ct, ph, (0, 20))[1] is None
+    assert max(calls) <= 4200
+
+
+@pytest.mark.parametrize('n,nz,rows', [(64, 64, 64), (128, 1, 1)])
+def test_get_sino_sees_unannounced_in_place_edits_of_power_of_two_volumes(hip, n, nz, rows):
+    """Advisor finding of round 3: with a sample stride that is a multiple of Nx (every power-of-two volume) all sampled
+    voxels lie in the x = 0 face and an in-place edit of the interior WITHOUT touch() returned the stale sinogram.  Now the
+    whole volume is checksummed (beside the GPU work) and the stride of the sample is coprime to the dimensions."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    ct, ph = small_scan(n=n, nz=nz, n_views=16, n_channels=64, n_rows=rows)
+    sp = spectra()[0]
+    a, _ = dx.get_sino(ct, ph, sp)
+    b, _ = dx.get_sino(ct, ph, sp)
+    assert np.array_equal(a, b)
+    ph.volume[nz // 2, n // 2 - 4:n // 2 + 4, n // 2 - 4:n // 2 + 4] = 2        # interior block, no touch()
+    c, _ = dx.get_sino(ct, ph, sp)
+    assert not np.array_equal(a, c)
+    ct2, ph2 = small_scan(n=n, nz=nz, n_views=16, n_channels=64, n_rows=rows)
+    ph2.volume[nz // 2, n // 2 - 4:n // 2 + 4, n // 2 - 4:n // 2 + 4] = 2
+    d, _ = dx.get_sino(ct2, ph2, sp)
+    assert np.array_equal(c, d)
+    # the strided sample itself now reaches the interior: for these shapes the samples cover many x, y and z
+    step = fp._sample_step(ph.volume.shape)
+    idx = np.arange(0, ph.volume.size, step)
+    z, y, x = np.unravel_index(idx, ph.volume.shape)
+    assert len(np.unique(x)) > 16 and len(np.unique(y)) > 16 and (nz == 1 or len(np.unique(z)) > 16)
 
 
 def test_integration_md_get_sino_stub_runs(hip):

@@ -111,11 +111,11 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.dexct_abi_version.restype = ctypes.c_int
-    assert lib.dexct_abi_version() == 2 == _native.ABI_VERSION
+    assert lib.dexct_abi_version() == 3 == _native.ABI_VERSION
     lib.dexct_strerror.restype = ctypes.c_char_p
     assert lib.dexct_strerror(-2) == b'size out of supported range'
     # struct layouts the binding mirrors
-    assert ctypes.sizeof(_native.FanGeom) == 72 and _native.PLAN_BYTES == 40
+    assert ctypes.sizeof(_native.FanGeom) == 72 and _native.PLAN_BYTES == 40 and ctypes.sizeof(_native.GnOptions) == 24
 
 
 def test_product_does_not_import_oracle():
@@ -176,12 +176,16 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_sino_log(one, None, 2, 16, one, None) == EINVAL and lib.dexct_sino_log(one, (C.c_float * 5)(), 5, 16, one, None) == ERANGE
     assert C.sizeof(_native.LogOut) == 24
     assert lib.dexct_add_noise(one, one, 2, 4, 1, 8, 2, 0, 1, None) == EINVAL
-    assert lib.dexct_gn_decompose(one, one, 1, 0, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == EINVAL    # no pixels
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 2, 0, None, 0.0, one, one, None) == EINVAL    # precision
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 8, 1, 5, 1, 0, None, 0.0, one, one, None) == EINVAL    # mixed + per-bin
+    assert lib.dexct_gn_decompose(one, one, 1, 0, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, None, one, None) == EINVAL    # no pixels
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 2, 0, None, 0.0, one, None, one, None) == EINVAL    # precision
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 8, 1, 5, 1, 0, None, 0.0, one, None, one, None) == EINVAL    # mixed + per-bin
     al = C.c_void_p(16)      # out_a must be 16-byte aligned (a pixel's pair is one 16-byte store)
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, None, 0.0, al, one, None) == ERANGE   # energies
-    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, one, None) == EINVAL    # out_a misaligned
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 5000, 1, 1, 5, 0, 0, None, 0.0, al, None, one, None) == ERANGE   # energies
+    assert lib.dexct_gn_decompose(one, one, 1, 4, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, one, None, one, None) == EINVAL    # out_a misaligned
+    # dexct_gn_options: the result order needs n_pix = k * rows * channels; kernel ids 0..2
+    assert lib.dexct_gn_decompose(one, one, 1, 12, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, al, _native.gn_options(0.0, 5, 2), one, None) == EINVAL
+    assert lib.dexct_gn_decompose(one, one, 1, 12, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, al, _native.gn_options(0.0, 3, 0), one, None) == EINVAL
+    assert lib.dexct_gn_decompose(one, one, 1, 12, one, one, 10, 1, 1, 5, 0, 0, None, 0.0, al, _native.gn_options(0.0, 0, 0, 3), one, None) == EINVAL
     assert lib.dexct_gn_workspace_bytes(140, 1) > 140 * 14 * 12 and lib.dexct_gn_workspace_bytes(0, 1) == 0
     # the guarded cone-beam layout (include/dexct.h): (nx ny + 1) columns of ((nz + 15) & ~15) + 32 bytes
     for nx, ny, nz in ((3, 5, 1), (8, 8, 16), (20, 17, 300), (512, 512, 512)):
@@ -240,3 +244,44 @@ def test_analysis_helpers_without_gpu():
         (2 * M).tofile(os.path.join(sub, 'mat2_recon_float32.bin'))
         a, b = plots.get_img_basismats('p', '140kV', '80kV', 5, 5, crop=4, N_matrix=10, out_dir=d)
         assert a.shape == (4, 4) and np.array_equal(b, 2 * a)
+
+
+def test_register_table_replaces_cached_mixtures():
+    """Advisor finding of round 3: registering a table again under an EXISTING name (element or whole formula) must
+    change what mixatten returns - the mixture cache is emptied by register_table."""
+    from dex_ct_sim_amd import xcompy
+    E = np.array([10.0, 100.0, 1000.0])
+    q = np.array([50.0, 200.0])
+    saved = dict(xcompy._user_tables)
+    try:
+        xcompy.register_table('Zz(100)', E, [1.0, 0.5, 0.1])
+        a = xcompy.mixatten('Zz(100)', q)
+        assert np.array_equal(a, xcompy.mixatten('Zz(100)', q))
+        xcompy.register_table('Zz(100)', E, [2.0, 1.0, 0.2])                  # same name, same table count
+        b = xcompy.mixatten('Zz(100)', q)
+        assert np.allclose(b, 2.0 * a)
+        xcompy.register_table('H', E, [0.4, 0.3, 0.1])
+        w1 = xcompy.mixatten('H(11.2)O(88.8)', q)
+        xcompy.register_table('H', E, [0.8, 0.6, 0.2])                        # an element under a mixture
+        w2 = xcompy.mixatten('H(11.2)O(88.8)', q)
+        assert np.all(w2 > w1)
+    finally:
+        xcompy._user_tables.clear()
+        xcompy._user_tables.update(saved)
+        xcompy._mix_cache.clear()
+
+
+def test_volume_sample_stride_is_coprime_to_the_dimensions():
+    """The O(1) cache key samples ~4096 voxels; for power-of-two volumes a stride of size / 4096 is a multiple of Nx and
+    only ever sees the x = 0 face (advisor finding of round 3)."""
+    from math import gcd
+    from dex_ct_sim_amd import forward_project as fp
+    for shape in ((256, 256, 256), (512, 512, 512), (1024, 1024, 1024), (1, 512, 512), (48, 48, 1), (300, 200, 100), (3, 5, 7)):
+        step = fp._sample_step(shape)
+        size = int(np.prod(shape))
+        assert all(d == 1 or gcd(step, d) == 1 for d in shape)
+        assert size / step <= 4200 and (size < 4096 or size / step >= 2000)
+        idx = np.arange(0, size, step)
+        z, y, x = np.unravel_index(idx, shape)
+        for coord, d in ((x, shape[2]), (y, shape[1]), (z, shape[0])):
+            assert len(np.unique(coord)) >= min(d, 16)

@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: gloo, world_size 2 (and 3 for ragged shards)."""
+"""Multi-rank path on CPU: gloo, world_size 2, 3 (ragged shards) and 8 (the node the path is built for)."""
 import os
 import sys
 
@@ -19,16 +19,24 @@ def _worker(rank, world, port, n_views, q):
     full = torch.arange(2 * n_views * 3 * 5, dtype=torch.float32).reshape(2, n_views, 3, 5)
     b, e = _shard.my_views(n_views)
     got = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1)
+    # results of the public path are owned by the caller: a second gather of the same shape must not overwrite the first
+    # (advisor finding of round 3); only reuse_out=True hands out the cached buffer
+    again = _shard.gather_views((full[:, b:e] + 1.0).contiguous(), n_views, view_dim=1)
+    owned = bool(torch.equal(got, full) and torch.equal(again, full + 1.0) and got.data_ptr() != again.data_ptr())
+    r1 = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, tag='t', reuse_out=True)
+    r2 = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, tag='t', reuse_out=True)
+    owned = owned and r1.data_ptr() == r2.data_ptr() and bool(torch.equal(r2, full))
     mx = _shard.global_max(torch.tensor(float(rank + 1), dtype=torch.float64))
     # np.max semantics over ranks (matdecomp.py:195-196): one rank's NaN makes the global maximum NaN on every rank;
     # -inf on a rank (an empty shard) does not disturb the others' values
     nan_mx = _shard.global_max(torch.tensor(float('nan') if rank == world - 1 else 5.0, dtype=torch.float64))
     inf_mx = _shard.global_max(torch.tensor(float('-inf') if rank == 0 else 2.5, dtype=torch.float64))
-    q.put((rank, (b, e), bool(torch.equal(got, full)), float(mx), float(nan_mx), float(inf_mx)))
+    q.put((rank, (b, e), bool(torch.equal(got, full)) and owned, float(mx), float(nan_mx), float(inf_mx)))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n_views', [(2, 10), (2, 7), (3, 8)])
+# world 8 is the target (BASELINE configs[2] 1000 views, configs[3]/[4] 2000 views; 1003: ragged shards of 126 and 125)
+@pytest.mark.parametrize('world,n_views', [(2, 10), (2, 7), (3, 8), (8, 1000), (8, 2000), (8, 1003)])
 def test_gather_views_and_global_max(world, n_views):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -36,9 +44,9 @@ def test_gather_views_and_global_max(world, n_views):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     covered = []
     for rank, (b, e), ok, mx, nan_mx, inf_mx in res:
