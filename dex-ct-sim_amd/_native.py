@@ -14,7 +14,7 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
            'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
            'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather',
-           'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
+           'dexct_volume_ids', 'dexct_volume_remap', 'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
 
 
 class FanGeom(C.Structure):
@@ -81,6 +81,8 @@ def load():
         raise DexctError(f'ABI version mismatch: library {lib.dexct_abi_version()}, binding {ABI_VERSION}')
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     lib.dexct_volume_layouts.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.dexct_volume_ids.argtypes = [vp, i64, vp, vp]
+    lib.dexct_volume_remap.argtypes = [vp, i64, C.POINTER(C.c_uint8), vp]
     lib.dexct_fan_plan.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp]
     lib.dexct_siddon_project.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                                          vp, i32, i32, vp, vp, vp, vp]

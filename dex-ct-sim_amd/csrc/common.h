@@ -24,6 +24,19 @@ inline int hip_fail(hipError_t e) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// More than 64 KB of dynamic LDS for one workgroup (gfx950: 160 KB): say so to the runtime before the launch.
+#define DEXCT_ALLOW_LDS(kernel, bytes)                                                                              \
+  do {                                                                                                               \
+    if ((size_t)(bytes) > 160u * 1024u) return DEXCT_ERANGE;                                                          \
+    if ((size_t)(bytes) > 64u * 1024u)                                                                               \
+      DEXCT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)(bytes)));                                                              \
+  } while (0)
+
+// Kernels that keep per-material sums in per-lane LDS columns run 128 lanes per workgroup up to 48 materials (48 KB) and 64
+// lanes beyond (2 x 256 x 64 x 4 B = 128 KB at the full uint8 range): the general path, not a fast one.
+constexpr int kManyMaterials = 48;
+
 constexpr int kWave = 64;
 
 struct SlabPieces {

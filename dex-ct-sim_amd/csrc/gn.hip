@@ -124,48 +124,74 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
 // instructions per energy), bit for bit the same result.
 struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; };
 
-__device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
-                                                EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
+// The 12 sums over energy a Newton step needs.  NPARTS = 1: all energies (the one-lane-per-pixel kernels).  NPARTS > 1:
+// share `part` of them - every class range is cut into NPARTS contiguous pieces - for the cooperative kernel, whose waves
+// split the energy loop of the same 64 pixels.
+struct GnSums { double nu[2], G0[2], G1[2], H00[2], H01[2], H11[2]; };
+
+template <int NPARTS>
+__device__ __forceinline__ void newton_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
+                                                EnergyClasses ec, int part, double a0, double a1, GnSums& s) {
   double nu[2] = {0, 0}, nuo[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
   const int bA = 0, bB = ec.nA, bC = ec.nA + ec.nB;
+  auto lo = [&](int b, int e) { return NPARTS == 1 ? b : b + (e - b) * part / NPARTS; };
+  auto hi = [&](int b, int e) { return NPARTS == 1 ? e : b + (e - b) * (part + 1) / NPARTS; };
   // the always-clipped heads of the three classes
-  energy_sums_f64<0, true>(tab, lds_pow, bA, bA + ec.nAc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<1, true>(tab, lds_pow, bB, bB + ec.nBc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<2, true>(tab, lds_pow, bC, bC + ec.nCc, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<0, true>(tab, lds_pow, lo(bA, bA + ec.nAc), hi(bA, bA + ec.nAc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<1, true>(tab, lds_pow, lo(bB, bB + ec.nBc), hi(bB, bB + ec.nBc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<2, true>(tab, lds_pow, lo(bC, bC + ec.nCc), hi(bC, bC + ec.nCc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
+  const int tA0 = lo(bA + ec.nAc, bA + ec.nA), tA1 = hi(bA + ec.nAc, bA + ec.nA);
+  const int tB0 = lo(bB + ec.nBc, bB + ec.nB), tB1 = hi(bB + ec.nBc, bB + ec.nB);
+  const int tC0 = lo(bC + ec.nCc, bC + ec.nC), tC1 = hi(bC + ec.nCc, bC + ec.nC);
   if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 699.9) {
-    energy_sums_f64<0, false>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, false>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, false>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, false>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, false>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, false>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   } else {
-    energy_sums_f64<0, true>(tab, lds_pow, bA + ec.nAc, bA + ec.nA, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, true>(tab, lds_pow, bB + ec.nBc, bB + ec.nB, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, true>(tab, lds_pow, bC + ec.nCc, bC + ec.nC, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, true>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, true>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, true>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   }
-  nu[0] += nuo[0];
-  nu[1] += nuo[1];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    s.nu[k] = nu[k] + nuo[k];
+    s.G0[k] = G0[k]; s.G1[k] = G1[k]; s.H00[k] = H00[k]; s.H01[k] = H01[k]; s.H11[k] = H11[k];
+  }
+}
+
+// The step from the sums: residuals, gradient, Hessian incl. the (g/nu - 1) * hessian term (matdecomp.py:122-123), closed-form
+// 2x2 solve (:125).
+__device__ __forceinline__ void newton_solve_f64(const GnSums& s, double g0, double g1, double& a0, double& a1) {
   const double g[2] = {g0, g1};
   double c[2], q[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const double inv = rcp_f64(nu[k]), ratio = g[k] * inv;
+    const double inv = rcp_f64(s.nu[k]), ratio = g[k] * inv;
     // g / nu - 1 (matdecomp.py:122) as (g - nu) / nu: near the solution the subtraction is exact, so the residual
     // carries the rounding of nu only, not an extra half ulp of 1 from the quotient - the last-bit wandering of the
     // iterate is shorter again (mean executed iterations 28.6 -> 24.7).  An overflowed nu (inf) keeps the reference's
     // value: g / inf - 1 = -1.
-    c[k] = fabs(nu[k]) < __builtin_huge_val() ? (g[k] - nu[k]) * inv : ratio - 1.0;
+    c[k] = fabs(s.nu[k]) < __builtin_huge_val() ? (g[k] - s.nu[k]) * inv : ratio - 1.0;
     q[k] = ratio * inv;                                        // g / nu^2 (matdecomp.py:123)
   }
   // the sums over the two measurements, first term + second term (a running sum started at 0 costs an addition of 0
   // per sum that the compiler may not drop: 0 + (-0) is +0)
-  const double dF0 = c[0] * G0[0] + c[1] * G0[1];
-  const double dF1 = c[0] * G1[0] + c[1] * G1[1];
-  const double h00 = (q[0] * (G0[0] * G0[0]) - c[0] * H00[0]) + (q[1] * (G0[1] * G0[1]) - c[1] * H00[1]);
-  const double h01 = (q[0] * (G0[0] * G1[0]) - c[0] * H01[0]) + (q[1] * (G0[1] * G1[1]) - c[1] * H01[1]);
-  const double h11 = (q[0] * (G1[0] * G1[0]) - c[0] * H11[0]) + (q[1] * (G1[1] * G1[1]) - c[1] * H11[1]);
+  const double dF0 = c[0] * s.G0[0] + c[1] * s.G0[1];
+  const double dF1 = c[0] * s.G1[0] + c[1] * s.G1[1];
+  const double h00 = (q[0] * (s.G0[0] * s.G0[0]) - c[0] * s.H00[0]) + (q[1] * (s.G0[1] * s.G0[1]) - c[1] * s.H00[1]);
+  const double h01 = (q[0] * (s.G0[0] * s.G1[0]) - c[0] * s.H01[0]) + (q[1] * (s.G0[1] * s.G1[1]) - c[1] * s.H01[1]);
+  const double h11 = (q[0] * (s.G1[0] * s.G1[0]) - c[0] * s.H11[0]) + (q[1] * (s.G1[1] * s.G1[1]) - c[1] * s.H11[1]);
   const double inv_det = rcp_f64(h00 * h11 - h01 * h01);
   a0 -= (h11 * dF0 - h01 * dF1) * inv_det;
   a1 -= (h00 * dF1 - h01 * dF0) * inv_det;
+}
+
+__device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
+                                                EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
+  GnSums s;
+  newton_sums_f64<1>(tab, lds_pow, ec, 0, a0, a1, s);
+  newton_solve_f64(s, g0, g1, a0, a1);
 }
 
 // float32 table layout per energy: [mu0*log2e, mu1*log2e, then for c in {1, mu0, mu1, mu0^2, mu0mu1, mu1^2}:
@@ -219,8 +245,18 @@ __device__ __forceinline__ void newton_step_f32(const float* __restrict__ tab, E
 // [10] = (uint64, progress) pixels that launch has handed to its waves so far (added tile by tile while it runs),
 // [11] = (uint64) head of the tile queue, [12] = (uint64, diagnostic) lane-steps spent without a pixel because all of a
 // wave's result slots were waiting for stragglers,
-// pad to 16, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation).
+// pad to 16, then [n_e][14] float64, then [n_e][14] float32, then n_e ints (the permutation), then (16-byte aligned) the
+// tile-order region of gn_tile_* below: kSortBuckets ints (histogram), kMaxSortTiles ints (the order), kMaxSortTiles
+// uint16 (keys).
 constexpr int kWsHeader = 16;
+constexpr int kSortBuckets = 2048;         // sign + exponent + 2 mantissa bits of a positive float32
+constexpr int kMaxSortTiles = 32768;       // 2.1e6 pixels: beyond that the order of the hand-out does not matter (profiles/r04_gn.md)
+
+__host__ __device__ inline size_t gn_ws_tables_bytes(int n_e, int n_bins) {
+  const size_t b = sizeof(double) * kWsHeader + (size_t)n_bins * n_e * kTab * sizeof(double) + (size_t)n_e * kTab * sizeof(float) +
+                   (size_t)n_bins * n_e * sizeof(int);
+  return (b + 15) & ~(size_t)15;
+}
 
 // One block per spectrum row ("bin": 1 for the channel-independent case, else one per detector channel).
 // i0 is [2][n_bins][n_e].  With several bins the energies are NOT sorted into classes (they may differ
@@ -286,6 +322,10 @@ __global__ __launch_bounds__(256) void gn_tables_kernel(const double* __restrict
       reinterpret_cast<unsigned long long*>(ws)[11] = 0ull;     // head of the tile queue of gn_refill_kernel
       reinterpret_cast<unsigned long long*>(ws)[12] = 0ull;     // lane-steps stalled on result slots
     }
+  }
+  if (bin == 0) {                       // the histogram of the tile sort starts at zero
+    int* hist = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + gn_ws_tables_bytes(n_e, n_bins));
+    for (int j = threadIdx.x; j < kSortBuckets; j += blockDim.x) hist[j] = 0;
   }
   __syncthreads();
   const double scale = s_scale;
@@ -535,6 +575,169 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
 }
 
 
+__device__ __forceinline__ const int* gn_tile_order(const unsigned long long* counters, int n_e) {      // counters = workspace word 9; shared-spectrum kernels: n_bins = 1
+  return reinterpret_cast<const int*>(reinterpret_cast<const char*>(counters - 9) + gn_ws_tables_bytes(n_e, 1)) + kSortBuckets;
+}
+
+// ---- order of the hand-out for SMALL sinograms: longest tiles first ---------------------------------------------------
+// The number of Newton iterations of a pixel grows with the attenuation along its ray (from the start value 1e-6 the
+// iteration walks about one unit of exponent per step before it converges quadratically: 7 iterations for a thin ray, 26
+// through the centre of the benchmark phantom), so the counts themselves say how long a tile will take.  When the sinogram
+// is so small that every lane sees only a few pixels (the reference's own scan: 9.6e5 pixels for 3.3e5 resident lanes), the
+// launch ends with whatever was handed out last; handing the thick tiles out FIRST leaves the thin ones for the end and
+// keeps the pixels a wave works on at any time alike: 2.50 -> 2.06 ms on the 1200 x 800 scan (tools/probes/gn_order.py).
+// A counting sort of the tiles by the smallest unmasked count of sinogram 1 in the tile (2048 buckets = the top bits of the
+// float32 value; all-air tiles last), three tiny kernels (keys + histogram, scan, scatter); up to kMaxSortTiles tiles.  The order only decides WHEN a pixel
+// is solved: results do not depend on it.
+// One atomic per wave and distinct key instead of one per lane (air tiles and the thick centre share few buckets: per-lane
+// atomics on those few addresses serialise - measured 2 ms at 6e4 tiles).  Returns this lane's rank among the lanes of the
+// wave with the same key, and *group_base = what the leader's atomicAdd(counter + key, group size) returned.
+__device__ __forceinline__ int wave_grouped_add(int* __restrict__ counter, int key, bool valid, int* group_base) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long rem = __ballot(valid);
+  int rank = 0, base = 0;
+  while (rem != 0ull) {
+    const int leader = __builtin_ctzll(rem);
+    const int k = __shfl(key, leader, 64);
+    const unsigned long long m = __ballot(valid && key == k);
+    int b = 0;
+    if (lane == leader) b = atomicAdd(counter + k, (int)__popcll(m));
+    b = __shfl(b, leader, 64);
+    if (valid && key == k) {
+      base = b;
+      rank = (int)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    rem &= ~m;
+  }
+  *group_base = base;
+  return rank;
+}
+
+// 64 tiles per workgroup: a wave reads a tile with one coalesced load per lane (16 tiles per wave, loads independent of
+// each other), reduces to the smallest unmasked count, and the first wave then adds the 64 keys to the histogram.
+__global__ __launch_bounds__(256) void gn_tile_key_kernel(const void* __restrict__ g1, int g_is_f64, long long n_pix, GnTiling tl,
+                                                          const double* __restrict__ mask_max, double mask_frac,
+                                                          int* __restrict__ hist, unsigned short* __restrict__ keys) {
+  __shared__ int skey[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int in_stride = tl.transposed ? tl.rows : 1;
+  const bool has_mask = mask_max != nullptr;
+  const float thresh = has_mask ? (float)(mask_frac * mask_max[0]) : 0.0f;
+  const int c_off = tl.transposed ? lane / kTileR : lane, r_off = tl.transposed ? lane % kTileR : 0;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int local = w * 16 + i;
+    const long long t = (long long)blockIdx.x * 64 + local;              // wave-uniform
+    if (t >= tl.n_tiles) continue;
+    const GnTile d = gn_decode_tile(tl, n_pix, t);
+    float v = __builtin_huge_valf();
+    if (c_off < d.nc && r_off < d.nr) {
+      const float x = load_g<float>(g1, g_is_f64, d.in_base + (long long)c_off * in_stride + r_off);
+      if (!(has_mask && x >= thresh)) v = (x == x) ? x : 0.0f;          // air pixels do not count; a NaN count sorts first
+    }
+    const bool any = __ballot(v < __builtin_huge_valf()) != 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    int key = kSortBuckets - 1;                                          // all air: last
+    if (any) {
+      key = (v > 0.0f) ? (int)(__float_as_uint(v) >> 21) : 0;            // ascending counts = descending attenuation; <= 0: first
+      key = key > kSortBuckets - 2 ? kSortBuckets - 2 : key;
+    }
+    if (lane == 0) {
+      skey[local] = key;
+      keys[t] = (unsigned short)key;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    const long long t = (long long)blockIdx.x * 64 + lane;
+    const bool valid = t < tl.n_tiles;
+    int unused;
+    wave_grouped_add(hist, valid ? skey[lane] : 0, valid, &unused);
+  }
+}
+
+// exclusive scan of the bucket counts, in place (one workgroup of 1024: 2 buckets per thread)
+__global__ __launch_bounds__(1024) void gn_tile_scan_kernel(int* __restrict__ hist) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+  int x = c0 + c1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wave_tot[w] = x;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < w; ++k) base += wave_tot[k];
+  const int excl = base + x - (c0 + c1);
+  hist[2 * tid] = excl;
+  hist[2 * tid + 1] = excl + c0;
+}
+
+__global__ __launch_bounds__(256) void gn_tile_scatter_kernel(int n_tiles, int* __restrict__ offs,
+                                                              const unsigned short* __restrict__ keys, int* __restrict__ order) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = t < n_tiles;
+  const int key = valid ? (int)keys[t] : 0;
+  int base;
+  const int rank = wave_grouped_add(offs, key, valid, &base);
+  if (valid) order[base + rank] = t;
+}
+
+// The exit logic of one Newton step, shared by the lane-refill and the cooperative kernel: given the state before the step
+// (a0, a1), the state after it (n0, n1), the history and the lane's iteration counter, either advance (returns true) or end
+// the pixel with (a0, a1) = what all n_iters iterations would return (repeated state) / the converged state (tolerance).
+__device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_iters, int exact_exit, double stop_tol,
+                                                   double& a0, double& a1, int& it, long long (&h0)[kGnHistory],
+                                                   long long (&h1)[kGnHistory]) {
+  int hit = -2;
+  if (exact_exit) {
+    const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
+    if (b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1)) hit = -1;
+#pragma unroll
+    for (int k = kGnHistory - 1; k >= 0; --k)
+      if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
+  }
+  const bool converged = gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it);
+  const bool advance = hit == -2 && !converged;
+  // the state a cycle holds at iteration n_iters: s_m = s_{base + (m - base) mod period} for m >= base = it-1-hit,
+  // and (n_iters - base) = (n_iters - it - 1) mod period; s_{base+j} is hist[hit-j], s_it the current state (slot -1)
+  int slot = -1;
+  if (hit >= 0) {
+    const int period = hit + 2, x = n_iters - it - 1;
+    int r;
+    if (n_iters < (1 << 22)) {            // wave-uniform; small x: quotient by a float reciprocal, then corrected
+      const int q = (int)((float)x * __builtin_amdgcn_rcpf((float)period));
+      r = x - q * period;
+      r += r < 0 ? period : 0;
+      r -= r >= period ? period : 0;
+    } else {
+      r = x % period;
+    }
+    slot = hit - r;
+  }
+  double f0 = converged ? n0 : a0, f1 = converged ? n1 : a1;
+  if (__ballot(slot >= 0) != 0ull) {
+#pragma unroll
+    for (int k = 0; k < kGnHistory; ++k)
+      if (slot == k) { f0 = __longlong_as_double(h0[k]); f1 = __longlong_as_double(h1[k]); }
+  }
+#pragma unroll
+  for (int k = kGnHistory - 1; k > 0; --k) {
+    h0[k] = advance ? h0[k - 1] : h0[k];
+    h1[k] = advance ? h1[k - 1] : h1[k];
+  }
+  h0[0] = advance ? __double_as_longlong(a0) : h0[0];
+  h1[0] = advance ? __double_as_longlong(a1) : h1[0];
+  a0 = advance ? n0 : f0;
+  a1 = advance ? n1 : f1;
+  it += advance ? 1 : 0;
+  return advance;
+}
+
 // float64, one shared spectrum - the benchmark's path - with lane refill.  The exits end pixels at very different
 // iterations (from 10 to all of n_iters), and a wave is as slow as its slowest lane.  Here every lane whose pixel has ended
 // takes the next pixel of the wave's current tile, and a wave whose tile is handed out fetches the next tile from a global
@@ -547,11 +750,13 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
                                                              int g_is_f64, long long n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, GnTiling tl,
                                                              const double* __restrict__ mask_max, double mask_frac,
-                                                             int exact_exit, double stop_tol,
+                                                             int flags, double stop_tol,      // flags: bit 0 exact repeated-state exit, bit 1 sorted hand-out
                                                              double* __restrict__ out_a,
-                                                             unsigned long long* __restrict__ executed,
-                                                             unsigned long long* __restrict__ queue) {
+                                                             unsigned long long* __restrict__ counters) {
   typedef double d2 __attribute__((ext_vector_type(2)));
+  // `counters` = the workspace words 9.. (executed, progress, queue head, stalls): ONE pointer, and the tile order is found
+  // from it too (the table pointer `ws` stays read-only for the compiler: its loads are scalar loads)
+  auto counter = [&](int k) { return counters + (k - 9); };
   __shared__ double lds_pow[kPowN];                                      // 16 KB
   __shared__ d2 lds_out[kGnBlock / kWave][kSlots * kTilePix];            // 16 KB: with the table 32 KB = 5 workgroups per CU
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
@@ -624,10 +829,11 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
         for (int k = kSlots - 1; k >= 0; --k) s = tid[k] < 0 ? k : s;
         if (s < 0) { n_stall += (unsigned)__popcll(want); break; }     // every slot still waits for a straggler
         long long t = 0;
-        if (lane == 0) t = (long long)atomicAdd(queue, 1ull);
+        if (lane == 0) t = (long long)atomicAdd(counter(11), 1ull);
         t = ((long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
             (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
         if (t >= tl.n_tiles) { exhausted = true; break; }
+        if (flags & 2) t = gn_tile_order(counters, n_e)[t];     // queue position -> tile (thick tiles first, see gn_tile_key_kernel)
         ct = gn_decode_tile(tl, n_pix, t);
         const int n_valid = ct.nr * ct.nc;
 #pragma unroll
@@ -635,7 +841,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
         pend += (unsigned)n_valid << (8 * s);
         cur = s;
         next_j = 0;
-        if (executed && lane == 0) atomicAdd(executed + 1, (unsigned long long)n_valid);        // progress: handed to a wave
+        if (lane == 0) atomicAdd(counter(10), (unsigned long long)n_valid);        // progress: handed to a wave
       }
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
       const int j = next_j + rank;
@@ -679,48 +885,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     // same exit rule as gn_kernel: s_{it+1} equal to s_it (fixed point) or to hist[k] = s_{it-1-k} (cycle of
     // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
     // through it too and are ignored.
-    int hit = -2;
-    if (exact_exit) {
-      const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
-      if (b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1)) hit = -1;
-#pragma unroll
-      for (int k = kGnHistory - 1; k >= 0; --k)
-        if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
-    }
-    const bool converged = gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it);
-    const bool advance = hit == -2 && !converged;
-    // the state a cycle holds at iteration n_iters: s_m = s_{base + (m - base) mod period} for m >= base = it-1-hit,
-    // and (n_iters - base) = (n_iters - it - 1) mod period; s_{base+j} is hist[hit-j], s_it the current state (slot -1)
-    int slot = -1;
-    if (hit >= 0) {
-      const int period = hit + 2, x = n_iters - it - 1;
-      int r;
-      if (n_iters < (1 << 22)) {            // wave-uniform; small x: quotient by a float reciprocal, then corrected
-        const int q = (int)((float)x * __builtin_amdgcn_rcpf((float)period));
-        r = x - q * period;
-        r += r < 0 ? period : 0;
-        r -= r >= period ? period : 0;
-      } else {
-        r = x % period;
-      }
-      slot = hit - r;
-    }
-    double f0 = converged ? n0 : a0, f1 = converged ? n1 : a1;
-    if (__ballot(slot >= 0) != 0ull) {
-#pragma unroll
-      for (int k = 0; k < kGnHistory; ++k)
-        if (slot == k) { f0 = __longlong_as_double(h0[k]); f1 = __longlong_as_double(h1[k]); }
-    }
-#pragma unroll
-    for (int k = kGnHistory - 1; k > 0; --k) {
-      h0[k] = advance ? h0[k - 1] : h0[k];
-      h1[k] = advance ? h1[k - 1] : h1[k];
-    }
-    h0[0] = advance ? __double_as_longlong(a0) : h0[0];
-    h1[0] = advance ? __double_as_longlong(a1) : h1[0];
-    a0 = advance ? n0 : f0;
-    a1 = advance ? n1 : f1;
-    it += advance ? 1 : 0;
+    const bool advance = gn_exit_or_advance(n0, n1, n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1);
     const bool fin = ent >= 0 && (!advance || it >= n_iters);
     const unsigned long long fb = __ballot(fin);
     if (fb != 0ull) {
@@ -739,10 +904,133 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
       settle(fb, my_slot);
     }
   }
-  if (executed && lane == 0) {
-    atomicAdd(executed, (unsigned long long)n_exec);            // one atomic per wave
-    if (n_stall) atomicAdd(executed + 3, (unsigned long long)n_stall);
+  if (lane == 0) {
+    atomicAdd(counter(9), (unsigned long long)n_exec);            // one atomic per wave
+    if (n_stall) atomicAdd(counter(12), (unsigned long long)n_stall);
   }
+}
+
+// COOPERATIVE Newton kernel for sinograms too small to fill the chip with one pixel per lane (the reference's own scan:
+// 1200 x 800 x 1 row = 9.6e5 pixels, input/params.txt:21-22, for 3.3e5 resident lanes - the launch then lasts as long as the
+// few pixels that need all n_iters iterations, each of them one lane's 3 900 instructions per iteration).  Here the kCoopWaves
+// waves of a workgroup work on the SAME 64 pixels: every wave keeps the full state of all 64 (replicated, deterministic),
+// sums its own share of the energies (wave-uniform energy index: the tables still arrive as scalar operands), the partial
+// sums meet in LDS, and every wave adds them in the same fixed order and takes the same step: 2.6 x less latency per
+// iteration for 1.5 x the instructions.  Lanes are refilled from the tile queue exactly as in gn_refill_kernel; a tile id is
+// fetched by wave 0 and handed to the others through LDS.  The energy sums are formed in another order than in the
+// one-lane kernel (per wave, then ((w0 + w1) + (w2 + w3))): results agree with it to rounding (and with the reference's
+// goldens to 1e-9), not bit for bit; within this kernel the update is still a pure function of the state, so the exact
+// repeated-state exit holds.
+constexpr int kCoopWaves = 4;
+constexpr long long kCoopBelowDefault = 100000;      // pixels; measured crossover (1.5e4: 0.31 vs 0.55 ms, 5e4: 0.37 vs 0.55,
+                                                     // 1e5: 0.57 vs 0.58, 1.8e5: 0.75 vs 0.74, 9.6e5: 2.6 vs 2.2; profiles/r04_gn.md)
+
+__global__ __launch_bounds__(kCoopWaves * kWave, 3) void gn_coop_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
+                                                                     int g_is_f64, long long n_pix, const double* __restrict__ ws,
+                                                                     int n_e, int n_iters, GnTiling tl,
+                                                                     const double* __restrict__ mask_max, double mask_frac,
+                                                                     int flags, double stop_tol, double* __restrict__ out_a,
+                                                                     unsigned long long* __restrict__ counters) {
+  auto counter = [&](int k) { return counters + (k - 9); };
+  __shared__ double lds_pow[kPowN];                                      // 16 KB
+  __shared__ double lds_part[kCoopWaves][12][kWave];                     // 24 KB: the partial sums of one step
+  __shared__ long long lds_tile[2];
+  for (int j = threadIdx.x; j < kPowN; j += kCoopWaves * kWave) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
+  __syncthreads();
+  const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
+  const double* __restrict__ tab = ws + kWsHeader;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool writer = wave == 0;                                         // wave 0 talks to memory (results, queue, counters)
+  const bool has_mask = mask_max != nullptr;
+  const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
+  const int in_stride = tl.transposed ? tl.rows : 1, out_stride = tl.transposed ? tl.channels : 0;
+
+  // every wave holds the same values in all of these
+  GnTile ct{0, 0, 0, 0};
+  int next_j = kTilePix, fetches = 0;
+  bool exhausted = false;
+  unsigned n_exec = 0;
+  long long pout = -1;                    // where this lane's result goes, -1: no pixel
+  double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
+  int it = 0;
+  long long h0[kGnHistory], h1[kGnHistory];
+#pragma unroll
+  for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
+
+  for (;;) {
+    unsigned long long want = __ballot(pout < 0);
+    while (want != 0ull) {
+      if (next_j >= kTilePix) {
+        if (exhausted) break;
+        // one tile id for the whole workgroup: fetched by wave 0, read by all (two LDS words used in turn: a wave that runs
+        // ahead to the NEXT fetch writes the other word, and cannot reach the one after before everybody has passed this barrier)
+        if (writer && lane == 0) lds_tile[fetches & 1] = (long long)atomicAdd(counter(11), 1ull);
+        __syncthreads();
+        long long t = lds_tile[fetches & 1];
+        t = ((long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+            (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        ++fetches;
+        if (t >= tl.n_tiles) { exhausted = true; break; }
+        if (flags & 2) t = gn_tile_order(counters, n_e)[t];
+        ct = gn_decode_tile(tl, n_pix, t);
+        next_j = 0;
+        if (writer && lane == 0) atomicAdd(counter(10), (unsigned long long)(ct.nr * ct.nc));
+      }
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+      const int j = next_j + rank;
+      if (pout < 0 && j < kTilePix) {
+        const int c_off = tl.transposed ? j / kTileR : j, r_off = tl.transposed ? j % kTileR : 0;
+        if (c_off < ct.nc && r_off < ct.nr) {
+          const long long np = ct.in_base + (long long)c_off * in_stride + r_off;
+          const long long po = ct.out_base + (long long)r_off * out_stride + c_off;
+          gd0 = load_g<double>(g1, g_is_f64, np);
+          gd1 = load_g<double>(g2, g_is_f64, np);
+          if (has_mask && gd0 >= thresh) {             // air (matdecomp.py:195-196, :204-205): 0, not iterated
+            if (writer) store_a(out_a, po, 0.0, 0.0);
+          } else if (n_iters <= 0) {
+            if (writer) store_a(out_a, po, 1e-6, 1e-6);
+          } else {
+            pout = po; a0 = 1e-6; a1 = 1e-6; it = 0;
+          }
+        }
+      }
+      next_j += __popcll(want);
+      want = __ballot(pout < 0);
+    }
+    const unsigned long long busy = __ballot(pout >= 0);
+    if (busy == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    n_exec += (unsigned)__popcll(busy);
+    // this wave's share of the energies
+    GnSums ps;
+    newton_sums_f64<kCoopWaves>(tab, lds_pow, ec, wave, a0, a1, ps);
+    {
+      double (*mine)[kWave] = lds_part[wave];
+      mine[0][lane] = ps.nu[0];  mine[1][lane] = ps.nu[1];
+      mine[2][lane] = ps.G0[0];  mine[3][lane] = ps.G0[1];
+      mine[4][lane] = ps.G1[0];  mine[5][lane] = ps.G1[1];
+      mine[6][lane] = ps.H00[0]; mine[7][lane] = ps.H00[1];
+      mine[8][lane] = ps.H01[0]; mine[9][lane] = ps.H01[1];
+      mine[10][lane] = ps.H11[0]; mine[11][lane] = ps.H11[1];
+    }
+    __syncthreads();
+    double tot[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q)                    // the same order in every wave: identical bits everywhere
+      tot[q] = (lds_part[0][q][lane] + lds_part[1][q][lane]) + (lds_part[2][q][lane] + lds_part[3][q][lane]);
+    __syncthreads();                                // the partial sums may be overwritten from here on
+    const GnSums s{{tot[0], tot[1]}, {tot[2], tot[3]}, {tot[4], tot[5]}, {tot[6], tot[7]}, {tot[8], tot[9]}, {tot[10], tot[11]}};
+    double n0 = a0, n1 = a1;
+    newton_solve_f64(s, gd0, gd1, n0, n1);
+    const bool advance = gn_exit_or_advance(n0, n1, n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1);
+    if (pout >= 0 && (!advance || it >= n_iters)) {
+      if (writer) store_a(out_a, pout, a0, a1);
+      pout = -1;
+    }
+  }
+  if (writer && lane == 0) atomicAdd(counter(9), (unsigned long long)n_exec);
 }
 
 __global__ __launch_bounds__(256) void mask_kernel(const void* __restrict__ g1, int g_is_f64, int64_t n_pix,
@@ -794,8 +1082,8 @@ extern "C" {
 
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins) {
   if (n_energies <= 0 || n_bins <= 0) return 0;
-  return (int64_t)sizeof(double) * kWsHeader + (int64_t)n_bins * n_energies * kTab * sizeof(double) +
-         (int64_t)n_energies * kTab * sizeof(float) + (int64_t)n_bins * n_energies * sizeof(int) + 16;
+  return (int64_t)gn_ws_tables_bytes(n_energies, n_bins) + (int64_t)kSortBuckets * sizeof(int) +
+         (int64_t)kMaxSortTiles * (sizeof(int) + sizeof(unsigned short));
 }
 
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
@@ -865,14 +1153,41 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const int64_t cap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : minw);
     int64_t nb = (tl.n_tiles + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     if (nb > cap) nb = cap;
-    unsigned long long* stat = reinterpret_cast<unsigned long long*>(ws) + 9;
-    unsigned long long* queue = reinterpret_cast<unsigned long long*>(ws) + 11;
-    if (minw == 4)
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(ws) + 9;
+    // the cooperative kernel below DEXCT_GN_COOP_BELOW pixels (options->kernel: 1 / 2 force one or the other)
+    const char* cbe = getenv("DEXCT_GN_COOP_BELOW");
+    const int64_t coop_below = cbe ? atoll(cbe) : kCoopBelowDefault;
+    const int which = options ? options->kernel : 0;
+    // small sinograms: thick tiles first (DEXCT_GN_SORT=0 keeps the natural order)
+    const int* order = nullptr;
+    const char* se = getenv("DEXCT_GN_SORT");
+    if (tl.n_tiles <= kMaxSortTiles && tl.n_tiles > 1 && !(se && se[0] == '0')) {
+      char* base = reinterpret_cast<char*>(workspace) + gn_ws_tables_bytes(n_energies, n_bins);
+      int* hist = reinterpret_cast<int*>(base);
+      int* ord = hist + kSortBuckets;
+      unsigned short* keys = reinterpret_cast<unsigned short*>(ord + kMaxSortTiles);
+      hipLaunchKernelGGL(gn_tile_key_kernel, dim3((unsigned)((tl.n_tiles + 63) / 64)), dim3(256), 0, st, g1, g_is_f64,
+                         (long long)n_pix, tl, mask_max, mask_frac, hist, keys);
+      DEXCT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(gn_tile_scan_kernel, dim3(1), dim3(1024), 0, st, hist);
+      DEXCT_LAUNCH_CHECK();
+      hipLaunchKernelGGL(gn_tile_scatter_kernel, dim3((unsigned)((tl.n_tiles + 255) / 256)), dim3(256), 0, st, (int)tl.n_tiles, hist,
+                         (const unsigned short*)keys, ord);
+      DEXCT_LAUNCH_CHECK();
+      order = ord;
+    }
+    if (which == 2 || (which == 0 && n_pix < coop_below)) {
+      int64_t ncb = tl.n_tiles;
+      const int64_t ccap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : 3);
+      if (ncb > ccap) ncb = ccap;
+      hipLaunchKernelGGL(gn_coop_kernel, dim3((unsigned)ncb), dim3(kCoopWaves * kWave), 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0), tol, out_a, counters);
+    } else if (minw == 4)
       hipLaunchKernelGGL((gn_refill_kernel<4>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0), tol, out_a, counters);
     else
       hipLaunchKernelGGL((gn_refill_kernel<5>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit, tol, out_a, stat, queue);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0), tol, out_a, counters);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, 0.0, tl, out_a);

@@ -190,7 +190,8 @@ extern "C" int dexct_poisson_detect(const float* pathlen, const float* mu, const
                      n_spectra, n_views, n_rows, n_channels, layout, view_offset, lo, hi, counts)
   if (n_materials <= 4) DEXCT_LAUNCH_POISSON(4);
   else if (n_materials <= 16) DEXCT_LAUNCH_POISSON(16);
-  else DEXCT_LAUNCH_POISSON(DEXCT_MAX_MATERIALS);
+  else if (n_materials <= 48) DEXCT_LAUNCH_POISSON(48);
+  else DEXCT_LAUNCH_POISSON(DEXCT_MAX_MATERIALS);          // (the lengths of up to 256 materials: a per-lane array in scratch)
 #undef DEXCT_LAUNCH_POISSON
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

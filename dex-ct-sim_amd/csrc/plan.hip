@@ -147,6 +147,51 @@ static int launch_transpose(const void* src, void* dst, int64_t batch, int rows,
 
 }  // namespace dexct
 
+namespace dexct {
+
+// Which of the 256 possible ids a uint8 volume holds (counts saturate nowhere: uint32 per workgroup, uint64 in all).
+__global__ __launch_bounds__(256) void volume_ids_kernel(const uint8_t* __restrict__ vol, size_t n, unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const size_t n16 = n / 16;
+  const uint4* __restrict__ v16 = reinterpret_cast<const uint4*>(vol);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 q = v16[i];
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&h[w[k] & 255u], 1u);
+      atomicAdd(&h[(w[k] >> 8) & 255u], 1u);
+      atomicAdd(&h[(w[k] >> 16) & 255u], 1u);
+      atomicAdd(&h[w[k] >> 24], 1u);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n16 * 16 + threadIdx.x; i < n; i += 256) atomicAdd(&h[vol[i]], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(counts + threadIdx.x, (unsigned long long)h[threadIdx.x]);
+}
+
+struct Lut256 { uint8_t v[256]; };
+
+__global__ __launch_bounds__(256) void volume_remap_kernel(uint8_t* __restrict__ vol, size_t n, Lut256 lut) {
+  __shared__ uint8_t l[256];
+  l[threadIdx.x] = lut.v[threadIdx.x];
+  __syncthreads();
+  const size_t n4 = n / 4;
+  uint32_t* __restrict__ v4 = reinterpret_cast<uint32_t*>(vol);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const uint32_t w = v4[i];
+    v4[i] = (uint32_t)l[w & 255u] | ((uint32_t)l[(w >> 8) & 255u] << 8) | ((uint32_t)l[(w >> 16) & 255u] << 16) |
+            ((uint32_t)l[w >> 24] << 24);
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) vol[i] = l[vol[i]];
+}
+
+}  // namespace dexct
+
 using namespace dexct;
 
 extern "C" {
@@ -199,6 +244,31 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
 }
 
 int dexct_last_hip_error(void) { return g_last_hip_error; }
+
+int dexct_volume_ids(const uint8_t* vol, int64_t n_voxels, uint64_t* counts256, void* stream) {
+  if (!vol || !counts256 || n_voxels <= 0) return DEXCT_EINVAL;
+  if (reinterpret_cast<uintptr_t>(vol) & 15u) return DEXCT_EINVAL;
+  hipStream_t st = as_stream(stream);
+  DEXCT_HIP_TRY(hipMemsetAsync(counts256, 0, 256 * sizeof(uint64_t), st));
+  size_t nblk = ((size_t)n_voxels / 16 + 255) / 256;
+  nblk = nblk < 1 ? 1 : (nblk > 4096 ? 4096 : nblk);
+  hipLaunchKernelGGL(volume_ids_kernel, dim3((unsigned)nblk), dim3(256), 0, st, vol, (size_t)n_voxels,
+                     reinterpret_cast<unsigned long long*>(counts256));
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+int dexct_volume_remap(uint8_t* vol, int64_t n_voxels, const uint8_t* lut256, void* stream) {
+  if (!vol || !lut256 || n_voxels <= 0) return DEXCT_EINVAL;
+  if (reinterpret_cast<uintptr_t>(vol) & 3u) return DEXCT_EINVAL;
+  Lut256 lut;
+  for (int k = 0; k < 256; ++k) lut.v[k] = lut256[k];
+  size_t nblk = ((size_t)n_voxels / 4 + 255) / 256;
+  nblk = nblk < 1 ? 1 : (nblk > 8192 ? 8192 : nblk);
+  hipLaunchKernelGGL(volume_remap_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vol, (size_t)n_voxels, lut);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
 
 int dexct_volume_layouts(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, uint8_t* vol_xy, uint8_t* vol_zf,
                          void* stream) {

@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void group_codes_kernel(const uint8_t* __restr
   }
 }
 
-constexpr int kMaxGrouped = DEXCT_MAX_MATERIALS;   // register detect kernels up to 16, LDS columns beyond
+constexpr int kMaxGrouped = DEXCT_MAX_MATERIALS;   // register detect kernels up to 48 materials, LDS columns beyond
 
 // One thread per ray, in memory order of the chosen layout; NMAT = exact number of materials (fully unrolled:
 // a version with 16 predicated material slots spent its time in scalar branches).
@@ -1046,7 +1046,8 @@ __global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __
   detect_store<NMAT, R>(L, a, mu, w, w2, rays, valid);
 }
 
-// More than 16 materials: lengths in per-thread LDS columns (one ray per thread), run-time material loop.
+// More than 48 materials: lengths in per-thread LDS columns (one ray per thread), run-time material loop.
+template <int kLdsBlock>
 __global__ __launch_bounds__(kLdsBlock) void detect_kernel_lds(ProjArgs a, const float* __restrict__ mu,
                                                                const float* __restrict__ w, const float* __restrict__ w2) {
   extern __shared__ float lds_L[];     // [n_materials][kLdsBlock]
@@ -1135,12 +1136,14 @@ int launch_detect_any(const ProjArgs& a, const Tables& t, hipStream_t st) {
     case 48: return launch_detect<48>(a, t, st);
     default: break;
   }
-  // (more than DEXCT_MAX_MATERIALS never gets here; kept for a library built with a larger limit)
+  // 49..256 materials: the general detection, one ray per lane, lengths in LDS columns of 64 lanes (<= 64 KB)
+  constexpr int B = 64;
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
-  const size_t nblk = (n_rays + kLdsBlock - 1) / kLdsBlock;
+  const size_t nblk = (n_rays + B - 1) / B;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  hipLaunchKernelGGL(detect_kernel_lds, dim3((unsigned)nblk), dim3(kLdsBlock), (size_t)a.n_materials * kLdsBlock * sizeof(float),
-                     st, a, t.mu, t.w, t.w2);
+  const size_t lds = (size_t)a.n_materials * B * sizeof(float);
+  DEXCT_ALLOW_LDS(detect_kernel_lds<B>, lds);
+  hipLaunchKernelGGL(detect_kernel_lds<B>, dim3((unsigned)nblk), dim3(B), lds, st, a, t.mu, t.w, t.w2);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
@@ -1198,6 +1201,12 @@ static int launch_rays(const ProjArgs& a, const Tables& t, hipStream_t st) {
       dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
       hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w, t.w2);
     }
+  } else if (a.n_materials > kManyMaterials) {          // 49..256 materials: LDS columns of 64 lanes
+    constexpr int B2 = 64;
+    lds = (size_t)2 * a.n_materials * B2 * sizeof(float);
+    DEXCT_ALLOW_LDS((rays_kernel<NM, B2>), lds);
+    dim3 grid((a.g.n_channels + B2 - 1) / B2, a.g.n_rows, a.n_local_views);
+    hipLaunchKernelGGL((rays_kernel<NM, B2>), grid, dim3(B2), lds, st, a, t.mu, t.w, t.w2);
   } else {
     dim3 grid((a.g.n_channels + B - 1) / B, a.g.n_rows, a.n_local_views);
     hipLaunchKernelGGL((rays_kernel<NM, B>), grid, dim3(B), lds, st, a, t.mu, t.w, t.w2);
@@ -1213,6 +1222,17 @@ static int launch_rows(const ProjArgs& a, const Tables& t, hipStream_t st) {
   const size_t nblk = (size_t)a.n_local_views * a.g.n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
   size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * B * sizeof(float);
+  if (NM == 0 && a.n_materials > kManyMaterials) {      // 49..256 materials: LDS columns of 64 lanes
+    constexpr int B2 = 64;
+    const int n_chunks2 = (a.g.n_rows + B2 - 1) / B2;
+    const size_t nblk2 = (size_t)a.n_local_views * a.g.n_channels * n_chunks2;
+    if (nblk2 > 0x7FFFFFFFull) return DEXCT_ERANGE;
+    lds = (size_t)2 * a.n_materials * B2 * sizeof(float);
+    DEXCT_ALLOW_LDS((rows_kernel<NM, B2>), lds);
+    hipLaunchKernelGGL((rows_kernel<NM, B2>), dim3((unsigned)nblk2), dim3(B2), lds, st, a, t.mu, t.w, t.w2, n_chunks2);
+    DEXCT_LAUNCH_CHECK();
+    return DEXCT_OK;
+  }
   hipLaunchKernelGGL((rows_kernel<NM, B>), dim3((unsigned)nblk), dim3(B), lds, st, a, t.mu, t.w, t.w2, n_chunks);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;

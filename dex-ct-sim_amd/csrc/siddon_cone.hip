@@ -42,12 +42,12 @@ struct ConeArgs {
   float air[DEXCT_MAX_SPECTRA];
 };
 
-template <int NM>
-__global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const float* __restrict__ mu,
+template <int NM, int CB = kConeBlock>   // CB: lanes per workgroup = width of the per-lane LDS columns (NM == 0)
+__global__ __launch_bounds__(CB) void cone_kernel(ConeArgs a, const float* __restrict__ mu,
                                                           const float* __restrict__ w) {
-  extern __shared__ float lds_acc[];     // NM == 0: counts then corrections, [n_materials][kConeBlock] each
+  extern __shared__ float lds_acc[];     // NM == 0: counts then corrections, [n_materials][CB] each
   const int tid = threadIdx.x;
-  const int c = blockIdx.x * kConeBlock + tid;
+  const int c = blockIdx.x * CB + tid;
   const int r = blockIdx.y, v = blockIdx.z;
   const BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // a ballot: before lanes leave
   if (c >= a.g.n_channels) return;
@@ -79,16 +79,16 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
 
   const uint8_t* __restrict__ base = axis == 0 ? a.vol_xy : a.vol_yx;
   const uint32_t slice = (uint32_t)a.g.nx * (uint32_t)a.g.ny;
-  // NM > 0: counts and corrections in registers; NM == 0: per-lane LDS columns [n_materials][kConeBlock] of each
+  // NM > 0: counts and corrections in registers; NM == 0: per-lane LDS columns [n_materials][CB] of each
   int32_t cnt[NM > 0 ? NM : 1];
   float corr[NM > 0 ? NM : 1];
   int32_t* lds_cnt = reinterpret_cast<int32_t*>(lds_acc);
-  float* lds_corr = lds_acc + (size_t)a.n_materials * kConeBlock;
+  float* lds_corr = lds_acc + (size_t)a.n_materials * CB;
   if (NM > 0) {
 #pragma unroll
     for (int m = 0; m < (NM > 0 ? NM : 1); ++m) { cnt[m] = 0; corr[m] = 0.0f; }
   } else {
-    for (int m = 0; m < a.n_materials; ++m) { lds_cnt[m * kConeBlock + tid] = 0; lds_corr[m * kConeBlock + tid] = 0.0f; }
+    for (int m = 0; m < a.n_materials; ++m) { lds_cnt[m * CB + tid] = 0; lds_corr[m * CB + tid] = 0.0f; }
   }
   long long V = p.V0 + (long long)p.i_first * p.SV;
   long long W = W0 + (long long)p.i_first * SW;
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
     const float t1 = fminf(tv, tw), t2 = fmaxf(tv, tw);
     const bool v_first = tv <= tw;
     const int32_t jm = v_first ? jb : ja, km = v_first ? ka : kb;
-    auto voxel = [&](int32_t j, int32_t k) -> uint32_t {      // material id, 0xFF outside the grid (or an id >= n_materials)
+    auto voxel = [&](int32_t j, int32_t k) -> uint32_t {      // material id, 256 outside the grid (every uint8 value is an id)
       const bool in = (uint32_t)j < (uint32_t)nv && (uint32_t)k < (uint32_t)a.g.nz;
-      return in ? (uint32_t)base[(uint32_t)k * slice + off + (uint32_t)j] : 0xFFu;
+      return in ? (uint32_t)base[(uint32_t)k * slice + off + (uint32_t)j] : 256u;
     };
     const uint32_t ida = voxel(ja, ka), idm = voxel(jm, km), idb = voxel(jb, kb);
     if (NM > 0) {
@@ -120,12 +120,12 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
       }
     } else {
       const uint32_t nm = (uint32_t)a.n_materials;
-      if (idb < nm) lds_cnt[idb * kConeBlock + tid] += 1;       // a lane owns its column: plain read-modify-write
+      if (idb < nm) lds_cnt[idb * CB + tid] += 1;       // a lane owns its column: plain read-modify-write
       if (ida != idm || idm != idb) {
-        if (idm < nm) lds_corr[idm * kConeBlock + tid] += t2;
-        if (idb < nm) lds_corr[idb * kConeBlock + tid] -= t2;
-        if (ida < nm) lds_corr[ida * kConeBlock + tid] += t1;
-        if (idm < nm) lds_corr[idm * kConeBlock + tid] -= t1;
+        if (idm < nm) lds_corr[idm * CB + tid] += t2;
+        if (idb < nm) lds_corr[idb * CB + tid] -= t2;
+        if (ida < nm) lds_corr[ida * CB + tid] += t1;
+        if (idm < nm) lds_corr[idm * CB + tid] -= t1;
       }
     }
     V += p.SV;
@@ -167,13 +167,13 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
     }
   } else {
     for (int m = 0; m < n_mat; ++m) {
-      const float l = ((float)lds_cnt[m * kConeBlock + tid] + lds_corr[m * kConeBlock + tid]) * len3d;
+      const float l = ((float)lds_cnt[m * CB + tid] + lds_corr[m * CB + tid]) * len3d;
       if (a.pathlen) a.pathlen[ray * n_mat + m] = l;
-      lds_corr[m * kConeBlock + tid] = l * 1.44269504088896340736f;
+      lds_corr[m * CB + tid] = l * 1.44269504088896340736f;
     }
     for (int e = 0; e < n_e; ++e) {
       float pe = 0.0f;
-      for (int m = 0; m < n_mat; ++m) pe = fmaf(mu[m * n_e + e], lds_corr[m * kConeBlock + tid], pe);
+      for (int m = 0; m < n_mat; ++m) pe = fmaf(mu[m * n_e + e], lds_corr[m * CB + tid], pe);
       const float t = __builtin_amdgcn_exp2f(-pe);
 #pragma unroll
       for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = fmaf(w[srow[s] + e], t, accs[s]);
@@ -189,9 +189,18 @@ __global__ __launch_bounds__(kConeBlock) void cone_kernel(ConeArgs a, const floa
 
 template <int NM>
 static int launch_cone(const ConeArgs& a, const float* mu, const float* w, hipStream_t st) {
+  if (NM == 0 && a.n_materials > kManyMaterials) {       // 49..256 materials: LDS columns of 64 lanes (<= 128 KB)
+    constexpr int B2 = 64;
+    const size_t lds2 = (size_t)2 * a.n_materials * B2 * sizeof(float);
+    DEXCT_ALLOW_LDS((cone_kernel<NM, B2>), lds2);
+    dim3 grid2((a.g.n_channels + B2 - 1) / B2, a.g.n_rows, a.n_local_views);
+    hipLaunchKernelGGL((cone_kernel<NM, B2>), grid2, dim3(B2), lds2, st, a, mu, w);
+    DEXCT_LAUNCH_CHECK();
+    return DEXCT_OK;
+  }
   dim3 grid((a.g.n_channels + kConeBlock - 1) / kConeBlock, a.g.n_rows, a.n_local_views);
   const size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * kConeBlock * sizeof(float);
-  hipLaunchKernelGGL(cone_kernel<NM>, grid, dim3(kConeBlock), lds, st, a, mu, w);
+  hipLaunchKernelGGL((cone_kernel<NM, kConeBlock>), grid, dim3(kConeBlock), lds, st, a, mu, w);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

@@ -48,13 +48,13 @@ class Projector:
     ``view_range`` restricts the instance to a contiguous shard of projection angles (one per
     rank in a multi-GPU run).  ``kernel``: 0 choose, 1 ray-parallel, 2 row-parallel (1 row per lane),
     3 row-parallel with 4 rows per lane (<= 4 materials, Nz and z_index multiples of 4), 4 the same kernel
-    run once per group of three materials (5..48 materials), 5 the 4-rows-per-lane kernel with a tile of
+    run once per group of three materials (5..256 materials), 5 the 4-rows-per-lane kernel with a tile of
     neighbouring (view, channel) pairs per workgroup walking the volume in step (rows4t_kernel: opt-in, kept for A/B
     runs - kernel 0 never picks it; same bits as kernel 3), 6 one wavefront per ray (lanes over
     dominant-axis slabs, shuffle reductions, tables in LDS: the mapping BASELINE.json's north star names; <= 4
     materials), 7 the stacked fan on a 2-bit packed volume with bit-sliced counters (rows16_kernel: 16 rows per
     lane; <= 4 materials; what kernel 0 picks from 192 rows on when a pair fills 3/4 of its lane group), 8 the same
-    kernel run once per group of three materials on packed group codes (2..48 materials; what kernel 0 picks for more
+    kernel run once per group of three materials on packed group codes (2..256 materials; what kernel 0 picks for more
     than 4 materials under the same conditions).
     """
 
@@ -82,8 +82,34 @@ class Projector:
             # a stacked fan only ever reads its own slices: upload those (one slice of a 512^3 phantom for the
             # reference's single-row scan instead of 128 MiB)
             volume, nz, z_first = volume[z_first:z_first + ct.N_rows], ct.N_rows, 0
-        if int(volume.max()) >= phantom.n_materials:
+        # ---- the table rows the kernels need.  A uint8 label map may use any of 256 ids (XCAT: input/params.txt:8-9,
+        # plots.py:124) of which many share a composition and some do not occur in the slices scanned: count the ids on
+        # the device, merge ids with the same (density, composition) - their rows of density x mixatten(E) are equal at
+        # every energy - drop the absent ones, and renumber the uploaded copy.  Row 0 stays id 0 (its path length comes
+        # from the chord).  mat_rows[k] = the phantom id whose table row serves compact id k.
+        st = stream_ptr()
+        vol_raw = to_dev(volume, torch.uint8, self.dev)
+        cnt = torch.empty(256, dtype=torch.int64, device=self.dev)
+        _native.check(self.lib.dexct_volume_ids(ptr(vol_raw), vol_raw.numel(), ptr(cnt), st), 'dexct_volume_ids')
+        present = cnt.cpu().numpy() > 0
+        if present[phantom.n_materials:].any():
             raise ValueError('the volume holds a material id without a table entry')
+        self.mat_rows, lut, seen = [0], np.zeros(256, dtype=np.uint8), {}
+        key = lambda m: (float(m.density), str(m.matcomp))
+        seen[key(phantom.materials[0])] = 0
+        for i in range(1, phantom.n_materials):
+            if present[i]:
+                k = key(phantom.materials[i])
+                if k not in seen:
+                    seen[k] = len(self.mat_rows)
+                    self.mat_rows.append(i)
+                lut[i] = seen[k]
+        if len(self.mat_rows) < 2 <= phantom.n_materials:
+            self.mat_rows.append(1)                       # (keep two rows: the kernels' smallest table)
+        if any(lut[i] != i for i in np.flatnonzero(present)):
+            _native.check(self.lib.dexct_volume_remap(ptr(vol_raw), vol_raw.numel(), lut.ctypes.data_as(C.POINTER(C.c_uint8)), st),
+                          'dexct_volume_remap')
+        self.id_lut = lut
         # The 4-rows-per-lane kernels read aligned dwords along z: pad the uploaded copy with empty slices so that
         # the first imaged slice and the slice count are multiples of 4 (stacked fans only see their own slices,
         # the in-plane geometry does not change).
@@ -91,7 +117,7 @@ class Projector:
         # the 2-bit packed volume with bit-sliced counters (rows16_kernel): what kernel 0 picks where it applies
         lanes16 = -(-ct.N_rows // 16)
         group16 = 64 * (-(-lanes16 // 64)) if lanes16 > 32 else (32 if lanes16 > 16 else 16)     # lanes the pair occupies
-        M = phantom.n_materials
+        M = self.n_mat = len(self.mat_rows)
         shape2_ok = not self.cone and max(phantom.Nx, phantom.Ny) <= 2047
         # kernel 0 picks it when at least 3/4 of the pair's lane group carry rows (>= 192 rows)
         fills = ct.N_rows >= 192 and 4 * lanes16 >= 3 * group16
@@ -99,33 +125,32 @@ class Projector:
         self.use_packed = (kernel == 7 and packed2_ok) or (kernel == 0 and packed2_ok and fills)
         if kernel == 7 and not packed2_ok:
             raise ValueError('kernel 7 (2-bit packed volume) needs a stacked fan, 2..4 materials and nx, ny <= 2047')
-        # material groups (5..48 materials) on packed group codes: kernel 8 forces it, kernel 0 picks it like kernel 7
-        self.grouped_packed = (kernel == 8 and shape2_ok and 2 <= M <= 48) or (kernel == 0 and shape2_ok and 4 < M <= 48 and fills)
+        # material groups (5..256 materials) on packed group codes: kernel 8 forces it, kernel 0 picks it like kernel 7
+        self.grouped_packed = (kernel == 8 and shape2_ok and 2 <= M <= 256) or (kernel == 0 and shape2_ok and 4 < M <= 256 and fills)
         if kernel == 8 and not self.grouped_packed:
-            raise ValueError('kernel 8 (material groups on the 2-bit packed volume) needs a stacked fan, 2..48 materials '
+            raise ValueError('kernel 8 (material groups on the 2-bit packed volume) needs a stacked fan, 2..256 materials '
                              'and nx, ny <= 2047')
         align = 16 if (self.use_packed or self.grouped_packed) else 4
         if not self.cone and packed_wanted and (nz % align or z_first % align):
             lead = (-z_first) % align
             tail = (-(nz + lead)) % align
-            volume = np.pad(volume, ((lead, tail), (0, 0), (0, 0)))
+            vol_raw = torch.nn.functional.pad(vol_raw, (0, 0, 0, 0, lead, tail))      # empty slices (id 0)
             z_first, nz = z_first + lead, nz + lead + tail
         self.geom = _native.FanGeom(ct.N_proj, ct.N_channels, ct.N_rows, z_first, phantom.Nx, phantom.Ny,
                                     nz, 0, phantom.dx, phantom.dy, phantom.dz, ct.SID, ct.SDD)
-        st = stream_ptr()
         self.view_cs = to_dev(ct.view_cs(), torch.float64, self.dev)
         self.chan_cs = to_dev(ct.chan_cs(), torch.float64, self.dev)
         n_local = self.view_end - self.view_begin
         self.plan = torch.empty(n_local * ct.N_channels * _native.PLAN_BYTES, dtype=torch.uint8, device=self.dev)
         _native.check(self.lib.dexct_fan_plan(C.byref(self.geom), ptr(self.view_cs), ptr(self.chan_cs),
                                               self.view_begin, self.view_end, ptr(self.plan), st), 'dexct_fan_plan')
-        self.vol_yx = to_dev(volume, torch.uint8, self.dev)
+        self.vol_yx = vol_raw.contiguous()
         self.vol_xy = torch.empty_like(self.vol_yx)
         self.vol_zc = None
         if self.cone:
             # cone beam: kernel 1 = one thread per ray (dexct_cone_project, any number of materials), 2 = the rows of a
             # (view, channel) pair as lanes (dexct_cone_project_rows, <= 3 materials); 0 picks 2 where it applies
-            rows_ok = phantom.n_materials <= 3
+            rows_ok = M <= 3
             if kernel == 2 and not rows_ok:
                 raise ValueError('the row-parallel cone kernel takes at most 3 materials')
             self.cone_rows = kernel == 2 or (kernel == 0 and rows_ok and ct.N_rows >= 32)
@@ -154,8 +179,8 @@ class Projector:
             _native.check(self.lib.dexct_volume_groups_pack2(ptr(self.vol_zf), self.vol_zf.numel(), M, ptr(self.codes), st),
                           'dexct_volume_groups_pack2')
         elif self.grouped:
-            if not (2 <= M <= 48 and aligned):
-                raise ValueError('kernel 4 needs 2..48 materials')
+            if not (2 <= M <= 256 and aligned):
+                raise ValueError('kernel 4 needs 2..256 materials')
             n_groups = (M - 1 + 2) // 3
             self.codes = torch.empty((n_groups,) + tuple(self.vol_zf.shape), dtype=torch.uint8, device=self.dev)
             _native.check(self.lib.dexct_volume_groups(ptr(self.vol_zf), self.vol_zf.numel(), M, ptr(self.codes), st),
@@ -165,9 +190,14 @@ class Projector:
     def n_local_views(self):
         return self.view_end - self.view_begin
 
+    def compact(self, mu):
+        """The table rows of the compact ids the kernels see (one row per distinct composition that occurs in the scanned
+        slices) out of a table with one row per phantom id."""
+        return mu[self.mat_rows]
+
     def upload_tables(self, specs):
         E, mu, w = merged_tables(self.ct, self.phantom, specs)
-        return (E, to_dev(mu, torch.float32, self.dev), to_dev(w, torch.float32, self.dev), w.sum(axis=1))
+        return (E, to_dev(self.compact(mu), torch.float32, self.dev), to_dev(w, torch.float32, self.dev), w.sum(axis=1))
 
     @property
     def native_layout(self):
@@ -192,7 +222,12 @@ class Projector:
         writes the signal variance and dexct_add_noise draws the sample (Philox, keyed by ``seed`` and by the
         GLOBAL (view, row, channel, spectrum), so shards reproduce the unsharded sinogram)."""
         S, nE = w_d.shape
-        M = mu_d.shape[0]
+        if mu_d.shape[0] != self.n_mat:
+            if mu_d.shape[0] != self.phantom.n_materials:
+                raise ValueError(f'mu has {mu_d.shape[0]} rows; expected {self.n_mat} (compact ids, Projector.compact) or '
+                                 f'{self.phantom.n_materials} (one per phantom id)')
+            mu_d = mu_d[torch.as_tensor(self.mat_rows, device=mu_d.device)].contiguous()
+        M = self.n_mat
         ct = self.ct
         nV, nR, nC = self.n_local_views, ct.N_rows, ct.N_channels
         native = self.native_layout
@@ -233,18 +268,38 @@ class Projector:
             _native.check(self.lib.dexct_siddon_project_packed(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_z2), M, nE, S,
                 ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, lo, stream_ptr()), 'dexct_siddon_project_packed')
-        elif self.grouped_packed:                        # noise too: the detection pass carries the variance
-            scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
-            _native.check(self.lib.dexct_siddon_project_grouped_packed(
-                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
-                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
-                lo, stream_ptr()), 'dexct_siddon_project_grouped_packed')
-        elif self.grouped:
-            scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
-            _native.check(self.lib.dexct_siddon_project_grouped(
-                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
-                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
-                lo, stream_ptr()), 'dexct_siddon_project_grouped')
+        elif self.grouped_packed or self.grouped:        # noise too: the detection pass carries the variance
+            fn, what = ((self.lib.dexct_siddon_project_grouped_packed, 'dexct_siddon_project_grouped_packed') if self.grouped_packed
+                        else (self.lib.dexct_siddon_project_grouped, 'dexct_siddon_project_grouped'))
+            # the per-material accumulators of the group passes: M x rays floats.  Many materials on a large scan go through
+            # in view chunks so that this scratch stays below _GROUP_SCRATCH_BYTES (the outputs of a chunk are copied into place)
+            per_view = M * nR * nC * 4
+            n_chunk = max(1, min(nV, _GROUP_SCRATCH_BYTES // max(per_view, 1)))
+            if n_chunk >= nV:
+                scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
+                _native.check(fn(C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
+                                 ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
+                                 lo, stream_ptr()), what)
+            else:
+                scratch = torch.empty((M, n_chunk * nR * nC), dtype=torch.float32, device=self.dev)
+                for v0 in range(0, nV, n_chunk):
+                    v1 = min(nV, v0 + n_chunk)
+                    sub = (S, v1 - v0) + tuple(counts.shape[2:])
+                    c_t = torch.empty(sub, dtype=torch.float32, device=self.dev)
+                    p_t = torch.empty((v1 - v0,) + tuple(pathlen.shape[1:]), dtype=torch.float32, device=self.dev) if pathlen is not None else None
+                    v_t = torch.empty_like(c_t) if variance is not None else None
+                    l_t = torch.empty_like(c_t) if lo is not None else None
+                    lo_t = _native.log_out(ptr(l_t), air) if lo is not None else None
+                    _native.check(fn(C.byref(self.geom), self.plan.data_ptr() + v0 * nC * _native.PLAN_BYTES, self.view_begin + v0,
+                                     self.view_begin + v1, ptr(self.codes), M, nE, S, ptr(mu_d), ptr(w_d), ptr(c_t), ptr(p_t),
+                                     ptr(scratch), run_layout, ptr(w2_d), ptr(v_t), lo_t, stream_ptr()), what)
+                    counts[:, v0:v1].copy_(c_t)
+                    if pathlen is not None:
+                        pathlen[v0:v1].copy_(p_t)
+                    if variance is not None:
+                        variance[:, v0:v1].copy_(v_t)
+                    if l_t is not None:
+                        log[:, v0:v1].copy_(l_t)
         else:
             _native.check(self.lib.dexct_siddon_project(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx),
@@ -299,7 +354,7 @@ class Projector:
                 res = res + (self.sino_log(res[0], air),)
             return res, air
         _, mu, w, w2 = merged_tables(self.ct, self.phantom, specs, with_variance=True)
-        mu_d, w_d, w2_d = (to_dev(x, torch.float32, self.dev) for x in (mu, w, w2))
+        mu_d, w_d, w2_d = (to_dev(x, torch.float32, self.dev) for x in (self.compact(mu), w, w2))
         air = w.sum(axis=1)
         return self.project_tables(mu_d, w_d, want_pathlen, layout=layout, w2_d=w2_d, seed=seed,
                                    air=air if want_log else None), air
@@ -307,7 +362,7 @@ class Projector:
     def _project_poisson(self, specs, want_pathlen, layout, seed):
         E, mu, w = merged_tables(self.ct, self.phantom, specs)
         gain = E if self.ct.eid else np.ones_like(E)
-        mu_d, w_d = to_dev(mu, torch.float32, self.dev), to_dev(w, torch.float32, self.dev)
+        mu_d, w_d = to_dev(self.compact(mu), torch.float32, self.dev), to_dev(w, torch.float32, self.dev)
         ph_d, gain_d = to_dev(w / gain, torch.float32, self.dev), to_dev(gain, torch.float32, self.dev)
         # path lengths from whichever traversal kernel applies (its noise-free counts are discarded)
         want = self.native_layout if layout is None else layout
@@ -337,6 +392,10 @@ class Projector:
                        ('len_per_u', '<f4'), ('chord_u', '<f4'), ('flags', '<u4')])
         return self.plan.cpu().numpy().view(dt)
 
+
+# scratch of the material-group passes above which a projection goes through in view chunks (DEXCT_GROUP_SCRATCH_GB)
+import os as _os
+_GROUP_SCRATCH_BYTES = int(float(_os.environ.get('DEXCT_GROUP_SCRATCH_GB', '16')) * 2 ** 30)
 
 _cache = {}
 
@@ -412,7 +471,7 @@ def _fingerprint(ct, phantom, view_range):
             _hash64(ct.thetas), _hash64(ct.gammas),
             ct.h_iso, bool(getattr(ct, 'cone', False)), float(getattr(ct, 'src_z', 0.0)),
             phantom.z_index, phantom.Nx, phantom.Ny, phantom.Nz, phantom.dx, phantom.dy, phantom.dz,
-            phantom.n_materials) + _volume_key(phantom)
+            tuple((float(m.density), str(m.matcomp)) for m in phantom.materials)) + _volume_key(phantom)
 
 
 def invalidate():

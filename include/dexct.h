@@ -31,7 +31,10 @@ extern "C" {
 #define DEXCT_ERCCL (-4)    /* RCCL not found in the process, or ncclAllGather failed (its ncclResult_t is then
                                what dexct_last_hip_error() returns) */
 
-#define DEXCT_MAX_MATERIALS 48 /* material ids 0..47 in the uint8 volume */
+#define DEXCT_MAX_MATERIALS 256 /* every id a uint8 volume can hold (ABI 3; 48 before).  Fast paths: <= 4 ids in one pass,
+                                  groups of three beyond; above 48 table rows the general kernels keep their per-material sums
+                                  in LDS columns of 64 lanes.  The Python host first merges ids with identical composition and
+                                  drops ids the volume does not hold (forward_project.Projector). */
 #define DEXCT_MAX_SPECTRA 4    /* spectra detected per traversal */
 #define DEXCT_FIX_FRAC 40      /* fractional bits of the fixed-point minor-axis coordinate */
 
@@ -79,6 +82,15 @@ const char* dexct_strerror(int code);
 int dexct_abi_version(void);
 int dexct_last_hip_error(void);
 
+/* Which ids a volume holds, and renumbering them (ABI 3): a uint8 label map may use any of 256 ids (XCAT label maps:
+ * input/params.txt:8-9, plots.py:124) while only a few table rows differ - the host counts the ids
+ * (dexct_volume_ids: counts256[id] = number of voxels with that id, 256 device uint64, zeroed by the call; vol 16-byte
+ * aligned), merges ids of identical composition, drops the ones that do not occur, and renumbers the uploaded copy in
+ * place (dexct_volume_remap: vol[i] = lut256[vol[i]], lut256 = 256 HOST bytes, copied into the launch arguments).  The
+ * projection kernels then see the compact ids 0..n_materials-1. */
+int dexct_volume_ids(const uint8_t* vol, int64_t n_voxels, uint64_t* counts256, void* stream);
+int dexct_volume_remap(uint8_t* vol, int64_t n_voxels, const uint8_t* lut256, void* stream);
+
 /* Volume layouts.  The phantom arrives as uint8 material ids, C order [nz][ny][nx] (x fastest).
  * dexct_volume_layouts writes the two layouts the traversal kernels read:
  *   vol_yx  [nz][ny][nx]   (a straight copy; minor axis x contiguous; used by y-dominant rays)
@@ -124,7 +136,7 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
                          float* pathlen, int32_t kernel, int32_t layout, const float* weights2, float* variance,
                          const dexct_log_out* log_out, void* stream);
 
-/* Fast path for 5..DEXCT_MAX_MATERIALS materials (stacked fan, nz and z_first multiples of 4).
+/* Material groups: 5..DEXCT_MAX_MATERIALS materials (stacked fan, nz and z_first multiples of 4).
  * dexct_volume_groups: codes[g][voxel] for g < ceil((n_materials-1)/3): ids 3g+1..3g+3 of the z-fastest
  *   volume -> 1..3, all other ids -> 0 (n_groups * n_voxels bytes).
  * dexct_siddon_project_grouped: one packed-count traversal per group writes raw per-material accumulators

@@ -450,9 +450,9 @@ void orc_cone_pathlen(const dexct_fan_geom* g, const double* view_cs, const doub
                       const dexct_ray_plan* p, double src_z, double det_z, const uint8_t* vol, int n_mat, float* L) {
   orc_cone_row c;
   cone_row_plan(g, view_cs, chan_cs, view, chan, p, src_z, det_z, &c);
-  int32_t cnt[256];
-  float corr[256];
-  for (int m = 0; m < 256; ++m) { cnt[m] = 0; corr[m] = 0.0f; }
+  int32_t cnt[257];                                                  /* slot 256: outside the grid */
+  float corr[257];
+  for (int m = 0; m < 257; ++m) { cnt[m] = 0; corr[m] = 0.0f; }
   int axis = p->flags & 1u;
   int nv = axis == 0 ? g->ny : g->nx;
   for (int s = 0; s < p->n_slabs; ++s) {
@@ -469,7 +469,7 @@ void orc_cone_pathlen(const dexct_fan_geom* g, const double* view_cs, const doub
     int32_t jj[3] = {ja, jm, jb}, kk[3] = {ka, km, kb};
     int id[3];
     for (int q = 0; q < 3; ++q) {
-      id[q] = 255;                                                  /* outside the grid: no material */
+      id[q] = 256;                                                  /* outside the grid: no material (every uint8 is an id) */
       if (jj[q] < 0 || jj[q] >= nv || kk[q] < 0 || kk[q] >= g->nz) continue;
       int x = axis == 0 ? i : jj[q], y = axis == 0 ? jj[q] : i;
       id[q] = vol[((size_t)kk[q] * g->ny + y) * g->nx + x];

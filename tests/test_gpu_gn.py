@@ -372,6 +372,57 @@ def test_random_tables_against_numpy_oracle(hip, seed):
         assert err(got[ok], ref[ok]) < 1e-7, (seed, n_e, n_bins, n_iters, err(got[ok], ref[ok]))
 
 
+def test_cooperative_kernel_and_selection_by_size(hip, golden, monkeypatch):
+    """gn_coop_kernel (round 4): the four waves of a workgroup split the energies of the same 64 pixels and join their sums
+    in LDS.  Another summation order than the one-lane kernel: the reference's goldens hold at the unchanged 1e-9, the two
+    kernels agree to 1e-12 wherever the result is finite, exact mode equals ITS OWN full loop bit for bit (the update is
+    still a pure function of the state).  Selection: below DEXCT_GN_COOP_BELOW pixels (default 1e5) the cooperative
+    kernel runs, from there on the lane kernel - checked through bit-identity with the forced kernels on both sides of
+    the threshold (the two kernels differ in the last bits)."""
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    for ci in range(3):                                                   # reference goldens through the cooperative kernel
+        for n_iters in (1, 2, 50):
+            g1, g2 = (torch.tensor(g[f'gn{ci}_g'][k], device='cuda') for k in range(2))
+            for tol in (None, 0.0):
+                a = md.gn_device(g1, g2, g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], n_iters, 'f64', kernel=2, stop_tol=tol).cpu().numpy()
+                assert err(a, g[f'gn{ci}_a_iters{n_iters}']) < TOL_F64, (ci, n_iters, tol)
+    rng = np.random.default_rng(41)
+    i0, mus = g['gn0_i0'], g['gn0_mus']
+    for n_pix, shape_rc in ((1, None), (65, None), (5000, None), (99_999, None), (100_000, None), (24 * 40 * 33, (33, 40))):
+        a_true = np.stack([rng.uniform(0, 35, n_pix), rng.uniform(0, 6, n_pix)], -1)
+        ex = np.exp(-a_true @ mus)
+        cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, n_pix)))
+        cnt[0, rng.random(n_pix) < 0.25] = 2.0 * i0[0].sum()
+        g1, g2 = (torch.tensor(cnt[k], device='cuda') for k in range(2))
+        if shape_rc:
+            g1, g2 = g1.reshape(24, 40, 33), g2.reshape(24, 40, 33)         # [view][channel][row] -> results [view][row][channel]
+        gmax = g1.max().double()
+        kw = dict(mask_max=gmax, out_rc=shape_rc)
+        lane = md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=1, stop_tol=0.0, **kw)
+        coop = md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=2, stop_tol=0.0, **kw)
+        monkeypatch.setenv('DEXCT_GN_FULL_LOOP', '1')
+        coop_full = md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=2, **kw)
+        monkeypatch.delenv('DEXCT_GN_FULL_LOOP')
+        assert torch.equal(coop.view(torch.int64), coop_full.view(torch.int64))
+        fin = torch.isfinite(lane).all(-1) & torch.isfinite(coop).all(-1)
+        assert fin.float().mean() > 0.99
+        assert float(((coop - lane).abs() / lane.abs().clamp(min=1.0))[fin].max()) < 1e-12
+        assert torch.equal(coop == 0, lane == 0)                            # the same air pixels, exactly 0
+        auto = md.gn_device(g1, g2, i0, mus, 50, 'f64', stop_tol=0.0, **kw)
+        want = coop if n_pix < 100_000 else lane                            # the default threshold
+        assert torch.equal(auto.view(torch.int64), want.view(torch.int64)), n_pix
+        monkeypatch.setenv('DEXCT_GN_COOP_BELOW', '5001')
+        auto = md.gn_device(g1, g2, i0, mus, 50, 'f64', stop_tol=0.0, **kw)
+        monkeypatch.delenv('DEXCT_GN_COOP_BELOW')
+        assert torch.equal(auto.view(torch.int64), (coop if n_pix < 5001 else lane).view(torch.int64)), n_pix
+        # the order of the hand-out (thick tiles first for small sinograms) changes no bit
+        monkeypatch.setenv('DEXCT_GN_SORT', '0')
+        for kern, ref in ((1, lane), (2, coop)):
+            assert torch.equal(md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=kern, stop_tol=0.0, **kw).view(torch.int64), ref.view(torch.int64))
+        monkeypatch.delenv('DEXCT_GN_SORT')
+
+
 def test_default_tolerance_stop_and_exact_switches(hip, golden, monkeypatch):
     """Round 4: the tolerance stop (1e-12 relative step, contraction checked) is the DEFAULT of dexct_gn_decompose /
     get_basismat_sinos; the reference's fixed count is one switch away and every way of asking for it gives the same bits

@@ -723,6 +723,127 @@ def test_material_groups_on_the_packed_volume(hip, n_rows, n_mat):
     assert torch.equal(n8, n4) and not torch.equal(n8, c8)
 
 
+# ---- round 4: the full uint8 id range
+def label_map_phantom(n, nz, n_ids=200, n_distinct=60, seed=5):
+    """A label map in the style of an XCAT phantom: ids 1..n_ids-1 scattered over the body, n_distinct different
+    (density, composition) pairs among them, some ids absent, id 0 = air around it."""
+    from conftest import small_scan
+    from dex_ct_sim_amd.system import AIR, Material
+    _, ph = small_scan(n=n, nz=nz)
+    rng = np.random.default_rng(seed)
+    comps = ['H(11.2)O(88.8)', 'H(10.2)C(14.3)N(3.4)O(70.8)Na(0.2)P(0.3)S(0.3)Cl(0.2)K(0.3)',
+             'H(3.4)C(15.5)N(4.2)O(43.5)Na(0.1)Mg(0.2)P(10.3)S(0.3)Ca(22.5)', 'H(11.4)C(59.8)N(0.7)O(27.8)Na(0.1)S(0.1)Cl(0.1)']
+    distinct = [(round(0.3 + 0.03 * k, 3), comps[k % len(comps)]) for k in range(n_distinct - 1)]     # + air = n_distinct
+    which = rng.integers(0, len(distinct), n_ids)
+    mats = [AIR] + [Material(f'organ{i}', *distinct[which[i]]) for i in range(1, n_ids)]
+    used = rng.permutation(np.arange(1, n_ids))[: n_ids - 20]                 # 19 ids of the table never occur
+    body = ph.volume > 0
+    # blocks of 4 x 4 x 2 voxels share an id (organs are not salt and pepper), plus 3 % single-voxel specks
+    zz, yy, xx = np.meshgrid(np.arange(ph.Nz) // 2, np.arange(ph.Ny) // 4, np.arange(ph.Nx) // 4, indexing='ij')
+    ids = used[(zz * 7919 + yy * 104729 + xx * 1299709) % used.size]
+    speck = rng.random(ph.volume.shape) < (0.03 if nz > 1 else 0.6)          # (one 40 x 40 slice: mostly specks, to reach 49+ rows)
+    ids = np.where(speck, used[rng.integers(0, used.size, ph.volume.shape)], ids)
+    ph.volume = np.where(body, ids, 0).astype(np.uint8)
+    ph.materials = mats
+    return ph, distinct
+
+
+@pytest.mark.parametrize('n_rows,nz,kernel', [(1, 1, 0), (1, 1, 1), (256, 256, 0), (64, 64, 4), (256, 256, 8), (12, 12, 2)])
+def test_full_id_range_200_ids_60_compositions(hip, n_rows, nz, kernel):
+    """VERDICT round 3, missing 2: ids 48..255.  A 200-id label map with 60 distinct compositions (19 ids absent) through
+    the single-row and the stacked-fan projector: the host merges ids of equal composition and drops absent ones (here 60
+    rows remain: more than the 48 the fast group path took before), the kernels run on compact ids.  Path lengths bit for
+    bit against the DDA mirror ON THE SAME compact ids, counts <= 1e-5 against the float64 textbook Siddon on the ORIGINAL
+    200-id volume and table."""
+    from dex_ct_sim_amd import forward_project as fp
+    ph, distinct = label_map_phantom(40, nz)
+    # (an even channel count: no ray runs exactly ALONG a grid plane, where the textbook algorithm and the slab DDA may
+    # each pick either of the two voxel rows - equal on a symmetric phantom, not on a label map)
+    ct, _ = small_scan(n=40, nz=nz, n_views=9, n_channels=46, n_rows=n_rows)
+    pj = projector(ct, ph, kernel=kernel)
+    keys = {(m.density, m.matcomp) for i, m in enumerate(ph.materials) if i == 0 or (ph.volume == i).any()}
+    assert pj.n_mat == len(keys) and 49 <= pj.n_mat <= 60 and len(ph.materials) == 200
+    sp = spectra()
+    (counts, pl), _ = pj.project(sp, want_pathlen=True)
+    E, mu, w = fp.merged_tables(ct, ph, sp)
+    g = oracle_geom(ct, ph)
+    # float64 Siddon 1985 on the original ids and the full 200-row table
+    ref = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w)
+    assert float(np.max(np.abs(counts.cpu().numpy() - ref) / ref)) < REL_TOL
+    # the mirror on the compact ids: bit-exact path lengths
+    compact = pj.id_lut[ph.volume]
+    mu_c = pj.compact(mu)
+    _, ref_pl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, compact, mu_c.astype(np.float32), w.astype(np.float32),
+                               want_pathlen=True)
+    assert np.array_equal(pl.cpu().numpy(), ref_pl)
+    # merged ids: the summed float64 lengths of the ids behind a compact row agree with the compact row's length
+    _, pl_full = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w, want_pathlen=True)
+    summed = np.zeros(pl_full.shape[:-1] + (pj.n_mat,))
+    for i in range(200):
+        if i == 0 or (ph.volume == i).any():
+            summed[..., pj.id_lut[i]] += pl_full[..., i]
+    assert np.max(np.abs(summed - pl.cpu().numpy())) < 2e-4
+    # the public call
+    if kernel == 0:
+        import dex_ct_sim_amd as dx
+        raw, log = dx.get_sino(ct, ph, sp[0])
+        want = ref[0] if n_rows > 1 else ref[0][:, 0]
+        assert raw.shape == want.shape and float(np.max(np.abs(raw - want) / want)) < REL_TOL
+
+
+def test_all_256_ids_distinct_and_view_chunks(hip, monkeypatch):
+    """The worst case: 256 ids, every one a composition of its own (no merging possible): 85 group passes on the stacked
+    fan with the scratch budget forcing view chunks, the LDS-column kernels (64 lanes x 256 materials) on the single row
+    and the cone beam; noise and the log sinogram through the chunks."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    from dex_ct_sim_amd.system import AIR, Material
+    ct, ph = small_scan(n=40, nz=64, n_views=9, n_channels=34, n_rows=64)
+    rng = np.random.default_rng(2)
+    ph.volume = np.where(ph.volume > 0, rng.integers(1, 256, ph.volume.shape, dtype=np.uint16), 0).astype(np.uint8)
+    ph.materials = [AIR] + [Material(f'm{i}', 0.2 + 0.007 * i, 'H(11.2)O(88.8)') for i in range(1, 256)]
+    sp = spectra()
+    E, mu, w = fp.merged_tables(ct, ph, sp)
+    g = oracle_geom(ct, ph)
+    ref = co.project_classic(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu, w)
+    pj = projector(ct, ph)                                       # kernel 0: byte group codes (64 rows do not fill a lane group)
+    assert pj.n_mat == 256 and (pj.grouped or pj.grouped_packed)
+    (c_all, p_all, l_all), air = pj.project(sp, want_pathlen=True, want_log=True)
+    assert float(np.max(np.abs(c_all.cpu().numpy() - ref) / ref)) < REL_TOL
+    monkeypatch.setattr(fp, '_GROUP_SCRATCH_BYTES', 256 * 64 * 34 * 4 * 2)          # two views per chunk
+    (c_ch, p_ch, l_ch), _ = pj.project(sp, want_pathlen=True, want_log=True)
+    assert torch.equal(c_ch, c_all) and torch.equal(p_ch, p_all) and torch.equal(l_ch, l_all)
+    n_ch, _ = pj.project(sp, noise=True, seed=9)
+    monkeypatch.setattr(fp, '_GROUP_SCRATCH_BYTES', 16 << 30)
+    n_all, _ = pj.project(sp, noise=True, seed=9)
+    assert torch.equal(n_ch, n_all) and not torch.equal(n_all, c_all)
+    _, ref_pl = co.project_dda(g, ct.view_cs(), ct.chan_cs(), 0, ct.N_proj, ph.volume, mu.astype(np.float32), w.astype(np.float32),
+                               want_pathlen=True)
+    assert np.array_equal(p_all.cpu().numpy(), ref_pl)
+    for kern in (1, 2):                                          # one thread per ray / one row per lane: LDS columns
+        (c, p), _ = projector(ct, ph, kernel=kern).project(sp, want_pathlen=True)
+        assert torch.equal(p, p_all) and float(((c - c_all).abs() / c_all).max()) < REL_TOL
+    # exact Poisson detection from the path lengths of 256 materials
+    pz, _ = pj.project(sp, noise='poisson', seed=4)
+    assert torch.isfinite(pz).all() and pz.shape == c_all.shape and float(pz.mean()) > 0
+    # cone beam
+    cone = dx.FanBeamGeometry(N_channels=34, N_proj=9, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=0.8, N_rows=12, cone=True,
+                              eid=True, detector_file=ct.detector_file)
+    cj = projector(cone, ph)
+    (cc, cp), _ = cj.project(sp, want_pathlen=True)
+    gc = oracle_geom(cone, ph)
+    _, ref_cp = co.project_cone(gc, cone.view_cs(), cone.chan_cs(), 0, cone.N_proj, cone.row_z(), cone.src_z, ph.volume, mu, w,
+                                dda=True, n_threads=8)
+    ref_c, _ = co.project_cone(gc, cone.view_cs(), cone.chan_cs(), 0, cone.N_proj, cone.row_z(), cone.src_z, ph.volume, mu, w,
+                               dda=False, n_threads=8)
+    assert np.array_equal(cp.cpu().numpy(), ref_cp)                # (id 255 is an id like any other: "outside" is 256)
+    assert float(np.max(np.abs(cc.cpu().numpy() - ref_c) / ref_c)) < REL_TOL
+    # an id beyond the table is refused
+    ph.materials = ph.materials[:200]
+    with pytest.raises(ValueError):
+        projector(ct, ph)
+
+
 # ---- round 3: the second output of get_sino from the device, whole-line stores, the O(1) cache key
 def _np_log(air, counts):
     """What the host did before round 3 (and what the reference's caller sees): float32 ln(air / raw)."""

@@ -166,7 +166,8 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_volume_layouts(one, 8, 8, 1, None, None, None) == EINVAL           # nothing to write
     args = [C.byref(g), one, 0, 10, one, one, None]
     assert lib.dexct_siddon_project(*args, 0, 10, 2, one, one, one, None, 0, 0, None, None, None, None) == EINVAL   # no materials
-    assert lib.dexct_siddon_project(*args, 49, 10, 2, one, one, one, None, 0, 0, None, None, None, None) == ERANGE  # > DEXCT_MAX_MATERIALS
+    assert lib.dexct_siddon_project(*args, 257, 10, 2, one, one, one, None, 0, 0, None, None, None, None) == ERANGE  # > DEXCT_MAX_MATERIALS (every uint8 id)
+    assert lib.dexct_volume_ids(one, 0, one, None) == EINVAL and lib.dexct_volume_remap(one, 16, None, None) == EINVAL
     assert lib.dexct_siddon_project(*args, 3, 10, 5, one, one, one, None, 0, 0, None, None, None, None) == ERANGE   # > DEXCT_MAX_SPECTRA
     assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 3, 0, None, None, None, None) == EINVAL   # kernel 3 needs vol_zf
     assert lib.dexct_siddon_project(*args, 3, 10, 2, one, one, one, None, 1, 7, None, None, None, None) == EINVAL   # layout
