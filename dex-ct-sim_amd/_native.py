@@ -14,7 +14,7 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
            'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
            'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather',
-           'dexct_volume_ids', 'dexct_volume_remap', 'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
+           'dexct_volume_ids', 'dexct_volume_remap', 'dexct_fbp_parker', 'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
 
 
 class FanGeom(C.Structure):
@@ -110,6 +110,7 @@ def load():
     lib.dexct_siddon_project_grouped_packed.argtypes = lib.dexct_siddon_project_grouped.argtypes
     lib.dexct_transpose_batched.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     lib.dexct_fbp_filter.argtypes = [vp, vp, vp, i64, i32, f64, vp, vp]
+    lib.dexct_fbp_parker.argtypes = [vp, i32, i32, i32, f64, f64, i32, i32, vp, vp]
     lib.dexct_fbp_backproject.argtypes = [vp, vp, i32, i32, i32, f64, f64, f64, i32, f64, vp, vp]
     lib.dexct_siddon_trace.argtypes = [C.POINTER(FanGeom), vp, vp, i32, i32, vp, vp, vp, vp]
     lib.dexct_gn_decompose.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, i32, i32, i32, i32, vp, f64, vp, C.POINTER(GnOptions), vp, vp]

@@ -8,7 +8,8 @@ FBP with a windowed ramp filter.  This build implements Kak & Slaney 3.4.1 for t
 band-limited ramp as a fraction of the Nyquist frequency (``ramp_filter_percent_Nyquist``,
 input/params.txt:35), ``recon_raw`` is in 1/cm on an ``N_matrix`` x ``N_matrix`` grid over ``FOV`` cm,
 ``recon_HU = 1000 (raw - mu_w) / mu_w`` with the spectrum- and detector-weighted water attenuation.
-The convolution and the back-projection run in the HIP library (dexct_fbp_filter, dexct_fbp_backproject).
+The convolution and the back-projection run in the HIP library (dexct_fbp_filter, dexct_fbp_backproject).  Rotations shorter than 2 pi (``rotation_angle_total``,
+input/params.txt:24) down to pi + the fan angle are reconstructed with Parker's short-scan weights (dexct_fbp_parker).
 """
 import numpy as np
 import torch
@@ -95,14 +96,24 @@ def recon_device(sino_d, ct, N_matrix, FOV, ramp, window=None, slices=None):
     n_views, n_rows, n_ch = s.shape
     if n_views != ct.N_proj or n_ch != ct.N_channels:
         raise ValueError(f'sinogram {tuple(sino_d.shape)} does not match the scanner ({ct.N_proj} x {ct.N_channels})')
-    if abs(ct.theta_tot - 2 * np.pi) > 1e-4:
-        raise NotImplementedError('only full 2 pi rotations are reconstructed')
+    st = stream_ptr()
+    if ct.theta_tot > 2 * np.pi + 1e-4:
+        raise ValueError(f'rotation_angle_total = {ct.theta_tot:.6g} exceeds 2 pi: more than one rotation is not reconstructed')
+    if ct.theta_tot < 2 * np.pi - 1e-4:
+        # a short scan (rotation_angle_total, input/params.txt:24): Parker's weights make every ray count once
+        need = np.pi + (n_ch - 1) * ct.dgamma
+        if ct.theta_tot < need * (1 - 1e-12):
+            raise ValueError(f'rotation_angle_total = {ct.theta_tot:.6g} rad is less than a short scan (pi + fan angle = '
+                             f'{need:.6g} rad): projections are missing')
+        sw = torch.empty_like(s)
+        _native.check(lib.dexct_fbp_parker(ptr(s), n_views, n_rows, n_ch, float(ct.theta_tot), float(ct.dgamma), 0, n_views,
+                                           ptr(sw), st), 'dexct_fbp_parker')
+        s = sw
     cone = bool(getattr(ct, 'cone', False)) and n_rows > 1
     taps = to_dev(ramp_taps(n_ch, ct.dgamma, ramp, window or default_window()), torch.float32, dev)
     weight = to_dev(ct.SID * np.cos(ct.gammas), torch.float32, dev)
     view_cs = to_dev(ct.view_cs(), torch.float64, dev)
     q = torch.empty_like(s)
-    st = stream_ptr()
     _native.check(lib.dexct_fbp_filter(ptr(s), ptr(taps), ptr(weight), n_views * n_rows, n_ch, ct.dgamma, ptr(q), st),
                   'dexct_fbp_filter')
     if cone:

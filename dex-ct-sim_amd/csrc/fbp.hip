@@ -154,6 +154,38 @@ __global__ __launch_bounds__(kFbpBlock) void fdk_backproject_kernel(const float*
 
 using namespace dexct;
 
+// Short-scan (Parker) weights.  A scan over theta_tot < 2 pi measures some rays once and some twice: ray (beta, gamma) is
+// the ray (beta + pi + 2 gamma, -gamma) seen from the other side (this build's geometry: source at angle beta, channel
+// looking along beta + pi + gamma).  With Gamma' = (theta_tot - pi) / 2 (>= the half fan angle, else data are missing),
+//   w = sin^2(pi/4 * beta / (Gamma' - gamma))                        0 <= beta <= 2 Gamma' - 2 gamma
+//   w = 1                                                            between
+//   w = sin^2(pi/4 * (pi + 2 Gamma' - beta) / (Gamma' + gamma))      pi - 2 gamma <= beta <= theta_tot
+// (Parker 1982 with Silver's virtual fan angle for scans longer than the minimum) - the two weights of a ray measured
+// twice add up to 1, smoothly.  The full-scan formula of dexct_fbp_filter / _backproject counts every ray twice (the
+// factor 1/2 sits in its filter taps), so the sinogram is multiplied by 2 w.
+__global__ __launch_bounds__(256) void parker_kernel(const float* __restrict__ sino, int n_views, int n_rows, int n_channels,
+                                                     double theta_tot, double dgamma, int view_offset, int n_views_total,
+                                                     float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = (size_t)n_views * n_rows * n_channels;
+  if (i >= n) return;
+  const int c = (int)(i % n_channels);
+  const int v = (int)(i / ((size_t)n_rows * n_channels)) + view_offset;
+  const double kPi = 3.14159265358979323846;
+  const double beta = theta_tot * (double)v / (double)n_views_total;
+  const double gam = ((double)c - 0.5 * (double)(n_channels - 1)) * dgamma;
+  const double G = 0.5 * (theta_tot - kPi);
+  double w = 1.0;
+  if (beta < 2.0 * (G - gam)) {
+    const double sn = sin(0.25 * kPi * beta / (G - gam));
+    w = sn * sn;
+  } else if (beta > kPi - 2.0 * gam) {
+    const double sn = sin(0.25 * kPi * (kPi + 2.0 * G - beta) / (G + gam));
+    w = sn * sn;
+  }
+  out[i] = (float)(2.0 * w * (double)sino[i]);
+}
+
 extern "C" {
 
 int dexct_fbp_filter(const float* sino, const float* taps, const float* weight, int64_t n_lines, int32_t n_channels,
@@ -163,6 +195,24 @@ int dexct_fbp_filter(const float* sino, const float* taps, const float* weight, 
   const size_t lds = (size_t)(3 * n_channels - 1) * sizeof(float);
   hipLaunchKernelGGL(fbp_filter_kernel, dim3((unsigned)n_lines), dim3(kFbpBlock), lds, as_stream(stream), sino, taps,
                      weight, n_channels, (float)dgamma, q);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+int dexct_fbp_parker(const float* sino, int32_t n_views, int32_t n_rows, int32_t n_channels, double theta_tot, double dgamma,
+                      int32_t view_offset, int32_t n_views_total, float* out, void* stream) {
+  if (!sino || !out || n_views < 1 || n_rows < 1 || n_channels < 1 || n_views_total < n_views || view_offset < 0 ||
+      view_offset + n_views > n_views_total)
+    return DEXCT_EINVAL;
+  const double kPi = 3.14159265358979323846;
+  const double half_fan = 0.5 * (double)(n_channels - 1) * dgamma;
+  // a short scan needs pi + the full fan angle; 2 pi and beyond is not a short scan
+  if (!(dgamma > 0.0) || !(theta_tot < 2.0 * kPi) || !(0.5 * (theta_tot - kPi) >= half_fan * (1.0 - 1e-12))) return DEXCT_EINVAL;
+  const size_t n = (size_t)n_views * n_rows * n_channels;
+  const size_t nblk = (n + 255) / 256;
+  if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(parker_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), sino, n_views, n_rows, n_channels,
+                     theta_tot, dgamma, view_offset, n_views_total, out);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

@@ -251,19 +251,26 @@ class Projector:
         # fused into the detection store, except for noisy sinograms (their counts exist after the sampling)
         lo = _native.log_out(ptr(log), air) if (log is not None and w2_d is None) else None
         if self.cone:
-            if w2_d is not None:
-                raise NotImplementedError('noise is not available for cone-beam scans')
             max_dz = float(np.max(np.abs(self.ct.row_z() - self.ct.src_z)))
-            if self.cone_rows:
-                _native.check(self.lib.dexct_cone_project_rows(
-                    C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
-                    self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
-                    ptr(w_d), ptr(counts), ptr(pathlen), lo, stream_ptr()), 'dexct_cone_project_rows')
-            else:
-                _native.check(self.lib.dexct_cone_project(
-                    C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
-                    self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
-                    ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), lo, stream_ptr()), 'dexct_cone_project')
+
+            def cone_call(weights, out_counts, out_pathlen, out_log):
+                if self.cone_rows:
+                    _native.check(self.lib.dexct_cone_project_rows(
+                        C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                        self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
+                        ptr(weights), ptr(out_counts), ptr(out_pathlen), out_log, stream_ptr()), 'dexct_cone_project_rows')
+                else:
+                    _native.check(self.lib.dexct_cone_project(
+                        C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                        self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
+                        ptr(mu_d), ptr(weights), ptr(out_counts), ptr(out_pathlen), out_log, stream_ptr()), 'dexct_cone_project')
+
+            cone_call(w_d, counts, pathlen, lo)
+            if w2_d is not None:
+                # quantum noise on a cone-beam scan: the variance of the detected signal, sum_e w2[e] exp(-...), is the same
+                # detection with the weights w2 - a second pass of the same kernel (the cone kernels carry no variance
+                # output of their own); dexct_add_noise then draws the sample below, keyed by the global (view, row, channel)
+                cone_call(w2_d, variance, None, None)
         elif self.use_packed and w2_d is None:           # (with noise the byte-volume kernel below runs: it carries the variance)
             _native.check(self.lib.dexct_siddon_project_packed(
                 C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_z2), M, nE, S,

@@ -331,7 +331,15 @@ int dexct_reduce_max(const void* g1, int32_t g_is_f64, int64_t n_pix, double* ou
  *   dexct_fbp_filter:      q[line][n] = dgamma * sum_m sino[line][m] * weight[m] * taps[(n - m) + n_channels - 1]
  *                          (weight[m] = SID cos(gamma_m); taps = 2*n_channels - 1 equiangular ramp taps)
  *   dexct_fbp_backproject: image[row][iy][ix] = dbeta * sum_views q(view, row, gamma'(x, y)) / L^2, pixel
- *                          driven, linear interpolation; q is [view][row][channel]; image float32 in 1/cm. */
+ *                          driven, linear interpolation; q is [view][row][channel]; image float32 in 1/cm.
+ * (A 2 pi scan; a short scan first goes through dexct_fbp_parker.) */
+/* Short scans (rotation_angle_total < 2 pi, input/params.txt:24): out = 2 w(beta, gamma) * sino with Parker's weights for a
+ * scan over theta_tot (views at beta_v = theta_tot * (view_offset + v) / n_views_total, channels at gamma_c = (c - (n_channels
+ * - 1) / 2) * dgamma), so that dexct_fbp_filter + dexct_fbp_backproject (dbeta = theta_tot / n_views_total) reconstruct it.
+ * theta_tot must cover pi + the fan angle (DEXCT_EINVAL otherwise: data are missing) and be below 2 pi; sino and out
+ * [n_views][n_rows][n_channels] float32, may be the same buffer. */
+int dexct_fbp_parker(const float* sino, int32_t n_views, int32_t n_rows, int32_t n_channels, double theta_tot, double dgamma,
+                     int32_t view_offset, int32_t n_views_total, float* out, void* stream);
 int dexct_fbp_filter(const float* sino, const float* taps, const float* weight, int64_t n_lines,
                      int32_t n_channels, double dgamma, float* q, void* stream);
 int dexct_fbp_backproject(const float* q, const double* view_cs, int32_t n_views, int32_t n_channels,

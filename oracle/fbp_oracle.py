@@ -95,7 +95,31 @@ def back_project(q, thetas, gammas, sid, n_matrix, fov):
     return img * dbeta
 
 
-def get_recon(sino_log, thetas, gammas, sid, n_matrix, fov, ramp, mu_water=None, window='rect'):
+def parker_weights(thetas, gammas, theta_tot):
+    """Short-scan weights w[view, channel] (Parker, Med. Phys. 9, 254 (1982); Silver's virtual fan angle
+    G = (theta_tot - pi) / 2 for scans longer than pi + fan), for this build's geometry, in which ray (beta, gamma) is
+    measured a second time as (beta + pi + 2 gamma, -gamma).  The weights of such a pair add up to 1."""
+    b = np.asarray(thetas, dtype=np.float64)[:, None]
+    g = np.asarray(gammas, dtype=np.float64)[None, :]
+    G = 0.5 * (theta_tot - np.pi)
+    if G < np.max(np.abs(g)) * (1 - 1e-12):
+        raise ValueError('less than a short scan')
+    w = np.ones(np.broadcast(b, g).shape)
+    early = b < 2.0 * (G - g)
+    late = b > np.pi - 2.0 * g
+    with np.errstate(divide='ignore', invalid='ignore'):
+        w = np.where(early, np.sin(0.25 * np.pi * b / (G - g)) ** 2, w)
+        w = np.where(late & ~early, np.sin(0.25 * np.pi * (np.pi + 2.0 * G - b) / (G + g)) ** 2, w)
+    return w
+
+
+def get_recon(sino_log, thetas, gammas, sid, n_matrix, fov, ramp, mu_water=None, window='rect', theta_tot=None):
+    """theta_tot: None or 2 pi = a full rotation; less: a short scan, weighted by 2 * parker_weights first (the
+    full-scan formula counts every ray twice)."""
+    sino_log = np.asarray(sino_log, dtype=np.float64)
+    if theta_tot is not None and theta_tot < 2 * np.pi - 1e-9:
+        w = 2.0 * parker_weights(thetas, gammas, theta_tot)
+        sino_log = sino_log * (w if sino_log.ndim == 2 else w[:, None, :])
     raw = back_project(filter_sino(sino_log, gammas, sid, ramp, window), thetas, gammas, sid, n_matrix, fov)
     hu = None if mu_water is None else 1000.0 * (raw - mu_water) / mu_water
     return raw, hu

@@ -119,3 +119,56 @@ def test_fdk_oracle_reconstructs_a_ball():
         tol = 0.004 if z == 0.0 else 0.012
         assert abs(vol[k][inside].mean() - 0.2) < tol, (z, vol[k][inside].mean())
         assert abs(vol[k][outside].mean()) < 0.01, (z, vol[k][outside].mean())
+
+
+def short_scan(theta_tot, n_views=400, n_ch=257):
+    dg = 0.8230337 / n_ch
+    return np.arange(n_views) * theta_tot / n_views, (np.arange(n_ch) - (n_ch - 1) / 2) * dg
+
+
+@pytest.mark.parametrize('extra', [0.0, 0.35, 1.2])
+def test_parker_weights_of_a_conjugate_pair_add_up_to_one(extra):
+    """In this build's geometry ray (beta, gamma) is seen again as (beta + pi + 2 gamma, -gamma): wherever both lie in the
+    scan their weights add up to 1, a ray seen once has weight 1, and the weights are continuous."""
+    fan = 0.8230337
+    theta_tot = np.pi + fan + extra
+    G = 0.5 * (theta_tot - np.pi)
+    rng = np.random.default_rng(0)
+    beta = rng.uniform(0, theta_tot, 20000)
+    gam = rng.uniform(-fan / 2, fan / 2, 20000)
+    w = np.array([fo.parker_weights([b], [g], theta_tot)[0, 0] for b, g in zip(beta[:3000], gam[:3000])])
+    bp = beta[:3000] + np.pi + 2 * gam[:3000]
+    bm = beta[:3000] - np.pi + 2 * gam[:3000]               # (the partner of the late views lies earlier)
+    partner = np.where(bp <= theta_tot, bp, np.where(bm >= 0, bm, np.nan))
+    wp = np.array([fo.parker_weights([b], [-g], theta_tot)[0, 0] if np.isfinite(b) else 0.0 for b, g in zip(partner, gam[:3000])])
+    assert np.allclose(w + wp, 1.0, atol=1e-12)
+    assert (np.isnan(partner)).any() and (np.isfinite(partner)).any()
+    # continuity along beta for a fixed channel
+    b = np.linspace(0, theta_tot, 20001)
+    for g in (-0.4, 0.0, 0.37):
+        col = fo.parker_weights(b, [g], theta_tot)[:, 0]
+        assert np.abs(np.diff(col)).max() < 2e-2 and col.min() >= 0 and col.max() <= 1 + 1e-15      # (steep near the fan edge, never a jump)
+    with pytest.raises(ValueError):
+        fo.parker_weights([0.0], [-fan / 2, fan / 2], np.pi + 0.9 * fan)
+    assert np.isclose(G, 0.5 * (fan + extra))
+
+
+@pytest.mark.parametrize('theta_tot', [np.pi + 0.8230337, 4.5, 6.0])
+def test_short_scan_reconstructs_discs(theta_tot):
+    """A short scan (pi + fan angle), a longer one and an almost full one reconstruct the analytic discs to their
+    densities and agree with the 2 pi reconstruction of the same object."""
+    th, gam = short_scan(theta_tot)
+    discs = [(0, 0, 10.0, 0.2), (5.0, -3.0, 2.0, 0.3), (-6.0, 4.0, 1.5, -0.1)]
+    s = disc_sino(th, gam, discs)
+    raw, _ = fo.get_recon(s, th, gam, SID, 128, 40.0, 1.0, theta_tot=theta_tot)
+    th2, _ = scan(400, 257)
+    full, _ = fo.get_recon(disc_sino(th2, gam, discs), th2, gam, SID, 128, 40.0, 1.0)
+    c = (np.arange(128) - 64 + 0.5) * (40 / 128)
+    x, y = np.meshgrid(c, c)
+    bg = (x ** 2 + y ** 2 < 8.0 ** 2) & ~((x - 5) ** 2 + (y + 3) ** 2 < 2.6 ** 2) & ~((x + 6) ** 2 + (y - 4) ** 2 < 2.1 ** 2)
+    small = (x - 5) ** 2 + (y + 3) ** 2 < 1.5 ** 2
+    assert abs(raw[bg].mean() - 0.2) < 5e-4
+    assert abs(raw[small].mean() - 0.5) < 2e-3
+    assert abs(raw[x ** 2 + y ** 2 > 12 ** 2].mean()) < 1e-3
+    inner = x ** 2 + y ** 2 < 9.0 ** 2
+    assert np.abs(raw - full)[inner].mean() < 2e-3                   # the same image up to discretisation

@@ -204,3 +204,79 @@ def test_non_finite_sinogram_values_do_not_poison_the_image(hip):
         dirty, _ = dx.get_recon(s2, ct, spec, 64, 30.0, 1.0)
     assert np.all(np.isfinite(dirty))
     assert np.abs(dirty - clean).max() < 0.2 * clean.max()        # two lost samples of 11 610: a local streak
+
+
+@pytest.mark.parametrize('theta_tot', [np.pi + 0.8230337, 4.5, 6.0])
+def test_short_scan_parker_matches_oracle(hip, theta_tot):
+    """rotation_angle_total < 2 pi (input/params.txt:24): Parker-weighted short-scan FBP (dexct_fbp_parker) against the
+    float64 oracle, through the public get_recon; the image agrees with the full-rotation image of the same object."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import synthetic
+    ct = dx.FanBeamGeometry(N_channels=257, N_proj=400, gamma_fan=0.8230337, SID=60.0, SDD=100.0, theta_tot=theta_tot)
+    assert np.isclose(ct.thetas[-1], theta_tot * 399 / 400)
+    discs = [(0, 0, 10.0, 0.2), (5.0, -3.0, 2.0, 0.3), (-6.0, 4.0, 1.5, -0.1)]
+    s = disc_sino(ct.thetas, ct.gammas, discs).astype(np.float32)
+    spec = synthetic.kramers_spectrum(120)
+    raw, _ = dx.get_recon(s, ct, spec, 128, 40.0, 0.9)
+    ref, _ = fo.get_recon(s, ct.thetas, ct.gammas, 60.0, 128, 40.0, 0.9, theta_tot=theta_tot)
+    assert np.max(np.abs(raw - ref)) < 3e-5 * np.abs(ref).max()
+    full_ct = dx.FanBeamGeometry(N_channels=257, N_proj=400, gamma_fan=0.8230337, SID=60.0, SDD=100.0)
+    full, _ = dx.get_recon(disc_sino(full_ct.thetas, full_ct.gammas, discs), full_ct, spec, 128, 40.0, 0.9)
+    c = (np.arange(128) - 64 + 0.5) * (40 / 128)
+    x, y = np.meshgrid(c, c)
+    assert np.abs(raw - full)[x ** 2 + y ** 2 < 81.0].mean() < 2e-3
+
+
+def test_short_scan_limits_rows_and_cone(hip):
+    """Less than pi + fan angle is refused (projections are missing), more than one rotation too; a stacked sinogram is
+    weighted row by row; a cone-beam short scan goes through Feldkamp with the same weights and stays close to the full
+    rotation's image in the central slices."""
+    import dex_ct_sim_amd as dx
+    import torch
+    from dex_ct_sim_amd import _native, back_project as bp
+    fan = 0.8230337
+    short = dx.FanBeamGeometry(N_channels=129, N_proj=200, gamma_fan=fan, SID=60.0, SDD=100.0, theta_tot=np.pi + 0.5 * fan)
+    s = disc_sino(short.thetas, short.gammas, [(1.0, 2.0, 6.0, 0.2)]).astype(np.float32)
+    with pytest.raises(ValueError, match='short scan'):
+        bp.recon_device(torch.tensor(s, device='cuda'), short, 64, 30.0, 1.0)
+    twice = dx.FanBeamGeometry(N_channels=129, N_proj=200, gamma_fan=fan, SID=60.0, SDD=100.0, theta_tot=4 * np.pi)
+    with pytest.raises(ValueError, match='exceeds'):
+        bp.recon_device(torch.tensor(s, device='cuda'), twice, 64, 30.0, 1.0)
+    lib = _native.load()
+    one = torch.zeros(16, device='cuda')
+    assert lib.dexct_fbp_parker(one.data_ptr(), 2, 1, 8, 3.2, 0.1, 0, 2, one.data_ptr(), None) == -1      # pi + fan = 3.84 > 3.2
+    assert lib.dexct_fbp_parker(one.data_ptr(), 2, 1, 8, 6.3, 0.1, 0, 2, one.data_ptr(), None) == -1      # >= 2 pi
+    # stacked rows
+    ct = dx.FanBeamGeometry(N_channels=129, N_proj=240, gamma_fan=fan, SID=60.0, SDD=100.0, N_rows=3, theta_tot=4.4)
+    a = disc_sino(ct.thetas, ct.gammas, [(2.0, 1.0, 6.0, 0.2)])
+    b = disc_sino(ct.thetas, ct.gammas, [(-3.0, 0.0, 3.0, 0.4)])
+    stack = np.stack([a, b, a + 2 * b], axis=1).astype(np.float32)
+    img = bp.recon_device(torch.tensor(stack, device='cuda'), ct, 64, 30.0, 1.0).cpu().numpy()
+    ref, _ = fo.get_recon(a.astype(np.float32), ct.thetas, ct.gammas, 60.0, 64, 30.0, 1.0, theta_tot=4.4)
+    assert np.max(np.abs(img[0] - ref)) < 3e-5 * np.abs(ref).max()
+    assert np.max(np.abs(img[2] - (img[0] + 2 * img[1]))) < 1e-5 * np.abs(img).max()
+    # cone beam: a centred ball seen by a short and by a full rotation
+    def ball_sino(cone):
+        th, gam, rz = cone.thetas, cone.gammas, cone.row_z()
+        out = np.zeros((th.size, rz.size, gam.size))
+        R, mu = 6.0, 0.2
+        for i, b_ in enumerate(th):
+            src = np.array([60.0 * np.cos(b_), 60.0 * np.sin(b_), cone.src_z])
+            ang = b_ + np.pi + gam
+            for r, z in enumerate(rz):
+                d = np.stack([100.0 * np.cos(ang), 100.0 * np.sin(ang), np.full(gam.size, z - cone.src_z)], -1)
+                d /= np.linalg.norm(d, axis=-1, keepdims=True)
+                t = -(d @ src)
+                dist2 = src @ src - t * t
+                out[i, r] = mu * 2 * np.sqrt(np.maximum(R * R - dist2, 0))
+        return out.astype(np.float32)
+    kw = dict(N_channels=129, N_proj=240, gamma_fan=fan, SID=60.0, SDD=100.0, N_rows=9, cone=True, h_iso=0.5)
+    cs, cf = dx.FanBeamGeometry(theta_tot=4.4, **kw), dx.FanBeamGeometry(**kw)
+    vs = bp.recon_device(torch.tensor(ball_sino(cs), device='cuda'), cs, 64, 30.0, 1.0).cpu().numpy()
+    vf = bp.recon_device(torch.tensor(ball_sino(cf), device='cuda'), cf, 64, 30.0, 1.0).cpu().numpy()
+    c = (np.arange(64) - 32 + 0.5) * (30 / 64)
+    x, y = np.meshgrid(c, c)
+    inner = x ** 2 + y ** 2 < 16.0
+    assert vs.shape == vf.shape == (9, 64, 64) and np.isfinite(vs).all()
+    assert abs(vs[4][inner].mean() - 0.2) < 4e-3 and abs(vf[4][inner].mean() - 0.2) < 4e-3
+    assert np.abs(vs[3:6] - vf[3:6])[:, inner].mean() < 5e-3

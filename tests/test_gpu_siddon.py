@@ -897,6 +897,27 @@ def test_log_sinogram_of_noisy_and_cone_beam_scans(hip):
         plain, _ = pjc.project(sp)
         assert torch.equal(counts, plain)
         assert np.allclose(log.cpu().numpy(), _np_log(air, counts.cpu().numpy()), rtol=5e-6, atol=5e-7)
+        # round 4: quantum noise on cone-beam scans (Philox; the variance from a second detection pass with the variance
+        # weights): reproducible, the same sample from both cone kernels and from view shards, moments as predicted
+        (noisy, nlog), _ = pjc.project(sp, noise=True, seed=11, want_log=True)
+        again, _ = pjc.project(sp, noise=True, seed=11)
+        other, _ = pjc.project(sp, noise=True, seed=12)
+        assert torch.equal(noisy, again) and not torch.equal(noisy, other) and not torch.equal(noisy, plain)
+        assert np.allclose(nlog.cpu().numpy(), _np_log(air, noisy.cpu().numpy()), rtol=5e-6, atol=5e-7)
+        if k == 1:
+            first = noisy
+        else:
+            assert torch.equal(noisy, first)
+        lo_shard, _ = projector(cone, ph, kernel=k, view_range=(0, 4)).project(sp, noise=True, seed=11)
+        hi_shard, _ = projector(cone, ph, kernel=k, view_range=(4, 10)).project(sp, noise=True, seed=11)
+        assert torch.equal(torch.cat([lo_shard, hi_shard], dim=1), noisy)
+        from dex_ct_sim_amd import forward_project as fp
+        _, _, w, w2 = fp.merged_tables(cone, ph, sp, with_variance=True)
+        z = ((noisy - plain).double() / plain.double().clamp(min=1e-30).sqrt())          # ~ N(0, var / counts)
+        ratio = float((w2.sum() / w.sum()))                                             # unattenuated variance / signal
+        assert abs(float(z.mean())) < 0.05 * np.sqrt(ratio) and 0.3 * ratio < float(z.var()) < 3.0 * ratio
+        pz, _ = pjc.project(sp, noise='poisson', seed=5)
+        assert torch.isfinite(pz).all() and not torch.equal(pz, plain)
 
 
 @pytest.mark.parametrize('n_rows,n_channels,n_mat,n_spec', [(256, 53, 3, 2), (512, 7, 3, 2), (1024, 5, 3, 1), (200, 10, 3, 2),
