@@ -1,5 +1,6 @@
 """rows16_kernel, round 4: detection with the air term folded into per-pair weight tables (DEXCT_P16_FOLD, default 1)
-against the plain form, on the benchmark scan (512^3, 1000 x 800 x 512, dual spectrum) and on configs[1]'s
+against the plain form (NOTE: the folded kernel lost and was not committed - profiles/r04_notes_rows16.md; with the
+committed library both settings run the plain form), on the benchmark scan (512^3, 1000 x 800 x 512, dual spectrum) and on configs[1]'s
 (256^3, 360 x 512 x 256, one spectrum): time, counts difference, log sinogram."""
 import os
 import sys
