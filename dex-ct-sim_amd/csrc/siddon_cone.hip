@@ -572,7 +572,11 @@ void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const floa
   uint32_t cnt[3] = {0, 0, 0};
   // W carries the guard and the offset of the staging buffer in use: (W >> 40) is the LDS byte offset of the lane's
   // voxel inside column 0 of that buffer.  Only the fraction bits enter the exact path below.
-  long long W = W0 + (long long)p.i_first * SW + ((long long)kConeGuard << DEXCT_FIX_FRAC);
+  // The fast path reads its bytes with ds_read_u8 from inline assembly at RAW LDS addresses: the base of cols[] (wherever
+  // the compiler placed the array - nothing in the source pins it to 0) rides in W together with the guard and the
+  // buffer offset, and in the clamp bounds; the exact path, which indexes cols[] in C++, takes it off again.
+  const uint32_t cbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)cols;
+  long long W = W0 + (long long)p.i_first * SW + ((long long)(kConeGuard + (int)cbase) << DEXCT_FIX_FRAC);
   uint32_t bufoff = 0;
   for (int s0 = 0; s0 < p.n_slabs; s0 += kConeRows) {
     const int n_here = min(kConeRows, p.n_slabs - s0);
@@ -604,8 +608,8 @@ void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const floa
         if (more) stage_load(s + kB);                            // in flight while this batch is consumed
         static_assert(kB == 8 || kB == 4, "a byte or a nibble of the crossing mask per batch");
         const uint32_t vxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)vx_bytes[s >> 3]) >> (kB == 4 ? (s & 4) : 0);
-        const int hi = (int)(bufoff + zs - 1u);
-        int lo = (int)bufoff;
+        const int hi = (int)(cbase + bufoff + zs - 1u);
+        int lo = (int)(cbase + bufoff);
         asm volatile("" : "+v"(lo));                             // a VGPR: v_med3_i32 takes one scalar operand only
         auto slice = [&](long long Wx) {                         // clamp((int)(Wx >> 40), lo, hi): v_ashr + v_med3_i32
           int kq;
@@ -664,7 +668,7 @@ void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const floa
             if (dm[j] != 0ull && __builtin_amdgcn_inverse_ballot_w64(dm[j])) {
               // the oracle's slab, operation for operation (orc_cone_pathlen); only bits 8..39 of W enter
               const long long Wj = Wb + (long long)j * SW;
-              const int ka = slice(Wj), kb = slice(Wj + SW);
+              const int ka = slice(Wj) - (int)cbase, kb = slice(Wj + SW) - (int)cbase;      // (cols[] is indexed from its own start)
               const uint32_t ida = cols[ka + (2 * j + 1) * CB], idb = cols[kb + (2 * j) * CB];
               const float tv = rec[s + j].tv;
               const float tw = fminf((float)((uint32_t)((unsigned long long)Wj >> 8) ^ wpos) * kfw, 1.0f);

@@ -69,10 +69,12 @@ for case in range(n_cases):
         g = co.make_geom(n_views, n_ch, n_rows, 0, nx, ny, nz, dxv, dyv, dzv, sid, sdd)
         _, rpl = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), src_z, vol, mu, w, dda=True,
                                  n_threads=8)
-        c1, p1 = fp.Projector(cone, ph, kernel=1).project_tables(mu_d, w_d, want_pathlen=True)
-        if not np.array_equal(p1.cpu().numpy(), rpl):
+        pj1 = fp.Projector(cone, ph, kernel=1)
+        c1, p1 = pj1.project_tables(mu_d, w_d, want_pathlen=True)
+        # (round 4: the kernels see compact ids - ids the volume does not hold are dropped, Projector.mat_rows)
+        if not np.array_equal(p1.cpu().numpy(), rpl[..., pj1.mat_rows]):
             bad.append('cone_kernel vs the oracle mirror: path lengths differ')
-        if n_mat <= 3:
+        if pj1.n_mat <= 3:
             c2, p2 = fp.Projector(cone, ph, kernel=2).project_tables(mu_d, w_d, want_pathlen=True)
             n_rows_kernel += 1
             if not torch.equal(p2, p1):
