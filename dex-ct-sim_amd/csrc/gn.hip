@@ -744,7 +744,7 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // counter at once, while its other lanes still iterate: all 64 lanes keep iterating until the sinogram is used up, the load
 // balances itself over CUs and XCDs.  The energy loops stay wave-uniform (scalar table loads) because the tables do not
 // depend on the pixel.  Pixels are independent problems: results are bit-identical to gn_kernel's in any order.
-// MINW: minimum waves per SIMD the register allocation must allow (5: 96 VGPRs, 4: 128).
+// MINW: minimum waves per SIMD the register allocation must allow (4, the default: 110 VGPRs, no scratch; 5: 96 VGPRs + 48 B).
 template <int MINW>
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, long long n_pix, const double* __restrict__ ws,
@@ -1136,7 +1136,7 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, tol, tl, out_a);
   } else if (precision == 0) {
-    // Lane refill from a queue of 64-pixel tiles; no more workgroups than can be resident: 32 KB of LDS and 96 VGPRs allow 5 per CU
+    // Lane refill from a queue of 64-pixel tiles; no more workgroups than can be resident: 28 KB of LDS and the registers allow 4 - 5 per CU
     // (those beyond would start when the queue is already empty).  Round 3 measured the fetch size: 64 / 128 / 256 / 512 /
     // 1024 pixels = 766 / 764 / 769 / 771 / 773 ms on the benchmark sinograms and 64 ahead below 1e8 pixels
     // (tools/probes/gn_small2.py): the tail of a launch is the last fetches' slowest pixels.
@@ -1148,8 +1148,11 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
       return n;
     }();
     const char* be = getenv("DEXCT_GN_BLOCKS_PER_CU");          // tuning knob
-    const char* ve = getenv("DEXCT_GN_MINW");                   // 4: 128 VGPRs (no spills), 4 waves per SIMD
-    const int minw = (ve && atoi(ve) == 4) ? 4 : 5;
+    // Register allocation: 4 waves per SIMD with 110 VGPRs and NO scratch (the default since round 4), or 5 with 96 VGPRs
+    // and 48 B of scratch per lane (DEXCT_GN_MINW=5).  Same speed within 1 % (profiles/r04_gn.md), but the spill traffic of
+    // the 5-wave form is written back to HBM: WRITE_SIZE 1.45 x the results against 1.06 - 1.09 x.
+    const char* ve = getenv("DEXCT_GN_MINW");
+    const int minw = (ve && atoi(ve) == 5) ? 5 : 4;
     const int64_t cap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : minw);
     int64_t nb = (tl.n_tiles + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     if (nb > cap) nb = cap;

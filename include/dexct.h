@@ -309,8 +309,10 @@ typedef struct dexct_gn_options {
  * stop (the default, see dexct_gn_options) a converging pixel ends a few iterations earlier still.
  * Environment (read per call, for checking and tuning only): DEXCT_GN_FULL_LOOP=1 executes every iteration (no exit of any
  * kind); DEXCT_GN_EXACT=1 / DEXCT_GN_STOP_TOL=<t> change the DEFAULT tolerance (an explicit options->stop_tol >= 0 wins);
- * DEXCT_GN_BLOCKS_PER_CU=<n> caps the grid of the queue kernel at n workgroups per CU (default 5 = what is resident);
- * DEXCT_GN_MINW=4 selects the variant compiled for 128 registers per lane. */
+ * DEXCT_GN_BLOCKS_PER_CU=<n> caps the grid of the queue kernel at n workgroups per CU (default = what is resident);
+ * DEXCT_GN_MINW=5 selects the variant compiled for 5 waves per SIMD (96 registers per lane + scratch; default 4: no scratch);
+ * DEXCT_GN_COOP_BELOW=<pixels> moves the size below which the cooperative kernel runs; DEXCT_GN_SORT=0 hands small sinograms
+ * out in their natural order instead of thick tiles first. */
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,

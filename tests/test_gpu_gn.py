@@ -246,7 +246,7 @@ def test_repeated_state_exit_changes_no_bit(hip, golden):
 def test_lane_refill_ragged_sizes_tiles_and_mask(hip, golden):
     """gn_refill_kernel: every pixel is solved exactly once and lands in its place - pixel counts around the wave and
     tile boundaries, with and without the fused air mask, 0 and 1 iterations, any cap on the grid of the tile queue, the
-    128-register variant; and with the results written in the reference's [view][row][channel] order from
+    5-waves-per-SIMD variant; and with the results written in the reference's [view][row][channel] order from
     [view][channel][row] input (4 x 16 tiles collected in LDS, ragged row / channel counts): the same bits as the plain
     order transposed.  Exact mode (stop_tol = 0) for the bit comparisons; the result matches the C oracle."""
     import os
@@ -271,7 +271,7 @@ def test_lane_refill_ragged_sizes_tiles_and_mask(hip, golden):
             ref = co.gn_decompose(cnt[0], cnt[1], i0, mus, 30, n_threads=8)
             results = {}
             for masked in (False, True):
-                for env in ({}, {'DEXCT_GN_BLOCKS_PER_CU': '1'}, {'DEXCT_GN_BLOCKS_PER_CU': '3'}, {'DEXCT_GN_MINW': '4'}):
+                for env in ({}, {'DEXCT_GN_BLOCKS_PER_CU': '1'}, {'DEXCT_GN_BLOCKS_PER_CU': '3'}, {'DEXCT_GN_MINW': '5'}):
                     os.environ.update(env)
                     out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
                     md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None, stop_tol=0.0, kernel=1)

@@ -3,11 +3,14 @@ profiles/).  Every case draws tables (1..300 energies, all energy classes, atten
 and then), measurements (noise-free, noisy, photon-starved, zero, negative, inf, NaN pixels mixed in) and an iteration
 count 0..80, and demands, BIT FOR BIT including the NaN payloads:
 
-  * the repeated-state exit returns what the full loop returns (DEXCT_GN_FULL_LOOP=1);
-  * every history length of the exit (DEXCT_GN_HIST 4..12) returns the same;
-  * the register-allocation / exponent / history variants (DEXCT_GN_MINW=4, DEXCT_GN_IEXP=1, DEXCT_GN_HLDS=1, DEXCT_GN_RING=1)
-    return the same, and so do static pixel runs (DEXCT_GN_QUEUE=0) against the run queue and other run lengths;
+  * (exact mode, stop_tol = 0) the repeated-state exit returns what the full loop returns (DEXCT_GN_FULL_LOOP=1);
+  * the 5-waves-per-SIMD register allocation (DEXCT_GN_MINW=5), any cap on the grid of the tile queue, the natural instead
+    of the thick-first order of the hand-out (DEXCT_GN_SORT=0) and the results written in the reference's order from
+    [view][channel][row] input (out_rc: 4 x 16 tiles collected in LDS) return the same;
+  * the cooperative kernel (4 waves per 64 pixels) returns what ITS full loop returns;
   * with the air mask: masked pixels are exactly 0 and the others unchanged;
+and, NOT bit for bit (round 4): the default tolerance stop within 1e-10 of the exact result, and the cooperative kernel
+within 1e-9 of the lane kernel, on the pixels the NumPy restatement answers stably (below);
 and, as a sanity check of the arithmetic (a statistic, not an invariant), agreement to 1e-9 with the NumPy restatement of
 the reference on the pixels where that one is finite and insensitive both to a 1e-13 perturbation of its input and to the
 order of its own sums.  The few pixels beyond 1e-9 that this screen lets through (about 1 in 1e5 here) are of two kinds,
@@ -31,18 +34,17 @@ sys.path.insert(0, ROOT)
 from dex_ct_sim_amd import matdecomp as md
 from oracle import gn_oracle
 
-KNOBS = ('DEXCT_GN_FULL_LOOP', 'DEXCT_GN_HIST', 'DEXCT_GN_MINW', 'DEXCT_GN_IEXP', 'DEXCT_GN_HLDS', 'DEXCT_GN_RING', 'DEXCT_GN_QUEUE',
-         'DEXCT_GN_CHUNK')
+KNOBS = ('DEXCT_GN_FULL_LOOP', 'DEXCT_GN_MINW', 'DEXCT_GN_BLOCKS_PER_CU', 'DEXCT_GN_SORT')
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device('cuda:0')
 
 
-def run(g, i0, mus, n_iters, env, mask_max=None):
+def run(g, i0, mus, n_iters, env, mask_max=None, stop_tol=0.0, kernel=1, out_rc=None):
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    out = md.gn_device(g[0], g[1], i0, mus, n_iters, 'f64', mask_max=mask_max)
+    out = md.gn_device(g[0], g[1], i0, mus, n_iters, 'f64', mask_max=mask_max, stop_tol=stop_tol, kernel=kernel, out_rc=out_rc)
     torch.cuda.synchronize()
     for k in KNOBS:
         os.environ.pop(k, None)
@@ -106,13 +108,24 @@ for case in range(n_cases):
     try:
         base = run(g_d, i0, mus, n_iters, {})
         bits = base.view(torch.int64)
-        for env in ([{'DEXCT_GN_FULL_LOOP': '1'}] + [{'DEXCT_GN_HIST': str(h)} for h in (4, 5, 6, 7, 10, 12)] +
-                    [{'DEXCT_GN_MINW': '4'}, {'DEXCT_GN_IEXP': '1'}, {'DEXCT_GN_HLDS': '1'},
-                     {'DEXCT_GN_MINW': '6', 'DEXCT_GN_HIST': '4'}, {'DEXCT_GN_RING': '1'}, {'DEXCT_GN_RING': '1', 'DEXCT_GN_MINW': '4'},
-                     {'DEXCT_GN_QUEUE': '0'}, {'DEXCT_GN_QUEUE': '0', 'DEXCT_GN_CHUNK': '3'}, {'DEXCT_GN_CHUNK': '1'}, {'DEXCT_GN_CHUNK': '7'}]):
+        for env in ({'DEXCT_GN_FULL_LOOP': '1'}, {'DEXCT_GN_MINW': '5'}, {'DEXCT_GN_BLOCKS_PER_CU': '1'}, {'DEXCT_GN_BLOCKS_PER_CU': '3'},
+                    {'DEXCT_GN_SORT': '0'}, {'DEXCT_GN_SORT': '0', 'DEXCT_GN_MINW': '5'}):
             got = run(g_d, i0, mus, n_iters, env)
             if not torch.equal(got.view(torch.int64), bits):
                 bad.append(f'{env}: {int((got.view(torch.int64) != bits).sum())} values differ')
+        # the same pixels read as [view][channel][row] with the results written as [view][row][channel]
+        rr = int(rng.choice([1, 3, 16, 17]))
+        if n_c % rr == 0 and n_c // rr >= 1:
+            g3 = g_d.reshape(2, n_v, n_c // rr, rr)
+            got = run(g3, i0, mus, n_iters, {}, out_rc=(rr, n_c // rr))
+            want = base.reshape(n_v, n_c // rr, rr, 2).permute(0, 2, 1, 3).contiguous()
+            if not torch.equal(got.view(torch.int64), want.view(torch.int64)):
+                bad.append(f'out_rc=({rr}, {n_c // rr}): {int((got.view(torch.int64) != want.view(torch.int64)).sum())} values differ')
+        coop = run(g_d, i0, mus, n_iters, {}, kernel=2)
+        coop_full = run(g_d, i0, mus, n_iters, {'DEXCT_GN_FULL_LOOP': '1'}, kernel=2)
+        if not torch.equal(coop.view(torch.int64), coop_full.view(torch.int64)):
+            bad.append('cooperative kernel: exact exit differs from its full loop')
+        default = run(g_d, i0, mus, n_iters, {}, stop_tol=None)
         gmax = torch.tensor(float(np.nanmax(np.where(np.isfinite(g[0]), g[0], -np.inf))), dtype=torch.float64, device=dev)
         masked = run(g_d, i0, mus, n_iters, {}, mask_max=gmax)
         air = g_d[0].double() >= 0.95 * gmax
@@ -132,6 +145,13 @@ for case in range(n_cases):
             size = np.maximum(np.abs(ref).max(-1), 1.0)
             ok &= (np.abs(ref - ref_p).max(-1) <= 1e-11 * size) & (np.abs(ref - ref_q).max(-1) <= 1e-11 * size)
             err = np.abs(base.cpu().numpy() - ref)[ok] / np.maximum(np.abs(ref[ok]).max(-1, keepdims=True), 1.0)
+            # (not with one or two energies: the Hessian is singular there and any two arithmetics part ways - the case the
+            # condition-number check below handles for the comparison with the restatement)
+            for name, other, tol in (() if few else (('default tolerance stop', default, 1e-10), ('cooperative kernel', coop, 1e-9))):
+                d = (np.abs(other.cpu().numpy() - base.cpu().numpy())[ok] / np.maximum(np.abs(ref[ok]).max(-1, keepdims=True), 1.0)) if ok.any() else np.zeros(1)
+                n_bad = int((~(d.max(-1) <= tol)).sum()) if ok.any() else 0
+                if n_bad > max(2, 1e-3 * ok.sum()):
+                    bad.append(f'{name}: {n_bad} of {int(ok.sum())} stable pixels beyond {tol:g} of the exact lane kernel')
         if err.size:
             n_cmp += int(ok.sum())
             dev_px = ~(err.max(-1) <= 1e-9)
@@ -157,7 +177,7 @@ for case in range(n_cases):
         fails += 1
         print(f'FAIL seed {seed}: {n_e} energies, {n_v} x {n_c} pixels, {kind}, {n_iters} iterations: ' + '; '.join(bad), flush=True)
     if case % 100 == 99 or case == n_cases - 1:
-        print(f'{case + 1} cases, {fails} failed, {n_pix:.3g} pixels x 19 kernel variants, {n_cmp:.3g} stable pixels compared with the '
+        print(f'{case + 1} cases, {fails} failed, {n_pix:.3g} pixels x 12 launches, {n_cmp:.3g} stable pixels compared with the '
               f'NumPy restatement ({n_off} beyond 1e-9 with >= 3 energies; with 1-2 energies {n_few} beyond 1e-9, the best '
               f'conditioned of them has Hessian cond {min_cond_few:.1e}), {time.time() - t0:.0f} s', flush=True)
 sys.exit(1 if fails else 0)
