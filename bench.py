@@ -505,8 +505,11 @@ def main():
     gstats = md.last_gn_stats()            # of the last timed step's launch (the default mode)
     roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
             'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': gn_ms,
-            'traffic': (prof.get('gn_fetch_bytes_x2_corrected', 0) + prof.get('gn_write_bytes', 0)) or None,
+            'traffic': ((prof.get('gn_fetch_bytes_raw', 0) if prof.get('gn_fetch_counted_in_full') else prof.get('gn_fetch_bytes_x2_corrected', 0))
+                        + prof.get('gn_write_bytes', 0)) or None,
             'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': 24 * n_rays,
+            'traffic_note': 'HBM-side bytes (FETCH_SIZE + WRITE_SIZE) of this kernel from the rocprofv3 --pmc passes of the same command '
+                            'recorded in traffic_source (counters cannot be read from inside the timed run)',
             'bound_note': 'neither HBM (24 B/pixel against ~2e5 flops/pixel) nor MFMA (no dense contraction; FP64 MFMA and '
                           'FP64 VALU do not overlap on gfx950, DESIGN.md 4.4): bound = FP64 vector issue'}
     if gstats and gstats.get('pixel_iterations'):

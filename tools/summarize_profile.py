@@ -84,6 +84,11 @@ if cal:
         if 'gn_refill_kernel' in k or 'gn_kernel<false' in k:
             traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
             traffic['gn_write_bytes'] = write.get(k, 0.0)
+            # round 4: in the reference-order mode (what bench.py runs on stacked fans) the kernel reads its pixels as 64-byte
+            # runs, which FETCH_SIZE counts in full (tools/probes/gn_write2.py: 0.77 GB for 0.82 GB of input; the plain order's
+            # dword-per-lane stream shows half): no doubling for the round-4 kernel
+            traffic['gn_fetch_bytes_raw'] = fetch[k]
+            traffic['gn_fetch_counted_in_full'] = 'gn_refill_kernel<4>' in k or 'gn_refill_kernel<5>' in k
     for k, d in sq.items():
         if ('rows' in k and 'kernel' in k and 'cone_' not in k) or 'gn_refill_kernel' in k:
             tag2 = 'siddon' if 'rows' in k else 'gn'
