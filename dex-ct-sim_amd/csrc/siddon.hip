@@ -1046,28 +1046,74 @@ __global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __
   detect_store<NMAT, R>(L, a, mu, w, w2, rays, valid);
 }
 
-// More than 48 materials: lengths in per-thread LDS columns (one ray per thread), run-time material loop.
-template <int kLdsBlock>
-__global__ __launch_bounds__(kLdsBlock) void detect_kernel_lds(ProjArgs a, const float* __restrict__ mu,
-                                                               const float* __restrict__ w, const float* __restrict__ w2) {
-  extern __shared__ float lds_L[];     // [n_materials][kLdsBlock]
+// More than 48 table rows (49 ... 256): one ray per lane, the EXPONENTS of a block of 32 energies in registers, the materials
+// in a run-time loop - every material's accumulator plane is read once per block of energies (coalesced, L2 resident), its
+// 32 table values arrive as scalar operands.  M x n_energies FMAs per ray like every detection, and nothing in LDS (round
+// 4's first form kept the lengths of all materials in per-lane LDS columns and re-read them per energy: 242 ms for 58 rows
+// on 1e8 rays, profiles/r04_ids.log; this form: the FMA count).  Same operations in the same order as detect_store_lds
+// (exponent summed from material 0 up, exp2 of -p log2 e, energies in order): the same counts bit for bit.
+constexpr int kDetChunk = 32;
+__global__ __launch_bounds__(256) void detect_kernel_chunked(ProjArgs a, const float* __restrict__ mu,
+                                                             const float* __restrict__ w, const float* __restrict__ w2) {
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
-  const size_t ray = (size_t)blockIdx.x * kLdsBlock + threadIdx.x;
+  const size_t ray = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (ray >= n_rays) return;
-  const int tid = threadIdx.x;
   size_t q = ray;
   int v, c;
   if (a.layout == 0) { c = q % a.g.n_channels; q /= a.g.n_channels; v = (int)(q / a.g.n_rows); }
   else               { q /= a.g.n_rows; c = q % a.g.n_channels; v = (int)(q / a.g.n_channels); }
   const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];
+  const int n_e = a.n_energies, n_mat = a.n_materials;
+  const size_t sstride = n_rays;
+  // material 0 fills what the others leave of the chord (same sum, same order as detect_kernel_lds)
   float others = 0.0f;
-  for (int m = 1; m < a.n_materials; ++m) {
+  for (int m = 1; m < n_mat; ++m) {
     const float l = a.acc_out[(size_t)m * n_rays + ray];
-    lds_L[m * kLdsBlock + tid] = l * p.len_per_u;
+    if (a.pathlen) a.pathlen[ray * n_mat + m] = l * p.len_per_u;
     others += l;
   }
-  lds_L[tid] = (p.chord_u - others) * p.len_per_u;
-  detect_store_lds(lds_L, tid, kLdsBlock, a, mu, w, w2, ray);
+  const float L0 = (p.chord_u - others) * p.len_per_u;
+  if (a.pathlen) a.pathlen[ray * n_mat] = L0;
+  float acc[DEXCT_MAX_SPECTRA], var[DEXCT_MAX_SPECTRA];
+#pragma unroll
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) acc[s] = var[s] = 0.0f;
+  for (int e0 = 0; e0 < n_e; e0 += kDetChunk) {
+    const int ne = min(kDetChunk, n_e - e0);                      // wave-uniform
+    float pe[kDetChunk];
+#pragma unroll
+    for (int k = 0; k < kDetChunk; ++k) pe[k] = 0.0f;
+    for (int m = 0; m < n_mat; ++m) {
+      const float L = m == 0 ? L0 : a.acc_out[(size_t)m * n_rays + ray] * p.len_per_u;
+      const float* __restrict__ row = mu + (size_t)m * n_e + e0;  // wave-uniform: scalar loads
+      if (ne == kDetChunk) {
+#pragma unroll
+        for (int k = 0; k < kDetChunk; ++k) pe[k] = fmaf(row[k], L, pe[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < kDetChunk; ++k)
+          if (k < ne) pe[k] = fmaf(row[k], L, pe[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kDetChunk; ++k) {
+      if (k < ne) {
+        const float t = __builtin_amdgcn_exp2f(-pe[k] * kLog2e);
+#pragma unroll
+        for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+          if (s < a.n_spectra) {
+            acc[s] = fmaf(w[s * n_e + e0 + k], t, acc[s]);
+            if (a.variance) var[s] = fmaf(w2[s * n_e + e0 + k], t, var[s]);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+    if (s < a.n_spectra) {
+      a.counts[ray + s * sstride] = acc[s];
+      if (a.sino_log) a.sino_log[ray + s * sstride] = log_ratio(a.air[s], acc[s]);
+      if (a.variance) a.variance[ray + s * sstride] = var[s];
+    }
 }
 
 // rays per thread: 4 up to 16 materials, 2 up to 32, 1 beyond (the lengths of all materials live in registers)
@@ -1136,14 +1182,11 @@ int launch_detect_any(const ProjArgs& a, const Tables& t, hipStream_t st) {
     case 48: return launch_detect<48>(a, t, st);
     default: break;
   }
-  // 49..256 materials: the general detection, one ray per lane, lengths in LDS columns of 64 lanes (<= 64 KB)
-  constexpr int B = 64;
+  // 49..256 table rows: the general detection (exponents of 32 energies in registers, run-time material loop)
   const size_t n_rays = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
-  const size_t nblk = (n_rays + B - 1) / B;
+  const size_t nblk = (n_rays + 255) / 256;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  const size_t lds = (size_t)a.n_materials * B * sizeof(float);
-  DEXCT_ALLOW_LDS(detect_kernel_lds<B>, lds);
-  hipLaunchKernelGGL(detect_kernel_lds<B>, dim3((unsigned)nblk), dim3(B), lds, st, a, t.mu, t.w, t.w2);
+  hipLaunchKernelGGL(detect_kernel_chunked, dim3((unsigned)nblk), dim3(256), 0, st, a, t.mu, t.w, t.w2);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

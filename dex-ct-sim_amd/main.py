@@ -65,6 +65,9 @@ def main(argv=None):
     ap.add_argument('--pairs', nargs='+', default=['detunedMV:80kV:9:1'],
                     help='spec1:spec2:dose1_mGy:dose2_mGy (reference default, main.py:101)')
     ap.add_argument('--n-iters', type=int, default=50)
+    ap.add_argument('--gn-exact', action='store_true',
+                    help='run the fixed iteration count of matdecomp.py:114 bit for bit (stop_tol = 0) instead of ending a '
+                         'pixel once the distance it still has to go is below 1e-12 relative (the default)')
     ap.add_argument('--show', action='store_true')
     ap.add_argument('--noise', default='off', choices=['off', 'gaussian', 'poisson'],
                     help='quantum noise for the dose of each spectrum (default off: the noise-free expectation); '
@@ -120,7 +123,8 @@ def main(argv=None):
             sub_dir = os.path.join(out_dir, f'matdecomp_{s1}_{s2}_{int(d1 * 1000):04}uGy_{int(d2 * 1000):04}uGy/')
             print('Decomposing into basis material sinograms!')
             matsino1, matsino2 = get_basismat_sinos(ct, sinos[0][0], sinos[1][0], specs[0], specs[1],
-                                                    n_iters=args.n_iters, verbose=True)     # progress lines of :111-112
+                                                    n_iters=args.n_iters, verbose=True,     # progress lines of :111-112
+                                                    stop_tol=0.0 if args.gn_exact else None)
             if rank == 0:
                 os.makedirs(sub_dir, exist_ok=True)
                 print(f'\n*** {sub_dir} ***')
