@@ -1,8 +1,8 @@
-"""profiles/r03_shard_of.md: what ONE rank of a K-GPU strong-scaling run does, measured alone on one GPU
+"""profiles/r0N_shard_of.md: what ONE rank of a K-GPU strong-scaling run does, measured alone on one GPU
 (`bench.py --shard-of K`), for K = 1, 2, 4, 8 on BASELINE configs[2] (1000 x 800) and configs[3] (2000 x 1024) - the
 prediction the driver's first N-rank RCCL line is to be compared with.
 
-    python tools/shard_of_table.py > profiles/r03_shard_of.md
+    python tools/shard_of_table.py > profiles/r04_shard_of.md
 """
 import json
 import os
@@ -39,7 +39,7 @@ for workload, views, chans in (('config2', 1000, 800), ('config3', 2000, 1024)):
             print(f'{workload} K={K} rank={rank}: step {j["ms_per_step"]:.1f} ms', file=sys.stderr, flush=True)
 
 print('# One rank\'s share of a K-GPU strong-scaling run, measured alone on one MI355X (`bench.py --shard-of K`)\n')
-print('Step = plan + fused dual-spectrum projection (sino_raw + sino_log) + global max + 50-iteration Newton + transposes, on the')
+print('Step = plan + fused dual-spectrum projection (sino_raw + sino_log) + global max + Newton (n_iters 50, default tolerance stop) + transposes, on the')
 print('rank\'s contiguous views of the FIXED scan; no collective runs here.  `gather` = bytes the rank RECEIVES in the one')
 print('all-gather of the raw sinograms (both spectra, float32, reference order).  The collective is started right after the')
 print('projection and overlaps the Newton kernel, so only `max(0, gather - Newton)` is exposed.  Two gather estimates at an')
