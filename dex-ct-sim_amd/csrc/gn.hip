@@ -24,7 +24,10 @@
 namespace dexct {
 
 // States kept for the exact repeated-state exit of the float64 Newton loop (cycles up to kGnHistory + 1).
-constexpr int kGnHistory = 8;
+#ifndef DEXCT_GN_HISTORY
+#define DEXCT_GN_HISTORY 8
+#endif
+constexpr int kGnHistory = DEXCT_GN_HISTORY;
 
 constexpr int kGnBlock = 256;
 constexpr int kTab = 14;  // -mu0 K, -mu1 K (K = 2048/ln2), then per k: i0, i0*mu0, i0*mu1, i0*mu0^2, i0*mu0*mu1, i0*mu1^2

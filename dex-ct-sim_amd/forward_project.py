@@ -42,6 +42,27 @@ def merged_tables(ct, phantom, specs, with_variance=False):
     return E, phantom.mu_table(E), w
 
 
+def compact_ids(present, materials):
+    """Which table rows a projection needs, and the renumbering of the ids: ``present[i]`` says whether id i occurs in the
+    scanned voxels.  Ids with the same (density, composition) share a row (their rows of density x mixatten(E) are equal at
+    every energy), absent ids get none, row 0 stays id 0 (its path length comes from the chord); at least two rows are kept
+    when the table has them (the kernels' smallest table).  Returns (mat_rows, lut): mat_rows[k] = the id whose table row
+    serves compact id k; lut[i] = compact id of id i (256 uint8 values; 0 for absent ids)."""
+    mat_rows, lut, seen = [0], np.zeros(256, dtype=np.uint8), {}
+    key = lambda m: (float(m.density), str(m.matcomp))
+    seen[key(materials[0])] = 0
+    for i in range(1, len(materials)):
+        if present[i]:
+            k = key(materials[i])
+            if k not in seen:
+                seen[k] = len(mat_rows)
+                mat_rows.append(i)
+            lut[i] = seen[k]
+    if len(mat_rows) < 2 <= len(materials):
+        mat_rows.append(1)
+    return mat_rows, lut
+
+
 class Projector:
     """Device-resident state of one (scanner, phantom) pair: volume layouts and ray plans.
 
@@ -94,18 +115,7 @@ class Projector:
         present = cnt.cpu().numpy() > 0
         if present[phantom.n_materials:].any():
             raise ValueError('the volume holds a material id without a table entry')
-        self.mat_rows, lut, seen = [0], np.zeros(256, dtype=np.uint8), {}
-        key = lambda m: (float(m.density), str(m.matcomp))
-        seen[key(phantom.materials[0])] = 0
-        for i in range(1, phantom.n_materials):
-            if present[i]:
-                k = key(phantom.materials[i])
-                if k not in seen:
-                    seen[k] = len(self.mat_rows)
-                    self.mat_rows.append(i)
-                lut[i] = seen[k]
-        if len(self.mat_rows) < 2 <= phantom.n_materials:
-            self.mat_rows.append(1)                       # (keep two rows: the kernels' smallest table)
+        self.mat_rows, lut = compact_ids(present, phantom.materials)
         if any(lut[i] != i for i in np.flatnonzero(present)):
             _native.check(self.lib.dexct_volume_remap(ptr(vol_raw), vol_raw.numel(), lut.ctypes.data_as(C.POINTER(C.c_uint8)), st),
                           'dexct_volume_remap')

@@ -286,3 +286,24 @@ def test_volume_sample_stride_is_coprime_to_the_dimensions():
         z, y, x = np.unravel_index(idx, shape)
         for coord, d in ((x, shape[2]), (y, shape[1]), (z, shape[0])):
             assert len(np.unique(coord)) >= min(d, 16)
+
+
+def test_compact_ids_merges_equal_compositions_and_drops_absent_ids():
+    """The renumbering the projector applies to a label map (round 4: all 256 ids): equal (density, composition) share a
+    row, absent ids get none, id 0 stays row 0, at least two rows."""
+    from dex_ct_sim_amd import forward_project as fp
+    from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
+    mats = [AIR, WATER, BONE, Material('w2', 1.0, WATER.matcomp), Material('dense water', 1.1, WATER.matcomp),
+            Material('air again', AIR.density, AIR.matcomp), Material('unused', 3.0, 'H(100)')]
+    present = np.zeros(256, dtype=bool)
+    present[[0, 1, 3, 4, 5]] = True                       # bone (2) and id 6 do not occur
+    rows, lut = fp.compact_ids(present, mats)
+    assert rows == [0, 1, 4]                               # air, water (ids 1 and 3), dense water
+    assert list(lut[:7]) == [0, 1, 0, 1, 2, 0, 0]         # id 5 = air's composition -> row 0; absent ids -> 0 (never read)
+    present[:] = False
+    present[0] = True
+    rows, lut = fp.compact_ids(present, mats)
+    assert rows == [0, 1] and not lut.any()                # an empty volume still gets the kernels' smallest table
+    full = [AIR] + [Material(f'm{i}', 0.5 + 0.01 * i, WATER.matcomp) for i in range(1, 256)]
+    rows, lut = fp.compact_ids(np.ones(256, dtype=bool), full)
+    assert rows == list(range(256)) and list(lut) == list(range(256))
