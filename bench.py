@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--skip-single-row', action='store_true')
+    ap.add_argument('--skip-quadrature', action='store_true', help='leave out the reduced-quadrature measurement')
     ap.add_argument('--skip-dropin', action='store_true', help='omit the public-boundary (NumPy in/out) timing')
     ap.add_argument('--skip-dropin-full', action='store_true', help='public-boundary timing at configs[0] size only')
     ap.add_argument('--skip-gn-full-loop', action='store_true',
@@ -286,6 +287,7 @@ def main():
     out_rc = (rows, args.channels) if native == 1 else None
     # None: the default of get_basismat_sinos / dexct_gn_decompose (tolerance stop, 1e-12); 0.0: the fixed count exactly
     gn_tol = [None]
+    gn_mode = [None]                    # two_level of gn_device: None = its default (the two-level solve), False = one launch
     gmax = torch.empty((), dtype=torch.float64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     precision = args.gn_precision or md.DEFAULT_PRECISION
@@ -312,8 +314,9 @@ def main():
         if timed:
             ev[2].record()
         # air mask fused into the Newton kernel: threshold = 0.95 * (all-reduced) max, read from the device scalar
-        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, precision, out=a_out, out_rc=out_rc, mask_max=gm,
-                     mask_frac=0.95, stop_tol=gn_tol[0])
+        # (the tables as host arrays: gn_device keeps their device copies, and those of the two-level solve, by content)
+        md.gn_device(counts_nat[0], counts_nat[1], i0, mus, args.iters, precision, out=a_out, out_rc=out_rc, mask_max=gm,
+                     mask_frac=0.95, stop_tol=gn_tol[0], two_level=gn_mode[0])
         if timed:
             ev[3].record()
         if native == 1:       # hand the sinograms over in the reference's [view][row][channel] order
@@ -501,42 +504,74 @@ def main():
     n_both = int(((i0[0] != 0) & (i0[1] != 0)).sum())
     n_one = int(((i0[0] != 0) ^ (i0[1] != 0)).sum())
     hw_share = (29.0 * n_both + 17.0 * n_one) / (29.0 * i0.shape[1])
-    gn_name = 'gn_refill_kernel' if precision == 'f64' else 'gn_kernel<true,false>'
-    gstats = md.last_gn_stats()            # of the last timed step's launch (the default mode)
+    gstats = md.last_gn_stats()            # of the last timed step's launches (the default mode)
+    two_level = bool(gstats) and gstats.get('mode') in ('coarse', 'start')
+    gn_name = ('gn_refill_kernel<4, 2> (refining launch of the two-level solve)' if two_level else 'gn_refill_kernel<4, 0>') \
+        if precision == 'f64' else 'gn_kernel<true,false>'
+    main_ms = gstats['main_ms'] if gstats else gn_ms      # HIP events around the launch, on its stream, last timed step
     roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
-            'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': gn_ms,
+            'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': main_ms, 'gn_ms_all_launches': gn_ms,
             'traffic': ((prof.get('gn_fetch_bytes_raw', 0) if prof.get('gn_fetch_counted_in_full') else prof.get('gn_fetch_bytes_x2_corrected', 0))
                         + prof.get('gn_write_bytes', 0)) or None,
-            'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': 24 * n_rays,
+            'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': (24 + (17 if two_level and gstats.get('mode') == 'coarse' else 0)) * n_rays,
             'traffic_note': 'HBM-side bytes (FETCH_SIZE + WRITE_SIZE) of this kernel from the rocprofv3 --pmc passes of the same command '
-                            'recorded in traffic_source (counters cannot be read from inside the timed run)',
-            'bound_note': 'neither HBM (24 B/pixel against ~2e5 flops/pixel) nor MFMA (no dense contraction; FP64 MFMA and '
+                            'recorded in traffic_source (counters cannot be read from inside the timed run); algorithmic: 8 B of counts '
+                            'in and 16 B of results out per pixel, plus 16 B of coarse result and 1 B of step count in for the refining launch',
+            'bound_note': 'neither HBM (24 - 41 B/pixel against >= 2e4 flops/pixel) nor MFMA (no dense contraction; FP64 MFMA and '
                           'FP64 VALU do not overlap on gfx950, DESIGN.md 4.4): bound = FP64 vector issue'}
     if gstats and gstats.get('pixel_iterations'):
         # EXECUTED work of the timed launch itself: the kernel counts the pixel-iterations it ran
         ex_flops = gstats['pixel_iterations'] * flops_per_pixel_iter
-        roof.update({'achieved': ex_flops / (gn_ms * 1e-3) / 1e12, 'frac': ex_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+        live = max((1.0 - masked) * n_rays, 1.0)
+        roof.update({'achieved': ex_flops / (main_ms * 1e-3) / 1e12, 'frac': ex_flops / (main_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      'executed_pixel_iterations': gstats['pixel_iterations'],
-                     'mean_iterations_per_unmasked_pixel': gstats['pixel_iterations'] / max((1.0 - masked) * n_rays, 1.0),
+                     'mean_iterations_per_unmasked_pixel': gstats['pixel_iterations'] / live,
                      'exit_saving': 1.0 - gstats['pixel_iterations'] / max((1.0 - masked) * n_rays * args.iters, 1.0),
                      'stalled_lane_steps': gstats.get('stalled_lane_steps'),
                      'hardware_fp64_flop_share': hw_share,
-                     'hardware_fp64_utilisation': hw_share * ex_flops / (gn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                     'note': 'achieved = flops of the iterations the timed launch EXECUTED (counted by the kernel; SURVEY 8d: '
-                             '28 flops + 1 exp per energy and iteration, unmasked pixels) / its time.  The 29 flop per energy '
+                     'hardware_fp64_utilisation': hw_share * ex_flops / (main_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     'note': 'achieved = flops of the iterations the timed launch EXECUTED on the full tables (counted by the kernel; '
+                             'SURVEY 8d: 28 flops + 1 exp per energy and iteration, unmasked pixels) / its time.  The 29 flop per energy '
                              'are ALGORITHMIC: of the %d energies of the union grid %d carry both spectra, %d only one '
                              '(6 accumulations instead of 12) and %d none (dropped), so the FP64 flops the hardware issues are '
                              'hardware_fp64_flop_share = %.2f of that and hardware_fp64_utilisation = share x frac; the rest of '
                              'the fully busy vector pipe is integer / move work and the per-iteration 2x2 solve '
-                             '(profiles/r03_gn_isa.md).  exit_saving = share of the n_iters x pixels iterations the exits '
-                             '(repeated state, tolerance) made unnecessary - reported separately, not as throughput'
+                             '(profiles/r03_gn_isa.md).  exit_saving = share of the n_iters x pixels full-table iterations the '
+                             'two-level solve and the exits made unnecessary - reported separately, not as throughput'
                              % (i0.shape[1], n_both, n_one, i0.shape[1] - n_both - n_one, hw_share)})
+        if two_level:
+            roof['two_level'] = {
+                'mode': gstats['mode'], 'coarse_launch_ms': gstats.get('coarse_ms'), 'refine_launch_ms': main_ms,
+                'coarse_energies': gstats.get('coarse_energies'), 'full_energies': int(i0.shape[1]),
+                'coarse_steps_per_unmasked_pixel': gstats.get('coarse_pixel_iterations', 0) / live,
+                'full_steps_per_unmasked_pixel': gstats['pixel_iterations'] / live,
+                'coarse_achieved_TFLOPs': (gstats.get('coarse_pixel_iterations', 0) * 29 * (gstats.get('coarse_energies') or 0)
+                                           / (gstats['coarse_ms'] * 1e-3) / 1e12) if gstats.get('coarse_ms') else None,
+                'note': 'start values from a polynomial in the two log attenuations, ~2 steps on a short quadrature of the spectra '
+                        '(gn_refill_kernel<4, 1>), then the full tables: two steps per pixel, the second being the tolerance '
+                        'rule\'s evidence of convergence of the FULL model; pixels without that evidence are solved from 1e-6 '
+                        'with all n_iters steps.  Compared with the exact mode on every pixel below (gn_exact)'}
     out['roofline'] = roof
     if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
         # ---- the reference's fixed iteration count, EXACTLY (stop_tol = 0): the same step timed the same way -> value_exact;
         # checked bit for bit against a launch that executes every iteration (DEXCT_GN_FULL_LOOP=1), and the default step's
         # results checked against it on every pixel
         a_default = a_out.clone()
+        if two_level:
+            # ---- the default tolerance stop in ONE launch from the reference's start value (round 4's first form of the default)
+            gn_mode[0] = False
+            step(False)
+            torch.cuda.synchronize()
+            t_gn_1 = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(True)
+                torch.cuda.synchronize()
+                t_gn_1.append(ev[2].elapsed_time(ev[3]))
+            elapsed_1 = time.perf_counter() - t0
+            st1 = md.last_gn_stats()
+            a_single = a_out.clone()
+            gn_mode[0] = None
         gn_tol[0] = 0.0
         step(False)
         torch.cuda.synchronize()
@@ -566,7 +601,22 @@ def main():
         if not exact_is_full:
             raise SystemExit('bench.py: the exact launch (stop_tol = 0) differs from the full 50-iteration loop')
         if not (diff <= 1e-12 and same_nan):
-            raise SystemExit(f'bench.py: the default tolerance stop moved a pixel by {diff:.3e} (> 1e-12) from the exact launch')
+            raise SystemExit(f'bench.py: the default mode moved a pixel by {diff:.3e} (> 1e-12) from the exact launch')
+        if two_level:
+            diff1 = float(torch.nan_to_num((a_single - a_exact).abs() / a_exact.abs().clamp(min=1.0), nan=0.0).max().item())
+            if not (diff1 <= 1e-12 and bool(torch.equal(torch.isnan(a_single), torch.isnan(a_exact)))):
+                raise SystemExit(f'bench.py: the single-launch tolerance stop moved a pixel by {diff1:.3e} (> 1e-12) from the exact launch')
+            g1_ms = float(np.mean(t_gn_1))
+            out['value_single_launch'] = integrals_per_step / (elapsed_1 / args.steps)
+            out['gn_single_launch'] = {
+                'gn_ms': g1_ms, 'ms_per_step': 1e3 * elapsed_1 / args.steps, 'executed_pixel_iterations': st1['pixel_iterations'],
+                'mean_iterations_per_unmasked_pixel': st1['pixel_iterations'] / max((1.0 - masked) * n_rays, 1.0),
+                'achieved': st1['pixel_iterations'] * flops_per_pixel_iter / (g1_ms * 1e-3) / 1e12,
+                'frac': st1['pixel_iterations'] * flops_per_pixel_iter / (g1_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                'max_diff_vs_exact': diff1,
+                'note': 'two_level=False / DEXCT_GN_TWO_LEVEL=0: every pixel from the reference\'s start value 1e-6 on the full '
+                        'tables, ended by the same tolerance rule (what `value` was before the two-level solve)'}
+            del a_single
         gn_ex_ms = float(np.mean(t_gn_ex))
         out['value_exact'] = integrals_per_step / (elapsed_ex / args.steps)
         out['gn_exact'] = {'stop_tol': 0.0, 'gn_ms': gn_ex_ms, 'ms_per_step': 1e3 * elapsed_ex / args.steps,
@@ -581,9 +631,10 @@ def main():
                            'default_within_1e-12_of_exact_on_every_pixel': True,
                            'note': 'value_exact: the same step with stop_tol = 0 - the fixed iteration count of '
                                    'matdecomp.py:114, every bit of it (checked here against a launch that executes all '
-                                   'iterations).  `value` is the default mode: a pixel also ends when a Newton step moves it by '
-                                   '<= 1e-12 * max(|a|, 1) and that step is at most half the previous one; its results are '
-                                   'compared with the exact ones on every pixel above'}
+                                   'iterations).  `value` is the default mode: every pixel ends at a fixed point of the full model '
+                                   'that the tolerance rule has verified to 1e-12 * max(|a|, 1) - reached by the two-level solve - '
+                                   'or after the reference\'s own n_iters steps; its results are compared with the exact ones on '
+                                   'every pixel above'}
         gn_tol[0] = None
         step(False)                                                                  # the default results are back in place
         torch.cuda.synchronize()
@@ -609,6 +660,43 @@ def main():
                                      'note': 'DEXCT_GN_PRECISION=mixed: first n-4 iterations float32, last 4 float64; '
                                              'opt-in, not the reference arithmetic, not used for value'}
         del a_mixed, diff
+
+    # ---- the opt-in reduced energy quadrature (dex-ct-sim_amd/quadrature.py): same kernel, shorter table with a verified
+    # error bound; reported beside the step, never part of `value` (the step detects on the full grid)
+    if not args.skip_quadrature and world == 1:
+        t0 = time.perf_counter()
+        _, mu_r, w_r, _ = pj.upload_tables(specs, 'reduced')
+        prep_s = time.perf_counter() - t0
+        qi = pj.quadrature_info
+        if qi is None:
+            out['siddon_reduced_quadrature'] = {'applied': False}
+        else:
+            c_red, l_red = torch.empty_like(counts_nat), torch.empty_like(log_nat)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pj.project_tables(mu_r, w_r, out=c_red, layout=None, air=air, log_out=l_red)
+            e0.record()
+            for _ in range(5):
+                pj.project_tables(mu_r, w_r, out=c_red, layout=None, air=air, log_out=l_red)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_r = e0.elapsed_time(e1) / 5
+            dev_c = max(float(((c_red[:, v0:v0 + 50].double() - counts_nat[:, v0:v0 + 50].double()).abs()
+                               / counts_nat[:, v0:v0 + 50].double()).max()) for v0 in range(0, nV, 50))
+            dev_l = max(float((l_red[:, v0:v0 + 50] - log_nat[:, v0:v0 + 50]).abs().max()) for v0 in range(0, nV, 50))
+            if dev_c > 2e-6:
+                raise SystemExit(f'bench.py: reduced quadrature {dev_c:.2e} from the full grid (bound 2e-6)')
+            out['siddon_reduced_quadrature'] = {
+                'applied': True, 'opt_in': "get_sino(..., quadrature='reduced') / DEXCT_QUADRATURE=reduced", 'siddon_ms': ms_r,
+                'full_grid_siddon_ms': sid_ms, 'speedup': sid_ms / ms_r, 'nodes': qi['nodes'], 'full_grid_bins': qi['n_full'],
+                'nodes_per_spectrum': qi['nodes_per_spectrum'], 'verified_max_rel_err_f64': qi['max_rel_err'],
+                'points_verified': qi['n_validated'], 'path_bounds_cm': qi['l_max'],
+                'max_rel_deviation_of_counts_all_rays': dev_c, 'max_abs_deviation_of_log_sinogram_all_rays': dev_l,
+                'host_preparation_s_once_per_phantom_and_spectra': prep_s,
+                'rays_per_s': n_rays / (ms_r * 1e-3),
+                'note': 'positive-weight generalised Gauss quadrature on a subset of the grid (linear programme), verified in '
+                        'float64 over every path length the phantom allows; deviation measured here on every ray of the '
+                        'step against the full-grid launch (two float32 kernels); not used for value'}
+            del c_red, l_red
 
     # ---- single-row (the reference's own 2-D case), ray-parallel kernel
     if not args.skip_single_row and world == 1:

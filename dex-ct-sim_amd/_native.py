@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libdexct_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every entry point include/dexct.h declares
 SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
@@ -41,14 +41,20 @@ def log_out(sino_log_ptr, air):
 
 
 class GnOptions(C.Structure):
-    """dexct_gn_options (ABI 3)"""
+    """dexct_gn_options (ABI 4)"""
     _fields_ = [('stop_tol', C.c_double), ('out_rows', C.c_int32), ('out_channels', C.c_int32), ('kernel', C.c_int32),
-                ('reserved_', C.c_int32)]
+                ('gn_pass', C.c_int32), ('iterations', C.c_void_p), ('start', C.c_void_p)]
 
 
-def gn_options(stop_tol=None, out_rows=0, out_channels=0, kernel=0):
-    """byref-able dexct_gn_options; ``stop_tol=None`` asks for the library default (a negative value in the struct)."""
-    o = GnOptions(-1.0 if stop_tol is None else float(stop_tol), int(out_rows), int(out_channels), int(kernel), 0)
+GN_PASS_COARSE, GN_PASS_REFINE = 1, 2
+
+
+def gn_options(stop_tol=None, out_rows=0, out_channels=0, kernel=0, gn_pass=0, iterations=None, start=None):
+    """byref-able dexct_gn_options; ``stop_tol=None`` asks for the library default (a negative value in the struct).
+    ``gn_pass`` / ``iterations`` (device address of n_pix bytes) / ``start`` (device address of the start polynomial): the
+    two launches of the two-level solve."""
+    o = GnOptions(-1.0 if stop_tol is None else float(stop_tol), int(out_rows), int(out_channels), int(kernel), int(gn_pass),
+                  iterations, start)
     return C.byref(o)
 
 

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void gn_tile_scatter_kernel(int n_tiles, int* 
 // the pixel with (a0, a1) = what all n_iters iterations would return (repeated state) / the converged state (tolerance).
 __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_iters, int exact_exit, double stop_tol,
                                                    double& a0, double& a1, int& it, long long (&h0)[kGnHistory],
-                                                   long long (&h1)[kGnHistory]) {
+                                                   long long (&h1)[kGnHistory], bool* by_rule = nullptr) {
   int hit = -2;
   if (exact_exit) {
     const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
@@ -709,6 +709,7 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
       if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
   }
   const bool converged = gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it);
+  if (by_rule) *by_rule = converged;
   const bool advance = hit == -2 && !converged;
   // the state a cycle holds at iteration n_iters: s_m = s_{base + (m - base) mod period} for m >= base = it-1-hit,
   // and (n_iters - base) = (n_iters - it - 1) mod period; s_{base+j} is hist[hit-j], s_it the current state (slot -1)
@@ -745,6 +746,58 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
   return advance;
 }
 
+// Start values of the two-level solve (dexct_gn_options.start): nothing ties the coarse pass - or a refining pass that runs
+// without one - to the reference's start value 1e-6, because what is returned is decided by the tolerance rule of the full
+// model (or, failing that, by the reference's own solve from 1e-6).  A polynomial in the two log attenuations, fitted by the
+// host over the domain of the short tables, puts a pixel within a few 1e-3 of its solution: 2 coarse steps instead of 16.
+//
+// THE GATE.  The reference returns the state after n_iters steps from 1e-6 - the fixed point only if its own iteration gets
+// there in time.  So a pixel may take the short cut only where that is known: the start array carries a table, over cells of
+// the (a0, a1) domain, of the number of steps the reference's iteration (this library's single launch, run by the host on
+// the cell corners when the tables are prepared) needs to end by the tolerance rule AT the true solution - the maximum over the
+// cell and its neighbours plus a margin, infinity where it does not get there or outside the domain.
+//   * before: a pixel takes the short cut only if its START value falls in (or within half a cell below) a cell with
+//     n_iters >= that number (gn_gate with slack: a filter, so that hopeless pixels do not pay for the attempt);
+//   * after: the refining pass accepts the result only if the SOLUTION it found lies in such a cell (gn_gate without slack:
+//     the guarantee - the reference's iteration was seen to arrive at the solutions all around it within n_iters steps).
+// Every other pixel (few steps asked for, an ill-conditioned pair of spectra, counts outside the domain, NaN) is solved the
+// reference's way.
+// Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] degree d; [4] cells per axis n; [5] lower edge of the cell grid
+// in the normalised coordinates f_0 = a_0 * [7], f_1 = (a_1 + [9] * a_0) * [8] (the skew [9] keeps rays with a slightly
+// negative second component inside the grid); [6] cells per unit of f; then
+// c_0[(d+1)(d+2)/2], c_1[..] (c_m[i][j] of u0^i u1^j, j fastest), then the n x n step table (row = cell of f0).
+constexpr int kStartHeader = 10;
+__device__ __forceinline__ void gn_start_poly(const double* __restrict__ start, double g0, double g1, double& s0, double& s1) {
+  const double u0 = log(start[0] / g0) * start[2], u1 = log(start[1] / g1) * start[2];
+  const int deg = (int)start[3];
+  const int n_terms = (deg + 1) * (deg + 2) / 2;
+  const double* __restrict__ c0 = start + kStartHeader;
+  const double* __restrict__ c1 = c0 + n_terms;
+  s0 = 0.0;
+  s1 = 0.0;
+  for (int i = deg; i >= 0; --i) {                 // sum_i u0^i (sum_j c[i][j] u1^j), Horner in both
+    const int off = i * (deg + 1) - i * (i - 1) / 2, len = deg + 1 - i;
+    double r0 = 0.0, r1 = 0.0;
+    for (int jj = len - 1; jj >= 0; --jj) {
+      r0 = fma(r0, u1, c0[off + jj]);
+      r1 = fma(r1, u1, c1[off + jj]);
+    }
+    s0 = fma(s0, u0, r0);
+    s1 = fma(s1, u0, r1);
+  }
+}
+
+__device__ __forceinline__ bool gn_gate(const double* __restrict__ start, int n_iters, double a0, double a1, double slack) {
+  const int deg = (int)start[3];
+  const int n = (int)start[4];
+  double f0 = (a0 * start[7] - start[5]) * start[6], f1 = ((a1 + start[9] * a0) * start[8] - start[5]) * start[6];
+  bool ok = f0 >= -slack && f1 >= -slack && f0 < (double)n && f1 < (double)n;      // (NaN compares false)
+  f0 = fmax(f0, 0.0);
+  f1 = fmax(f1, 0.0);
+  if (ok) ok = (double)n_iters >= (start + kStartHeader + (deg + 1) * (deg + 2))[(int)f0 * n + (int)f1];
+  return ok;
+}
+
 // float64, one shared spectrum - the benchmark's path - with lane refill.  The exits end pixels at very different
 // iterations (from 10 to all of n_iters), and a wave is as slow as its slowest lane.  Here every lane whose pixel has ended
 // takes the next pixel of the wave's current tile, and a wave whose tile is handed out fetches the next tile from a global
@@ -752,20 +805,38 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // balances itself over CUs and XCDs.  The energy loops stay wave-uniform (scalar table loads) because the tables do not
 // depend on the pixel.  Pixels are independent problems: results are bit-identical to gn_kernel's in any order.
 // MINW: minimum waves per SIMD the register allocation must allow (4, the default: 110 VGPRs, no scratch; 5: 96 VGPRs + 48 B).
-template <int MINW>
+//
+// PASS (dexct_gn_options.pass): the two launches of the two-level solve (host side: matdecomp.gn_device).
+//   0  one launch, everything above.
+//   1  COARSE: the same iteration on whatever tables it is given (the host passes a short quadrature of the spectra: a fifth of
+//      the energies); besides the result, `iters` receives per pixel (result order) the number of steps after which the
+//      tolerance rule ended it, or 255 when it ended any other way (n_iters reached, repeated state, NaN).
+//   2  REFINE: on the full tables.  A pixel whose byte k is not 255 and leaves at least two steps of the budget starts from
+//      the coarse result in out_a with n_iters - k steps left (the coarse steps count against the budget, so no pixel gets
+//      more iterations than the reference gives it); it ends by the same tolerance rule - i.e. only after a step of the FULL
+//      model has been seen to contract to within stop_tol - or at a repeated state.  A pixel that does not (budget used up,
+//      NaN) and every pixel marked 255 is solved from the reference's start value with all n_iters steps, exactly as PASS 0
+//      does: the result of the pair of launches is either a verified fixed point of the full model or the reference's own
+//      trajectory, never the coarse model's answer.
+template <int MINW, int PASS>
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, long long n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, GnTiling tl,
                                                              const double* __restrict__ mask_max, double mask_frac,
-                                                             int flags, double stop_tol,      // flags: bit 0 exact repeated-state exit, bit 1 sorted hand-out
+                                                             int flags, double stop_tol,      // flags: bit 0 exact repeated-state exit, bit 1 sorted hand-out, bits 8..: tiles per queue reservation
                                                              double* __restrict__ out_a,
-                                                             unsigned long long* __restrict__ counters) {
+                                                             unsigned long long* __restrict__ counters,
+                                                             unsigned char* __restrict__ iters,
+                                                             const double* __restrict__ start) {
   typedef double d2 __attribute__((ext_vector_type(2)));
+  constexpr int kWarmBit = 1 << 20;       // PASS 2, in `ent`: this lane's pixel started from the coarse result
   // `counters` = the workspace words 9.. (executed, progress, queue head, stalls): ONE pointer, and the tile order is found
   // from it too (the table pointer `ws` stays read-only for the compiler: its loads are scalar loads)
   auto counter = [&](int k) { return counters + (k - 9); };
   __shared__ double lds_pow[kPowN];                                      // 16 KB
   __shared__ d2 lds_out[kGnBlock / kWave][kSlots * kTilePix];            // 16 KB: with the table 32 KB = 5 workgroups per CU
+  __shared__ unsigned char lds_it[PASS == 1 ? kGnBlock / kWave : 1][PASS == 1 ? kSlots * kTilePix : 1];
+  unsigned char* __restrict__ my_it = lds_it[PASS == 1 ? (threadIdx.x >> 6) : 0];
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
@@ -786,10 +857,14 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   GnTile ct{0, 0, 0, 0};                  // the tile being handed out
   bool exhausted = false;
   unsigned n_exec = 0, n_stall = 0;       // Newton steps executed; lane-steps spent waiting for a free slot (diagnostic)
+  const int batch = (flags >> 8) > 0 ? (flags >> 8) : 1;      // queue positions reserved per atomic (flags bits 8..)
+  int q_next = 0, q_end = 0;              // the reserved positions not yet handed out (n_tiles < 2^31)
+  unsigned handed = 0u;                   // pixels of the tiles handed out since the last reservation (progress word)
 
   int ent = -1;                           // slot * 64 + place of this lane's result in the slot, -1: no pixel
   double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
   int it = 0;
+  int budget = n_iters;                   // PASS 2: steps this lane's pixel may still take (PASS 0 / 1: n_iters, uniform)
   long long h0[kGnHistory], h1[kGnHistory];
 #pragma unroll
   for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
@@ -820,6 +895,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
       if (c_off < d.nc && r_off < d.nr) {
         const d2 v = my_out[k * kTilePix + lane];
         __builtin_nontemporal_store(v, reinterpret_cast<d2*>(out_a) + (d.out_base + (long long)r_off * out_stride + c_off));
+        if (PASS == 1) iters[d.out_base + (long long)r_off * out_stride + c_off] = my_it[k * kTilePix + lane];
       }
 #endif
       __builtin_amdgcn_wave_barrier();
@@ -835,11 +911,24 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
 #pragma unroll
         for (int k = kSlots - 1; k >= 0; --k) s = tid[k] < 0 ? k : s;
         if (s < 0) { n_stall += (unsigned)__popcll(want); break; }     // every slot still waits for a straggler
-        long long t = 0;
-        if (lane == 0) t = (long long)atomicAdd(counter(11), 1ull);
-        t = ((long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
-            (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= tl.n_tiles) { exhausted = true; break; }
+        if (q_next >= q_end) {
+          // reserve the next `batch` queue positions: ONE atomic on the queue head for `batch` tiles, and one for the progress
+          // word (the pixels of the tiles handed out since the last reservation).  All waves of the chip hit these two words:
+          // at one tile per atomic a launch of two steps per pixel spends more time queueing for them than iterating
+          // (profiles/r04_gn_two_level.md: about 12 ns per atomic on one address, 6.4e6 tiles per pass at the benchmark's size).
+          long long t = 0;
+          if (lane == 0) {
+            t = (long long)atomicAdd(counter(11), (unsigned long long)batch);
+            if (handed) atomicAdd(counter(10), (unsigned long long)handed);        // progress: handed to a wave
+          }
+          handed = 0u;
+          t = ((long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+              (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+          if (t >= tl.n_tiles) { exhausted = true; break; }
+          q_next = (int)t;
+          q_end = t + batch < tl.n_tiles ? (int)t + batch : (int)tl.n_tiles;
+        }
+        long long t = q_next++;
         if (flags & 2) t = gn_tile_order(counters, n_e)[t];     // queue position -> tile (thick tiles first, see gn_tile_key_kernel)
         ct = gn_decode_tile(tl, n_pix, t);
         const int n_valid = ct.nr * ct.nc;
@@ -848,7 +937,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
         pend += (unsigned)n_valid << (8 * s);
         cur = s;
         next_j = 0;
-        if (lane == 0) atomicAdd(counter(10), (unsigned long long)n_valid);        // progress: handed to a wave
+        handed += (unsigned)n_valid;
       }
       const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
       const int j = next_j + rank;
@@ -867,12 +956,43 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
 #else
             my_out[place] = d2{0.0, 0.0};
 #endif
+            if (PASS == 1) my_it[place] = 255;
             done_now = true;
           } else if (n_iters <= 0) {
             my_out[place] = d2{1e-6, 1e-6};
+            if (PASS == 1) my_it[place] = 255;
             done_now = true;
           } else {
             ent = place; a0 = 1e-6; a1 = 1e-6; it = 0;
+            if (PASS == 1 && start != nullptr) {
+              double s0, s1;
+              gn_start_poly(start, gd0, gd1, s0, s1);
+              if (gn_gate(start, n_iters, s0, s1, 0.5)) {
+                a0 = s0; a1 = s1;
+              } else {             // not a pixel for the short cut: marked for the reference's own solve, no coarse steps
+                my_out[place] = d2{1e-6, 1e-6};
+                my_it[place] = 255;
+                ent = -1;
+                done_now = true;
+              }
+            }
+            if (PASS == 2) {
+              budget = n_iters;
+              if (iters == nullptr) {                      // no coarse pass: straight from the start polynomial, where the gate allows
+                double s0, s1;
+                gn_start_poly(start, gd0, gd1, s0, s1);
+                if (gn_gate(start, n_iters, s0, s1, 0.5)) { a0 = s0; a1 = s1; ent = place | kWarmBit; }
+              } else {
+                const long long po = ct.out_base + (long long)r_off * out_stride + c_off;
+                const int k = iters[po];
+                if (k != 255 && n_iters - k >= 2) {        // start from the coarse result, the coarse steps paid for
+                  const d2 v = reinterpret_cast<const d2*>(out_a)[po];
+                  a0 = v.x; a1 = v.y;
+                  budget = n_iters - k;
+                  ent = place | kWarmBit;
+                }
+              }
+            }
           }
         }
       }
@@ -892,10 +1012,21 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     // same exit rule as gn_kernel: s_{it+1} equal to s_it (fixed point) or to hist[k] = s_{it-1-k} (cycle of
     // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
     // through it too and are ignored.
-    const bool advance = gn_exit_or_advance(n0, n1, n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1);
-    const bool fin = ent >= 0 && (!advance || it >= n_iters);
+    bool by_rule = false;
+    const bool advance = gn_exit_or_advance(n0, n1, PASS == 2 ? budget : n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1,
+                                            PASS == 1 ? &by_rule : nullptr);
+    bool fin = ent >= 0 && (!advance || it >= (PASS == 2 ? budget : n_iters));
+    if (PASS == 2) {
+      // a pixel started from the coarse result that used up its budget or ran into NaN: the reference's own solve instead
+      // ... or whose solution lies where the reference's own iteration was not seen to arrive in time (gn_gate)
+      const bool redo = fin && (ent & kWarmBit) != 0 &&
+                        (advance || a0 != a0 || a1 != a1 || (start != nullptr && !gn_gate(start, n_iters, a0, a1, 0.0)));
+      if (redo) { a0 = 1e-6; a1 = 1e-6; it = 0; budget = n_iters; ent &= ~kWarmBit; fin = false; }
+      if (fin) ent &= ~kWarmBit;
+    }
     const unsigned long long fb = __ballot(fin);
     if (fb != 0ull) {
+      if (PASS == 1 && fin) my_it[ent] = (unsigned char)(by_rule ? (it + 1 < 255 ? it + 1 : 254) : 255);
 #ifdef DEXCT_GN_DIRECT
       if (fin) {                                     // experiment (plain order only): every result stored by itself
         int tile = tid[0];
@@ -914,6 +1045,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   if (lane == 0) {
     atomicAdd(counter(9), (unsigned long long)n_exec);            // one atomic per wave
     if (n_stall) atomicAdd(counter(12), (unsigned long long)n_stall);
+    if (handed) atomicAdd(counter(10), (unsigned long long)handed);
   }
 }
 
@@ -1121,6 +1253,13 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   }
   if (tl.n_tiles > 0x7FFFFFFFll) return DEXCT_ERANGE;
   if (options && (options->kernel < 0 || options->kernel > 2)) return DEXCT_EINVAL;
+  // the two launches of the two-level solve (see gn_refill_kernel): lane kernel, one shared spectrum, float64, counts in a byte
+  const int pass = options ? options->pass : 0;
+  if (pass < 0 || pass > 2) return DEXCT_EINVAL;
+  if (pass != 0 && (n_bins > 1 || precision != 0 || n_iters > 254 || options->kernel == 2)) return DEXCT_EINVAL;
+  const double* start = (pass != 0) ? options->start : nullptr;
+  if (pass == 1 && !options->iterations) return DEXCT_EINVAL;
+  if (pass == 2 && !options->iterations && !start) return DEXCT_EINVAL;      // start from the coarse result or from the polynomial
   hipStream_t st = as_stream(stream);
   double* ws = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(gn_tables_kernel, dim3(n_bins), dim3(256), 0, st, i0, mus, n_energies, n_bins, ws);
@@ -1138,6 +1277,7 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     if (!(tol >= 0.0)) tol = 0.0;
   }
   if (!exact_exit) tol = 0.0;                         // the full loop is the full loop
+  if (pass != 0 && !(tol > 0.0)) return DEXCT_EINVAL;  // both passes end pixels by the tolerance rule
   const dim3 grid((unsigned)nblk), block(kGnBlock);
   if (n_bins > 1) {
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
@@ -1171,7 +1311,7 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     // small sinograms: thick tiles first (DEXCT_GN_SORT=0 keeps the natural order)
     const int* order = nullptr;
     const char* se = getenv("DEXCT_GN_SORT");
-    if (tl.n_tiles <= kMaxSortTiles && tl.n_tiles > 1 && !(se && se[0] == '0')) {
+    if (pass == 0 && tl.n_tiles <= kMaxSortTiles && tl.n_tiles > 1 && !(se && se[0] == '0')) {    // (the passes: ~2 steps a pixel)
       char* base = reinterpret_cast<char*>(workspace) + gn_ws_tables_bytes(n_energies, n_bins);
       int* hist = reinterpret_cast<int*>(base);
       int* ord = hist + kSortBuckets;
@@ -1186,18 +1326,33 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
       DEXCT_LAUNCH_CHECK();
       order = ord;
     }
-    if (which == 2 || (which == 0 && n_pix < coop_below)) {
+    unsigned char* iters = options ? options->iterations : nullptr;
+    // tiles a wave reserves per atomic on the queue head: 1 for the single launch (measured in round 3: larger fetches gain
+    // nothing at ~17 steps per pixel and lengthen the tail), 8 for the two short passes of the two-level solve on sinograms
+    // large enough that eight tiles per wave are no tail (250 views of the benchmark, 1 / 2 / 4 / 8 / 16 tiles: coarse 38.6 /
+    // 19.4 / 9.9 / 7.5 / 7.6 ms, refine 38.7 / 20.4 / 17.7 / 17.6 / 17.8 ms); DEXCT_GN_TILES_PER_FETCH overrides
+    const char* tfe = getenv("DEXCT_GN_TILES_PER_FETCH");
+    int tiles_per_fetch = (pass != 0 && tl.n_tiles >= (int64_t)128 * cap) ? 8 : 1;
+    if (tfe && atoi(tfe) >= 1 && atoi(tfe) <= 1024) tiles_per_fetch = atoi(tfe);
+    const int qflags = tiles_per_fetch << 8;
+    if (pass == 1)
+      hipLaunchKernelGGL((gn_refill_kernel<4, 1>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
+    else if (pass == 2)
+      hipLaunchKernelGGL((gn_refill_kernel<4, 2>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
+    else if (which == 2 || (which == 0 && n_pix < coop_below)) {
       int64_t ncb = tl.n_tiles;
       const int64_t ccap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : 3);
       if (ncb > ccap) ncb = ccap;
       hipLaunchKernelGGL(gn_coop_kernel, dim3((unsigned)ncb), dim3(kCoopWaves * kWave), 0, st, g1, g2, g_is_f64, (long long)n_pix,
                          (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0), tol, out_a, counters);
     } else if (minw == 4)
-      hipLaunchKernelGGL((gn_refill_kernel<4>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0), tol, out_a, counters);
+      hipLaunchKernelGGL((gn_refill_kernel<4, 0>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
     else
-      hipLaunchKernelGGL((gn_refill_kernel<5>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0), tol, out_a, counters);
+      hipLaunchKernelGGL((gn_refill_kernel<5, 0>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, 0.0, tl, out_a);

@@ -10,6 +10,7 @@ the weighting that the reference's decomposition assumes (matdecomp.py:146-150):
 All work runs in the HIP library (dexct_fan_plan, dexct_volume_layouts, dexct_siddon_project).
 """
 import ctypes as C
+import os as _os
 
 import numpy as np
 import torch
@@ -88,6 +89,7 @@ class Projector:
         if not (0 <= vb < ve <= ct.N_proj):
             raise ValueError(f'bad view range {view_range}')
         self.view_begin, self.view_end = int(vb), int(ve)
+        self._bounds, self.quadrature_info = None, None
         self.cone = bool(getattr(ct, 'cone', False))
         z_first = 0 if self.cone else phantom.z_index
         if not self.cone and (z_first < 0 or z_first + ct.N_rows > phantom.Nz):
@@ -205,9 +207,43 @@ class Projector:
         slices) out of a table with one row per phantom id."""
         return mu[self.mat_rows]
 
-    def upload_tables(self, specs):
+    def path_bounds(self):
+        """(l_max [n_mat], c_max) in cm: no ray of this scan crosses more than l_max[k] of compact id k - the diagonal of the
+        bounding box of its voxels (in the slice plane for a stacked fan, whose rays stay in their slice; in space for a cone
+        beam); the grid's own diagonal for id 0 - nor more than c_max in total.  Computed once, on the device, from the
+        uploaded volume (the domain quadrature.reduce_tables guarantees its error bound on)."""
+        if self._bounds is None:
+            ph = self.phantom
+            v = self.vol_yx.view(-1, ph.Ny, ph.Nx)
+            d = (ph.dz, ph.dy, ph.dx)
+            axes = (0, 1, 2) if self.cone else (1, 2)
+            c_max = float(np.sqrt(sum((v.shape[a] * d[a]) ** 2 for a in axes)))
+            l_max = [c_max]
+            for k in range(1, self.n_mat):
+                m = v == k
+                ext2 = 0.0
+                for a in axes:
+                    idx = torch.nonzero(m.any(dim=[b for b in (0, 1, 2) if b != a])).flatten()
+                    if idx.numel():
+                        ext2 += (float(idx[-1] - idx[0] + 1) * d[a]) ** 2
+                l_max.append(min(c_max, float(np.sqrt(ext2))))
+            self._bounds = (l_max, c_max)
+        return self._bounds
+
+    def upload_tables(self, specs, quadrature=None):
+        """E, mu [n_mat, nE] and w [S, nE] on the device (float32) and the S unattenuated signals.  ``quadrature='reduced'``
+        (or DEXCT_QUADRATURE=reduced) swaps the energy grid for the shorter one of quadrature.reduce_tables where it applies
+        (<= 4 table rows, bound verified); ``self.quadrature_info`` then says what was used (None: the full grid)."""
         E, mu, w = merged_tables(self.ct, self.phantom, specs)
-        return (E, to_dev(self.compact(mu), torch.float32, self.dev), to_dev(w, torch.float32, self.dev), w.sum(axis=1))
+        mu_c, air = self.compact(mu), w.sum(axis=1)
+        self.quadrature_info = None
+        if _want_reduced(quadrature):
+            from . import quadrature as _q
+            red = _q.reduce_tables(mu_c, w, *self.path_bounds()) if self.n_mat <= _q.MAX_MATERIALS else None
+            if red is not None:
+                cols, w, self.quadrature_info = red
+                E, mu_c = E[cols], mu_c[:, cols]
+        return (E, to_dev(mu_c, torch.float32, self.dev), to_dev(w, torch.float32, self.dev), air)
 
     @property
     def native_layout(self):
@@ -357,12 +393,14 @@ class Projector:
                       'dexct_sino_log')
         return out
 
-    def project(self, specs, want_pathlen=False, layout=0, noise=False, seed=0, want_log=False):
+    def project(self, specs, want_pathlen=False, layout=0, noise=False, seed=0, want_log=False, quadrature=None):
         """noise: False (expectation), True / 'gaussian' (compound-Poisson variance, normal sample) or 'poisson'
         (per-energy-bin Poisson photon counts: exact for photon-starved rays, ~5x the projection time).
-        ``want_log``: also the log sinogram ln(air / counts), from the device (appended to the projection's result)."""
+        ``want_log``: also the log sinogram ln(air / counts), from the device (appended to the projection's result).
+        ``quadrature``: see upload_tables (noise-free projections only: the noisy ones keep the full grid, whose bins the
+        variance and the photon counts are defined on)."""
         if not noise:
-            _, mu_d, w_d, air = self.upload_tables(specs)
+            _, mu_d, w_d, air = self.upload_tables(specs, quadrature)
             return self.project_tables(mu_d, w_d, want_pathlen, layout=layout, air=air if want_log else None), air
         if noise == 'poisson':
             res, air = self._project_poisson(specs, want_pathlen, layout, seed)
@@ -410,8 +448,15 @@ class Projector:
         return self.plan.cpu().numpy().view(dt)
 
 
+def _want_reduced(quadrature):
+    """None: what DEXCT_QUADRATURE says (default 'full')."""
+    q = quadrature if quadrature is not None else _os.environ.get('DEXCT_QUADRATURE', 'full')
+    if q not in ('full', 'reduced'):
+        raise ValueError(f"quadrature must be 'full' or 'reduced', not {q!r}")
+    return q == 'reduced'
+
+
 # scratch of the material-group passes above which a projection goes through in view chunks (DEXCT_GROUP_SCRATCH_GB)
-import os as _os
 _GROUP_SCRATCH_BYTES = int(float(_os.environ.get('DEXCT_GROUP_SCRATCH_GB', '16')) * 2 ** 30)
 
 _cache = {}
@@ -495,7 +540,7 @@ def _projector(ct, phantom, view_range):
     return pj, bool(_verify_enabled() and pj.volume_hash is not None)
 
 
-def get_sinos(ct, phantom, specs, noise=False, seed=0):
+def get_sinos(ct, phantom, specs, noise=False, seed=0, quadrature=None):
     """Several spectra from ONE traversal (path lengths are energy independent).
 
     ``noise=True`` adds quantum noise for the dose the spectra are scaled to (compound-Poisson variance,
@@ -507,13 +552,14 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0):
     (or [N_proj, N_rows, N_channels] for N_rows > 1).  Both come from the device (the log sinogram is written by
     the projection kernel's detection store) through page-locked host memory: the arrays returned are views of a
     pinned buffer that belongs to them alone (torch's caching host allocator hands it out again once they are
-    garbage).  Under torch.distributed the projection angles are sharded over the ranks and every rank returns the
+    garbage).  ``quadrature='reduced'`` (opt-in; quadrature.py) evaluates the noise-free detection on a shorter energy grid
+    whose relative error is verified <= 1e-6 over every path length the phantom allows.  Under torch.distributed the projection angles are sharded over the ranks and every rank returns the
     full gathered sinograms.
     """
     vb, ve = _shard.my_views(ct.N_proj)
     pj, check = _projector(ct, phantom, (vb, ve))
     sharded = _shard.world()[1] > 1
-    res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded)
+    res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded, quadrature=quadrature)
     if sharded:
         counts = _shard.gather_views(res, ct.N_proj, view_dim=1, tag='get_sinos')
         log = pj.sino_log(counts, air)              # of the gathered sinogram: one collective instead of two
@@ -534,12 +580,12 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0):
         # takes the same branch.)
         del raw, lg, h_raw, h_lg, counts, log, res
         invalidate()
-        return get_sinos(ct, phantom, specs, noise=noise, seed=seed)
+        return get_sinos(ct, phantom, specs, noise=noise, seed=seed, quadrature=quadrature)
     if ct.N_rows == 1:
         raw, lg = raw[:, :, 0, :], lg[:, :, 0, :]
     return [(raw[k], lg[k]) for k in range(len(specs))]
 
 
-def get_sino(ct, phantom, spec, noise=False, seed=0):
+def get_sino(ct, phantom, spec, noise=False, seed=0, quadrature=None):
     """Drop-in for the reference call ``sino_raw, sino_log = get_sino(ct, phantom, spec)`` (main.py:120)."""
-    return get_sinos(ct, phantom, [spec], noise=noise, seed=seed)[0]
+    return get_sinos(ct, phantom, [spec], noise=noise, seed=seed, quadrature=quadrature)[0]

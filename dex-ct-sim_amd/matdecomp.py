@@ -56,8 +56,34 @@ def _as_device_counts(x, dev):
 # environment says otherwise (DEXCT_GN_STOP_TOL=<t>, DEXCT_GN_EXACT=1).  0 = the reference's fixed count, bit for bit.
 DEFAULT_STOP_TOL = None
 
+# The two-level solve (include/dexct.h, dexct_gn_options.pass / .start).  Most of the reference's ~17 Newton steps per pixel
+# are the walk from its start value 1e-6 to the neighbourhood of the solution; what it returns is the fixed point.  So:
+#   * start values from a polynomial in the two log attenuations (quadrature.newton_start_polynomial, fitted to the forward
+#     model in a few ms per pair of spectra): within a few 1e-3 of the solution;
+#   * a COARSE launch on a short quadrature of the two spectra (quadrature.coarse_newton_tables: ~23 of 140 energies, a quarter
+#     of the cost per step): ~2 steps to the short model's fixed point, 1e-5 from the full model's;
+#   * a REFINE launch on the full tables: two steps per pixel, the second of which is the tolerance rule's evidence that the
+#     FULL model has converged to stop_tol.  A pixel for which this does not happen (steps used up, NaN), or which the coarse
+#     launch could not end by its rule, is solved the reference's way - from 1e-6 with all n_iters steps - in the same launch.
+# What comes out is, per pixel, a fixed point of the full model verified to stop_tol, or the reference's own trajectory: the
+# same contract as the single launch with the tolerance stop, asserted against the exact mode on every pixel of the benchmark
+# (bench.py, tests/test_gpu_full_scale.py).  ~4.6 full-step equivalents per pixel instead of ~17.
+# Modes (``two_level=`` of the calls below; DEXCT_GN_TWO_LEVEL in the environment; DEFAULT_TWO_LEVEL):
+#   None / True  'coarse' from TWO_LEVEL_COARSE_MIN pixels on, else 'start'
+#   'coarse'     polynomial start + coarse launch + refining launch
+#   'start'      polynomial start + refining launch only (~3.6 full steps per pixel; no second launch)
+#   False / '0'  the single launch from 1e-6
+# It applies to float64 with one shared spectrum, the tolerance stop on, 4 <= n_iters <= 254 and >= 48 energies; anything
+# else runs the single launch.
+DEFAULT_TWO_LEVEL = None
+TWO_LEVEL_COARSE_MIN = 1 << 23          # 8.4e6 pixels (tools/probes/gn_two_level_small.py: 1.2e7 pixels 3.25 against 3.59 ms, 2.6e6 2.39 against 1.31)
+
 _last_ws = []          # workspaces of the most recent call (one per view chunk of the pipelined boundary)
+_last_ws_coarse = []   # ... of its coarse launches (two-level solve)
+_last_events = []      # (before, between, after) events of the launches of the most recent call(s)
 _last_zeroed = None
+_table_cache = {}
+COARSE_STOP_TOL = 1.0e-7     # tolerance of the coarse launch's stop rule (its model is ~1e-6 from the full one anyway)
 
 
 def last_gn_stats():
@@ -69,11 +95,98 @@ def last_gn_stats():
     if not _last_ws:
         return None
     words = torch.stack([w[72:104].view(torch.int64) for w in _last_ws]).sum(dim=0).tolist()
-    return {'pixel_iterations': int(words[0]), 'stalled_lane_steps': int(words[3]), 'launches': len(_last_ws)}
+    st = {'pixel_iterations': int(words[0]), 'stalled_lane_steps': int(words[3]), 'launches': len(_last_ws)}
+    if _last_ws_coarse:
+        # two-level solve: 'pixel_iterations' are the steps on the FULL tables, these the steps on the short ones
+        cw = torch.stack([w[72:104].view(torch.int64) for w in _last_ws_coarse]).sum(dim=0).tolist()
+        st['coarse_pixel_iterations'] = int(cw[0])
+        st['coarse_energies'] = _last_coarse_ne
+    st['mode'] = _last_mode
+    if _last_events:
+        torch.cuda.synchronize()
+        st['coarse_ms'] = sum(e[0].elapsed_time(e[1]) for e in _last_events)
+        st['main_ms'] = sum(e[1].elapsed_time(e[2]) for e in _last_events)       # the single launch / the refining launch
+    return st
+
+
+_last_coarse_ne = 0
+_last_mode = 'single'
+
+
+def _effective_stop_tol(stop_tol):
+    """What the library will use (dexct_gn_decompose): an explicit value, else DEXCT_GN_EXACT / DEXCT_GN_STOP_TOL / 1e-12;
+    0 under DEXCT_GN_FULL_LOOP=1."""
+    if os.environ.get('DEXCT_GN_FULL_LOOP', '')[:1] == '1':
+        return 0.0
+    if stop_tol is not None and stop_tol >= 0:
+        return float(stop_tol)
+    if os.environ.get('DEXCT_GN_EXACT', '')[:1] == '1':
+        return 0.0
+    try:
+        t = float(os.environ.get('DEXCT_GN_STOP_TOL', '1e-12'))
+    except ValueError:
+        t = 0.0
+    return t if t >= 0 else 0.0
+
+
+def _host_tables(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
+
+
+def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12):
+    """(i0_d [2, nBins, nE], mus_d [2, nE], coarse) for host or device tables, cached by content; coarse = (i0_short_d
+    [2, 1, n] or None, mus_short_d [2, n] or None, start array) or None; ``cal_tol``: the tolerance the gate is calibrated for.  Tables given as device tensors are used as they are (and read back once
+    per call only when the short tables are wanted: pass host arrays to avoid that synchronisation)."""
+    if isinstance(i0, torch.Tensor) and isinstance(mus, torch.Tensor) and not want_coarse:
+        i0_d, mus_d = to_dev(i0, torch.float64, dev), to_dev(mus, torch.float64, dev)
+        return (i0_d[:, None, :].contiguous() if i0_d.dim() == 2 else i0_d), mus_d, None
+    i0_h, mus_h = np.ascontiguousarray(_host_tables(i0), dtype=np.float64), np.ascontiguousarray(_host_tables(mus), dtype=np.float64)
+    key = (i0_h.shape, i0_h.tobytes(), mus_h.tobytes(), str(dev))
+    ent = _table_cache.get(key)
+    if ent is None:
+        if len(_table_cache) >= 8:
+            _table_cache.clear()
+        i0_d, mus_d = to_dev(i0_h, torch.float64, dev), to_dev(mus_h, torch.float64, dev)
+        if i0_d.dim() == 2:
+            i0_d = i0_d[:, None, :].contiguous()
+        ent = _table_cache[key] = {'i0': i0_d, 'mus': mus_d}
+    if want_coarse and ('coarse', cal_tol) not in ent:
+        ent[('coarse', cal_tol)] = None
+        if i0_h.ndim == 2 or i0_h.shape[1] == 1:
+            from . import quadrature
+            i0_2 = i0_h.reshape(2, -1)
+            pieces = quadrature.newton_start_polynomial(i0_2, mus_h)
+            start = None
+            if pieces is not None:
+                # THE GATE (csrc/gn.hip, gn_start_values): the reference's iteration - the library's own kernel, full tables,
+                # from 1e-6 - run on the noise-free counts of the cell corners of the domain; how many steps it takes to end by
+                # the tolerance rule, and whether it ends at the truth, decides where pixels may take the short cut
+                g = np.nan_to_num(pieces['corner_g'], nan=1.0)
+                g_d = to_dev(np.ascontiguousarray(g.T), torch.float64, dev)
+                n_c = g.shape[0]
+                a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
+                k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
+                lib = _native.load()
+                ws = torch.empty(lib.dexct_gn_workspace_bytes(i0_2.shape[1], 1), dtype=torch.uint8, device=dev)
+                _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(ent['i0']), ptr(ent['mus']), i0_2.shape[1], 1,
+                                                     1, 254, 0, 0, None, 0.95, ptr(a_c),
+                                                     _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COARSE, k_c.data_ptr()),
+                                                     ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
+                start_h, share = quadrature.gate_table(pieces, k_c.cpu().numpy(), a_c.cpu().numpy())
+                if share >= 0.25:               # (an ill-conditioned pair: the reference's iteration itself does not get there)
+                    start = to_dev(start_h, torch.float64, dev)
+            red = quadrature.coarse_newton_tables(i0_2, mus_h) if start is not None else None
+            i0_s = mus_s = None
+            if red is not None:
+                i0_s = to_dev(np.ascontiguousarray(red[1])[:, None, :], torch.float64, dev)
+                mus_s = to_dev(np.ascontiguousarray(mus_h[:, red[0]]), torch.float64, dev)
+            if start is not None:
+                ent[('coarse', cal_tol)] = (i0_s, mus_s, start)
+    return ent['i0'], ent['mus'], ent.get(('coarse', cal_tol)) if want_coarse else None
 
 
 def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1, mask_max=None,
-              mask_frac=0.95, stop_tol=None, out_rc=None, kernel=0, accumulate_stats=False):
+              mask_frac=0.95, stop_tol=None, out_rc=None, kernel=0, accumulate_stats=False, two_level=None):
     """g1, g2: device tensors of equal shape; mus: [2, nE] float64; i0: [2, nE] (one spectrum for all
     pixels) or [2, nBins, nE] (pixel p uses row (p // bin_div) % nBins: the reference's general layout).
     ``mask_max``: device float64 scalar (the global maximum of sinogram 1) - pixels with g1 >= mask_frac * max are
@@ -81,7 +194,7 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     ``stop_tol``: None = default (DEFAULT_STOP_TOL, else the library's 1e-12), 0 = the fixed iteration count exactly.
     ``out_rc=(rows, channels)``: the sinograms are [..., channel, row] (row fastest) and the result is written as
     [..., row, channel, 2], the reference's order, by the kernel itself.  ``kernel``: 0 choose, 1 lane per pixel,
-    2 cooperative (dexct_gn_options).
+    2 cooperative (dexct_gn_options).  ``two_level``: None = DEFAULT_TWO_LEVEL (see there), True / False.
     Returns a device tensor of shape g1.shape + (2,) float64 (with ``out_rc``: the last two sinogram dimensions swapped)."""
     lib = _native.load()
     dev = g1.device
@@ -90,15 +203,33 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
         raise ValueError(f'precision {precision!r}')
     if g1.shape != g2.shape or g1.dtype != g2.dtype:
         raise ValueError('the two sinograms must agree in shape and dtype')
-    i0_d = to_dev(i0, torch.float64, dev)
-    mus_d = to_dev(mus, torch.float64, dev)
-    if i0_d.dim() == 2:
-        i0_d = i0_d[:, None, :].contiguous()
-    if i0_d.dim() != 3 or i0_d.shape[0] != 2 or mus_d.shape != (2, i0_d.shape[2]):
+    if stop_tol is None:
+        stop_tol = DEFAULT_STOP_TOL
+    shp_i0, shp_mu = (tuple(x.shape) if hasattr(x, 'shape') else np.shape(x) for x in (i0, mus))
+    if len(shp_i0) not in (2, 3) or shp_i0[0] != 2 or shp_mu != (2, shp_i0[-1]):
         raise ValueError('i0 must be [2, nE] or [2, nBins, nE] and mus [2, nE]')
-    n_bins, n_e = i0_d.shape[1], i0_d.shape[2]
+    n_bins, n_e = (shp_i0[1] if len(shp_i0) == 3 else 1), shp_i0[-1]
     if n_bins > 1 and precision == 'mixed':
         precision = 'f64'               # mixed precision exists for the shared-spectrum fast path only
+    if two_level is None:
+        two_level = DEFAULT_TWO_LEVEL
+        env = os.environ.get('DEXCT_GN_TWO_LEVEL')
+        if env is not None:
+            two_level = {'0': False, '1': True, 'coarse': 'coarse', 'start': 'start'}.get(env, two_level)
+    if two_level is None or two_level is True:
+        two_level = 'coarse' if g1.numel() >= TWO_LEVEL_COARSE_MIN else 'start'
+    if two_level not in (False, 'coarse', 'start'):
+        raise ValueError(f'two_level={two_level!r}')
+    applies = (precision == 'f64' and n_bins == 1 and kernel != 2 and 4 <= int(n_iters) <= 254 and n_e >= 48
+               and _effective_stop_tol(stop_tol) > 0.0)
+    i0_d, mus_d, tabs = _device_tables(i0, mus, dev, bool(two_level and applies), min(_effective_stop_tol(stop_tol), 1.0e-12) or 1.0e-12)
+    coarse = start_only = None
+    if tabs is not None:                    # (None: no start values with a usable gate for these spectra - the single launch)
+        i0_s, mus_s, start = tabs
+        if two_level == 'coarse' and i0_s is not None:
+            coarse = (i0_s, mus_s, start)
+        else:
+            start_only = start              # 'start', or 'coarse' for spectra that have no short tables
     shape = tuple(g1.shape)
     rows = chans = 0
     if out_rc is not None:
@@ -109,20 +240,47 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     a = out if out is not None else torch.empty(shape + (2,), dtype=torch.float64, device=dev)
     if out is not None and (a.numel() != 2 * g1.numel() or a.dtype != torch.float64 or not a.is_contiguous()):
         raise ValueError('out must be a contiguous float64 tensor with two values per pixel')
-    if stop_tol is None:
-        stop_tol = DEFAULT_STOP_TOL
+    global _last_zeroed, _last_ws, _last_ws_coarse, _last_coarse_ne, _last_events, _last_mode
+    is64 = int(g1.dtype == torch.float64)
+    ws_c = None
+    iters = None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    if coarse is not None:
+        # COARSE launch: the same kernel on the short tables; per pixel, the steps it took (or 255) go to `iters`
+        i0_s, mus_s, start = coarse
+        n_s = int(mus_s.shape[1])
+        iters = torch.empty(g1.numel(), dtype=torch.uint8, device=dev)
+        ws_c = torch.empty(lib.dexct_gn_workspace_bytes(n_s, 1), dtype=torch.uint8, device=dev)
+        ws_c[72:104].zero_()
+        _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), is64, g1.numel(), ptr(i0_s), ptr(mus_s), n_s, 1, 1, int(n_iters),
+                                             0, 0, ptr(mask_max), float(mask_frac), ptr(a),
+                                             _native.gn_options(COARSE_STOP_TOL, rows, chans, 1, _native.GN_PASS_COARSE,
+                                                                iters.data_ptr(), None if start is None else start.data_ptr()),
+                                             ptr(ws_c), stream_ptr()),
+                      'dexct_gn_decompose (coarse pass)')
+        _last_coarse_ne = n_s
+    ev[1].record()
     ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, n_bins), dtype=torch.uint8, device=dev)
     ws[72:104].zero_()       # executed-iteration, progress, queue and stall counters: defined before anybody polls them
-    global _last_zeroed
     _last_zeroed = torch.cuda.Event()
     _last_zeroed.record()    # a progress poller on another stream waits for this (never reads uninitialised bytes)
-    _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), int(g1.dtype == torch.float64), g1.numel(), ptr(i0_d),
+    if coarse is not None:
+        opts = _native.gn_options(stop_tol, rows, chans, 1, _native.GN_PASS_REFINE, iters.data_ptr(), coarse[2].data_ptr())
+    elif start_only is not None:
+        opts = _native.gn_options(stop_tol, rows, chans, 1, _native.GN_PASS_REFINE, None, start_only.data_ptr())
+    else:
+        opts = _native.gn_options(stop_tol, rows, chans, kernel)
+    _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), is64, g1.numel(), ptr(i0_d),
                                          ptr(mus_d), n_e, n_bins, int(bin_div), int(n_iters),
                                          int(precision == 'mixed'), int(n_polish), ptr(mask_max), float(mask_frac), ptr(a),
-                                         _native.gn_options(stop_tol, rows, chans, kernel), ptr(ws), stream_ptr()),
+                                         opts, ptr(ws), stream_ptr()),
                   'dexct_gn_decompose')
-    global _last_ws
+    ev[2].record()
     _last_ws = (_last_ws + [ws]) if accumulate_stats else [ws]
+    _last_ws_coarse = ((_last_ws_coarse if accumulate_stats else []) + ([ws_c] if ws_c is not None else []))
+    _last_events = (_last_events if accumulate_stats else []) + [ev]
+    _last_mode = 'coarse' if coarse is not None else ('start' if start_only is not None else 'single')
     return a
 
 
@@ -154,7 +312,7 @@ def _progress_lines(ws, n_views, n_bins, done_event, t0, every=20, poll_s=0.05):
         time.sleep(poll_s)
 
 
-def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None, stop_tol=None):
+def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None, stop_tol=None, two_level=None):
     """Newton iterations for every pixel (signature of matdecomp.py:20 / :87).
     ``verbose`` prints the reference's progress line every 20 views (:111-112) from the kernel's finished-pixel
     counter; the drop-in callers below pass verbose=False unless asked (a benchmark should not print).
@@ -173,7 +331,7 @@ def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, preci
     g = _as_device_counts(np.asarray(Sino_gg), dev)
     import time
     t0 = time.time()
-    a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision, stop_tol=stop_tol)
+    a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision, stop_tol=stop_tol, two_level=two_level)
     if verbose:
         done = torch.cuda.Event()
         done.record()
@@ -197,13 +355,13 @@ def decomposition_tables(ct, spec1, spec2):
     return ee, i0, mus
 
 
-def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None, stop_tol=None):
+def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None, stop_tol=None, two_level=None):
     """[N_proj, N_channels, 2] density line integrals (matdecomp.py:130-164)."""
     _, i0, mus = decomposition_tables(ct, spec1, spec2)
     dev = device()
     g1 = _as_device_counts(sino1, dev)
     g2 = _as_device_counts(sino2, dev).to(g1.dtype)
-    a = gn_device(g1, g2, i0, mus, n_iters, precision, stop_tol=stop_tol)
+    a = gn_device(g1, g2, i0, mus, n_iters, precision, stop_tol=stop_tol, two_level=two_level)
     return a if isinstance(sino1, torch.Tensor) else to_host(a)
 
 
@@ -214,7 +372,7 @@ _PIPE_CHUNKS = 8                 # view chunks of the pipelined host boundary (t
 _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinogram) the plain sequence is as fast
 
 
-def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol):
+def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level=None):
     """get_basismat_sinos for NumPy sinograms of benchmark size: sinogram 1 goes to the device first (the mask needs its
     global maximum, matdecomp.py:195-196), then per view chunk: sinogram 2's chunk arrives on a copy stream, the Newton
     kernel runs on it, and the finished chunk leaves for page-locked host memory on the copy stream while the next chunk
@@ -254,11 +412,12 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
         t1 = torch.empty((n_views, nC, nR), dtype=dt, device=dev)
         t2 = torch.empty_like(t1)
         eb = 4 if dt == torch.float32 else 8
-    global _last_ws
-    _last_ws = []
+    global _last_ws, _last_ws_coarse, _last_events
+    _last_ws, _last_ws_coarse, _last_events = [], [], []
     for (b, e), ev in zip(bounds, arrived):
         main.wait_event(ev)
-        kw = dict(out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol, accumulate_stats=True)
+        kw = dict(out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol, accumulate_stats=True,
+                  two_level=two_level)
         if row_fastest:
             for src, dst in ((g1, t1), (g2, t2)):
                 _native.check(lib.dexct_transpose_batched(ptr(src[b:e]), ptr(dst[b:e]), e - b, nR, nC, eb, stream_ptr()),
@@ -286,7 +445,7 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
 
 
 def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None,
-                       strict=False, verbose=False, stop_tol=None):
+                       strict=False, verbose=False, stop_tol=None, two_level=None):
     """Basis-material sinograms (matdecomp.py:167-207): air mask from sinogram 1
     (``>= mask_thresh * max``), Newton decomposition, masked pixels set to exactly 0.
 
@@ -316,7 +475,8 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     if (world == 1 and not verbose and not isinstance(sino_raw_1, torch.Tensor) and np.ndim(sino_raw_1) >= 2
             and np.shape(sino_raw_1)[0] >= 2 * _PIPE_CHUNKS and np.size(sino_raw_1) >= _PIPE_MIN_PIXELS
             and np.shape(sino_raw_1) == np.shape(sino_raw_2)):
-        return _basismat_sinos_pipelined(lib, dev, sino_raw_1, sino_raw_2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol)
+        return _basismat_sinos_pipelined(lib, dev, sino_raw_1, sino_raw_2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol,
+                                         two_level)
     g1 = _as_device_counts(sino_raw_1, dev)
     g2 = _as_device_counts(sino_raw_2, dev).to(g1.dtype)
     is64 = int(g1.dtype == torch.float64)
@@ -326,7 +486,8 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     # the mask is applied inside the kernel (threshold read from the device scalar: no host round trip)
     import time
     t0 = time.time()
-    a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol)
+    a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol,
+                  two_level=two_level)
     if verbose and rank == 0 and g1.dim() >= 2:
         done = torch.cuda.Event()
         done.record()

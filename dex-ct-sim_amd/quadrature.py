@@ -1,0 +1,335 @@
+"""A shorter energy quadrature for the detection sum, with a verified error bound (opt-in: ``quadrature='reduced'``).
+
+The detected signal of a ray is ``sum_e w[s][e] exp(-sum_m mu[m][e] L_m)`` over the spectrum's energy grid (the weighting the
+reference's decomposition assumes, matdecomp.py:146-150; 134 weighted bins for the 140 kVp spectrum).  As functions of the
+energy these exponentials span a space of small numerical dimension (the attenuation curves of air / water / bone are smooth
+and monotone), so a handful of the SAME energies with NEW positive weights reproduces every signal in a bounded domain of path
+lengths to a few 1e-7 relative: a generalised Gauss quadrature.  The kernels run unchanged on the shorter table; the work per
+ray falls with the node count.
+
+What makes this usable rather than a guess:
+
+* the domain is rigorous for the phantom at hand: 0 <= L_m <= l_max[m] (the diagonal of material m's bounding box; the grid's
+  diagonal for id 0) and sum_m L_m <= c_max (the grid's diagonal) - no ray can leave it; signals attenuated below 1e-30 of
+  the unattenuated one (which float32 counts cannot hold either) are outside the bound;
+* the weights come from a linear programme (non-negative weights, every training signal within ``tol`` relative) whose vertex
+  solutions are sparse; nodes already chosen for one spectrum cost nothing for the next, so spectra share nodes (the fused
+  kernels evaluate one exponential per energy of the UNION grid);
+* the result is then evaluated in float64 on an independent validation set (a regular grid over the domain, its edges and
+  corners, and random points); points that exceed ``tol`` are added to the programme and it is solved again; the reduction is
+  only handed out when the validation maximum is <= ``max_err`` (default 1e-6 relative, half the 2e-6 budget named in the
+  round-3 review; the reference parity bar for this path is 1e-5), otherwise ``reduce_tables`` returns None and the caller
+  keeps the full grid.
+
+Everything here is host-side table preparation in NumPy / SciPy (like the reference's own spectrum handling); the detection
+itself stays in the HIP kernels.
+"""
+import numpy as np
+
+MAX_MATERIALS = 4          # the domain is sampled, not enumerated: only small tables
+FLOOR = 1.0e-30            # signals below FLOOR x the unattenuated one are outside the bound (float32 cannot hold them either)
+_cache = {}
+
+
+def _domain_points(l_max, c_max, n_random, n_axis, rng, cw):
+    """Points of {0 <= L_m <= l_max[m], sum_m cw[m] L_m <= c_max}: random ones (dense near the faces, where few materials are
+    present), every axis and every pairwise edge."""
+    l_max = np.asarray(l_max, dtype=np.float64)
+    M = l_max.size
+    pts = []
+    # random: a Dirichlet direction (alpha < 1 favours sparse mixes) scaled into the polytope
+    d = rng.dirichlet(np.full(M + 1, 0.7), n_random)[:, :M] * (c_max / cw)[None, :]
+    d = np.minimum(d, l_max[None, :])
+    pts.append(d)
+    t = np.linspace(0.0, 1.0, n_axis)
+    for m in range(M):                                   # one material alone
+        p = np.zeros((n_axis, M))
+        p[:, m] = t * min(l_max[m], c_max / cw[m])
+        pts.append(p)
+    for a in range(M):                                   # two materials filling the longest chord
+        for b in range(a + 1, M):
+            p = np.zeros((n_axis, M))
+            p[:, a] = np.minimum(t * c_max / cw[a], l_max[a])
+            p[:, b] = np.minimum((c_max - cw[a] * p[:, a]) / cw[b], l_max[b])
+            pts.append(p)
+    return np.vstack(pts)
+
+
+def _grid_points(l_max, c_max, per_axis, cw):
+    """A regular grid over the box, cut by sum_m cw[m] L_m <= c_max (points outside are projected onto the face)."""
+    l_max = np.asarray(l_max, dtype=np.float64)
+    axes = [np.linspace(0.0, min(l, c_max / c), per_axis) for l, c in zip(l_max, cw)]
+    g = np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, l_max.size)
+    s = g @ cw
+    over = s > c_max
+    g[over] *= (c_max / s[over])[:, None]
+    return g
+
+
+def _solve(expo, F, w_s, cols, tol, cost):
+    """min cost . u  s.t.  |sum_e u_e w_e exp_e(L) / F(L) - 1| <= tol for every training point, u >= 0."""
+    from scipy.optimize import linprog
+    A = expo[:, cols] * (w_s[cols] / 1.0)[None, :] / F[:, None]
+    n = len(F)
+    res = linprog(cost, A_ub=np.vstack([A, -A]), b_ub=np.concatenate([np.full(n, 1.0 + tol), np.full(n, tol - 1.0)]),
+                  bounds=(0, None), method='highs')
+    if res.status != 0:
+        return None
+    u = np.where(res.x > 1e-12 * res.x.max(), res.x, 0.0)
+    return u
+
+
+def reduce_tables(mu, w, l_max, c_max, tol=2.5e-7, max_err=1.0e-6, seed=0, rounds=6, total_weights=None):
+    """mu [M, nE] (1/cm), w [S, nE] (>= 0) -> (cols, w_red [S, len(cols)], info) with
+    ``|sum_c w_red[s][c] exp(-mu[:, cols[c]] . L) / sum_e w[s][e] exp(-mu[:, e] . L) - 1| <= info['max_rel_err'] <= max_err``
+    at every validated point of the domain, or None when no shorter table with that property was found (more than
+    MAX_MATERIALS rows, a failed programme, or a table that would not be shorter).  The domain: 0 <= L_m <= l_max[m] and
+    sum_m total_weights[m] L_m <= c_max (weights 1 by default: a bound on the total path)."""
+    mu = np.asarray(mu, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    cw = np.ones(mu.shape[0]) if total_weights is None else np.asarray(total_weights, dtype=np.float64)
+    l_max = np.minimum(np.asarray(l_max, dtype=np.float64), c_max / cw)
+    M, nE = mu.shape
+    S = w.shape[0]
+    if M > MAX_MATERIALS or M != l_max.size or np.any(w < 0.0) or nE < 24:
+        return None
+    key = (mu.tobytes(), w.tobytes(), l_max.tobytes(), cw.tobytes(), float(c_max), float(tol), float(max_err), int(seed))
+    if key in _cache:
+        return _cache[key]
+    rng = np.random.default_rng(seed)
+    train = _domain_points(l_max, c_max, 2500, 160, rng, cw)
+    per_axis = {1: 4001, 2: 301, 3: 41, 4: 17}[M]
+    valid = np.vstack([_grid_points(l_max, c_max, per_axis, cw), _domain_points(l_max, c_max, 60000, 1200, rng, cw)])
+    expo_v = np.exp(-(valid @ mu))
+    F_v = expo_v @ w.T                                                  # [n_valid, S]
+    air = w.sum(axis=1)
+    chosen = np.zeros(nE, dtype=bool)
+    u_all = np.zeros((S, nE))
+    worst = 0.0
+    order = np.argsort(-np.count_nonzero(w, axis=1))                    # the widest spectrum first: the others reuse its nodes
+    for s in order:
+        cols = np.flatnonzero(w[s])
+        pts = train
+        u = None
+        for _ in range(rounds):
+            expo = np.exp(-(pts @ mu))
+            F = expo @ w[s]
+            live = F >= FLOOR * air[s]
+            expo, F = expo[live], F[live]
+            # a random positive cost makes the vertex unique; nodes other spectra already use are (almost) free
+            cost = rng.uniform(0.5, 1.5, cols.size)
+            cost[chosen[cols]] *= 1e-3
+            u = _solve(expo, F, w[s], cols, tol, cost)
+            if u is None:
+                break
+            approx = expo_v[:, cols] @ (u * w[s][cols])
+            with np.errstate(divide='ignore', invalid='ignore'):
+                err = np.where(F_v[:, s] >= FLOOR * air[s], np.abs(approx / F_v[:, s] - 1.0), 0.0)
+            bad = np.flatnonzero(err > 2.0 * tol)
+            if bad.size == 0:
+                break
+            bad = bad[np.argsort(-err[bad])[:400]]                      # cutting planes: the worst validation points join
+            pts = np.vstack([pts, valid[bad]])
+        if u is None:                                                   # infeasible / solver failure: keep the full grid
+            return _remember(key, None)
+        # (a programme that still misses 2 x tol somewhere after the last round may yet meet max_err: settled below)
+        worst = max(worst, float(err.max()))
+        u_all[s, cols] = u * w[s][cols]
+        chosen |= u_all[s] > 0.0
+    keep = np.flatnonzero(chosen)
+    # the verdict comes from points the programme never saw: a finer grid and fresh random points
+    fresh = np.vstack([_grid_points(l_max, c_max, per_axis + per_axis // 2 + 1, cw), _domain_points(l_max, c_max, 60000, 1777, rng, cw)])
+    worst = max(worst, max_rel_error(mu, w, keep, u_all[:, keep], fresh))
+    n_checked = int(valid.shape[0] + fresh.shape[0])
+    if worst > max_err or keep.size * 4 > nE * 3:
+        return _remember(key, None)
+    w_red = u_all[:, keep]
+    info = dict(nodes=int(keep.size), n_full=int(nE), nodes_per_spectrum=[int(np.count_nonzero(w_red[s])) for s in range(S)],
+                max_rel_err=worst, n_validated=n_checked, tol=float(tol), l_max=[float(x) for x in l_max],
+                c_max=float(c_max))
+    return _remember(key, (keep, w_red, info))
+
+
+def _remember(key, value):
+    if len(_cache) >= 16:
+        _cache.clear()
+    _cache[key] = value
+    return value
+
+
+def max_rel_error(mu, w, cols, w_red, L):
+    """The reduction's relative error at the path lengths ``L`` [n, M], in float64 (tests, tools)."""
+    mu = np.asarray(mu, dtype=np.float64)
+    expo = np.exp(-(np.asarray(L, dtype=np.float64) @ mu))
+    w = np.asarray(w, dtype=np.float64)
+    full = expo @ w.T
+    red = expo[:, cols] @ np.asarray(w_red, dtype=np.float64).T
+    with np.errstate(divide='ignore', invalid='ignore'):
+        err = np.where(full >= FLOOR * w.sum(axis=1)[None, :], np.abs(red / full - 1.0), 0.0)
+    return float(err.max())
+
+
+def _sparse_nonneg_fit(A, tol_inf, prefer=None, max_nodes=64):
+    """Lawson-Hanson non-negative least squares of A x = 1, stopped as soon as every row is met to ``tol_inf`` (or at
+    ``max_nodes`` columns): the active-set method adds one column per round, so stopping early IS the sparse solution.
+    ``prefer`` (boolean per column): columns that win ties - their gradient counts four-fold (nodes other spectra use).
+    Returns x (zeros outside the chosen columns) and the largest row residual."""
+    m, n = A.shape
+    b = np.ones(m)
+    x = np.zeros(n)
+    passive = np.zeros(n, dtype=bool)
+    r = b.copy()
+    boost = np.where(prefer, 4.0, 1.0) if prefer is not None else np.ones(n)
+    for _ in range(3 * max_nodes):
+        if np.abs(r).max() <= tol_inf or passive.sum() >= max_nodes:
+            break
+        g = (A.T @ r) * boost
+        g[passive] = -np.inf
+        j = int(np.argmax(g))
+        if not g[j] > 0.0:
+            break
+        passive[j] = True
+        while True:
+            idx = np.flatnonzero(passive)
+            z = np.linalg.lstsq(A[:, idx], b, rcond=None)[0]
+            if np.all(z > 0.0):
+                x[:] = 0.0
+                x[idx] = z
+                break
+            neg = z <= 0.0                                        # step towards z until the first weight reaches zero; drop it
+            alpha = np.min(x[idx][neg] / (x[idx][neg] - z[neg]))
+            x[idx] = x[idx] + alpha * (z - x[idx])
+            drop = idx[(x[idx] <= 1e-300) | (neg & (np.abs(x[idx]) <= 1e-14 * np.abs(x[idx]).max()))]
+            if drop.size == 0:
+                drop = idx[neg][:1]
+            passive[drop] = False
+            x[drop] = 0.0
+        r = b - A @ x
+    return x, float(np.abs(r).max())
+
+
+def coarse_newton_tables(i0, mus, log_range=16.0, max_err=2.0e-6):
+    """The short tables of the two-level Newton decomposition (matdecomp.gn_device; include/dexct.h, dexct_gn_options.pass):
+    i0 [2, nE] effective spectra, mus [2, nE] basis mass attenuation -> (cols, i0_short [2, n]) or None.
+
+    The decomposition's forward model ``sum_e i0[k][e] exp(-a0 mus[0][e] - a1 mus[1][e])`` is the same kind of sum as the
+    detection; its short quadrature is built for every (a0, a1) >= 0 whose attenuation at the most penetrating energy stays
+    below exp(-log_range) (1e-7 of the open beam: beyond any sinogram a detector delivers).  No guarantee is needed here and
+    none is claimed: the coarse pass only brings a pixel near its solution, the refining pass ends it on the full tables.
+    So the cheap builder is used - a non-negative least-squares fit stopped at ``max_err`` on its sample (some tens of
+    milliseconds; the linear programme of reduce_tables takes seconds) - and checked on fresh points only to decide whether
+    the short tables are used at all."""
+    i0 = np.asarray(i0, dtype=np.float64)
+    mus = np.asarray(mus, dtype=np.float64)
+    if i0.ndim != 2 or mus.shape != (2, i0.shape[1]) or np.any(i0 < 0.0) or not np.all(np.isfinite(mus)):
+        return None
+    used = np.any(i0 > 0.0, axis=0)
+    if not used.any():
+        return None
+    mu_min = mus[:, used].min(axis=1)
+    if np.any(mu_min <= 0.0):
+        return None
+    rng = np.random.default_rng(0)
+    l_max = log_range / mu_min
+    pts = _domain_points(l_max, log_range, 1500, 120, rng, mu_min)
+    chk = _domain_points(l_max, log_range, 6000, 300, rng, mu_min)
+    expo, expo_c = np.exp(-(pts @ mus)), np.exp(-(chk @ mus))
+    chosen = np.zeros(i0.shape[1], dtype=bool)
+    short = np.zeros_like(i0)
+    for s in np.argsort(-np.count_nonzero(i0, axis=1)):
+        cols = np.flatnonzero(i0[s])
+        F = expo @ i0[s]
+        A = expo[:, cols] * i0[s][cols][None, :] / F[:, None]
+        x, _ = _sparse_nonneg_fit(A, 0.5 * max_err, prefer=chosen[cols])
+        short[s, cols] = x * i0[s][cols]
+        Fc = expo_c @ i0[s]
+        if not np.abs(expo_c @ short[s] / Fc - 1.0).max() <= 4.0 * max_err:
+            return None
+        chosen |= short[s] > 0.0
+    keep = np.flatnonzero(chosen)
+    if keep.size * 2 > i0.shape[1]:
+        return None
+    return keep, short[:, keep]
+
+
+START_HEADER = 10          # doubles before the coefficients (csrc/gn.hip, gn_start_values)
+GATE_CELLS = 40            # cells per axis of the step table
+GATE_LOW = -0.002          # lower edge of the cell grid in normalised coordinates f = a mu_min / log_range: about -0.2 g/cm2 (the
+                           # reference iteration does not reach solutions much below zero; start values may lie half a cell lower)
+GATE_MARGIN = 2            # steps added to the largest count seen around a cell
+
+
+def newton_start_polynomial(i0, mus, log_range=16.0, degree=5, n_grid=72):
+    """Start values for the two-level Newton decomposition (include/dexct.h, dexct_gn_options.start): least-squares
+    polynomials a_m(u0, u1), u_k = ln(air_k / g_k) / log_range, fitted to the forward model over the domain of
+    coarse_newton_tables (extended a little below a = 0).  Returns a dict: ``head`` (the START_HEADER doubles: air_0, air_1,
+    1 / log_range, degree, GATE_CELLS, GATE_LOW, cells per unit, the two normalisations mu_min[m] / log_range, the skew),
+    ``coef`` (c_0 then c_1; c_m[i][j] for u0^i u1^j, i = 0..degree, j = 0..degree - i, j fastest), ``corners`` [(n+1)^2, 2]
+    (the (a0, a1) of the cell corners, row = index along f0) and ``corner_g`` [(n+1)^2, 2] (their noise-free counts; NaN for
+    corners outside the domain) - what gate_table needs - or None.
+
+    Accuracy (140 / 80 kVp on tissue / bone): a few 1e-3 of max(|a|, 1) in the median, 2.5e-2 at worst - two or three Newton
+    steps of the short tables from the coarse model's fixed point, against sixteen from the reference's start value 1e-6."""
+    i0 = np.asarray(i0, dtype=np.float64)
+    mus = np.asarray(mus, dtype=np.float64)
+    if i0.ndim != 2 or mus.shape != (2, i0.shape[1]):
+        return None
+    used = np.any(i0 > 0.0, axis=0)
+    air = i0.sum(axis=1)
+    if not used.any() or np.any(air <= 0.0) or np.any(i0 < 0.0):
+        return None
+    mu_min = mus[:, used].min(axis=1)
+    if np.any(mu_min <= 0.0):
+        return None
+    norm = mu_min / log_range                                        # f_0 = a_0 norm[0], f_1 = (a_1 + skew a_0) norm[1]
+    i0, mus = i0[:, used], mus[:, used]                              # (energies no spectrum weights: 0 x exp(huge) otherwise)
+    # The second basis material may come out NEGATIVE for rays through matter that is not the first one (water in a tissue /
+    # bone basis: a_1 = -0.008 a_0); physically a_0 mu_0(E) + a_1 mu_1(E) >= 0 bounds it by -a_0 min_E(mu_0 / mu_1), and the
+    # reference's iteration reaches about half of that.  The cell grid is therefore laid out in a_1 + skew a_0 with a quarter
+    # of the physical bound, which keeps such rays inside it.
+    skew = 0.25 * float(np.min(mus[0] / mus[1]))
+    u = np.linspace(GATE_LOW, 1.0, n_grid)
+    f0, f1 = np.meshgrid(u, u, indexing='ij')
+    a_all = np.stack([f0.ravel() / norm[0], f1.ravel() / norm[1] - skew * f0.ravel() / norm[0]], axis=1)
+    keep = a_all @ norm <= 1.0                                       # attenuation exponent at the most penetrating energies <= log_range
+    a = a_all[keep]
+    with np.errstate(over='ignore', invalid='ignore'):
+        nu = np.exp(-(a @ mus)) @ i0.T
+    fin = np.all(np.isfinite(nu) & (nu > 0.0), axis=1)
+    a, nu = a[fin], nu[fin]
+    p = np.log(air[None, :] / nu) / log_range
+    terms = [(i, j) for i in range(degree + 1) for j in range(degree + 1 - i)]
+    V = np.stack([p[:, 0] ** i * p[:, 1] ** j for i, j in terms], axis=1)
+    wgt = 1.0 / (np.abs(a).max(axis=1) + 1.0)                       # errors relative to max(|a|, 1), as the stop rule measures
+    coef = np.concatenate([np.linalg.lstsq(V * wgt[:, None], a[:, m] * wgt, rcond=None)[0] for m in range(2)])
+    n = GATE_CELLS
+    per_unit = n / (1.0 - GATE_LOW)
+    head = np.array([air[0], air[1], 1.0 / log_range, float(degree), float(n), GATE_LOW, per_unit, norm[0], norm[1], skew])
+    e = GATE_LOW + np.arange(n + 1) / per_unit
+    c0, c1 = np.meshgrid(e, e, indexing='ij')
+    corners = np.stack([c0.ravel() / norm[0], c1.ravel() / norm[1] - skew * c0.ravel() / norm[0]], axis=1)
+    inside = corners @ norm <= 1.0 + 2.0 / per_unit
+    with np.errstate(over='ignore', invalid='ignore'):
+        g = np.exp(-(corners @ mus)) @ i0.T
+    g[~inside | ~np.all(np.isfinite(g) & (g > 0.0), axis=1)] = np.nan
+    if not (np.all(np.isfinite(coef)) and np.all(np.isfinite(head))):
+        return None
+    return dict(head=head, coef=coef, corners=corners, corner_g=g)
+
+
+def gate_table(pieces, steps, a_found, n_iters_cap=254):
+    """The step table of the start array from the reference iteration run on the cell corners (by the library's own kernel:
+    matdecomp._device_tables): ``steps`` [(n+1)^2] = steps after which the tolerance rule ended the corner's pixel (255: it did
+    not), ``a_found`` [(n+1)^2, 2] = where.  A corner counts only if it ended at its true (a0, a1) (1e-9 of max(|a|, 1)); a
+    cell needs the largest count among its own corners and those of the eight cells around it, plus GATE_MARGIN; infinity if
+    any of them does not count.  Returns the assembled start array and the share of cells that allow the short cut."""
+    n = GATE_CELLS
+    truth = pieces['corners']
+    ok = (np.asarray(steps) < min(255, n_iters_cap + 1)) & np.all(np.isfinite(a_found), axis=1) & ~np.isnan(pieces['corner_g'][:, 0])
+    err = np.abs(a_found - truth).max(axis=1) / np.maximum(np.abs(truth).max(axis=1), 1.0)
+    ok &= err <= 1.0e-9
+    k = np.where(ok, np.asarray(steps, dtype=np.float64), np.inf).reshape(n + 1, n + 1)
+    cell = np.maximum(np.maximum(k[:-1, :-1], k[1:, :-1]), np.maximum(k[:-1, 1:], k[1:, 1:]))
+    pad = np.pad(cell, 1, mode='edge')
+    need = np.max([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0) + GATE_MARGIN
+    return np.concatenate([pieces['head'], pieces['coef'], need.ravel()]), float(np.isfinite(need).mean())

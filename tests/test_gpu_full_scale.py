@@ -164,6 +164,19 @@ def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at
         got = _gpu_sample(counts, 1, [v - vb for v in sample_views], row0)
         rel = np.abs(got - ref) / ref
         assert rel.max() < REL_SINO, (row0, rel.max())
+    # the opt-in reduced energy quadrature (quadrature.py) on EVERY ray of the shard: <= 2e-6 from the full grid (the table's
+    # verified bound is <= 1e-6; two float32 launches), and inside the full grid's parity bar against the float64 oracle
+    _, mu_r, w_r, _ = pj.upload_tables(specs, 'reduced')
+    info = pj.quadrature_info
+    assert info is not None and 3 * info['nodes'] < info['n_full'] and info['max_rel_err'] <= 1e-6
+    cr = pj.project_tables(mu_r, w_r, layout=None)
+    worst = max(float(((cr[:, v0:v0 + 50].double() - counts[:, v0:v0 + 50].double()).abs() / counts[:, v0:v0 + 50].double()).max())
+                for v0 in range(0, counts.shape[1], 50))
+    assert worst <= 2e-6, worst
+    ref = _oracle_sample(ct, ph, mu64, w64, sample_views, rows_at[0])
+    got = _gpu_sample(cr, 1, [v - vb for v in sample_views], rows_at[0])
+    assert (np.abs(got - ref) / ref).max() < REL_SINO
+    del cr
     # decomposition exactly as get_basismat_sinos / bench.py run it on device tensors
     _, i0, mus = md.decomposition_tables(ct, specs[0], specs[1])
     gmax = torch.empty((), dtype=torch.float64, device='cuda')
@@ -234,6 +247,10 @@ def test_config2_256_cubed_120kvp_forward_only(hip):
         assert (np.abs(got - ref) / ref).max() < REL_SINO
         lref = np.log(air / ref)
         assert np.abs(log[views][:, row0:row0 + 8] - lref).max() < 2e-5 * max(1.0, lref.max())
+    # the same public call with the reduced quadrature (opt-in): every ray of the scan <= 2e-6 from the full grid
+    raw_r, log_r = dx.get_sino(ct, ph, spec, quadrature='reduced')
+    assert (np.abs(raw_r.astype(np.float64) - raw) / raw).max() <= 2e-6
+    assert np.abs(log_r.astype(np.float64) - log).max() <= 4e-6
 
 
 def test_config3_dual_energy_gn_full_size(hip):
@@ -272,6 +289,13 @@ def test_config5_energy_dependent_128_bins(hip):
         ref = _oracle_sample(ct, ph, mu64, w64, sample, row0)
         got = _gpu_sample(counts, 1, [v - views[0] for v in sample], row0)
         assert (np.abs(got - ref) / ref).max() < REL_SINO
+    # 128 bins -> the reduced quadrature's nodes (opt-in), every one of the shard's 2.6e8 rays
+    _, mu_r, w_r, _ = pj.upload_tables([spec], 'reduced')
+    assert pj.quadrature_info is not None and mu_r.shape[1] * 3 < 128
+    cr = pj.project_tables(mu_r, w_r, layout=None)
+    worst = max(float(((cr[:, v0:v0 + 25].double() - counts[:, v0:v0 + 25].double()).abs() / counts[:, v0:v0 + 25].double()).max())
+                for v0 in range(0, 250, 25))
+    assert worst <= 2e-6, worst
 
 
 def test_trace_against_textbook_siddon(hip):

@@ -1041,3 +1041,73 @@ def test_mfma_detection_experiment(hip, monkeypatch):
         assert torch.equal(p1, p0)
         assert float(((c1 - c0).abs() / c0).max()) < 3e-6
         assert torch.allclose(l1, l0, rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize('kind', ['single_row', 'stacked_256', 'rows_64', 'cone'])
+def test_reduced_quadrature_on_the_device(hip, kind, monkeypatch):
+    """quadrature='reduced' (opt-in; dex-ct-sim_amd/quadrature.py): the same kernels on a shorter energy table.  Against the
+    full grid on every ray <= 2e-6 relative (the table's verified bound is <= 1e-6; both launches round in float32),
+    against the float64 detection of the device's own path lengths inside the parity bar of the full grid (1e-5); the path
+    bounds the guarantee rests on really bound every ray; the default stays the full grid."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    if kind == 'cone':
+        ct, ph = small_scan(n=40, nz=24, n_views=20, n_channels=48, n_rows=10)
+        ct = dx.FanBeamGeometry(N_channels=48, N_proj=20, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=0.8, eid=True,
+                                detector_file=ct.detector_file, N_rows=10, cone=True, src_z=0.3)
+    else:
+        n_rows = {'single_row': 1, 'stacked_256': 256, 'rows_64': 64}[kind]
+        ct, ph = small_scan(n=64, nz=n_rows, n_views=24, n_channels=66, n_rows=n_rows)
+    sp = spectra()
+    pj = projector(ct, ph)
+    (full, pl), air = pj.project(sp, want_pathlen=True, layout=0)
+    assert pj.quadrature_info is None                                            # default: the full grid
+    (red, pl2), _ = pj.project(sp, want_pathlen=True, layout=0, quadrature='reduced')
+    info = pj.quadrature_info
+    assert info is not None and 3 * info['nodes'] < info['n_full'] and info['max_rel_err'] <= 1.0e-6
+    assert torch.equal(pl, pl2)                                                  # the traversal does not change
+    # the domain of the guarantee: no ray leaves it
+    l_max, c_max = pj.path_bounds()
+    assert float(pl.sum(-1).max()) <= c_max * (1 + 1e-6)
+    for k in range(pj.n_mat):
+        assert float(pl[..., k].max()) <= l_max[k] * (1 + 1e-6) + 1e-6
+    # NumPy bounding boxes of the same volume
+    vol = ph.volume if ct.cone or ct.N_rows == ph.Nz else ph.volume[ph.z_index:ph.z_index + ct.N_rows]
+    for k in range(1, pj.n_mat):
+        zz, yy, xx = np.nonzero(vol == pj.mat_rows[k])
+        ext = [(xx.max() - xx.min() + 1) * ph.dx, (yy.max() - yy.min() + 1) * ph.dy]
+        if ct.cone:
+            ext.append((zz.max() - zz.min() + 1) * ph.dz)
+        assert abs(l_max[k] - min(c_max, float(np.sqrt(np.sum(np.square(ext)))))) < 1e-9
+    rel = ((red.double() - full.double()).abs() / full.double()).max().item()
+    assert rel <= 2.0e-6, rel
+    # float64 detection of the device's path lengths on the FULL grid
+    _, mu64, w64 = fp.merged_tables(ct, ph, sp)
+    L = pl.double().cpu().numpy().reshape(-1, pj.n_mat)
+    ref = (np.exp(-(L @ mu64[pj.mat_rows])) @ w64.T).T.reshape(red.shape)
+    assert (np.abs(red.double().cpu().numpy() - ref) / ref).max() < REL_TOL
+    # the public call, and the environment default
+    raw_f, log_f = dx.get_sino(ct, ph, sp[0])
+    raw_r, log_r = dx.get_sino(ct, ph, sp[0], quadrature='reduced')
+    assert not np.array_equal(raw_f, raw_r)
+    assert (np.abs(raw_r.astype(np.float64) - raw_f) / raw_f).max() <= 2.0e-6
+    assert np.abs(log_r.astype(np.float64) - log_f).max() <= 4.0e-6
+    monkeypatch.setenv('DEXCT_QUADRATURE', 'reduced')
+    assert np.array_equal(dx.get_sino(ct, ph, sp[0])[0], raw_r)
+    assert np.array_equal(dx.get_sino(ct, ph, sp[0], quadrature='full')[0], raw_f)
+    # noisy sinograms keep the full grid (the variance and the photon counts are defined on its bins)
+    noisy_env = dx.get_sino(ct, ph, sp[0], noise=True, seed=3)[0]
+    monkeypatch.delenv('DEXCT_QUADRATURE')
+    assert np.array_equal(dx.get_sino(ct, ph, sp[0], noise=True, seed=3)[0], noisy_env)
+    with pytest.raises(ValueError):
+        dx.get_sino(ct, ph, sp[0], quadrature='fast')
+
+
+def test_reduced_quadrature_is_skipped_for_long_tables(hip):
+    """More than 4 table rows: the domain cannot be sampled densely enough for a verified bound - the full grid runs."""
+    ct, ph = small_scan(n=48, nz=1, n_views=12, n_channels=40)
+    ph = ph_many(ph, 7)
+    pj = projector(ct, ph)
+    a, _ = pj.project(spectra())
+    b, _ = pj.project(spectra(), quadrature='reduced')
+    assert pj.quadrature_info is None and torch.equal(a, b)

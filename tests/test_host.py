@@ -111,11 +111,11 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.dexct_abi_version.restype = ctypes.c_int
-    assert lib.dexct_abi_version() == 3 == _native.ABI_VERSION
+    assert lib.dexct_abi_version() == 4 == _native.ABI_VERSION
     lib.dexct_strerror.restype = ctypes.c_char_p
     assert lib.dexct_strerror(-2) == b'size out of supported range'
     # struct layouts the binding mirrors
-    assert ctypes.sizeof(_native.FanGeom) == 72 and _native.PLAN_BYTES == 40 and ctypes.sizeof(_native.GnOptions) == 24
+    assert ctypes.sizeof(_native.FanGeom) == 72 and _native.PLAN_BYTES == 40 and ctypes.sizeof(_native.GnOptions) == 40
 
 
 def test_product_does_not_import_oracle():

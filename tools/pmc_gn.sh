@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-gn-full-loop"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-gn-full-loop --skip-quadrature"
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/clk -- python3 $REPO/bench.py $ARGS "$@" > $OUT/clk.json 2> $OUT/clk.err
 rc=$?; echo "clk rc=$rc"; if [ $rc -ne 0 ]; then echo "rocprofv3 pass failed: stopping (no summary from partial CSVs)"; exit $rc; fi
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/a -- python3 $REPO/bench.py $ARGS "$@" > $OUT/a.json 2> $OUT/a.err

@@ -5,9 +5,9 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT/a -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --iters 10 "$@" > $OUT/a.json 2> $OUT/a.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $OUT/a -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-quadrature --iters 10 "$@" > $OUT/a.json 2> $OUT/a.err
 rc=$?; echo "rc=$rc"; if [ $rc -ne 0 ]; then echo "rocprofv3 pass failed: stopping (no summary from partial CSVs)"; exit $rc; fi
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --kernel-trace --output-format csv -d $OUT/b -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --iters 10 "$@" > $OUT/b.json 2> $OUT/b.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --kernel-trace --output-format csv -d $OUT/b -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --skip-single-row --skip-quadrature --iters 10 "$@" > $OUT/b.json 2> $OUT/b.err
 rc=$?; echo "rc=$rc"; if [ $rc -ne 0 ]; then echo "rocprofv3 pass failed: stopping (no summary from partial CSVs)"; exit $rc; fi
 python3 - <<PY
 import csv, glob, collections

@@ -11,7 +11,7 @@ REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 # the PMC passes keep the single-row and cone-beam legs of bench.py (their kernels get rooflines too) and drop the
 # CPU baseline, the public-boundary timing and the extra Newton launches
-LEAN="--steps 1 --warmup 0 --no-cpu-baseline --skip-gn-full-loop --skip-dropin"
+LEAN="--steps 1 --warmup 0 --no-cpu-baseline --skip-gn-full-loop --skip-dropin --skip-quadrature"
 run() {  # name, rocprofv3 args...
   local name=$1; shift
   rocprofv3 "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $REPO/bench.py $BENCH_ARGS > $OUT/bench_$name.json 2> $OUT/bench_$name.err
@@ -19,7 +19,7 @@ run() {  # name, rocprofv3 args...
   echo "$name rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 $OUT/bench_$name.err; exit $rc; fi
 }
-BENCH_ARGS="$* --skip-gn-full-loop --skip-dropin"
+BENCH_ARGS="$* --skip-gn-full-loop --skip-dropin --skip-quadrature"
 run stats --stats
 BENCH_ARGS="$* $LEAN"
 run pmc_fetch --pmc FETCH_SIZE

@@ -17,12 +17,12 @@ for workload, views, chans in (('config2', 1000, 800), ('config3', 2000, 1024)):
     for K in (1, 2, 4, 8):
         for rank in sorted({0, K // 2}):
             cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--shard-of', str(K), '--shard-rank',
-                   str(rank), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--skip-single-row', '--skip-gn-full-loop',
+                   str(rank), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--skip-single-row', '--skip-quadrature', '--skip-gn-full-loop',
                    '--skip-dropin']
             if K == 1:
                 cmd = [c for c in cmd if c not in ('--shard-of', '--shard-rank')][:]
                 cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--steps', '3', '--warmup', '1',
-                       '--no-cpu-baseline', '--skip-single-row', '--skip-gn-full-loop', '--skip-dropin']
+                       '--no-cpu-baseline', '--skip-single-row', '--skip-quadrature', '--skip-gn-full-loop', '--skip-dropin']
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             if p.returncode != 0:
                 print(p.stderr[-2000:], file=sys.stderr)
