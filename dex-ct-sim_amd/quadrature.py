@@ -40,8 +40,12 @@ def _domain_points(l_max, c_max, n_random, n_axis, rng, cw):
     # random: a Dirichlet direction (alpha < 1 favours sparse mixes) scaled into the polytope
     d = rng.dirichlet(np.full(M + 1, 0.7), n_random)[:, :M] * (c_max / cw)[None, :]
     d = np.minimum(d, l_max[None, :])
+    # every third one pulled towards the origin on a logarithmic scale: spectra with weight at a few keV have features at
+    # thicknesses of 1e-4 of the range (exp(-mu L) with mu in the thousands)
+    d[::3] *= 10.0 ** (-6.0 * rng.random((len(d[::3]), 1)))
     pts.append(d)
     t = np.linspace(0.0, 1.0, n_axis)
+    t[1::3] = 10.0 ** (-6.0 * (1.0 - t[1::3]))
     for m in range(M):                                   # one material alone
         p = np.zeros((n_axis, M))
         p[:, m] = t * min(l_max[m], c_max / cw[m])
@@ -254,8 +258,9 @@ def coarse_newton_tables(i0, mus, log_range=16.0, max_err=2.0e-6):
 
 START_HEADER = 10          # doubles before the coefficients (csrc/gn.hip, gn_start_values)
 GATE_CELLS = 40            # cells per axis of the step table
-GATE_LOW = -0.002          # lower edge of the cell grid in normalised coordinates f = a mu_min / log_range: about -0.2 g/cm2 (the
-                           # reference iteration does not reach solutions much below zero; start values may lie half a cell lower)
+GATE_LOW = -0.002          # lower edge of the cell grid in normalised coordinates f = a mu_min / log_range, at most: about -0.2 g/cm2.
+                           # Solutions below zero exist only as far as exp(+mu a) stays moderate at the softest weighted energy,
+                           # so the edge is drawn at -0.5 / mu_max where that is closer to zero (spectra with weight at 1 - 3 keV)
 GATE_MARGIN = 2            # steps added to the largest count seen around a cell
 
 
@@ -263,7 +268,7 @@ def newton_start_polynomial(i0, mus, log_range=16.0, degree=5, n_grid=72):
     """Start values for the two-level Newton decomposition (include/dexct.h, dexct_gn_options.start): least-squares
     polynomials a_m(u0, u1), u_k = ln(air_k / g_k) / log_range, fitted to the forward model over the domain of
     coarse_newton_tables (extended a little below a = 0).  Returns a dict: ``head`` (the START_HEADER doubles: air_0, air_1,
-    1 / log_range, degree, GATE_CELLS, GATE_LOW, cells per unit, the two normalisations mu_min[m] / log_range, the skew),
+    1 / log_range, degree, GATE_CELLS, the grid's lower edge, cells per unit, the two normalisations mu_min[m] / log_range, the skew),
     ``coef`` (c_0 then c_1; c_m[i][j] for u0^i u1^j, i = 0..degree, j = 0..degree - i, j fastest), ``corners`` [(n+1)^2, 2]
     (the (a0, a1) of the cell corners, row = index along f0) and ``corner_g`` [(n+1)^2, 2] (their noise-free counts; NaN for
     corners outside the domain) - what gate_table needs - or None.
@@ -288,7 +293,8 @@ def newton_start_polynomial(i0, mus, log_range=16.0, degree=5, n_grid=72):
     # reference's iteration reaches about half of that.  The cell grid is therefore laid out in a_1 + skew a_0 with a quarter
     # of the physical bound, which keeps such rays inside it.
     skew = 0.25 * float(np.min(mus[0] / mus[1]))
-    u = np.linspace(GATE_LOW, 1.0, n_grid)
+    low = -min(-GATE_LOW, 0.5 * float(np.min(norm / mus.max(axis=1))))
+    u = np.linspace(low, 1.0, n_grid)
     f0, f1 = np.meshgrid(u, u, indexing='ij')
     a_all = np.stack([f0.ravel() / norm[0], f1.ravel() / norm[1] - skew * f0.ravel() / norm[0]], axis=1)
     keep = a_all @ norm <= 1.0                                       # attenuation exponent at the most penetrating energies <= log_range
@@ -303,9 +309,9 @@ def newton_start_polynomial(i0, mus, log_range=16.0, degree=5, n_grid=72):
     wgt = 1.0 / (np.abs(a).max(axis=1) + 1.0)                       # errors relative to max(|a|, 1), as the stop rule measures
     coef = np.concatenate([np.linalg.lstsq(V * wgt[:, None], a[:, m] * wgt, rcond=None)[0] for m in range(2)])
     n = GATE_CELLS
-    per_unit = n / (1.0 - GATE_LOW)
-    head = np.array([air[0], air[1], 1.0 / log_range, float(degree), float(n), GATE_LOW, per_unit, norm[0], norm[1], skew])
-    e = GATE_LOW + np.arange(n + 1) / per_unit
+    per_unit = n / (1.0 - low)
+    head = np.array([air[0], air[1], 1.0 / log_range, float(degree), float(n), low, per_unit, norm[0], norm[1], skew])
+    e = low + np.arange(n + 1) / per_unit
     c0, c1 = np.meshgrid(e, e, indexing='ij')
     corners = np.stack([c0.ravel() / norm[0], c1.ravel() / norm[1] - skew * c0.ravel() / norm[0]], axis=1)
     inside = corners @ norm <= 1.0 + 2.0 / per_unit

@@ -187,7 +187,13 @@ def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at
         # round 4: the default (tolerance stop) against the reference's fixed count (stop_tol = 0) on EVERY pixel of the
         # scan: within 1e-12, identical where the exact run is not finite; and the results written in the reference's
         # [view][row][channel] order by the kernel itself are the same bits
-        st_default = md.last_gn_stats()['pixel_iterations']
+        st_d = md.last_gn_stats()
+        st_default = st_d['pixel_iterations']
+        # the default at this size is the two-level solve with the coarse launch: two full-table steps per unmasked pixel
+        live = int((counts[0] < 0.95 * gmax).sum())
+        assert st_d['mode'] == 'coarse' and 1.99 * live <= st_default <= 2.2 * live and st_d['coarse_pixel_iterations'] <= 3 * live
+        a_single = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, two_level=False)
+        assert md.last_gn_stats()['mode'] == 'single' and md.last_gn_stats()['pixel_iterations'] > 6 * st_default
         a_exact = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, stop_tol=0.0)
         st_exact = md.last_gn_stats()['pixel_iterations']
         worst, V = 0.0, a.shape[0]
@@ -195,9 +201,12 @@ def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at
             d, x = a[v0:v0 + 100], a_exact[v0:v0 + 100]
             assert torch.equal(torch.isnan(d), torch.isnan(x))
             worst = max(worst, float(torch.nan_to_num((d - x).abs() / x.abs().clamp(min=1.0), nan=0.0).max()))
+            s1 = a_single[v0:v0 + 100]
+            assert torch.equal(torch.isnan(s1), torch.isnan(x))
+            worst = max(worst, float(torch.nan_to_num((s1 - x).abs() / x.abs().clamp(min=1.0), nan=0.0).max()))
         assert worst <= 1e-12, worst
         assert st_default < 0.8 * st_exact, (st_default, st_exact)
-        del a_exact
+        del a_exact, a_single
         R, C = int(counts.shape[3]), int(counts.shape[2])
         a_ref = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, out_rc=(R, C))
         assert a_ref.shape == (V, R, C, 2)

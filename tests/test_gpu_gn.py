@@ -686,3 +686,159 @@ def test_pipelined_host_boundary_changes_no_bit(hip, golden, monkeypatch):
         assert np.array_equal(stacked[0].reshape(48, 96).view(np.int64), plain[0].view(np.int64))
         assert np.array_equal(stacked[1].reshape(48, 96).view(np.int64), plain[1].view(np.int64))
         assert 0 < (plain[0] == 0).sum() < plain[0].size // 2 and np.isfinite(plain[0]).mean() > 0.9      # (NaN payloads compared above too)
+
+
+def _noisy_counts(golden, n=60000, seed=77, noise=0.002, water=True):
+    """Counts of n pixels through up to 40 g/cm2 of the first and 8 of the second basis material (plus, with ``water``, rays
+    whose second component is slightly negative, as water gives in a tissue / bone basis), with relative noise."""
+    rng = np.random.default_rng(seed)
+    i0, mus = golden['gn0_i0'], golden['gn0_mus']
+    a_true = np.stack([rng.uniform(0, 40, n) * rng.choice([0.02, 0.3, 1.0], n), rng.uniform(0, 8, n) * rng.choice([0.0, 0.1, 1.0], n)], -1)
+    if water:
+        a_true[: n // 3, 1] = -0.008 * a_true[: n // 3, 0]
+    ex = np.exp(-a_true @ mus)
+    cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + noise * rng.standard_normal((2, n)))
+    return cnt.reshape(2, 100, n // 100), i0, mus
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_two_level_solve_modes_against_the_exact_count(hip, golden, dtype):
+    """The two-level solve (polynomial start values; 'coarse': ~2 steps on a short quadrature of the spectra, then the full
+    tables; 'start': the full tables only) returns what the single launch returns: within 1e-12 of the exact count on every
+    pixel, bit-identical where the exact run has not converged - and spends a fraction of the full-table steps."""
+    from dex_ct_sim_amd import matdecomp as md
+    from dex_ct_sim_amd._device import to_dev, to_host
+    cnt, i0, mus = _noisy_counts(golden)
+    cnt = cnt.astype(dtype)
+    g = to_dev(cnt, torch.float32 if dtype == np.float32 else torch.float64, torch.device('cuda'))
+    # the lane kernel throughout (kernel=1; it is what the two launches use): at this size the single launch would otherwise
+    # pick the cooperative kernel, whose different order of summation sends the one or two chaotic pixels of such noisy thin
+    # rays - a step that lands far away through a nearly singular Hessian - somewhere else
+    exact = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', stop_tol=0.0, kernel=1, two_level='coarse'))
+    st_exact = md.last_gn_stats()
+    assert st_exact['mode'] == 'single'                                  # the fixed count never takes a short cut
+    ok = np.isfinite(exact).all(-1)
+    assert ok.mean() > 0.99
+    steps = {}
+    for mode in (False, 'start', 'coarse'):
+        a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1, two_level=mode))
+        st = md.last_gn_stats()
+        assert st['mode'] == (mode or 'single')
+        assert err(a[ok], exact[ok]) < 1e-12, mode
+        assert np.array_equal(a[~ok].view(np.int64), exact[~ok].view(np.int64))
+        steps[mode] = (st['pixel_iterations'], st.get('coarse_pixel_iterations', 0))
+        if mode == 'coarse':
+            assert 16 <= st['coarse_energies'] <= i0.shape[1] // 3
+    # (noisy thin rays whose solution has a negative component lie below the gate's grid and are solved the reference's way)
+    assert steps['start'][0] < 0.7 * steps[False][0] and steps['coarse'][0] < 0.7 * steps[False][0]
+    # without noise every pixel takes the short cut: two full-table steps each
+    clean, _, _ = _noisy_counts(golden, n=30000, seed=3, noise=0.0)
+    clean = clean.astype(dtype)
+    n = clean[0].size
+    md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level=False)
+    one = md.last_gn_stats()['pixel_iterations']
+    md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level='coarse')
+    st = md.last_gn_stats()
+    assert 1.9 * n < st['pixel_iterations'] < 2.6 * n < 0.25 * one and 1.9 * n < st['coarse_pixel_iterations'] < 6.0 * n
+    md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level='start')
+    assert md.last_gn_stats()['pixel_iterations'] < 8.0 * n      # (real spectra with weight at a few keV: the polynomial is coarser)
+    # the default picks by size ('start' below matdecomp.TWO_LEVEL_COARSE_MIN pixels), the environment overrides
+    md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
+    assert md.last_gn_stats()['mode'] == 'start'
+    import os
+    for env, want in (('0', 'single'), ('coarse', 'coarse'), ('start', 'start')):
+        os.environ['DEXCT_GN_TWO_LEVEL'] = env
+        try:
+            md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
+            assert md.last_gn_stats()['mode'] == want
+        finally:
+            del os.environ['DEXCT_GN_TWO_LEVEL']
+
+
+@pytest.mark.parametrize('mode', ['start', 'coarse'])
+def test_two_level_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, golden, mode):
+    """The reference returns the state after n_iters steps from 1e-6 - the fixed point only if its iteration gets there in
+    time.  The gate (csrc/gn.hip gn_gate: step counts of the reference iteration itself over the (a0, a1) domain) lets a
+    pixel take the short cut only where it does: for every n_iters the two-level result is within 1e-12 of the exact count's
+    on every pixel - including those the exact count leaves far from their fixed point - and with very few steps nothing
+    takes the short cut at all (bit-identical to the single launch)."""
+    from dex_ct_sim_amd import matdecomp as md
+    from dex_ct_sim_amd._device import to_dev, to_host
+    cnt, i0, mus = _noisy_counts(golden, n=30000, seed=5, noise=0.0)
+    g = to_dev(cnt, torch.float64, torch.device('cuda'))
+    # (kernel=1: the lane kernel for the exact count and the single launch too - a state in the middle of the walk from 1e-6 is
+    # sensitive to the order of summation, 1e-11 between the lane and the cooperative kernel after a dozen steps)
+    solve = lambda n_iters, **kw: to_host(md.gn_device(g[0], g[1], i0, mus, n_iters, 'f64', kernel=1, **kw))
+    settled = solve(60, stop_tol=0.0, two_level=False)
+    warm_share = {}
+    for n_iters in (4, 5, 8, 12, 16, 20, 24, 30, 50):
+        exact = solve(n_iters, stop_tol=0.0, two_level=False)
+        single = solve(n_iters, two_level=False)
+        st1 = md.last_gn_stats()['pixel_iterations']
+        a = solve(n_iters, two_level=mode)
+        st = md.last_gn_stats()
+        assert st['mode'] == mode
+        assert err(a, exact) < 1e-12, n_iters
+        far = np.abs(exact - settled).max(-1) > 1e-6
+        if n_iters <= 5:
+            assert far.mean() > 0.9                                       # the reference is nowhere near its fixed points yet
+            assert np.array_equal(a.view(np.int64), single.view(np.int64))
+        assert np.array_equal(a[far].view(np.int64), exact[far].view(np.int64))
+        warm_share[n_iters] = 1.0 - st['pixel_iterations'] / st1
+    assert warm_share[5] <= 0.0 and warm_share[50] > 0.6 and warm_share[12] < warm_share[30]
+
+
+def test_two_level_is_not_used_where_it_cannot_be_trusted(hip, golden):
+    """An ill-conditioned pair of spectra (golden case 1: the reference's own iteration wanders there) gets no start values
+    at all; per-channel spectra, mixed precision, the fixed count and fewer than 48 energies run the single launch."""
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    a = run(g['gn1_g'], g['gn1_i0'], g['gn1_mus'], 50, 'f64')
+    assert md.last_gn_stats()['mode'] == 'single' and err(a, g['gn1_a_iters50']) < TOL_F64
+    cnt, i0, mus = _noisy_counts(golden, n=4000)
+    for kw in (dict(precision='mixed'), dict(precision='f64', stop_tol=0.0)):
+        md.optimize_sino(cnt, None, i0, mus, 50, verbose=False, two_level='coarse', **kw)
+        assert md.last_gn_stats()['mode'] == 'single'
+    md.optimize_sino(cnt, None, i0[:, ::4], mus[:, ::4], 50, verbose=False, two_level='coarse')      # 35 energies
+    assert md.last_gn_stats()['mode'] == 'single'
+    md.optimize_sino(cnt, None, i0, mus, 3, verbose=False, two_level='coarse')
+    assert md.last_gn_stats()['mode'] == 'single'
+    with pytest.raises(ValueError):
+        md.optimize_sino(cnt, None, i0, mus, 50, verbose=False, two_level='fast')
+
+
+def test_two_level_passes_through_the_c_abi(hip, golden):
+    """dexct_gn_options.pass / .iterations / .start as include/dexct.h documents them: the coarse pass without start values
+    (from 1e-6) followed by the refining pass; argument errors."""
+    from dex_ct_sim_amd import _native, matdecomp as md, quadrature as q
+    from dex_ct_sim_amd._device import ptr, stream_ptr, to_dev
+    lib = hip
+    cnt, i0, mus = _noisy_counts(golden, n=20000, noise=0.0)
+    dev = torch.device('cuda')
+    g = to_dev(cnt.reshape(2, -1), torch.float64, dev)
+    n = g.shape[1]
+    i0_d, mus_d = to_dev(i0[:, None, :], torch.float64, dev), to_dev(mus, torch.float64, dev)
+    cols, i0_s = q.coarse_newton_tables(i0, mus)
+    i0_sd, mus_sd = to_dev(np.ascontiguousarray(i0_s)[:, None, :], torch.float64, dev), to_dev(np.ascontiguousarray(mus[:, cols]), torch.float64, dev)
+    a = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    it = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+
+    def call(i0t, mut, n_iters, opts):
+        ne = int(mut.shape[1])
+        ws = torch.empty(lib.dexct_gn_workspace_bytes(ne, 1), dtype=torch.uint8, device=dev)
+        return lib.dexct_gn_decompose(ptr(g[0]), ptr(g[1]), 1, n, ptr(i0t), ptr(mut), ne, 1, 1, n_iters, 0, 0, None, 0.95, ptr(a),
+                                      opts, ptr(ws), stream_ptr())
+
+    assert call(i0_sd, mus_sd, 50, _native.gn_options(1e-7, 0, 0, 1, _native.GN_PASS_COARSE, it.data_ptr())) == 0
+    k = it.cpu().numpy()
+    assert k.max() < 255 and 2 <= k.min() and 12 < k.mean() < 22          # from 1e-6: the reference's long walk, on a sixth of the energies
+    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == 0
+    exact = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=0.0).reshape(-1, 2)
+    assert err(a.cpu().numpy(), exact) < 1e-12
+    EINVAL = -1
+    assert call(i0_sd, mus_sd, 50, _native.gn_options(1e-7, 0, 0, 1, _native.GN_PASS_COARSE, None)) == EINVAL        # nowhere to put the counts
+    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, None, None)) == EINVAL     # nothing to start from
+    assert call(i0_d, mus_d, 50, _native.gn_options(0.0, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL   # needs the tolerance rule
+    assert call(i0_d, mus_d, 255, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL  # counts are bytes
+    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 2, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL   # lane kernel only
+    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, 3, it.data_ptr())) == EINVAL

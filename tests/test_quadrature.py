@@ -73,3 +73,58 @@ def test_option_parsing():
     assert fp._want_reduced('reduced') and not fp._want_reduced('full') and not fp._want_reduced(None)
     with pytest.raises(ValueError):
         fp._want_reduced('fast')
+
+
+def newton_tables():
+    ct = dx.FanBeamGeometry(N_channels=8, N_proj=8, eid=True, detector_file=DET)
+    from dex_ct_sim_amd import matdecomp as md
+    return md.decomposition_tables(ct, synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80))
+
+
+def test_short_tables_of_the_coarse_newton_pass():
+    """quadrature.coarse_newton_tables: a sixth of the energies, non-negative weights on the spectra's own energies, the
+    forward model within a few 1e-6 over the decomposition's domain (attenuation down to exp(-16))."""
+    _, i0, mus = newton_tables()
+    cols, i0_s = q.coarse_newton_tables(i0, mus)
+    assert 16 <= len(cols) <= i0.shape[1] // 4 and np.all(i0_s >= 0) and not np.any((i0_s > 0) & (i0[:, cols] == 0))
+    rng = np.random.default_rng(3)
+    mu_min = mus[:, (i0 > 0).any(0)].min(1)
+    a = q._domain_points(16.0 / mu_min, 16.0, 40000, 600, rng, mu_min)
+    assert q.max_rel_error(mus, i0, cols, i0_s, a) < 1e-5
+    assert q.coarse_newton_tables(i0, -mus) is None and q.coarse_newton_tables(-i0, mus) is None
+
+
+def test_start_polynomial_and_gate_table():
+    """quadrature.newton_start_polynomial: start values within a few 1e-2 of max(|a|, 1) over the domain, including rays with
+    a slightly negative second component; gate_table: a cell needs the largest step count among its corners and those of
+    its neighbours plus the margin, and is closed (infinity) when any of them did not arrive at the truth."""
+    _, i0, mus = newton_tables()
+    p = q.newton_start_polynomial(i0, mus)
+    head, coef = p['head'], p['coef']
+    deg, n = int(head[3]), int(head[4])
+    assert n == q.GATE_CELLS and coef.size == (deg + 1) * (deg + 2) and p['corners'].shape == ((n + 1) ** 2, 2)
+    rng = np.random.default_rng(8)
+    a = np.stack([rng.uniform(0, 45, 5000), rng.uniform(0, 10, 5000)], 1)
+    a[:1500, 1] = -0.008 * a[:1500, 0]                                   # water in a tissue / bone basis
+    g = np.exp(-(a @ mus)) @ i0.T
+    u = np.log(head[:2][None, :] / g) * head[2]
+    terms = [(i, j) for i in range(deg + 1) for j in range(deg + 1 - i)]
+    V = np.stack([u[:, 0] ** i * u[:, 1] ** j for i, j in terms], 1)
+    s = np.stack([V @ coef[:len(terms)], V @ coef[len(terms):]], 1)
+    assert (np.abs(s - a).max(1) / np.maximum(np.abs(a).max(1), 1.0)).max() < 0.05
+    # every such ray lies inside the cell grid (skewed coordinates), away from its lower edge
+    f0 = (a[:, 0] * head[7] - head[5]) * head[6]
+    f1 = ((a[:, 1] + head[9] * a[:, 0]) * head[8] - head[5]) * head[6]
+    assert f0.min() >= 0 and f1.min() >= 0 and f0.max() < n and f1.max() < n
+    steps = np.full((n + 1) ** 2, 17)
+    steps[5 * (n + 1) + 7] = 30                                           # one slow corner
+    found = p['corners'].copy()
+    found[20 * (n + 1) + 20] += 1e-3                                      # one corner that ended somewhere else
+    start, share = q.gate_table(p, steps, found)
+    need = start[q.START_HEADER + coef.size:].reshape(n, n)
+    assert start.size == q.START_HEADER + coef.size + n * n
+    inside = ~np.isnan(p['corner_g'][:, 0]).reshape(n + 1, n + 1)
+    assert need[0, 0] == 17 + q.GATE_MARGIN and np.all(need[3:7, 5:9] == 30 + q.GATE_MARGIN) and need[2, 5] == need[7, 5] == 17 + q.GATE_MARGIN
+    assert np.all(np.isinf(need[18:22, 18:22])) and np.isfinite(need[17, 17]) and np.isfinite(need[22, 18]) == bool(inside[22:25, 18:21].all())
+    assert np.all(np.isinf(need[~(inside[:-1, :-1] & inside[1:, 1:])]))   # cells that reach outside the domain are closed
+    assert 0.3 < share < 0.6
