@@ -506,8 +506,8 @@ def main():
     hw_share = (29.0 * n_both + 17.0 * n_one) / (29.0 * i0.shape[1])
     gstats = md.last_gn_stats()            # of the last timed step's launches (the default mode)
     two_level = bool(gstats) and gstats.get('mode') in ('coarse', 'start')
-    gn_name = ('gn_refill_kernel<4, 2> (refining launch of the two-level solve)' if two_level else 'gn_refill_kernel<4, 0>') \
-        if precision == 'f64' else 'gn_kernel<true,false>'
+    gn_name = ('gn_refill_kernel<4, 2> (start values from the table of the reference\'s fixed points + full-table steps)' if two_level
+               else 'gn_refill_kernel<4, 0>') if precision == 'f64' else 'gn_kernel<true,false>'
     main_ms = gstats['main_ms'] if gstats else gn_ms      # HIP events around the launch, on its stream, last timed step
     roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
             'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': main_ms, 'gn_ms_all_launches': gn_ms,
@@ -516,7 +516,7 @@ def main():
             'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': (24 + (17 if two_level and gstats.get('mode') == 'coarse' else 0)) * n_rays,
             'traffic_note': 'HBM-side bytes (FETCH_SIZE + WRITE_SIZE) of this kernel from the rocprofv3 --pmc passes of the same command '
                             'recorded in traffic_source (counters cannot be read from inside the timed run); algorithmic: 8 B of counts '
-                            'in and 16 B of results out per pixel, plus 16 B of coarse result and 1 B of step count in for the refining launch',
+                            'in and 16 B of results out per pixel (mode coarse: plus 16 B of coarse result and 1 B of step count in)',
             'bound_note': 'neither HBM (24 - 41 B/pixel against >= 2e4 flops/pixel) nor MFMA (no dense contraction; FP64 MFMA and '
                           'FP64 VALU do not overlap on gfx950, DESIGN.md 4.4): bound = FP64 vector issue'}
     if gstats and gstats.get('pixel_iterations'):
@@ -540,17 +540,19 @@ def main():
                              'two-level solve and the exits made unnecessary - reported separately, not as throughput'
                              % (i0.shape[1], n_both, n_one, i0.shape[1] - n_both - n_one, hw_share)})
         if two_level:
-            roof['two_level'] = {
-                'mode': gstats['mode'], 'coarse_launch_ms': gstats.get('coarse_ms'), 'refine_launch_ms': main_ms,
-                'coarse_energies': gstats.get('coarse_energies'), 'full_energies': int(i0.shape[1]),
-                'coarse_steps_per_unmasked_pixel': gstats.get('coarse_pixel_iterations', 0) / live,
+            roof['short_cut'] = {
+                'mode': gstats['mode'], 'launch_ms': main_ms, 'full_energies': int(i0.shape[1]),
                 'full_steps_per_unmasked_pixel': gstats['pixel_iterations'] / live,
-                'coarse_achieved_TFLOPs': (gstats.get('coarse_pixel_iterations', 0) * 29 * (gstats.get('coarse_energies') or 0)
-                                           / (gstats['coarse_ms'] * 1e-3) / 1e12) if gstats.get('coarse_ms') else None,
-                'note': 'start values from a polynomial in the two log attenuations, ~2 steps on a short quadrature of the spectra '
-                        '(gn_refill_kernel<4, 1>), then the full tables: two steps per pixel, the second being the tolerance '
-                        'rule\'s evidence of convergence of the FULL model; pixels without that evidence are solved from 1e-6 '
-                        'with all n_iters steps.  Compared with the exact mode on every pixel below (gn_exact)'}
+                'coarse_launch_ms': gstats.get('coarse_ms') if gstats['mode'] == 'coarse' else None,
+                'coarse_energies': gstats.get('coarse_energies') if gstats['mode'] == 'coarse' else None,
+                'coarse_steps_per_unmasked_pixel': (gstats.get('coarse_pixel_iterations', 0) / live) if gstats['mode'] == 'coarse' else None,
+                'note': 'what the reference returns is the fixed point its walk from 1e-6 ends at - a function of the two counts, '
+                        'tabulated once per pair of spectra by running the single launch on a 129 x 129 grid of counts.  A pixel '
+                        'in a cell where that walk ends by the tolerance rule within n_iters steps, smoothly, starts from the '
+                        'interpolated fixed point and takes two full-table steps, the second being the tolerance rule\'s '
+                        'evidence of convergence of the FULL model; accepted only on the reference\'s branch; every other pixel '
+                        'is solved from 1e-6 with all n_iters steps in the same launch.  Compared with the exact count on every '
+                        'pixel below (gn_exact)'}
     out['roofline'] = roof
     if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
         # ---- the reference's fixed iteration count, EXACTLY (stop_tol = 0): the same step timed the same way -> value_exact;
@@ -615,7 +617,7 @@ def main():
                 'frac': st1['pixel_iterations'] * flops_per_pixel_iter / (g1_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                 'max_diff_vs_exact': diff1,
                 'note': 'two_level=False / DEXCT_GN_TWO_LEVEL=0: every pixel from the reference\'s start value 1e-6 on the full '
-                        'tables, ended by the same tolerance rule (what `value` was before the two-level solve)'}
+                        'tables, ended by the same tolerance rule (what `value` was before the short cut)'}
             del a_single
         gn_ex_ms = float(np.mean(t_gn_ex))
         out['value_exact'] = integrals_per_step / (elapsed_ex / args.steps)
@@ -632,9 +634,9 @@ def main():
                            'note': 'value_exact: the same step with stop_tol = 0 - the fixed iteration count of '
                                    'matdecomp.py:114, every bit of it (checked here against a launch that executes all '
                                    'iterations).  `value` is the default mode: every pixel ends at a fixed point of the full model '
-                                   'that the tolerance rule has verified to 1e-12 * max(|a|, 1) - reached by the two-level solve - '
-                                   'or after the reference\'s own n_iters steps; its results are compared with the exact ones on '
-                                   'every pixel above'}
+                                   'that the tolerance rule has verified to 1e-12 * max(|a|, 1) - reached from the tabulated fixed '
+                                   'points of the reference\'s walk - or after the reference\'s own n_iters steps; its results are '
+                                   'compared with the exact ones on every pixel above'}
         gn_tol[0] = None
         step(False)                                                                  # the default results are back in place
         torch.cuda.synchronize()

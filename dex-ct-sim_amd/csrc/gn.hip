@@ -748,53 +748,65 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 
 // Start values of the two-level solve (dexct_gn_options.start): nothing ties the coarse pass - or a refining pass that runs
 // without one - to the reference's start value 1e-6, because what is returned is decided by the tolerance rule of the full
-// model (or, failing that, by the reference's own solve from 1e-6).  A polynomial in the two log attenuations, fitted by the
-// host over the domain of the short tables, puts a pixel within a few 1e-3 of its solution: 2 coarse steps instead of 16.
+// model (or, failing that, by the reference's own solve from 1e-6).
 //
-// THE GATE.  The reference returns the state after n_iters steps from 1e-6 - the fixed point only if its own iteration gets
-// there in time.  So a pixel may take the short cut only where that is known: the start array carries a table, over cells of
-// the (a0, a1) domain, of the number of steps the reference's iteration (this library's single launch, run by the host on
-// the cell corners when the tables are prepared) needs to end by the tolerance rule AT the true solution - the maximum over the
-// cell and its neighbours plus a margin, infinity where it does not get there or outside the domain.
-//   * before: a pixel takes the short cut only if its START value falls in (or within half a cell below) a cell with
-//     n_iters >= that number (gn_gate with slack: a filter, so that hopeless pixels do not pay for the attempt);
-//   * after: the refining pass accepts the result only if the SOLUTION it found lies in such a cell (gn_gate without slack:
-//     the guarantee - the reference's iteration was seen to arrive at the solutions all around it within n_iters steps).
-// Every other pixel (few steps asked for, an ill-conditioned pair of spectra, counts outside the domain, NaN) is solved the
-// reference's way.
-// Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] degree d; [4] cells per axis n; [5] lower edge of the cell grid
-// in the normalised coordinates f_0 = a_0 * [7], f_1 = (a_1 + [9] * a_0) * [8] (the skew [9] keeps rays with a slightly
-// negative second component inside the grid); [6] cells per unit of f; then
-// c_0[(d+1)(d+2)/2], c_1[..] (c_m[i][j] of u0^i u1^j, j fastest), then the n x n step table (row = cell of f0).
+// THE GATE.  What the reference returns is a function of a pixel's two counts alone: the state its iteration reaches from
+// 1e-6 in n_iters steps - the fixed point only if it gets there in time, and, where noisy counts admit several fixed
+// points, the one ITS walk ends at.  So the short cut is laid out in DATA space.  When the tables of a pair of spectra are
+// prepared, the host runs the reference's iteration (this library's single launch, full tables, from 1e-6) on the counts at
+// the corners of a cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / log_range, and records where it ends and after
+// how many steps.  The start array carries, per corner, that fixed point; per cell, the number of steps a pixel needs (the
+// largest count among the corners of the cell and of its eight neighbours, plus a margin; infinity where a corner did not end
+// by the tolerance rule, or where the corners' fixed points do not vary smoothly - a boundary between two basins crosses the
+// cell) and an acceptance radius (the spread of the corners' fixed points).  A pixel takes the short cut iff its counts fall
+// in a cell with n_iters >= that number; it starts from the bilinear interpolant s of the corners' fixed points - a point on
+// the REFERENCE'S branch - and its result is accepted only within the radius of s.  Every other pixel (few steps asked for,
+// an ill-conditioned pair of spectra, counts outside the grid, another fixed point, NaN) is solved the reference's way.
+// Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] cells per axis n; [4] ln of the smallest u0 of the grid;
+// [5] cells per unit of ln u0; [6] smallest ratio u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] reserved; then
+// the corners' fixed points a0[(n+1)^2], a1[(n+1)^2] (row = index along ln u0), then need[n^2], radius[n^2].
 constexpr int kStartHeader = 10;
-__device__ __forceinline__ void gn_start_poly(const double* __restrict__ start, double g0, double g1, double& s0, double& s1) {
+__device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n_iters, double g0, double g1, double& s0,
+                                         double& s1, double& radius) {
   const double u0 = log(start[0] / g0) * start[2], u1 = log(start[1] / g1) * start[2];
-  const int deg = (int)start[3];
-  const int n_terms = (deg + 1) * (deg + 2) / 2;
-  const double* __restrict__ c0 = start + kStartHeader;
-  const double* __restrict__ c1 = c0 + n_terms;
+  const int n = (int)start[3];
+  const double fx = (log(u0) - start[4]) * start[5], fy = (u1 / u0 - start[6]) * start[7];
+  bool ok = fx >= 0.0 && fy >= 0.0 && fx < (double)n && fy < (double)n;        // (NaN compares false)
+  const int i = ok ? (int)fx : 0, j = ok ? (int)fy : 0;
+  const double* __restrict__ r0 = start + kStartHeader;
+  const double* __restrict__ r1 = r0 + (n + 1) * (n + 1);
+  const double* __restrict__ need = r1 + (n + 1) * (n + 1);
+  ok = ok && (double)n_iters >= need[i * n + j];
+  // Catmull-Rom interpolation of the corners' fixed points over the 4 x 4 corners around the cell (the corners of the 3 x 3
+  // cells the step table vouches for; cells on the border of the grid are closed by the host): 1e-6 of |a| where the
+  // bilinear interpolant is 6e-4 off - the difference between two and three steps of the full tables per pixel
+  const double wx = fx - (double)i, wy = fy - (double)j;
+  auto weights = [](double t, double (&w)[4]) {
+    const double t2 = t * t, t3 = t2 * t;
+    w[0] = -0.5 * t3 + t2 - 0.5 * t;
+    w[1] = 1.5 * t3 - 2.5 * t2 + 1.0;
+    w[2] = -1.5 * t3 + 2.0 * t2 + 0.5 * t;
+    w[3] = 0.5 * t3 - 0.5 * t2;
+  };
+  double cx[4], cy[4];
+  weights(wx, cx);
+  weights(wy, cy);
+  const int i0c = i > 0 ? i - 1 : 0, j0c = j > 0 ? j - 1 : 0;               // (closed border cells never get here with ok)
+  const int base = (i0c <= n - 3 ? i0c : n - 3) * (n + 1) + (j0c <= n - 3 ? j0c : n - 3);
   s0 = 0.0;
   s1 = 0.0;
-  for (int i = deg; i >= 0; --i) {                 // sum_i u0^i (sum_j c[i][j] u1^j), Horner in both
-    const int off = i * (deg + 1) - i * (i - 1) / 2, len = deg + 1 - i;
-    double r0 = 0.0, r1 = 0.0;
-    for (int jj = len - 1; jj >= 0; --jj) {
-      r0 = fma(r0, u1, c0[off + jj]);
-      r1 = fma(r1, u1, c1[off + jj]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    double ra = 0.0, rb = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ra = fma(cy[q], r0[base + p * (n + 1) + q], ra);
+      rb = fma(cy[q], r1[base + p * (n + 1) + q], rb);
     }
-    s0 = fma(s0, u0, r0);
-    s1 = fma(s1, u0, r1);
+    s0 = fma(cx[p], ra, s0);
+    s1 = fma(cx[p], rb, s1);
   }
-}
-
-__device__ __forceinline__ bool gn_gate(const double* __restrict__ start, int n_iters, double a0, double a1, double slack) {
-  const int deg = (int)start[3];
-  const int n = (int)start[4];
-  double f0 = (a0 * start[7] - start[5]) * start[6], f1 = ((a1 + start[9] * a0) * start[8] - start[5]) * start[6];
-  bool ok = f0 >= -slack && f1 >= -slack && f0 < (double)n && f1 < (double)n;      // (NaN compares false)
-  f0 = fmax(f0, 0.0);
-  f1 = fmax(f1, 0.0);
-  if (ok) ok = (double)n_iters >= (start + kStartHeader + (deg + 1) * (deg + 2))[(int)f0 * n + (int)f1];
+  radius = (need + n * n)[i * n + j];
   return ok;
 }
 
@@ -837,6 +849,9 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   __shared__ d2 lds_out[kGnBlock / kWave][kSlots * kTilePix];            // 16 KB: with the table 32 KB = 5 workgroups per CU
   __shared__ unsigned char lds_it[PASS == 1 ? kGnBlock / kWave : 1][PASS == 1 ? kSlots * kTilePix : 1];
   unsigned char* __restrict__ my_it = lds_it[PASS == 1 ? (threadIdx.x >> 6) : 0];
+  // PASS 2: the acceptance radius of a pixel on the short cut (its start value waits in the pixel's result slot of lds_out)
+  __shared__ double lds_rad[PASS == 2 ? kGnBlock / kWave : 1][PASS == 2 ? kSlots * kTilePix : 1];
+  double* __restrict__ my_rad = lds_rad[PASS == 2 ? (threadIdx.x >> 6) : 0];
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
@@ -965,9 +980,8 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
           } else {
             ent = place; a0 = 1e-6; a1 = 1e-6; it = 0;
             if (PASS == 1 && start != nullptr) {
-              double s0, s1;
-              gn_start_poly(start, gd0, gd1, s0, s1);
-              if (gn_gate(start, n_iters, s0, s1, 0.5)) {
+              double s0, s1, rad;
+              if (gn_start(start, n_iters, gd0, gd1, s0, s1, rad)) {
                 a0 = s0; a1 = s1;
               } else {             // not a pixel for the short cut: marked for the reference's own solve, no coarse steps
                 my_out[place] = d2{1e-6, 1e-6};
@@ -978,20 +992,25 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
             }
             if (PASS == 2) {
               budget = n_iters;
-              if (iters == nullptr) {                      // no coarse pass: straight from the start polynomial, where the gate allows
-                double s0, s1;
-                gn_start_poly(start, gd0, gd1, s0, s1);
-                if (gn_gate(start, n_iters, s0, s1, 0.5)) { a0 = s0; a1 = s1; ent = place | kWarmBit; }
+              double s0 = 0.0, s1 = 0.0, rad = __builtin_huge_val();
+              const bool open = start == nullptr || gn_start(start, n_iters, gd0, gd1, s0, s1, rad);
+              if (iters == nullptr) {                      // no coarse pass: straight from the gate's start value
+                if (open) { a0 = s0; a1 = s1; ent = place | kWarmBit; }
               } else {
                 const long long po = ct.out_base + (long long)r_off * out_stride + c_off;
                 const int k = iters[po];
-                if (k != 255 && n_iters - k >= 2) {        // start from the coarse result, the coarse steps paid for
+                if (open && k != 255 && n_iters - k >= 2) { // from the coarse result, the coarse steps paid for ...
                   const d2 v = reinterpret_cast<const d2*>(out_a)[po];
-                  a0 = v.x; a1 = v.y;
-                  budget = n_iters - k;
-                  ent = place | kWarmBit;
+                  // ... if it lies on the reference's branch (without a start array: unchecked, s = the coarse result itself)
+                  if (start == nullptr) { s0 = v.x; s1 = v.y; }
+                  if (fmax(fabs(v.x - s0), fabs(v.y - s1)) <= rad) {
+                    a0 = v.x; a1 = v.y;
+                    budget = n_iters - k;
+                    ent = place | kWarmBit;
+                  }
                 }
               }
+              if (ent & kWarmBit) { my_out[place] = d2{s0, s1}; my_rad[place] = rad; }
             }
           }
         }
@@ -1018,9 +1037,12 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     bool fin = ent >= 0 && (!advance || it >= (PASS == 2 ? budget : n_iters));
     if (PASS == 2) {
       // a pixel started from the coarse result that used up its budget or ran into NaN: the reference's own solve instead
-      // ... or whose solution lies where the reference's own iteration was not seen to arrive in time (gn_gate)
-      const bool redo = fin && (ent & kWarmBit) != 0 &&
-                        (advance || a0 != a0 || a1 != a1 || (start != nullptr && !gn_gate(start, n_iters, a0, a1, 0.0)));
+      // ... or that ended away from the reference's branch (farther from its start value s than the cell's acceptance radius)
+      bool redo = false;
+      if (fin && (ent & kWarmBit) != 0) {
+        const d2 sv = my_out[ent & ~kWarmBit];
+        redo = advance || !(fmax(fabs(a0 - sv.x), fabs(a1 - sv.y)) <= my_rad[ent & ~kWarmBit]);        // (NaN: redo)
+      }
       if (redo) { a0 = 1e-6; a1 = 1e-6; it = 0; budget = n_iters; ent &= ~kWarmBit; fin = false; }
       if (fin) ent &= ~kWarmBit;
     }

@@ -56,27 +56,32 @@ def _as_device_counts(x, dev):
 # environment says otherwise (DEXCT_GN_STOP_TOL=<t>, DEXCT_GN_EXACT=1).  0 = the reference's fixed count, bit for bit.
 DEFAULT_STOP_TOL = None
 
-# The two-level solve (include/dexct.h, dexct_gn_options.pass / .start).  Most of the reference's ~17 Newton steps per pixel
-# are the walk from its start value 1e-6 to the neighbourhood of the solution; what it returns is the fixed point.  So:
-#   * start values from a polynomial in the two log attenuations (quadrature.newton_start_polynomial, fitted to the forward
-#     model in a few ms per pair of spectra): within a few 1e-3 of the solution;
-#   * a COARSE launch on a short quadrature of the two spectra (quadrature.coarse_newton_tables: ~23 of 140 energies, a quarter
-#     of the cost per step): ~2 steps to the short model's fixed point, 1e-5 from the full model's;
-#   * a REFINE launch on the full tables: two steps per pixel, the second of which is the tolerance rule's evidence that the
-#     FULL model has converged to stop_tol.  A pixel for which this does not happen (steps used up, NaN), or which the coarse
-#     launch could not end by its rule, is solved the reference's way - from 1e-6 with all n_iters steps - in the same launch.
-# What comes out is, per pixel, a fixed point of the full model verified to stop_tol, or the reference's own trajectory: the
-# same contract as the single launch with the tolerance stop, asserted against the exact mode on every pixel of the benchmark
-# (bench.py, tests/test_gpu_full_scale.py).  ~4.6 full-step equivalents per pixel instead of ~17.
+# The short cut of the Newton solve (include/dexct.h, dexct_gn_options.pass / .start; csrc/gn.hip gn_start).  Most of the
+# reference's ~17 Newton steps per pixel are the walk from its start value 1e-6 to the neighbourhood of the solution; what it
+# returns is the fixed point its walk ends at.  That is a function of the pixel's two counts alone, so it is tabulated once
+# per pair of spectra: the library's own single launch (full tables, from 1e-6) is run on the counts at the corners of a
+# 128 x 128 cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / 16 (quadrature.newton_start_grid / assemble_start: where
+# does the walk end, after how many steps, how smoothly does that vary).  A pixel whose counts fall in an open cell - the
+# walk ends by the tolerance rule within n_iters steps at all corners around it, and the fixed points vary smoothly (no
+# boundary between two basins) - starts from the Catmull-Rom interpolant of those fixed points (1e-6 of |a| from its own)
+# and takes TWO steps on the full tables: the second is the tolerance rule's evidence that the FULL model has converged to
+# stop_tol.  The result is accepted only within the cell's radius of the interpolant (the reference's branch); a pixel
+# without that evidence or acceptance, or in a closed cell (few steps asked for, an ill-conditioned pair, counts outside the
+# grid, NaN), is solved from 1e-6 with all n_iters steps in the same launch.  What comes out is, per pixel, a fixed point of
+# the full model verified to stop_tol on the reference's branch, or the reference's own trajectory: the contract of the
+# single launch with the tolerance stop, asserted against the exact count on every pixel of the benchmark (bench.py,
+# tests/test_gpu_full_scale.py), on the reference goldens at 1 / 2 / 5 / 50 iterations and in tools/soak_gn.py.
+# 2.0 full-table steps per pixel instead of ~17.
 # Modes (``two_level=`` of the calls below; DEXCT_GN_TWO_LEVEL in the environment; DEFAULT_TWO_LEVEL):
-#   None / True  'coarse' from TWO_LEVEL_COARSE_MIN pixels on, else 'start'
-#   'coarse'     polynomial start + coarse launch + refining launch
-#   'start'      polynomial start + refining launch only (~3.6 full steps per pixel; no second launch)
+#   None / True / 'start'   the above (one launch)
+#   'coarse'     two launches: ~2 steps on a SHORT quadrature of the spectra (quadrature.coarse_newton_tables: ~23 of 140
+#                energies) from the same start values, then the full tables from there.  The first form of the short cut, when
+#                start values came from a polynomial and cost three full steps; with the interpolated fixed points it is 15 %
+#                slower than 'start' (profiles/r04_gn_two_level.md) and kept as an option
 #   False / '0'  the single launch from 1e-6
 # It applies to float64 with one shared spectrum, the tolerance stop on, 4 <= n_iters <= 254 and >= 48 energies; anything
 # else runs the single launch.
 DEFAULT_TWO_LEVEL = None
-TWO_LEVEL_COARSE_MIN = 1 << 23          # 8.4e6 pixels (tools/probes/gn_two_level_small.py: 1.2e7 pixels 3.25 against 3.59 ms, 2.6e6 2.39 against 1.31)
 
 _last_ws = []          # workspaces of the most recent call (one per view chunk of the pipelined boundary)
 _last_ws_coarse = []   # ... of its coarse launches (two-level solve)
@@ -133,7 +138,7 @@ def _host_tables(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
 
 
-def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12):
+def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12, want_short=False):
     """(i0_d [2, nBins, nE], mus_d [2, nE], coarse) for host or device tables, cached by content; coarse = (i0_short_d
     [2, 1, n] or None, mus_short_d [2, n] or None, start array) or None; ``cal_tol``: the tolerance the gate is calibrated for.  Tables given as device tensors are used as they are (and read back once
     per call only when the short tables are wanted: pass host arrays to avoid that synchronisation)."""
@@ -155,15 +160,14 @@ def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12):
         if i0_h.ndim == 2 or i0_h.shape[1] == 1:
             from . import quadrature
             i0_2 = i0_h.reshape(2, -1)
-            pieces = quadrature.newton_start_polynomial(i0_2, mus_h)
+            pieces = quadrature.newton_start_grid(i0_2, mus_h)
             start = None
             if pieces is not None:
-                # THE GATE (csrc/gn.hip, gn_start_values): the reference's iteration - the library's own kernel, full tables,
-                # from 1e-6 - run on the noise-free counts of the cell corners of the domain; how many steps it takes to end by
-                # the tolerance rule, and whether it ends at the truth, decides where pixels may take the short cut
-                g = np.nan_to_num(pieces['corner_g'], nan=1.0)
-                g_d = to_dev(np.ascontiguousarray(g.T), torch.float64, dev)
-                n_c = g.shape[0]
+                # THE GATE (csrc/gn.hip, gn_start): the reference's iteration - the library's own kernel, full tables, from
+                # 1e-6 - run on the counts at the corners of a cell grid in data space; where it ends, after how many steps,
+                # and how smoothly that varies decides where pixels may take the short cut and where they start
+                g_d = to_dev(np.ascontiguousarray(pieces['corner_g'].T), torch.float64, dev)
+                n_c = g_d.shape[1]
                 a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
                 k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
                 lib = _native.load()
@@ -172,17 +176,21 @@ def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12):
                                                      1, 254, 0, 0, None, 0.95, ptr(a_c),
                                                      _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COARSE, k_c.data_ptr()),
                                                      ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
-                start_h, share = quadrature.gate_table(pieces, k_c.cpu().numpy(), a_c.cpu().numpy())
-                if share >= 0.25:               # (an ill-conditioned pair: the reference's iteration itself does not get there)
+                start_h, share = quadrature.assemble_start(pieces, k_c.cpu().numpy(), a_c.cpu().numpy())
+                if share >= 0.1:                # (an ill-conditioned pair: the reference's iteration itself wanders)
                     start = to_dev(start_h, torch.float64, dev)
-            red = quadrature.coarse_newton_tables(i0_2, mus_h) if start is not None else None
-            i0_s = mus_s = None
-            if red is not None:
-                i0_s = to_dev(np.ascontiguousarray(red[1])[:, None, :], torch.float64, dev)
-                mus_s = to_dev(np.ascontiguousarray(mus_h[:, red[0]]), torch.float64, dev)
             if start is not None:
-                ent[('coarse', cal_tol)] = (i0_s, mus_s, start)
-    return ent['i0'], ent['mus'], ent.get(('coarse', cal_tol)) if want_coarse else None
+                ent[('coarse', cal_tol)] = [None, None, start]
+    tabs = ent.get(('coarse', cal_tol)) if want_coarse else None
+    if tabs is not None and want_short and 'short' not in ent:
+        # the short tables of the 'coarse' mode (only when it is asked for: 40 ms of host time per pair of spectra)
+        from . import quadrature
+        red = quadrature.coarse_newton_tables(i0_h.reshape(2, -1), mus_h)
+        ent['short'] = None if red is None else (to_dev(np.ascontiguousarray(red[1])[:, None, :], torch.float64, dev),
+                                                 to_dev(np.ascontiguousarray(mus_h[:, red[0]]), torch.float64, dev))
+    if tabs is not None and want_short and ent.get('short') is not None:
+        tabs = [ent['short'][0], ent['short'][1], tabs[2]]
+    return ent['i0'], ent['mus'], tabs
 
 
 def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1, mask_max=None,
@@ -217,12 +225,13 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
         if env is not None:
             two_level = {'0': False, '1': True, 'coarse': 'coarse', 'start': 'start'}.get(env, two_level)
     if two_level is None or two_level is True:
-        two_level = 'coarse' if g1.numel() >= TWO_LEVEL_COARSE_MIN else 'start'
+        two_level = 'start'
     if two_level not in (False, 'coarse', 'start'):
         raise ValueError(f'two_level={two_level!r}')
     applies = (precision == 'f64' and n_bins == 1 and kernel != 2 and 4 <= int(n_iters) <= 254 and n_e >= 48
                and _effective_stop_tol(stop_tol) > 0.0)
-    i0_d, mus_d, tabs = _device_tables(i0, mus, dev, bool(two_level and applies), min(_effective_stop_tol(stop_tol), 1.0e-12) or 1.0e-12)
+    i0_d, mus_d, tabs = _device_tables(i0, mus, dev, bool(two_level and applies), min(_effective_stop_tol(stop_tol), 1.0e-12) or 1.0e-12,
+                                       want_short=two_level == 'coarse')
     coarse = start_only = None
     if tabs is not None:                    # (None: no start values with a usable gate for these spectra - the single launch)
         i0_s, mus_s, start = tabs

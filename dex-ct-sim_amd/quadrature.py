@@ -256,86 +256,91 @@ def coarse_newton_tables(i0, mus, log_range=16.0, max_err=2.0e-6):
     return keep, short[:, keep]
 
 
-START_HEADER = 10          # doubles before the coefficients (csrc/gn.hip, gn_start_values)
-GATE_CELLS = 40            # cells per axis of the step table
-GATE_LOW = -0.002          # lower edge of the cell grid in normalised coordinates f = a mu_min / log_range, at most: about -0.2 g/cm2.
-                           # Solutions below zero exist only as far as exp(+mu a) stays moderate at the softest weighted energy,
-                           # so the edge is drawn at -0.5 / mu_max where that is closer to zero (spectra with weight at 1 - 3 keV)
+START_HEADER = 10          # doubles before the tables (csrc/gn.hip, gn_start)
+GATE_CELLS = 128           # cells per axis of the grid over (ln u0, u1 / u0)
+GATE_U_MIN = 1.0e-4        # smallest u0 = ln(air_0 / g_0) / log_range of the grid: thinner rays walk from 1e-6 (a handful of steps)
 GATE_MARGIN = 2            # steps added to the largest count seen around a cell
 
 
-def newton_start_polynomial(i0, mus, log_range=16.0, degree=5, n_grid=72):
-    """Start values for the two-level Newton decomposition (include/dexct.h, dexct_gn_options.start): least-squares
-    polynomials a_m(u0, u1), u_k = ln(air_k / g_k) / log_range, fitted to the forward model over the domain of
-    coarse_newton_tables (extended a little below a = 0).  Returns a dict: ``head`` (the START_HEADER doubles: air_0, air_1,
-    1 / log_range, degree, GATE_CELLS, the grid's lower edge, cells per unit, the two normalisations mu_min[m] / log_range, the skew),
-    ``coef`` (c_0 then c_1; c_m[i][j] for u0^i u1^j, i = 0..degree, j = 0..degree - i, j fastest), ``corners`` [(n+1)^2, 2]
-    (the (a0, a1) of the cell corners, row = index along f0) and ``corner_g`` [(n+1)^2, 2] (their noise-free counts; NaN for
-    corners outside the domain) - what gate_table needs - or None.
-
-    Accuracy (140 / 80 kVp on tissue / bone): a few 1e-3 of max(|a|, 1) in the median, 2.5e-2 at worst - two or three Newton
-    steps of the short tables from the coarse model's fixed point, against sixteen from the reference's start value 1e-6."""
+def newton_start_grid(i0, mus, log_range=16.0):
+    """The grid of the two-level Newton decomposition's gate (csrc/gn.hip, gn_start; include/dexct.h, dexct_gn_options.start),
+    laid out in DATA space: cells over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / log_range, u0 from GATE_U_MIN to 1 and the ratio
+    over what the forward model produces on the decomposition's domain (attenuation down to exp(-log_range), second component
+    down to a quarter of its physical lower bound), widened by a quarter on both sides for noisy counts.  Returns a dict:
+    ``head`` (the START_HEADER doubles) and ``corner_g`` [(n+1)^2, 2], the counts at the cell corners (row = index along ln u0)
+    - what the reference's iteration is run on (matdecomp._device_tables) before ``assemble_start`` builds the tables -
+    or None."""
     i0 = np.asarray(i0, dtype=np.float64)
     mus = np.asarray(mus, dtype=np.float64)
     if i0.ndim != 2 or mus.shape != (2, i0.shape[1]):
         return None
     used = np.any(i0 > 0.0, axis=0)
     air = i0.sum(axis=1)
-    if not used.any() or np.any(air <= 0.0) or np.any(i0 < 0.0):
+    if not used.any() or np.any(air <= 0.0) or np.any(i0 < 0.0) or not np.all(np.isfinite(mus)):
         return None
-    mu_min = mus[:, used].min(axis=1)
+    i0, mus = i0[:, used], mus[:, used]
+    mu_min = mus.min(axis=1)
     if np.any(mu_min <= 0.0):
         return None
-    norm = mu_min / log_range                                        # f_0 = a_0 norm[0], f_1 = (a_1 + skew a_0) norm[1]
-    i0, mus = i0[:, used], mus[:, used]                              # (energies no spectrum weights: 0 x exp(huge) otherwise)
-    # The second basis material may come out NEGATIVE for rays through matter that is not the first one (water in a tissue /
-    # bone basis: a_1 = -0.008 a_0); physically a_0 mu_0(E) + a_1 mu_1(E) >= 0 bounds it by -a_0 min_E(mu_0 / mu_1), and the
-    # reference's iteration reaches about half of that.  The cell grid is therefore laid out in a_1 + skew a_0 with a quarter
-    # of the physical bound, which keeps such rays inside it.
+    # the ratio u1 / u0 over the domain: a0, a1 >= 0 plus rays whose second component is negative (water in a tissue / bone
+    # basis: a1 = -0.008 a0; physically a0 mu0(E) + a1 mu1(E) >= 0 bounds it by -a0 min_E(mu0 / mu1); a quarter of that)
     skew = 0.25 * float(np.min(mus[0] / mus[1]))
-    low = -min(-GATE_LOW, 0.5 * float(np.min(norm / mus.max(axis=1))))
-    u = np.linspace(low, 1.0, n_grid)
-    f0, f1 = np.meshgrid(u, u, indexing='ij')
-    a_all = np.stack([f0.ravel() / norm[0], f1.ravel() / norm[1] - skew * f0.ravel() / norm[0]], axis=1)
-    keep = a_all @ norm <= 1.0                                       # attenuation exponent at the most penetrating energies <= log_range
-    a = a_all[keep]
+    f = np.linspace(0.0, 1.0, 48)
+    f0, f1 = np.meshgrid(f, f, indexing='ij')
+    a = np.stack([f0.ravel() * log_range / mu_min[0], f1.ravel() * log_range / mu_min[1] - skew * f0.ravel() * log_range / mu_min[0]], axis=1)
+    a = a[(a @ mu_min <= log_range) & (np.abs(a).sum(axis=1) > 0.0)]
+    a = np.vstack([a, a * 1e-2, a * 1e-4])                           # thin rays: the ratio depends on the thickness (beam hardening)
     with np.errstate(over='ignore', invalid='ignore'):
         nu = np.exp(-(a @ mus)) @ i0.T
-    fin = np.all(np.isfinite(nu) & (nu > 0.0), axis=1)
-    a, nu = a[fin], nu[fin]
-    p = np.log(air[None, :] / nu) / log_range
-    terms = [(i, j) for i in range(degree + 1) for j in range(degree + 1 - i)]
-    V = np.stack([p[:, 0] ** i * p[:, 1] ** j for i, j in terms], axis=1)
-    wgt = 1.0 / (np.abs(a).max(axis=1) + 1.0)                       # errors relative to max(|a|, 1), as the stop rule measures
-    coef = np.concatenate([np.linalg.lstsq(V * wgt[:, None], a[:, m] * wgt, rcond=None)[0] for m in range(2)])
-    n = GATE_CELLS
-    per_unit = n / (1.0 - low)
-    head = np.array([air[0], air[1], 1.0 / log_range, float(degree), float(n), low, per_unit, norm[0], norm[1], skew])
-    e = low + np.arange(n + 1) / per_unit
-    c0, c1 = np.meshgrid(e, e, indexing='ij')
-    corners = np.stack([c0.ravel() / norm[0], c1.ravel() / norm[1] - skew * c0.ravel() / norm[0]], axis=1)
-    inside = corners @ norm <= 1.0 + 2.0 / per_unit
-    with np.errstate(over='ignore', invalid='ignore'):
-        g = np.exp(-(corners @ mus)) @ i0.T
-    g[~inside | ~np.all(np.isfinite(g) & (g > 0.0), axis=1)] = np.nan
-    if not (np.all(np.isfinite(coef)) and np.all(np.isfinite(head))):
+    u = np.log(air[None, :] / nu)
+    ok = np.all(np.isfinite(u), axis=1) & (u[:, 0] > 0.0)
+    if not ok.any():
         return None
-    return dict(head=head, coef=coef, corners=corners, corner_g=g)
-
-
-def gate_table(pieces, steps, a_found, n_iters_cap=254):
-    """The step table of the start array from the reference iteration run on the cell corners (by the library's own kernel:
-    matdecomp._device_tables): ``steps`` [(n+1)^2] = steps after which the tolerance rule ended the corner's pixel (255: it did
-    not), ``a_found`` [(n+1)^2, 2] = where.  A corner counts only if it ended at its true (a0, a1) (1e-9 of max(|a|, 1)); a
-    cell needs the largest count among its own corners and those of the eight cells around it, plus GATE_MARGIN; infinity if
-    any of them does not count.  Returns the assembled start array and the share of cells that allow the short cut."""
+    t = u[ok, 1] / u[ok, 0]
+    t_lo, t_hi = float(t.min()), float(t.max())
+    if not (np.isfinite(t_lo) and t_hi > t_lo):
+        return None
+    w = t_hi - t_lo
+    t_lo, t_hi = t_lo - 0.25 * w, t_hi + 0.25 * w
     n = GATE_CELLS
-    truth = pieces['corners']
-    ok = (np.asarray(steps) < min(255, n_iters_cap + 1)) & np.all(np.isfinite(a_found), axis=1) & ~np.isnan(pieces['corner_g'][:, 0])
-    err = np.abs(a_found - truth).max(axis=1) / np.maximum(np.abs(truth).max(axis=1), 1.0)
-    ok &= err <= 1.0e-9
-    k = np.where(ok, np.asarray(steps, dtype=np.float64), np.inf).reshape(n + 1, n + 1)
-    cell = np.maximum(np.maximum(k[:-1, :-1], k[1:, :-1]), np.maximum(k[:-1, 1:], k[1:, 1:]))
-    pad = np.pad(cell, 1, mode='edge')
+    per_x = n / -np.log(GATE_U_MIN)
+    per_t = n / (t_hi - t_lo)
+    head = np.array([air[0], air[1], 1.0 / log_range, float(n), np.log(GATE_U_MIN), per_x, t_lo, per_t, 0.0, 0.0])
+    x = np.log(GATE_U_MIN) + np.arange(n + 1) / per_x
+    tt = t_lo + np.arange(n + 1) / per_t
+    u0 = np.exp(x)[:, None] * np.ones((1, n + 1))
+    u1 = u0 * tt[None, :]
+    g = np.stack([air[0] * np.exp(-u0.ravel() * log_range), air[1] * np.exp(-u1.ravel() * log_range)], axis=1)
+    return dict(head=head, corner_g=g)
+
+
+def assemble_start(pieces, steps, roots):
+    """The start array (csrc/gn.hip, gn_start) from the reference iteration run on the cell corners (by the library's own
+    kernel: matdecomp._device_tables): ``steps`` [(n+1)^2] = steps after which the tolerance rule ended the corner's pixel
+    (255: it did not), ``roots`` [(n+1)^2, 2] = where.  A cell is open when all four corners ended by the rule at finite fixed
+    points that vary smoothly over it (the mixed second difference is at most half the largest edge difference: no boundary
+    between two basins crosses it); it needs the largest step count among its own corners and those of the eight cells around
+    it plus GATE_MARGIN (infinity if any of those cells is closed); its acceptance radius is the spread of its corners' fixed
+    points.  Returns the array and the share of open cells."""
+    n = int(pieces['head'][3])
+    steps = np.asarray(steps).reshape(n + 1, n + 1).astype(np.float64)
+    r = np.asarray(roots, dtype=np.float64).reshape(n + 1, n + 1, 2)
+    good = (steps < 255) & np.all(np.isfinite(r), axis=2) & np.all(np.isfinite(pieces['corner_g']), axis=1).reshape(n + 1, n + 1)
+    c00, c01, c10, c11 = r[:-1, :-1], r[:-1, 1:], r[1:, :-1], r[1:, 1:]
+    with np.errstate(invalid='ignore'):
+        edges = np.max([np.abs(c01 - c00), np.abs(c11 - c10), np.abs(c10 - c00), np.abs(c11 - c01)], axis=0).max(axis=2)
+        twist = np.abs(c00 + c11 - c01 - c10).max(axis=2)
+        spread = np.max([np.abs(c01 - c00), np.abs(c10 - c00), np.abs(c11 - c00), np.abs(c11 - c01), np.abs(c11 - c10),
+                         np.abs(c10 - c01)], axis=0).max(axis=2)
+    cell_ok = good[:-1, :-1] & good[:-1, 1:] & good[1:, :-1] & good[1:, 1:] & (twist <= 0.5 * edges + 1e-12)
+    k = np.max([steps[:-1, :-1], steps[:-1, 1:], steps[1:, :-1], steps[1:, 1:]], axis=0)
+    k = np.where(cell_ok, k, np.inf)
+    pad = np.pad(k, 1, mode='edge')
     need = np.max([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0) + GATE_MARGIN
-    return np.concatenate([pieces['head'], pieces['coef'], need.ravel()]), float(np.isfinite(need).mean())
+    # the kernel interpolates the fixed points over the 4 x 4 corners around a cell (Catmull-Rom): the cells on the border of
+    # the grid, which lack a ring of neighbours, are closed
+    need[0, :] = need[-1, :] = need[:, 0] = need[:, -1] = np.inf
+    radius = np.where(cell_ok, spread + 1e-9, 0.0)
+    r = np.where(good[:, :, None], r, 0.0)
+    out = np.concatenate([pieces['head'], r[:, :, 0].ravel(), r[:, :, 1].ravel(), need.ravel(), radius.ravel()])
+    return out, float(np.isfinite(need).mean())

@@ -189,9 +189,10 @@ def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at
         # [view][row][channel] order by the kernel itself are the same bits
         st_d = md.last_gn_stats()
         st_default = st_d['pixel_iterations']
-        # the default at this size is the two-level solve with the coarse launch: two full-table steps per unmasked pixel
+        # the default: start values from the gate's table of the reference's fixed points, then two full-table steps per
+        # unmasked pixel (the second one is the tolerance rule's evidence of convergence)
         live = int((counts[0] < 0.95 * gmax).sum())
-        assert st_d['mode'] == 'coarse' and 1.99 * live <= st_default <= 2.2 * live and st_d['coarse_pixel_iterations'] <= 3 * live
+        assert st_d['mode'] == 'start' and 1.99 * live <= st_default <= 2.2 * live
         a_single = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, two_level=False)
         assert md.last_gn_stats()['mode'] == 'single' and md.last_gn_stats()['pixel_iterations'] > 6 * st_default
         a_exact = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, stop_tol=0.0)

@@ -94,37 +94,46 @@ def test_short_tables_of_the_coarse_newton_pass():
     assert q.coarse_newton_tables(i0, -mus) is None and q.coarse_newton_tables(-i0, mus) is None
 
 
-def test_start_polynomial_and_gate_table():
-    """quadrature.newton_start_polynomial: start values within a few 1e-2 of max(|a|, 1) over the domain, including rays with
-    a slightly negative second component; gate_table: a cell needs the largest step count among its corners and those of
-    its neighbours plus the margin, and is closed (infinity) when any of them did not arrive at the truth."""
+def test_gate_grid_and_start_array():
+    """quadrature.newton_start_grid: a cell grid in data space that holds every ray of the domain (incl. water in a tissue /
+    bone basis, whose second component is slightly negative); assemble_start: a cell needs the largest step count among its
+    corners and those of its neighbours plus the margin, and is closed (infinity) around a corner that did not end by the
+    rule or whose fixed point breaks the smoothness of its neighbours (another basin)."""
     _, i0, mus = newton_tables()
-    p = q.newton_start_polynomial(i0, mus)
-    head, coef = p['head'], p['coef']
-    deg, n = int(head[3]), int(head[4])
-    assert n == q.GATE_CELLS and coef.size == (deg + 1) * (deg + 2) and p['corners'].shape == ((n + 1) ** 2, 2)
+    p = q.newton_start_grid(i0, mus)
+    head = p['head']
+    n = int(head[3])
+    assert n == q.GATE_CELLS and p['corner_g'].shape == ((n + 1) ** 2, 2) and np.all(p['corner_g'] > 0)
     rng = np.random.default_rng(8)
-    a = np.stack([rng.uniform(0, 45, 5000), rng.uniform(0, 10, 5000)], 1)
+    a = np.stack([rng.uniform(0.05, 45, 5000), rng.uniform(0, 10, 5000)], 1)
     a[:1500, 1] = -0.008 * a[:1500, 0]                                   # water in a tissue / bone basis
     g = np.exp(-(a @ mus)) @ i0.T
     u = np.log(head[:2][None, :] / g) * head[2]
-    terms = [(i, j) for i in range(deg + 1) for j in range(deg + 1 - i)]
-    V = np.stack([u[:, 0] ** i * u[:, 1] ** j for i, j in terms], 1)
-    s = np.stack([V @ coef[:len(terms)], V @ coef[len(terms):]], 1)
-    assert (np.abs(s - a).max(1) / np.maximum(np.abs(a).max(1), 1.0)).max() < 0.05
-    # every such ray lies inside the cell grid (skewed coordinates), away from its lower edge
-    f0 = (a[:, 0] * head[7] - head[5]) * head[6]
-    f1 = ((a[:, 1] + head[9] * a[:, 0]) * head[8] - head[5]) * head[6]
-    assert f0.min() >= 0 and f1.min() >= 0 and f0.max() < n and f1.max() < n
+    fx = (np.log(u[:, 0]) - head[4]) * head[5]
+    fy = (u[:, 1] / u[:, 0] - head[6]) * head[7]
+    inside = u[:, 0] < 1.0
+    assert fx[inside].min() >= 0 and fx[inside].max() < n and 0.15 * n < fy[inside].min() and fy[inside].max() < 0.85 * n
+    # the corners' counts are what the header says: row = index along ln u0, column = index of the ratio
+    i, j = 11, 40
+    cg = p['corner_g'].reshape(n + 1, n + 1, 2)[i, j]
+    u0 = np.exp(head[4] + i / head[5])
+    assert np.allclose(np.log(head[:2] / cg) * head[2], [u0, u0 * (head[6] + j / head[7])], rtol=1e-12)
+    # a smooth synthetic field of fixed points, one slow corner, one corner that did not end, one corner in another basin
+    ii, jj = np.meshgrid(np.arange(n + 1.0), np.arange(n + 1.0), indexing='ij')
+    roots = np.stack([0.3 * ii + 0.01 * ii * jj, 0.2 * jj - 0.05 * ii], -1).reshape(-1, 2)
     steps = np.full((n + 1) ** 2, 17)
-    steps[5 * (n + 1) + 7] = 30                                           # one slow corner
-    found = p['corners'].copy()
-    found[20 * (n + 1) + 20] += 1e-3                                      # one corner that ended somewhere else
-    start, share = q.gate_table(p, steps, found)
-    need = start[q.START_HEADER + coef.size:].reshape(n, n)
-    assert start.size == q.START_HEADER + coef.size + n * n
-    inside = ~np.isnan(p['corner_g'][:, 0]).reshape(n + 1, n + 1)
-    assert need[0, 0] == 17 + q.GATE_MARGIN and np.all(need[3:7, 5:9] == 30 + q.GATE_MARGIN) and need[2, 5] == need[7, 5] == 17 + q.GATE_MARGIN
-    assert np.all(np.isinf(need[18:22, 18:22])) and np.isfinite(need[17, 17]) and np.isfinite(need[22, 18]) == bool(inside[22:25, 18:21].all())
-    assert np.all(np.isinf(need[~(inside[:-1, :-1] & inside[1:, 1:])]))   # cells that reach outside the domain are closed
-    assert 0.3 < share < 0.6
+    steps[5 * (n + 1) + 7] = 30
+    steps[30 * (n + 1) + 30] = 255
+    roots[45 * (n + 1) + 20] += [3.0, -2.0]
+    start, share = q.assemble_start(p, steps, roots)
+    assert start.size == q.START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n
+    r0 = start[q.START_HEADER:q.START_HEADER + (n + 1) ** 2].reshape(n + 1, n + 1)
+    need = start[q.START_HEADER + 2 * (n + 1) ** 2:q.START_HEADER + 2 * (n + 1) ** 2 + n * n].reshape(n, n)
+    radius = start[-n * n:].reshape(n, n)
+    assert np.array_equal(r0.ravel()[steps < 255], roots[steps < 255, 0]) and r0[30, 30] == 0.0      # (a corner that did not end: zeroed)
+    assert need[1, 1] == 17 + q.GATE_MARGIN and np.isinf(need[0, 5]) and np.isinf(need[7, n - 1]) and np.all(need[3:7, 5:9] == 30 + q.GATE_MARGIN) and need[2, 5] == need[7, 5] == 17 + q.GATE_MARGIN
+    assert np.all(np.isinf(need[28:32, 28:32])) and np.isfinite(need[27, 27]) and np.isfinite(need[32, 30])
+    assert np.all(np.isinf(need[43:47, 18:22])) and np.isfinite(need[42, 20]) and np.isfinite(need[47, 19])
+    assert 0.93 < share < 1.0
+    # the acceptance radius: the spread of the corners' fixed points (here the x-step 0.3 + 0.01 j plus the cross term)
+    assert abs(radius[10, 10] - (0.3 + 0.01 * 11 + 0.01 * 10 + 1e-9)) < 1e-12 and radius[29, 29] == 0.0

@@ -9,8 +9,9 @@ count 0..80, and demands, BIT FOR BIT including the NaN payloads:
     [view][channel][row] input (out_rc: 4 x 16 tiles collected in LDS) return the same;
   * the cooperative kernel (4 waves per 64 pixels) returns what ITS full loop returns;
   * with the air mask: masked pixels are exactly 0 and the others unchanged;
-and, NOT bit for bit (round 4): the default tolerance stop within 1e-10 of the exact result, and the cooperative kernel
-within 1e-9 of the lane kernel, on the pixels the NumPy restatement answers stably (below);
+and, NOT bit for bit (round 4): the default tolerance stop and both modes of the two-level solve (start values only; with the
+coarse launch - where the tables allow them, else they fall back to the single launch) within 1e-10 of the exact result, and
+the cooperative kernel within 1e-9 of the lane kernel, on the pixels the NumPy restatement answers stably (below);
 and, as a sanity check of the arithmetic (a statistic, not an invariant), agreement to 1e-9 with the NumPy restatement of
 the reference on the pixels where that one is finite and insensitive both to a 1e-13 perturbation of its input and to the
 order of its own sums.  The few pixels beyond 1e-9 that this screen lets through (about 1 in 1e5 here) are of two kinds,
@@ -40,11 +41,12 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device('cuda:0')
 
 
-def run(g, i0, mus, n_iters, env, mask_max=None, stop_tol=0.0, kernel=1, out_rc=None):
+def run(g, i0, mus, n_iters, env, mask_max=None, stop_tol=0.0, kernel=1, out_rc=None, two_level=False):
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
-    out = md.gn_device(g[0], g[1], i0, mus, n_iters, 'f64', mask_max=mask_max, stop_tol=stop_tol, kernel=kernel, out_rc=out_rc)
+    out = md.gn_device(g[0], g[1], i0, mus, n_iters, 'f64', mask_max=mask_max, stop_tol=stop_tol, kernel=kernel, out_rc=out_rc,
+                       two_level=two_level)
     torch.cuda.synchronize()
     for k in KNOBS:
         os.environ.pop(k, None)
@@ -71,6 +73,7 @@ def hessian_cond(a, g, i0, mus):
 t0 = time.time()
 fails, n_pix, n_cmp, n_off = 0, 0, 0, 0
 n_few, min_cond_few = 0, float('inf')
+n_mode = {}
 for case in range(n_cases):
     seed = seed0 + case
     rng = np.random.default_rng(770000 + seed)
@@ -126,6 +129,12 @@ for case in range(n_cases):
         if not torch.equal(coop.view(torch.int64), coop_full.view(torch.int64)):
             bad.append('cooperative kernel: exact exit differs from its full loop')
         default = run(g_d, i0, mus, n_iters, {}, stop_tol=None)
+        # the two-level solve (round 4): polynomial start values (+ a coarse launch on a short quadrature), gated by the
+        # reference iteration's own step counts - same contract as the tolerance stop
+        modes = {}
+        for mode in ('start', 'coarse'):
+            modes[mode] = run(g_d, i0, mus, n_iters, {}, stop_tol=None, two_level=mode)
+            n_mode[md.last_gn_stats()['mode']] = n_mode.get(md.last_gn_stats()['mode'], 0) + 1
         gmax = torch.tensor(float(np.nanmax(np.where(np.isfinite(g[0]), g[0], -np.inf))), dtype=torch.float64, device=dev)
         masked = run(g_d, i0, mus, n_iters, {}, mask_max=gmax)
         air = g_d[0].double() >= 0.95 * gmax
@@ -147,7 +156,9 @@ for case in range(n_cases):
             err = np.abs(base.cpu().numpy() - ref)[ok] / np.maximum(np.abs(ref[ok]).max(-1, keepdims=True), 1.0)
             # (not with one or two energies: the Hessian is singular there and any two arithmetics part ways - the case the
             # condition-number check below handles for the comparison with the restatement)
-            for name, other, tol in (() if few else (('default tolerance stop', default, 1e-10), ('cooperative kernel', coop, 1e-9))):
+            for name, other, tol in (() if few else (('default tolerance stop', default, 1e-10), ('cooperative kernel', coop, 1e-9),
+                                                     ('two-level solve, start values only', modes['start'], 1e-10),
+                                                     ('two-level solve with the coarse launch', modes['coarse'], 1e-10))):
                 d = (np.abs(other.cpu().numpy() - base.cpu().numpy())[ok] / np.maximum(np.abs(ref[ok]).max(-1, keepdims=True), 1.0)) if ok.any() else np.zeros(1)
                 n_bad = int((~(d.max(-1) <= tol)).sum()) if ok.any() else 0
                 if n_bad > max(2, 1e-3 * ok.sum()):
@@ -179,5 +190,5 @@ for case in range(n_cases):
     if case % 100 == 99 or case == n_cases - 1:
         print(f'{case + 1} cases, {fails} failed, {n_pix:.3g} pixels x 12 launches, {n_cmp:.3g} stable pixels compared with the '
               f'NumPy restatement ({n_off} beyond 1e-9 with >= 3 energies; with 1-2 energies {n_few} beyond 1e-9, the best '
-              f'conditioned of them has Hessian cond {min_cond_few:.1e}), {time.time() - t0:.0f} s', flush=True)
+              f'conditioned of them has Hessian cond {min_cond_few:.1e}); two-level launches ended up as {n_mode}; {time.time() - t0:.0f} s', flush=True)
 sys.exit(1 if fails else 0)

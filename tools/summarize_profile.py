@@ -30,7 +30,9 @@ def pmc(which):
         return out
     for r in csv.DictReader(open(files[0])):
         out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']) * 1024.0)
-    return {k: sum(v) / len(v) for k, v in out.items()}
+    # (the step-counting instantiation of the Newton kernel is also dispatched once on the 16 641 pixels of the gate calibration:
+    # the large dispatches are the ones of the steps)
+    return {k: (max(v) if 'gn_refill_kernel<4, 1>' in k else sum(v) / len(v)) for k, v in out.items()}
 
 
 fetch, write = pmc('fetch'), pmc('write')
@@ -56,6 +58,20 @@ lines = [f'# rocprofv3 summary `{tag}`', '',
 for r in rows[:8]:
     lines.append(f'| `{r["Name"][:70]}` | {r["Calls"]} | {float(r["AverageNs"]) / 1e6:.3f} | {r["Percentage"]} |')
 lines += ['', f'bench.py (same run) HIP-event averages: {bench["kernel_ms"]}', '']
+tl = (bench.get('roofline') or {}).get('short_cut')
+if tl:
+    trace = os.path.join(os.path.dirname(stats), os.path.basename(stats).replace('kernel_stats', 'kernel_trace'))
+    big = {}
+    for r in csv.DictReader(open(trace)):
+        for pat in ('gn_refill_kernel<4, 1>', 'gn_refill_kernel<4, 2>'):
+            if pat in r['Kernel_Name']:
+                big.setdefault(pat, []).append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e6)
+    for pat, v in big.items():
+        step = [x for x in v if x > 0.25 * max(v)]
+        lines.append(f'`{pat}`: {len(v)} dispatches, of which {len(step)} are step launches averaging {sum(step) / len(step):.2f} ms'
+                     + (' (the others: the gate calibration on the 16 641 cell corners, once per pair of spectra)' if len(step) < len(v) else ''))
+    lines += [f'Newton launch in bench.py (HIP events around it, last timed step; mode {tl["mode"]}): {tl["launch_ms"]:.2f} ms'
+              + (f', coarse launch {tl["coarse_launch_ms"]:.2f} ms' if tl.get('coarse_launch_ms') else ''), '']
 cal = [k for k in fetch if 'transpose_xy' in k]
 traffic = {}
 if cal:
@@ -81,17 +97,25 @@ if cal:
             traffic['siddon_fetch_bytes'] = corr * fetch[k]
             traffic['siddon_write_bytes'] = write.get(k, 0.0)
             traffic['siddon_hbm_bytes_per_launch'] = corr * fetch[k] + write.get(k, 0.0)
-        if 'gn_refill_kernel' in k or 'gn_kernel<false' in k:
+        # the Newton kernel of the step: the refining launch of the two-level solve (gn_refill_kernel<4, 2>) where it ran, else
+        # the single launch (<4, 0> / <5, 0>); the coarse launch (<4, 1>) is recorded beside it
+        is_main = ('gn_refill_kernel<4, 2>' in k) or (('gn_refill_kernel' in k or 'gn_kernel<false' in k) and 'gn_refill_kernel<4, 1>' not in k
+                                                      and not any('gn_refill_kernel<4, 2>' in kk for kk in fetch))
+        if is_main:
+            traffic['gn_kernel'] = k.split('(')[0].replace('void dexct::', '')
             traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
             traffic['gn_write_bytes'] = write.get(k, 0.0)
             # round 4: in the reference-order mode (what bench.py runs on stacked fans) the kernel reads its pixels as 64-byte
             # runs, which FETCH_SIZE counts in full (tools/probes/gn_write2.py: 0.77 GB for 0.82 GB of input; the plain order's
             # dword-per-lane stream shows half): no doubling for the round-4 kernel
             traffic['gn_fetch_bytes_raw'] = fetch[k]
-            traffic['gn_fetch_counted_in_full'] = 'gn_refill_kernel<4>' in k or 'gn_refill_kernel<5>' in k
+            traffic['gn_fetch_counted_in_full'] = 'gn_refill_kernel<4' in k or 'gn_refill_kernel<5' in k
+        if 'gn_refill_kernel<4, 1>' in k:
+            traffic['gn_coarse_fetch_bytes_raw'] = fetch[k]
+            traffic['gn_coarse_write_bytes'] = write.get(k, 0.0)
     for k, d in sq.items():
         if ('rows' in k and 'kernel' in k and 'cone_' not in k) or 'gn_refill_kernel' in k:
-            tag2 = 'siddon' if 'rows' in k else 'gn'
+            tag2 = 'siddon' if 'rows' in k else ('gn_coarse' if 'gn_refill_kernel<4, 1>' in k else 'gn')
             traffic[f'{tag2}_valu_insts'] = d.get('SQ_INSTS_VALU')
             if d.get('GRBM_GUI_ACTIVE'):
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's waves; GRBM_GUI_ACTIVE sums the 8 XCDs
