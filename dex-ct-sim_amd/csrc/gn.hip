@@ -764,7 +764,8 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // an ill-conditioned pair of spectra, counts outside the grid, another fixed point, NaN) is solved the reference's way.
 // Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] cells per axis n; [4] ln of the smallest u0 of the grid;
 // [5] cells per unit of ln u0; [6] smallest ratio u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] reserved; then
-// the corners' fixed points a0[(n+1)^2], a1[(n+1)^2] (row = index along ln u0), then need[n^2], radius[n^2].
+// the corners' fixed points as pairs (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair (need, radius)[n^2];
+// the array is 16-byte aligned (pairs are read with one load).
 constexpr int kStartHeader = 10;
 __device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n_iters, double g0, double g1, double& s0,
                                          double& s1, double& radius) {
@@ -773,10 +774,11 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n
   const double fx = (log(u0) - start[4]) * start[5], fy = (u1 / u0 - start[6]) * start[7];
   bool ok = fx >= 0.0 && fy >= 0.0 && fx < (double)n && fy < (double)n;        // (NaN compares false)
   const int i = ok ? (int)fx : 0, j = ok ? (int)fy : 0;
-  const double* __restrict__ r0 = start + kStartHeader;
-  const double* __restrict__ r1 = r0 + (n + 1) * (n + 1);
-  const double* __restrict__ need = r1 + (n + 1) * (n + 1);
-  ok = ok && (double)n_iters >= need[i * n + j];
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2* __restrict__ roots = reinterpret_cast<const d2*>(start + kStartHeader);       // (a0, a1) per corner
+  const d2* __restrict__ cells = roots + (n + 1) * (n + 1);                               // (need, radius) per cell
+  const d2 cell = cells[i * n + j];
+  ok = ok && (double)n_iters >= cell.x;
   // Catmull-Rom interpolation of the corners' fixed points over the 4 x 4 corners around the cell (the corners of the 3 x 3
   // cells the step table vouches for; cells on the border of the grid are closed by the host): 1e-6 of |a| where the
   // bilinear interpolant is 6e-4 off - the difference between two and three steps of the full tables per pixel
@@ -800,13 +802,14 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n
     double ra = 0.0, rb = 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ra = fma(cy[q], r0[base + p * (n + 1) + q], ra);
-      rb = fma(cy[q], r1[base + p * (n + 1) + q], rb);
+      const d2 r = roots[base + p * (n + 1) + q];
+      ra = fma(cy[q], r.x, ra);
+      rb = fma(cy[q], r.y, rb);
     }
     s0 = fma(cx[p], ra, s0);
     s1 = fma(cx[p], rb, s1);
   }
-  radius = (need + n * n)[i * n + j];
+  radius = cell.y;
   return ok;
 }
 
@@ -818,18 +821,21 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n
 // depend on the pixel.  Pixels are independent problems: results are bit-identical to gn_kernel's in any order.
 // MINW: minimum waves per SIMD the register allocation must allow (4, the default: 110 VGPRs, no scratch; 5: 96 VGPRs + 48 B).
 //
-// PASS (dexct_gn_options.pass): the two launches of the two-level solve (host side: matdecomp.gn_device).
-//   0  one launch, everything above.
-//   1  COARSE: the same iteration on whatever tables it is given (the host passes a short quadrature of the spectra: a fifth of
-//      the energies); besides the result, `iters` receives per pixel (result order) the number of steps after which the
-//      tolerance rule ended it, or 255 when it ended any other way (n_iters reached, repeated state, NaN).
-//   2  REFINE: on the full tables.  A pixel whose byte k is not 255 and leaves at least two steps of the budget starts from
-//      the coarse result in out_a with n_iters - k steps left (the coarse steps count against the budget, so no pixel gets
-//      more iterations than the reference gives it); it ends by the same tolerance rule - i.e. only after a step of the FULL
-//      model has been seen to contract to within stop_tol - or at a repeated state.  A pixel that does not (budget used up,
-//      NaN) and every pixel marked 255 is solved from the reference's start value with all n_iters steps, exactly as PASS 0
-//      does: the result of the pair of launches is either a verified fixed point of the full model or the reference's own
-//      trajectory, never the coarse model's answer.
+// PASS (dexct_gn_options.pass; the short cut past the reference's walk from 1e-6: gn_start above, matdecomp.gn_device):
+//   0  one launch from 1e-6, everything above.
+//   1  the same iteration on whatever tables it is given, counting steps: besides the result, `iters` receives per pixel
+//      (result order) the number of steps after which the tolerance rule ended it, or 255 when it ended any other way
+//      (n_iters reached, repeated state, NaN).  Run by the host on a grid of counts with the full tables to tabulate where the
+//      reference's walk ends (the gate), and - "coarse" mode - on short tables from the gate's start values.
+//   2  the short cut, on the full tables.  With `start` and without `iters` (the default): a pixel in an open cell starts from
+//      the interpolated fixed point of the reference's walk.  With `iters` (coarse mode): a pixel whose byte k is not 255 and
+//      leaves at least two steps of the budget starts from the coarse result in out_a - if that lies within the cell's radius
+//      of the interpolant - with n_iters - k steps left (the coarse steps count against the budget, so no pixel gets more
+//      iterations than the reference gives it).  Either way it ends by the same tolerance rule - i.e. only after a step of
+//      the FULL model has been seen to contract to within stop_tol - or at a repeated state, and is accepted only within the
+//      radius.  A pixel that does not (budget used up, NaN, another fixed point), every pixel in a closed cell and every pixel
+//      marked 255 is solved from the reference's start value with all n_iters steps, exactly as PASS 0 does: the result is
+//      either a verified fixed point of the full model on the reference's branch or the reference's own trajectory.
 template <int MINW, int PASS>
 __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, long long n_pix, const double* __restrict__ ws,

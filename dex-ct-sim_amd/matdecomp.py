@@ -166,17 +166,24 @@ def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12, want_short=False)
                 # THE GATE (csrc/gn.hip, gn_start): the reference's iteration - the library's own kernel, full tables, from
                 # 1e-6 - run on the counts at the corners of a cell grid in data space; where it ends, after how many steps,
                 # and how smoothly that varies decides where pixels may take the short cut and where they start
-                g_d = to_dev(np.ascontiguousarray(pieces['corner_g'].T), torch.float64, dev)
-                n_c = g_d.shape[1]
-                a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
-                k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
                 lib = _native.load()
-                ws = torch.empty(lib.dexct_gn_workspace_bytes(i0_2.shape[1], 1), dtype=torch.uint8, device=dev)
-                _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(ent['i0']), ptr(ent['mus']), i0_2.shape[1], 1,
-                                                     1, 254, 0, 0, None, 0.95, ptr(a_c),
-                                                     _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COARSE, k_c.data_ptr()),
-                                                     ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
-                start_h, share = quadrature.assemble_start(pieces, k_c.cpu().numpy(), a_c.cpu().numpy())
+
+                def walk(g):
+                    """the reference's iteration on counts g [n, 2]: (steps until the tolerance rule fired | 255, where)"""
+                    g_d = to_dev(np.ascontiguousarray(g.T), torch.float64, dev)
+                    n_c = g_d.shape[1]
+                    a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
+                    k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
+                    ws = torch.empty(lib.dexct_gn_workspace_bytes(i0_2.shape[1], 1), dtype=torch.uint8, device=dev)
+                    _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(ent['i0']), ptr(ent['mus']), i0_2.shape[1],
+                                                         1, 1, 254, 0, 0, None, 0.95, ptr(a_c),
+                                                         _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COARSE, k_c.data_ptr()),
+                                                         ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
+                    return k_c.cpu().numpy(), a_c.cpu().numpy()
+
+                start_h, share = quadrature.assemble_start(pieces, *walk(pieces['corner_g']))
+                # ... and the table is checked against what it stands for at every cell's centre
+                start_h, share, _ = quadrature.validate_start(start_h, pieces, *walk(quadrature.cell_centres(pieces)))
                 if share >= 0.1:                # (an ill-conditioned pair: the reference's iteration itself wanders)
                     start = to_dev(start_h, torch.float64, dev)
             if start is not None:

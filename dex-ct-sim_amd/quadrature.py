@@ -259,7 +259,15 @@ def coarse_newton_tables(i0, mus, log_range=16.0, max_err=2.0e-6):
 START_HEADER = 10          # doubles before the tables (csrc/gn.hip, gn_start)
 GATE_CELLS = 128           # cells per axis of the grid over (ln u0, u1 / u0)
 GATE_U_MIN = 1.0e-4        # smallest u0 = ln(air_0 / g_0) / log_range of the grid: thinner rays walk from 1e-6 (a handful of steps)
+GATE_U_MAX = 0.75          # largest u0 with open cells: attenuation exp(-12), six counts per million.  Beyond, the long walk from 1e-6 is
+                           # fragile - photon-starved counts inside a cell whose corners all arrive have been seen to end at another
+                           # root or to diverge (tools/soak_gn.py seeds 245, 283: 10 and 23 counts of 7e6) - and is left to the reference
 GATE_MARGIN = 2            # steps added to the largest count seen around a cell
+GATE_RADIUS = 0.05         # acceptance radius of a result around the interpolated fixed point, in units of the spread of the cell's
+                           # corner fixed points.  The interpolant is within ~1e-6 of |a| of the pixel's own fixed point on the
+                           # reference's branch (the spread is ~0.1 |a|), so this leaves a margin of a few thousand - and a second
+                           # root of the two equations, where tables far from anything physical admit one, has been seen as close
+                           # as 0.9 spreads (tools/soak_gn.py seed 270: the coarse launch found it)
 
 
 def newton_start_grid(i0, mus, log_range=16.0):
@@ -311,36 +319,104 @@ def newton_start_grid(i0, mus, log_range=16.0):
     u0 = np.exp(x)[:, None] * np.ones((1, n + 1))
     u1 = u0 * tt[None, :]
     g = np.stack([air[0] * np.exp(-u0.ravel() * log_range), air[1] * np.exp(-u1.ravel() * log_range)], axis=1)
-    return dict(head=head, corner_g=g)
+    return dict(head=head, corner_g=g, i0=i0, mus=mus)
 
 
 def assemble_start(pieces, steps, roots):
     """The start array (csrc/gn.hip, gn_start) from the reference iteration run on the cell corners (by the library's own
     kernel: matdecomp._device_tables): ``steps`` [(n+1)^2] = steps after which the tolerance rule ended the corner's pixel
-    (255: it did not), ``roots`` [(n+1)^2, 2] = where.  A cell is open when all four corners ended by the rule at finite fixed
-    points that vary smoothly over it (the mixed second difference is at most half the largest edge difference: no boundary
-    between two basins crosses it); it needs the largest step count among its own corners and those of the eight cells around
-    it plus GATE_MARGIN (infinity if any of those cells is closed); its acceptance radius is the spread of its corners' fixed
-    points.  Returns the array and the share of open cells."""
+    (255: it did not), ``roots`` [(n+1)^2, 2] = where.  A corner counts only if its fixed point REPRODUCES its counts (the
+    forward model with the reference's clip of the exponent, matdecomp.py:116, within 1e-8): an isolated root of the two
+    equations.  Where the clip is active (attenuation tables far above anything physical) or the gradient vanishes for another
+    reason the iteration also comes to rest - on a valley of the clipped likelihood, at points that are not isolated: another
+    start value rests elsewhere on it, so there is nothing to tabulate.  A cell is open when all four corners count, at finite
+    fixed points that vary smoothly over it and along the grid lines through its corners (mixed and axial second differences at
+    most half the largest first difference: no boundary between two basins crosses or borders it); it needs the largest step count among its own corners and those of the eight cells around
+    it plus GATE_MARGIN (infinity if any of those cells is closed); its acceptance radius is GATE_RADIUS x the spread of its
+    corners' fixed points.  Returns the array and the share of open cells."""
     n = int(pieces['head'][3])
     steps = np.asarray(steps).reshape(n + 1, n + 1).astype(np.float64)
     r = np.asarray(roots, dtype=np.float64).reshape(n + 1, n + 1, 2)
     good = (steps < 255) & np.all(np.isfinite(r), axis=2) & np.all(np.isfinite(pieces['corner_g']), axis=1).reshape(n + 1, n + 1)
+    with np.errstate(all='ignore'):
+        rr = np.where(np.isfinite(r), r, 0.0).reshape(-1, 2)
+        nu = np.exp(np.clip(-(rr @ pieces['mus']), -700.0, 700.0)) @ pieces['i0'].T
+        resid = np.abs(nu / pieces['corner_g'] - 1.0).max(axis=1).reshape(n + 1, n + 1)
+    good &= resid <= 1.0e-8
     c00, c01, c10, c11 = r[:-1, :-1], r[:-1, 1:], r[1:, :-1], r[1:, 1:]
     with np.errstate(invalid='ignore'):
         edges = np.max([np.abs(c01 - c00), np.abs(c11 - c10), np.abs(c10 - c00), np.abs(c11 - c01)], axis=0).max(axis=2)
         twist = np.abs(c00 + c11 - c01 - c10).max(axis=2)
         spread = np.max([np.abs(c01 - c00), np.abs(c10 - c00), np.abs(c11 - c00), np.abs(c11 - c01), np.abs(c11 - c10),
                          np.abs(c10 - c01)], axis=0).max(axis=2)
+    # ... nor runs along a grid line: along either axis the step from a corner to its neighbour may not differ from the step
+    # before by more than half the larger of the two (smooth fields change by a few per cent from cell to cell)
+    kink = np.zeros((n + 1, n + 1), dtype=bool)
+    with np.errstate(invalid='ignore'):
+        for ax in (0, 1):
+            rm = np.moveaxis(r, ax, 0)
+            d0, d1 = rm[1:-1] - rm[:-2], rm[2:] - rm[1:-1]
+            k = np.abs(d1 - d0).max(axis=-1) > 0.5 * np.maximum(np.abs(d1).max(axis=-1), np.abs(d0).max(axis=-1)) + 1e-12
+            gm = np.moveaxis(good, ax, 0)
+            k &= gm[1:-1] & gm[:-2] & gm[2:]                 # (corners that do not count close their cells anyway)
+            np.moveaxis(kink, ax, 0)[1:-1] |= k
+    good = good & ~kink
     cell_ok = good[:-1, :-1] & good[:-1, 1:] & good[1:, :-1] & good[1:, 1:] & (twist <= 0.5 * edges + 1e-12)
     k = np.max([steps[:-1, :-1], steps[:-1, 1:], steps[1:, :-1], steps[1:, 1:]], axis=0)
     k = np.where(cell_ok, k, np.inf)
     pad = np.pad(k, 1, mode='edge')
     need = np.max([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0) + GATE_MARGIN
     # the kernel interpolates the fixed points over the 4 x 4 corners around a cell (Catmull-Rom): the cells on the border of
-    # the grid, which lack a ring of neighbours, are closed
+    # the grid, which lack a ring of neighbours, are closed; so are the cells of photon-starved counts (GATE_U_MAX)
     need[0, :] = need[-1, :] = need[:, 0] = need[:, -1] = np.inf
-    radius = np.where(cell_ok, spread + 1e-9, 0.0)
+    x_hi = pieces['head'][4] + (np.arange(n) + 1.0) / pieces['head'][5]            # ln u0 at the upper edge of each cell row
+    need[x_hi > np.log(GATE_U_MAX), :] = np.inf
+    radius = np.where(cell_ok, GATE_RADIUS * spread + 1e-9, 0.0)
     r = np.where(good[:, :, None], r, 0.0)
-    out = np.concatenate([pieces['head'], r[:, :, 0].ravel(), r[:, :, 1].ravel(), need.ravel(), radius.ravel()])
+    out = np.concatenate([pieces['head'], r.ravel(), np.stack([need, radius], axis=-1).ravel()])          # pairs: (a0, a1), (need, radius)
     return out, float(np.isfinite(need).mean())
+
+
+def cell_centres(pieces):
+    """The counts at the centres of the grid's cells [n^2, 2] (row = index along ln u0): what validate_start is given the
+    reference's walk on."""
+    h = pieces['head']
+    n = int(h[3])
+    x = h[4] + (np.arange(n) + 0.5) / h[5]
+    t = h[6] + (np.arange(n) + 0.5) / h[7]
+    u0 = np.exp(x)[:, None] * np.ones((1, n))
+    u1 = u0 * t[None, :]
+    return np.stack([h[0] * np.exp(-u0.ravel() / h[2]), h[1] * np.exp(-u1.ravel() / h[2])], axis=1)
+
+
+def validate_start(start, pieces, steps, roots):
+    """The table checked against the thing it stands for, at one interior point per cell: the reference's walk run on the counts
+    at the cell CENTRES (``steps``, ``roots`` as in assemble_start, n^2 of them).  An open cell stays open only if that walk
+    ended by the rule within the cell's step budget (need - 1) at a fixed point that reproduces the centre's counts and lies
+    within the cell's acceptance radius of the Catmull-Rom interpolant the kernel would start from; a cell that fails is closed
+    together with the eight around it.  Returns the array and the share of open cells."""
+    h = pieces['head']
+    n = int(h[3])
+    out = np.array(start, dtype=np.float64, copy=True)
+    r = out[START_HEADER:START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)
+    cells = out[START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)
+    steps = np.asarray(steps, dtype=np.float64).reshape(n, n)
+    rc = np.asarray(roots, dtype=np.float64).reshape(n, n, 2)
+    w = np.array([-1.0, 9.0, 9.0, -1.0]) / 16.0                      # Catmull-Rom weights at t = 1/2
+    s = np.zeros((n, n, 2))
+    for p in range(4):
+        for q_ in range(4):
+            i0_, j0_ = p - 1, q_ - 1                                 # corner (i + p - 1, j + q - 1) of cell (i, j), interior cells
+            s[1:-1, 1:-1] += w[p] * w[q_] * r[1 + i0_:n - 1 + i0_, 1 + j0_:n - 1 + j0_]
+    g = cell_centres(pieces)
+    with np.errstate(all='ignore'):
+        rr = np.where(np.isfinite(rc), rc, 0.0).reshape(-1, 2)
+        nu = np.exp(np.clip(-(rr @ pieces['mus']), -700.0, 700.0)) @ pieces['i0'].T
+        resid = np.abs(nu / g - 1.0).max(axis=1).reshape(n, n)
+        off = np.abs(rc - s).max(axis=2)
+        fine = (steps < 255) & np.all(np.isfinite(rc), axis=2) & (resid <= 1.0e-8) & (off <= cells[:, :, 1]) & (steps <= cells[:, :, 0] - 1.0)
+    bad = np.isfinite(cells[:, :, 0]) & ~fine
+    pad = np.pad(bad, 1, mode='constant')
+    near = np.any([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
+    cells[near, 0] = np.inf
+    return out, float(np.isfinite(cells[:, :, 0]).mean()), int(bad.sum())

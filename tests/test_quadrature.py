@@ -118,22 +118,71 @@ def test_gate_grid_and_start_array():
     cg = p['corner_g'].reshape(n + 1, n + 1, 2)[i, j]
     u0 = np.exp(head[4] + i / head[5])
     assert np.allclose(np.log(head[:2] / cg) * head[2], [u0, u0 * (head[6] + j / head[7])], rtol=1e-12)
-    # a smooth synthetic field of fixed points, one slow corner, one corner that did not end, one corner in another basin
+    # a smooth synthetic field of fixed points (made consistent: the corners' counts are set to the model's at those points),
+    # one slow corner, one corner that did not end, one corner in another basin, one corner resting where it does not
+    # reproduce its counts (a valley of the clipped likelihood)
     ii, jj = np.meshgrid(np.arange(n + 1.0), np.arange(n + 1.0), indexing='ij')
-    roots = np.stack([0.3 * ii + 0.01 * ii * jj, 0.2 * jj - 0.05 * ii], -1).reshape(-1, 2)
+    roots = np.stack([0.15 * ii + 0.005 * ii * jj / 4, 0.1 * jj - 0.025 * ii], -1).reshape(-1, 2)
+    p = dict(p, corner_g=np.exp(-(roots @ p['mus'])) @ p['i0'].T)
     steps = np.full((n + 1) ** 2, 17)
     steps[5 * (n + 1) + 7] = 30
     steps[30 * (n + 1) + 30] = 255
+    roots = roots.copy()
     roots[45 * (n + 1) + 20] += [3.0, -2.0]
+    roots[70 * (n + 1) + 60] += [1e-4, 0.0]
     start, share = q.assemble_start(p, steps, roots)
     assert start.size == q.START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n
-    r0 = start[q.START_HEADER:q.START_HEADER + (n + 1) ** 2].reshape(n + 1, n + 1)
-    need = start[q.START_HEADER + 2 * (n + 1) ** 2:q.START_HEADER + 2 * (n + 1) ** 2 + n * n].reshape(n, n)
-    radius = start[-n * n:].reshape(n, n)
-    assert np.array_equal(r0.ravel()[steps < 255], roots[steps < 255, 0]) and r0[30, 30] == 0.0      # (a corner that did not end: zeroed)
+    r0 = start[q.START_HEADER:q.START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)[:, :, 0]          # pairs (a0, a1)
+    cells = start[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)                                        # pairs (need, radius)
+    need, radius = cells[:, :, 0], cells[:, :, 1]
+    ok = np.ones((n + 1) ** 2, bool)
+    ok[[30 * (n + 1) + 30, 45 * (n + 1) + 20, 70 * (n + 1) + 60]] = False
+    assert np.array_equal(r0.ravel()[ok], roots[ok, 0]) and r0[30, 30] == 0.0 and r0[70, 60] == 0.0         # (corners that do not count: zeroed)
     assert need[1, 1] == 17 + q.GATE_MARGIN and np.isinf(need[0, 5]) and np.isinf(need[7, n - 1]) and np.all(need[3:7, 5:9] == 30 + q.GATE_MARGIN) and need[2, 5] == need[7, 5] == 17 + q.GATE_MARGIN
-    assert np.all(np.isinf(need[28:32, 28:32])) and np.isfinite(need[27, 27]) and np.isfinite(need[32, 30])
-    assert np.all(np.isinf(need[43:47, 18:22])) and np.isfinite(need[42, 20]) and np.isfinite(need[47, 19])
+    for ci, cj in ((30, 30), (45, 20), (70, 60)):
+        assert np.all(np.isinf(need[ci - 2:ci + 2, cj - 2:cj + 2])) and np.isfinite(need[ci - 3, cj - 3]) and np.isfinite(need[ci + 2, cj])
     assert 0.93 < share < 1.0
-    # the acceptance radius: the spread of the corners' fixed points (here the x-step 0.3 + 0.01 j plus the cross term)
-    assert abs(radius[10, 10] - (0.3 + 0.01 * 11 + 0.01 * 10 + 1e-9)) < 1e-12 and radius[29, 29] == 0.0
+    # the acceptance radius: a twentieth of the spread of the corners' fixed points
+    c = roots.reshape(n + 1, n + 1, 2)
+    want = max(np.abs(c[11, 11] - c[10, 10]).max(), np.abs(c[11, 10] - c[10, 11]).max(), np.abs(c[11, 10] - c[10, 10]).max(),
+               np.abs(c[10, 11] - c[10, 10]).max(), np.abs(c[11, 11] - c[10, 11]).max(), np.abs(c[11, 11] - c[11, 10]).max())
+    assert abs(radius[10, 10] - (q.GATE_RADIUS * want + 1e-9)) < 1e-12 and radius[29, 29] == 0.0
+
+
+def test_gate_table_is_validated_at_the_cell_centres():
+    """quadrature.validate_start: the reference's walk at the centre of every cell must end, within the cell's step budget,
+    next to the Catmull-Rom interpolant the kernel would start from; a cell where it does not is closed with its neighbours."""
+    _, i0, mus = newton_tables()
+    p = q.newton_start_grid(i0, mus)
+    n = int(p['head'][3])
+    h = p['head']
+    field = lambda x, t: np.stack([40.0 * np.exp(x) * (1.0 + 0.1 * t), 3.0 * np.exp(x) * (t - 1.2)], -1)      # smooth in (ln u0, ratio)
+    xc, tc = h[4] + np.arange(n + 1) / h[5], h[6] + np.arange(n + 1) / h[7]
+    roots = field(xc[:, None], tc[None, :]).reshape(-1, 2)
+    p = dict(p, corner_g=np.exp(-(roots @ p['mus'])) @ p['i0'].T)
+    start, share = q.assemble_start(p, np.full((n + 1) ** 2, 17), roots)
+    assert share > 0.85                                                    # (rows beyond GATE_U_MAX and the border are closed)
+    xm, tm = h[4] + (np.arange(n) + 0.5) / h[5], h[6] + (np.arange(n) + 0.5) / h[7]
+    centre_roots = field(xm[:, None], tm[None, :]).reshape(-1, 2)
+    # the centres' counts must be the model's at those roots for the residual test: override what cell_centres would give
+    g_c = np.exp(-(centre_roots @ p['mus'])) @ p['i0'].T
+    orig = q.cell_centres
+    try:
+        q.cell_centres = lambda pieces: g_c
+        ok, share_ok, n_bad = q.validate_start(start, p, np.full(n * n, 17), centre_roots)
+        assert n_bad == 0 and share_ok == share                           # the interpolant is within the radius of a smooth field
+        moved = centre_roots.copy().reshape(n, n, 2)
+        moved[40, 50] += [0.5, 0.0]                                        # the walk from this centre ends somewhere else
+        late = np.full((n, n), 17)
+        late[60, 70] = 19                                                  # ... and this one needs more steps than the cell allows
+        out, share_bad, n_bad = q.validate_start(start, p, late.ravel(), moved.reshape(-1, 2))
+    finally:
+        q.cell_centres = orig
+    need = out[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)[:, :, 0]
+    assert n_bad == 2 and share_bad < share
+    for ci, cj in ((40, 50), (60, 70)):
+        assert np.all(np.isinf(need[ci - 1:ci + 2, cj - 1:cj + 2])) and np.isfinite(need[ci - 2, cj]) and np.isfinite(need[ci, cj + 2])
+    # cell_centres itself: the counts at (x_i + 1/2, t_j + 1/2)
+    g = q.cell_centres(p).reshape(n, n, 2)
+    u = np.log(h[:2] / g[7, 9]) * h[2]
+    assert np.allclose([np.log(u[0]), u[1] / u[0]], [xm[7], tm[9]], rtol=1e-12)

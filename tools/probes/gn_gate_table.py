@@ -34,9 +34,18 @@ for name, i0, mus in cases:
                                          ptr(a_c), _native.gn_options(1e-12, 0, 0, 1, _native.GN_PASS_COARSE, k_c.data_ptr()), ptr(ws),
                                          stream_ptr()), 'cal')
     k = k_c.cpu().numpy().reshape(n + 1, n + 1)
-    start, share = q.assemble_start(p, k_c.cpu().numpy(), a_c.cpu().numpy())
-    need = start[q.START_HEADER + 2 * (n + 1) ** 2:q.START_HEADER + 2 * (n + 1) ** 2 + n * n].reshape(n, n)
-    radius = start[-n * n:].reshape(n, n)
+    start, share0 = q.assemble_start(p, k_c.cpu().numpy(), a_c.cpu().numpy())
+    # the same walk on the cell centres: the table checked against what it stands for
+    gc = to_dev(np.ascontiguousarray(q.cell_centres(p).T), torch.float64, dev)
+    a2 = torch.empty((gc.shape[1], 2), dtype=torch.float64, device=dev)
+    k2 = torch.empty(gc.shape[1], dtype=torch.uint8, device=dev)
+    _native.check(lib.dexct_gn_decompose(ptr(gc[0]), ptr(gc[1]), 1, gc.shape[1], ptr(i0_d), ptr(mus_d), i0.shape[1], 1, 1, 254, 0, 0, None, 0.95,
+                                         ptr(a2), _native.gn_options(1e-12, 0, 0, 1, _native.GN_PASS_COARSE, k2.data_ptr()), ptr(ws),
+                                         stream_ptr()), 'cal')
+    start, share, n_bad = q.validate_start(start, p, k2.cpu().numpy(), a2.cpu().numpy())
+    print(f'   open cells before / after the check at the centres: {share0:.3f} / {share:.3f} ({n_bad} centres failed)')
+    cells = start[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)
+    need, radius = cells[:, :, 0], cells[:, :, 1]
     print(f'== {name}: ratio u1/u0 from {p["head"][6]:.3f} in cells of {1 / p["head"][7]:.4f}; open cells {share:.3f}')
     print('steps at every 4th corner (rows: ln u0 from 1e-4 to 1, columns: ratio):')
     print(k[::4, ::4])

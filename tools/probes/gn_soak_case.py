@@ -57,3 +57,19 @@ for mode in ('start', 'coarse'):
     print(mode, st, 'pixels beyond 1e-10 of the exact count:', len(bad))
     for b in bad[:6]:
         print('   pixel', b, 'g', gg[:, b], 'true', a_true.reshape(-1, 2)[b], '| exact', exact[b], '| after 250', long[b], '| single', single[b], '| two-level', a[b])
+
+# the gate for the pixels listed last: cell, need, radius, interpolated start value (host emulation of csrc/gn.hip gn_start)
+from dex_ct_sim_amd import quadrature as q
+ent = [v for v in md._table_cache.values()][0]
+tabs = [v for k, v in ent.items() if isinstance(k, tuple) and k[0] == 'coarse'][0]
+st = tabs[2].cpu().numpy()
+n = int(st[3])
+roots = st[q.START_HEADER:q.START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)
+cells = st[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)
+print('open cells', np.isfinite(cells[:, :, 0]).mean())
+for b in bad[:6]:
+    u0, u1 = np.log(st[0] / gg[0, b]) * st[2], np.log(st[1] / gg[1, b]) * st[2]
+    fx, fy = (np.log(u0) - st[4]) * st[5], (u1 / u0 - st[6]) * st[7]
+    i, j = int(fx), int(fy)
+    inside = 0 <= fx < n and 0 <= fy < n
+    print('   pixel', b, 'u', u0, u1, 'cell', (fx, fy), 'need/radius', cells[i, j] if inside else None, 'corner fixed points', roots[i:i + 2, j:j + 2].reshape(-1, 2).tolist() if inside else None)
