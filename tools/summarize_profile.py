@@ -18,14 +18,20 @@ import sys
 tag = sys.argv[1]
 src = os.path.join('gpurun_out', f'prof_{tag}')
 os.makedirs('profiles', exist_ok=True)
-stats = glob.glob(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
+def newest(pattern):
+    """the most recent match (gpurun merges a call's files into gpurun_out/ beside those of earlier calls with the same tag)"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
+stats = newest(os.path.join(src, 'stats', '*', '*_kernel_stats.csv'))[0]
 shutil.copy(stats, os.path.join('profiles', f'{tag}_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats)))
 
 
 def pmc(which):
     out = {}
-    files = glob.glob(os.path.join(src, f'pmc_{which}', '*', '*_counter_collection.csv'))
+    files = newest(os.path.join(src, f'pmc_{which}', '*', '*_counter_collection.csv'))
     if not files:
         return out
     for r in csv.DictReader(open(files[0])):
@@ -41,7 +47,7 @@ fetch, write = pmc('fetch'), pmc('write')
 def pmc_raw(which):
     """{kernel: {counter: mean value per dispatch}} of a multi-counter pass (no unit scaling)."""
     out = {}
-    files = glob.glob(os.path.join(src, f'pmc_{which}', '*', '*_counter_collection.csv'))
+    files = newest(os.path.join(src, f'pmc_{which}', '*', '*_counter_collection.csv'))
     if not files:
         return out
     for r in csv.DictReader(open(files[0])):
@@ -67,9 +73,13 @@ if tl:
             if pat in r['Kernel_Name']:
                 big.setdefault(pat, []).append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e6)
     for pat, v in big.items():
+        if pat.endswith('1>') and tl.get('mode') != 'coarse':
+            lines.append(f'`{pat}` (the step-counting instantiation): {len(v)} dispatches averaging {sum(v) / len(v):.2f} ms - the reference\'s walk on '
+                         f'the gate\'s 16 641 cell corners and 16 384 cell centres, once per pair of spectra')
+            continue
         step = [x for x in v if x > 0.25 * max(v)]
         lines.append(f'`{pat}`: {len(v)} dispatches, of which {len(step)} are step launches averaging {sum(step) / len(step):.2f} ms'
-                     + (' (the others: the gate calibration on the 16 641 cell corners, once per pair of spectra)' if len(step) < len(v) else ''))
+                     + (' (the others: the gate calibration, once per pair of spectra)' if len(step) < len(v) else ''))
     lines += [f'Newton launch in bench.py (HIP events around it, last timed step; mode {tl["mode"]}): {tl["launch_ms"]:.2f} ms'
               + (f', coarse launch {tl["coarse_launch_ms"]:.2f} ms' if tl.get('coarse_launch_ms') else ''), '']
 cal = [k for k in fetch if 'transpose_xy' in k]
