@@ -841,7 +841,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
                                                              int g_is_f64, long long n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, GnTiling tl,
                                                              const double* __restrict__ mask_max, double mask_frac,
-                                                             int flags, double stop_tol,      // flags: bit 0 exact repeated-state exit, bit 1 sorted hand-out, bits 8..: tiles per queue reservation
+                                                             int flags, double stop_tol,      // flags: bit 0 exact repeated-state exit, bit 1 sorted hand-out, bits 8..19: tiles per queue reservation, 20..26: lanes waiting before a hand-out
                                                              double* __restrict__ out_a,
                                                              unsigned long long* __restrict__ counters,
                                                              unsigned char* __restrict__ iters,
@@ -878,7 +878,8 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   GnTile ct{0, 0, 0, 0};                  // the tile being handed out
   bool exhausted = false;
   unsigned n_exec = 0, n_stall = 0;       // Newton steps executed; lane-steps spent waiting for a free slot (diagnostic)
-  const int batch = (flags >> 8) > 0 ? (flags >> 8) : 1;      // queue positions reserved per atomic (flags bits 8..)
+  const int batch = ((flags >> 8) & 0xFFF) > 0 ? ((flags >> 8) & 0xFFF) : 1;      // queue positions reserved per atomic (flags bits 8..19)
+  const int refill_min = (flags >> 20) & 0x7F;                // lanes that must be waiting before pixels are handed out (bits 20..26)
   int q_next = 0, q_end = 0;              // the reserved positions not yet handed out (n_tiles < 2^31)
   unsigned handed = 0u;                   // pixels of the tiles handed out since the last reservation (progress word)
 
@@ -925,6 +926,11 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
 
   for (;;) {
     unsigned long long want = __ballot(ent < 0);
+    // The hand-out below runs for the whole wave whenever one lane wants a pixel.  With ~17 steps per pixel that is cheap
+    // next to a step; on the short cut a pixel takes two steps and its hand-out includes gn_start (three float64 logarithms,
+    // 16 table loads, the interpolation: a third of a step), and the one pixel in 60 that needs a third step would pull its
+    // whole wave through it once more per step.  So a few waiting lanes wait until `refill_min` of them do (or nobody iterates).
+    if (PASS != 0 && (int)__popcll(want) < refill_min && __ballot(ent >= 0) != 0ull) want = 0ull;
     while (want != 0ull) {
       if (next_j >= kTilePix) {
         if (exhausted) break;
@@ -1362,7 +1368,11 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const char* tfe = getenv("DEXCT_GN_TILES_PER_FETCH");
     int tiles_per_fetch = (pass != 0 && tl.n_tiles >= (int64_t)128 * cap) ? 8 : 1;
     if (tfe && atoi(tfe) >= 1 && atoi(tfe) <= 1024) tiles_per_fetch = atoi(tfe);
-    const int qflags = tiles_per_fetch << 8;
+    // lanes that must be waiting before the hand-out runs (short-cut passes only; see the loop head of gn_refill_kernel)
+    const char* rme = getenv("DEXCT_GN_REFILL_MIN");
+    int refill_min = pass != 0 ? 32 : 0;
+    if (rme && atoi(rme) >= 0 && atoi(rme) <= 64) refill_min = atoi(rme);
+    const int qflags = (tiles_per_fetch << 8) | (refill_min << 20);
     if (pass == 1)
       hipLaunchKernelGGL((gn_refill_kernel<4, 1>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
                          (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);

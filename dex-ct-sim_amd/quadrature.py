@@ -263,11 +263,12 @@ GATE_U_MAX = 0.75          # largest u0 with open cells: attenuation exp(-12), s
                            # fragile - photon-starved counts inside a cell whose corners all arrive have been seen to end at another
                            # root or to diverge (tools/soak_gn.py seeds 245, 283: 10 and 23 counts of 7e6) - and is left to the reference
 GATE_MARGIN = 2            # steps added to the largest count seen around a cell
-GATE_RADIUS = 0.05         # acceptance radius of a result around the interpolated fixed point, in units of the spread of the cell's
+GATE_RADIUS = 0.01         # acceptance radius of a result around the interpolated fixed point, in units of the spread of the cell's
                            # corner fixed points.  The interpolant is within ~1e-6 of |a| of the pixel's own fixed point on the
-                           # reference's branch (the spread is ~0.1 |a|), so this leaves a margin of a few thousand - and a second
-                           # root of the two equations, where tables far from anything physical admit one, has been seen as close
-                           # as 0.9 spreads (tools/soak_gn.py seed 270: the coarse launch found it)
+                           # reference's branch (the spread is ~0.1 |a|), so this leaves a margin of a thousand.  What it keeps out, on
+                           # tables far from anything physical (tools/soak_gn.py): a second root of the two equations 0.9 spreads away
+                           # (seed 270), and a critical point of the likelihood that is no root at all - singular Jacobian, counts
+                           # reproduced to 2e-3 only - 0.04 spreads away (seed 969); both reached by the coarse launch only
 
 
 def newton_start_grid(i0, mus, log_range=16.0):
@@ -322,12 +323,34 @@ def newton_start_grid(i0, mus, log_range=16.0):
     return dict(head=head, corner_g=g, i0=i0, mus=mus)
 
 
+GATE_MAX_COND = 1.0e4      # largest condition number of the forward model's log-Jacobian d ln nu_k / d a_m at a tabulated fixed point (physical tables: 15 - 140)
+
+
+def _counts_and_condition(pieces, a, g):
+    """For fixed points a [n, 2] and the counts g [n, 2] they belong to: how well the forward model (with the reference's clip of
+    the exponent, matdecomp.py:116) reproduces the counts, and the condition number of its log-Jacobian there - an ISOLATED root
+    of the two equations has a small one; where tables far from anything physical (attenuation x 30 at the low energies: clipped
+    exponents) make the equations dependent, roots come in families and a start value next to one rests next to it, not on it."""
+    with np.errstate(all='ignore'):
+        a = np.where(np.isfinite(a), a, 0.0)
+        expo = -(a @ pieces['mus'])
+        att = np.exp(np.clip(expo, -700.0, 700.0))
+        nu = att @ pieces['i0'].T                                                    # [n, 2]
+        live = att * (np.abs(expo) < 700.0)                                          # the clipped exponent has no slope
+        jac = -np.einsum('ke,me,ne->nkm', pieces['i0'], pieces['mus'], live) / nu[:, :, None]
+        resid = np.abs(nu / g - 1.0).max(axis=1)
+        fro2 = (jac ** 2).sum(axis=(1, 2))
+        det = np.abs(jac[:, 0, 0] * jac[:, 1, 1] - jac[:, 0, 1] * jac[:, 1, 0])
+        cond = (fro2 + np.sqrt(np.maximum(fro2 * fro2 - 4.0 * det * det, 0.0))) / (2.0 * det)       # sigma_max / sigma_min of a 2 x 2
+    return resid, np.where(np.isfinite(cond), cond, np.inf)
+
+
 def assemble_start(pieces, steps, roots):
     """The start array (csrc/gn.hip, gn_start) from the reference iteration run on the cell corners (by the library's own
     kernel: matdecomp._device_tables): ``steps`` [(n+1)^2] = steps after which the tolerance rule ended the corner's pixel
     (255: it did not), ``roots`` [(n+1)^2, 2] = where.  A corner counts only if its fixed point REPRODUCES its counts (the
-    forward model with the reference's clip of the exponent, matdecomp.py:116, within 1e-8): an isolated root of the two
-    equations.  Where the clip is active (attenuation tables far above anything physical) or the gradient vanishes for another
+    forward model with the reference's clip of the exponent, matdecomp.py:116, within 1e-8) and the model's log-Jacobian is
+    well conditioned there (GATE_MAX_COND): an isolated root of the two equations.  Where the clip is active (attenuation tables far above anything physical) or the gradient vanishes for another
     reason the iteration also comes to rest - on a valley of the clipped likelihood, at points that are not isolated: another
     start value rests elsewhere on it, so there is nothing to tabulate.  A cell is open when all four corners count, at finite
     fixed points that vary smoothly over it and along the grid lines through its corners (mixed and axial second differences at
@@ -338,11 +361,8 @@ def assemble_start(pieces, steps, roots):
     steps = np.asarray(steps).reshape(n + 1, n + 1).astype(np.float64)
     r = np.asarray(roots, dtype=np.float64).reshape(n + 1, n + 1, 2)
     good = (steps < 255) & np.all(np.isfinite(r), axis=2) & np.all(np.isfinite(pieces['corner_g']), axis=1).reshape(n + 1, n + 1)
-    with np.errstate(all='ignore'):
-        rr = np.where(np.isfinite(r), r, 0.0).reshape(-1, 2)
-        nu = np.exp(np.clip(-(rr @ pieces['mus']), -700.0, 700.0)) @ pieces['i0'].T
-        resid = np.abs(nu / pieces['corner_g'] - 1.0).max(axis=1).reshape(n + 1, n + 1)
-    good &= resid <= 1.0e-8
+    resid, cond = _counts_and_condition(pieces, r.reshape(-1, 2), pieces['corner_g'])
+    good &= (resid.reshape(n + 1, n + 1) <= 1.0e-8) & (cond.reshape(n + 1, n + 1) <= GATE_MAX_COND)
     c00, c01, c10, c11 = r[:-1, :-1], r[:-1, 1:], r[1:, :-1], r[1:, 1:]
     with np.errstate(invalid='ignore'):
         edges = np.max([np.abs(c01 - c00), np.abs(c11 - c10), np.abs(c10 - c00), np.abs(c11 - c01)], axis=0).max(axis=2)
@@ -409,12 +429,11 @@ def validate_start(start, pieces, steps, roots):
             i0_, j0_ = p - 1, q_ - 1                                 # corner (i + p - 1, j + q - 1) of cell (i, j), interior cells
             s[1:-1, 1:-1] += w[p] * w[q_] * r[1 + i0_:n - 1 + i0_, 1 + j0_:n - 1 + j0_]
     g = cell_centres(pieces)
+    resid, cond = _counts_and_condition(pieces, rc.reshape(-1, 2), g)
     with np.errstate(all='ignore'):
-        rr = np.where(np.isfinite(rc), rc, 0.0).reshape(-1, 2)
-        nu = np.exp(np.clip(-(rr @ pieces['mus']), -700.0, 700.0)) @ pieces['i0'].T
-        resid = np.abs(nu / g - 1.0).max(axis=1).reshape(n, n)
         off = np.abs(rc - s).max(axis=2)
-        fine = (steps < 255) & np.all(np.isfinite(rc), axis=2) & (resid <= 1.0e-8) & (off <= cells[:, :, 1]) & (steps <= cells[:, :, 0] - 1.0)
+        fine = ((steps < 255) & np.all(np.isfinite(rc), axis=2) & (resid.reshape(n, n) <= 1.0e-8) & (cond.reshape(n, n) <= GATE_MAX_COND)
+                & (off <= cells[:, :, 1]) & (steps <= cells[:, :, 0] - 1.0))
     bad = np.isfinite(cells[:, :, 0]) & ~fine
     pad = np.pad(bad, 1, mode='constant')
     near = np.any([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)

@@ -845,3 +845,35 @@ def test_two_level_passes_through_the_c_abi(hip, golden):
     assert call(i0_d, mus_d, 255, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL  # counts are bytes
     assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 2, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL   # lane kernel only
     assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, 3, it.data_ptr())) == EINVAL
+
+
+@pytest.mark.parametrize('dose', [1e3, 1e5, 1e7])
+def test_short_cut_on_poisson_counts_of_physical_spectra(hip, dose):
+    """The default mode on photon counts (Poisson, open-beam signals of 1e3 .. 1e7: from a scan where most thick rays are
+    photon-starved to a clinical one) of the benchmark's spectra, 1e6 pixels through up to 45 g/cm2: within 1e-12 of the
+    exact count wherever that one is finite, identical where it is not - and it is the short cut that produced most of them."""
+    import os
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import matdecomp as md, synthetic
+    from dex_ct_sim_amd._device import to_dev, to_host
+    from conftest import INPUT
+    ct = dx.FanBeamGeometry(N_channels=8, N_proj=8, eid=True, detector_file=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'))
+    _, i0, mus = md.decomposition_tables(ct, synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80))
+    i0 = i0 * (dose / i0.sum(axis=1, keepdims=True))
+    rng = np.random.default_rng(int(dose))
+    n = 1 << 20
+    a_true = np.stack([rng.uniform(0, 45, n) * rng.choice([0.02, 0.3, 1.0], n), rng.uniform(0, 6, n) * rng.choice([0.0, 0.1, 1.0], n)], -1)
+    a_true[: n // 3, 1] = -0.008 * a_true[: n // 3, 0]                    # water in a tissue / bone basis
+    lam = np.exp(-(a_true @ mus)) @ i0.T
+    cnt = np.maximum(rng.poisson(lam), 0).astype(np.float64).T.reshape(2, 1024, n // 1024)        # zeros included: ln(air / 0) = inf
+    g = to_dev(cnt, torch.float64, torch.device('cuda'))
+    exact = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', stop_tol=0.0, kernel=1, two_level=False))
+    n_exact = md.last_gn_stats()['pixel_iterations']
+    a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1))
+    st = md.last_gn_stats()
+    assert st['mode'] == 'start'
+    ok = np.isfinite(exact).all(-1) & (np.abs(exact).max(-1) < 1e6)
+    assert ok.mean() > (0.5 if dose < 1e4 else 0.95)
+    assert err(a[ok], exact[ok]) < 1e-12
+    assert np.array_equal(np.isfinite(a).all(-1), np.isfinite(exact).all(-1))
+    assert st['pixel_iterations'] < (0.8 if dose < 1e4 else 0.4) * n_exact

@@ -186,3 +186,24 @@ def test_gate_table_is_validated_at_the_cell_centres():
     g = q.cell_centres(p).reshape(n, n, 2)
     u = np.log(h[:2] / g[7, 9]) * h[2]
     assert np.allclose([np.log(u[0]), u[1] / u[0]], [xm[7], tm[9]], rtol=1e-12)
+
+
+def test_isolated_roots_are_told_from_families_of_them():
+    """quadrature._counts_and_condition: the log-Jacobian of the forward model is well conditioned at physical thicknesses (an
+    isolated root of the two equations) and singular when the two basis materials attenuate proportionally (every point of a
+    line reproduces the counts) or when the exponent is clipped at every energy (no slope left)."""
+    _, i0, mus = newton_tables()
+    p = q.newton_start_grid(i0, mus)
+    a = np.array([[0.01, 0.0], [1.0, 0.1], [20.0, 2.0], [40.0, 0.0], [5.0, 8.0], [30.0, -0.24]])
+    g = np.exp(-(a @ p['mus'])) @ p['i0'].T
+    resid, cond = q._counts_and_condition(p, a, g)
+    assert resid.max() < 1e-14 and cond.max() < 200.0 < q.GATE_MAX_COND
+    resid, _ = q._counts_and_condition(p, a + [0.0, 1e-3], g)
+    assert resid.min() > 1e-5                                              # a point next to the root does not reproduce the counts
+    same = dict(p, mus=np.stack([p['mus'][0], 2.0 * p['mus'][0]]))
+    g2 = np.exp(-(a @ same['mus'])) @ same['i0'].T
+    assert q._counts_and_condition(same, a, g2)[1].min() > 1e12            # a1 and 2 a0 are interchangeable: roots come in lines
+    clipped = dict(p, mus=1e4 * p['mus'])
+    far = np.array([[40.0, 5.0]])
+    with np.errstate(all='ignore'):
+        assert not np.isfinite(q._counts_and_condition(clipped, far, np.ones((1, 2)))[1][0]) or q._counts_and_condition(clipped, far, np.ones((1, 2)))[1][0] > 1e12

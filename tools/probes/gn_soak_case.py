@@ -73,3 +73,10 @@ for b in bad[:6]:
     i, j = int(fx), int(fy)
     inside = 0 <= fx < n and 0 <= fy < n
     print('   pixel', b, 'u', u0, u1, 'cell', (fx, fy), 'need/radius', cells[i, j] if inside else None, 'corner fixed points', roots[i:i + 2, j:j + 2].reshape(-1, 2).tolist() if inside else None)
+
+# are both answers roots of the two equations?  residual of the counts and condition of the log-Jacobian at each
+pc = q.newton_start_grid(i0, mus)
+for b in bad[:4]:
+    for name, pt in (('exact', exact[b]), ('two-level', a[b]), ('true', a_true.reshape(-1, 2)[b])):
+        res, cond = q._counts_and_condition(pc, np.asarray(pt)[None, :], gg[:, b][None, :])
+        print('   pixel', b, name, pt, 'residual of the counts', res[0], 'cond', cond[0])
