@@ -1293,7 +1293,8 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   if (pass != 0 && (n_bins > 1 || precision != 0 || n_iters > 254 || options->kernel == 2)) return DEXCT_EINVAL;
   const double* start = (pass != 0) ? options->start : nullptr;
   if (pass == 1 && !options->iterations) return DEXCT_EINVAL;
-  if (pass == 2 && !options->iterations && !start) return DEXCT_EINVAL;      // start from the coarse result or from the polynomial
+  if (pass == 2 && !options->iterations && !start) return DEXCT_EINVAL;      // start from the coarse result or from the table
+  if (start && (reinterpret_cast<uintptr_t>(start) & 15u)) return DEXCT_EINVAL;   // its pairs are read with 16-byte loads
   hipStream_t st = as_stream(stream);
   double* ws = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(gn_tables_kernel, dim3(n_bins), dim3(256), 0, st, i0, mus, n_energies, n_bins, ws);

@@ -1,4 +1,13 @@
-"""A shorter energy quadrature for the detection sum, with a verified error bound (opt-in: ``quadrature='reduced'``).
+"""Host-side table preparation for two things the kernels run on (NumPy / SciPy, like the reference's own spectrum handling;
+no ray and no pixel is computed here):
+
+1. ``reduce_tables`` - a shorter energy quadrature for the DETECTION sum, with a verified error bound (opt-in:
+   ``quadrature='reduced'``), described below;
+2. the tables of the Newton decomposition's short cut (matdecomp.gn_device; csrc/gn.hip gn_start; include/dexct.h,
+   dexct_gn_options.pass / .start): ``newton_start_grid`` lays a cell grid over the plane of the two counts,
+   ``assemble_start`` / ``validate_start`` turn what the library's own kernel returns on its corners and centres - where the
+   reference's walk from 1e-6 ends, after how many steps - into the table of start values, step budgets and acceptance radii
+   (profiles/r04_gn_two_level.md); ``coarse_newton_tables`` builds the short spectra of the optional 'coarse' mode.
 
 The detected signal of a ray is ``sum_e w[s][e] exp(-sum_m mu[m][e] L_m)`` over the spectrum's energy grid (the weighting the
 reference's decomposition assumes, matdecomp.py:146-150; 134 weighted bins for the 140 kVp spectrum).  As functions of the

@@ -703,8 +703,8 @@ def _noisy_counts(golden, n=60000, seed=77, noise=0.002, water=True):
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
 def test_two_level_solve_modes_against_the_exact_count(hip, golden, dtype):
-    """The two-level solve (polynomial start values; 'coarse': ~2 steps on a short quadrature of the spectra, then the full
-    tables; 'start': the full tables only) returns what the single launch returns: within 1e-12 of the exact count on every
+    """The short cut of the Newton solve (start values interpolated from the tabulated fixed points of the reference's walk;
+    'start': two steps on the full tables; 'coarse': ~2 steps on a short quadrature of the spectra in between) returns what the single launch returns: within 1e-12 of the exact count on every
     pixel, bit-identical where the exact run has not converged - and spends a fraction of the full-table steps."""
     from dex_ct_sim_amd import matdecomp as md
     from dex_ct_sim_amd._device import to_dev, to_host
@@ -741,7 +741,7 @@ def test_two_level_solve_modes_against_the_exact_count(hip, golden, dtype):
     st = md.last_gn_stats()
     assert 1.9 * n < st['pixel_iterations'] < 2.6 * n < 0.25 * one and 1.9 * n < st['coarse_pixel_iterations'] < 6.0 * n
     md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level='start')
-    assert md.last_gn_stats()['pixel_iterations'] < 8.0 * n      # (real spectra with weight at a few keV: the polynomial is coarser)
+    assert md.last_gn_stats()['pixel_iterations'] < 8.0 * n      # (the reference's bundled spectra, weight down to 1 keV: more cells are closed)
     # the default is 'start' (one launch), the environment overrides
     md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
     assert md.last_gn_stats()['mode'] == 'start'
@@ -845,6 +845,13 @@ def test_two_level_passes_through_the_c_abi(hip, golden):
     assert call(i0_d, mus_d, 255, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL  # counts are bytes
     assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 2, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL   # lane kernel only
     assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, 3, it.data_ptr())) == EINVAL
+    # the table of fixed points must be 16-byte aligned (pairs are read with one load)
+    tabs = md._device_tables(i0, mus, dev, True)[2]
+    shifted = torch.empty(tabs[2].numel() + 1, dtype=torch.float64, device=dev)
+    shifted[1:].copy_(tabs[2])
+    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, None, shifted[1:].data_ptr())) == EINVAL
+    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, None, tabs[2].data_ptr())) == 0
+    assert err(a.cpu().numpy(), exact) < 1e-12
 
 
 @pytest.mark.parametrize('dose', [1e3, 1e5, 1e7])

@@ -129,7 +129,7 @@ for case in range(n_cases):
         if not torch.equal(coop.view(torch.int64), coop_full.view(torch.int64)):
             bad.append('cooperative kernel: exact exit differs from its full loop')
         default = run(g_d, i0, mus, n_iters, {}, stop_tol=None)
-        # the two-level solve (round 4): polynomial start values (+ a coarse launch on a short quadrature), gated by the
+        # the short cut (round 4): start values from the tabulated fixed points (+ a coarse launch on a short quadrature), gated by the
         # reference iteration's own step counts - same contract as the tolerance stop
         modes = {}
         for mode in ('start', 'coarse'):
