@@ -1363,11 +1363,14 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     }
     unsigned char* iters = options ? options->iterations : nullptr;
     // tiles a wave reserves per atomic on the queue head: 1 for the single launch (measured in round 3: larger fetches gain
-    // nothing at ~17 steps per pixel and lengthen the tail), 8 for the two short passes of the two-level solve on sinograms
-    // large enough that eight tiles per wave are no tail (250 views of the benchmark, 1 / 2 / 4 / 8 / 16 tiles: coarse 38.6 /
-    // 19.4 / 9.9 / 7.5 / 7.6 ms, refine 38.7 / 20.4 / 17.7 / 17.6 / 17.8 ms); DEXCT_GN_TILES_PER_FETCH overrides
+    // nothing at ~17 steps per pixel and lengthen the tail).  On the short-cut passes (two steps per pixel) the one word all
+    // waves of the chip queue for is the limit (12 ns per atomic): 2 / 4 / 8 tiles per reservation once a wave gets 3 / 8 / 128
+    // tiles on average (tools/probes/gn_tpf_small.py, 1 / 2 / 4 / 8 tiles: 1200 x 800: 0.69 / 0.57 / 0.60 / 0.74 ms; 2.6e6 pixels:
+    // 1.29 / 0.85 / 0.82 / 0.84; 1.2e7: 4.75 / 2.62 / 2.49 / 2.55; 250 views of the benchmark: 38.7 / 20.4 / 17.7 / 17.6);
+    // DEXCT_GN_TILES_PER_FETCH overrides
     const char* tfe = getenv("DEXCT_GN_TILES_PER_FETCH");
-    int tiles_per_fetch = (pass != 0 && tl.n_tiles >= (int64_t)128 * cap) ? 8 : 1;
+    const int64_t tiles_per_wave = tl.n_tiles / (nb * (kGnBlock / kWave));
+    int tiles_per_fetch = pass == 0 ? 1 : (tiles_per_wave >= 128 ? 8 : tiles_per_wave >= 8 ? 4 : tiles_per_wave >= 3 ? 2 : 1);
     if (tfe && atoi(tfe) >= 1 && atoi(tfe) <= 1024) tiles_per_fetch = atoi(tfe);
     // lanes that must be waiting before the hand-out runs (short-cut passes only; see the loop head of gn_refill_kernel)
     const char* rme = getenv("DEXCT_GN_REFILL_MIN");
