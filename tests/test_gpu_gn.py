@@ -884,3 +884,50 @@ def test_short_cut_on_poisson_counts_of_physical_spectra(hip, dose):
     assert err(a[ok], exact[ok]) < 1e-12
     assert np.array_equal(np.isfinite(a).all(-1), np.isfinite(exact).all(-1))
     assert st['pixel_iterations'] < (0.8 if dose < 1e4 else 0.4) * n_exact
+
+
+def test_short_cut_tables_are_cached_by_content_and_accept_device_tensors(hip, golden):
+    """matdecomp._device_tables: the gate's table is built once per pair of spectra (keyed by the tables' CONTENT, so a new
+    array with the same numbers reuses it and changed numbers do not), and tables handed over as device tensors give the
+    same bits (they are read back to prepare the short cut)."""
+    from dex_ct_sim_amd import matdecomp as md
+    from dex_ct_sim_amd._device import to_dev, to_host
+    cnt, i0, mus = _noisy_counts(golden, n=20000, noise=0.0)
+    dev = torch.device('cuda')
+    g = to_dev(cnt, torch.float64, dev)
+    md._table_cache.clear()
+    a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1))
+    assert md.last_gn_stats()['mode'] == 'start' and len(md._table_cache) == 1
+    start0 = next(iter(md._table_cache.values()))[('coarse', 1e-12)][2]
+    b = to_host(md.gn_device(g[0], g[1], i0.copy(), mus.copy(), 50, 'f64', kernel=1))
+    assert len(md._table_cache) == 1 and next(iter(md._table_cache.values()))[('coarse', 1e-12)][2] is start0
+    c = to_host(md.gn_device(g[0], g[1], to_dev(i0, torch.float64, dev), to_dev(mus, torch.float64, dev), 50, 'f64', kernel=1))
+    assert md.last_gn_stats()['mode'] == 'start' and len(md._table_cache) == 1
+    assert np.array_equal(a.view(np.int64), b.view(np.int64)) and np.array_equal(a.view(np.int64), c.view(np.int64))
+    md.gn_device(g[0], g[1], 1.5 * i0, mus, 50, 'f64', kernel=1)                   # other spectra: another table
+    assert len(md._table_cache) == 2
+    # a tighter tolerance than the library's default gets a gate calibrated for it (more steps needed per cell)
+    md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1, stop_tol=1e-14)
+    ent = [v for v in md._table_cache.values() if ('coarse', 1e-14) in v]
+    assert len(ent) == 1 and ('coarse', 1e-12) in ent[0]
+
+
+def test_short_cut_through_the_public_boundary(hip):
+    """get_basismat_sinos on NumPy sinograms (the reference call, matdecomp.py:167): default mode = the short cut, same
+    arrays as with every pixel walked from 1e-6 to 1e-12, masked air pixels exactly 0 in both."""
+    import os
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import matdecomp as md, synthetic
+    from conftest import small_scan
+    ct, ph = small_scan(n=64, nz=1, n_views=90, n_channels=128)
+    specs = [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
+    (r1, _), (r2, _) = dx.get_sinos(ct, ph, specs)
+    m1, m2 = md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50)
+    assert md.last_gn_stats()['mode'] == 'start'
+    w1, w2 = md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50, two_level=False)
+    assert md.last_gn_stats()['mode'] == 'single'
+    x1, x2 = md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50, stop_tol=0.0)
+    air = r1 >= 0.95 * r1.max()
+    assert air.any() and np.all(m1[air] == 0) and np.all(m2[air] == 0) and np.all(w1[air] == 0)
+    for got in ((m1, m2), (w1, w2)):
+        assert err(np.stack(got, -1), np.stack([x1, x2], -1)) < 1e-12
