@@ -52,7 +52,7 @@ GN_PASS_COARSE, GN_PASS_REFINE = 1, 2
 def gn_options(stop_tol=None, out_rows=0, out_channels=0, kernel=0, gn_pass=0, iterations=None, start=None):
     """byref-able dexct_gn_options; ``stop_tol=None`` asks for the library default (a negative value in the struct).
     ``gn_pass`` / ``iterations`` (device address of n_pix bytes) / ``start`` (device address of the table of the reference's fixed points): the
-    two launches of the two-level solve."""
+    Newton short cut (include/dexct.h)."""
     o = GnOptions(-1.0 if stop_tol is None else float(stop_tol), int(out_rows), int(out_channels), int(kernel), int(gn_pass),
                   iterations, start)
     return C.byref(o)

@@ -84,7 +84,7 @@ DEFAULT_STOP_TOL = None
 DEFAULT_TWO_LEVEL = None
 
 _last_ws = []          # workspaces of the most recent call (one per view chunk of the pipelined boundary)
-_last_ws_coarse = []   # ... of its coarse launches (two-level solve)
+_last_ws_coarse = []   # ... of its coarse launches ('coarse' mode of the short cut)
 _last_events = []      # (before, between, after) events of the launches of the most recent call(s)
 _last_zeroed = None
 _table_cache = {}
@@ -102,7 +102,7 @@ def last_gn_stats():
     words = torch.stack([w[72:104].view(torch.int64) for w in _last_ws]).sum(dim=0).tolist()
     st = {'pixel_iterations': int(words[0]), 'stalled_lane_steps': int(words[3]), 'launches': len(_last_ws)}
     if _last_ws_coarse:
-        # two-level solve: 'pixel_iterations' are the steps on the FULL tables, these the steps on the short ones
+        # 'coarse' mode: 'pixel_iterations' are the steps on the FULL tables, these the steps on the short ones
         cw = torch.stack([w[72:104].view(torch.int64) for w in _last_ws_coarse]).sum(dim=0).tolist()
         st['coarse_pixel_iterations'] = int(cw[0])
         st['coarse_energies'] = _last_coarse_ne

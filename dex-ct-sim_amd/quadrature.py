@@ -222,7 +222,7 @@ def _sparse_nonneg_fit(A, tol_inf, prefer=None, max_nodes=64):
 
 
 def coarse_newton_tables(i0, mus, log_range=16.0, max_err=2.0e-6):
-    """The short tables of the two-level Newton decomposition (matdecomp.gn_device; include/dexct.h, dexct_gn_options.pass):
+    """The short tables of the 'coarse' mode of the Newton short cut (matdecomp.gn_device; include/dexct.h, dexct_gn_options.pass):
     i0 [2, nE] effective spectra, mus [2, nE] basis mass attenuation -> (cols, i0_short [2, n]) or None.
 
     The decomposition's forward model ``sum_e i0[k][e] exp(-a0 mus[0][e] - a1 mus[1][e])`` is the same kind of sum as the
@@ -281,7 +281,7 @@ GATE_RADIUS = 0.01         # acceptance radius of a result around the interpolat
 
 
 def newton_start_grid(i0, mus, log_range=16.0):
-    """The grid of the two-level Newton decomposition's gate (csrc/gn.hip, gn_start; include/dexct.h, dexct_gn_options.start),
+    """The grid of the Newton short cut's gate (csrc/gn.hip, gn_start; include/dexct.h, dexct_gn_options.start),
     laid out in DATA space: cells over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / log_range, u0 from GATE_U_MIN to 1 and the ratio
     over what the forward model produces on the decomposition's domain (attenuation down to exp(-log_range), second component
     down to a quarter of its physical lower bound), widened by a quarter on both sides for noisy counts.  Returns a dict:

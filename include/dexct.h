@@ -23,7 +23,7 @@ extern "C" {
 
 #define DEXCT_ABI_VERSION 4   /* 2: log_out argument of the projection entry points, dexct_sino_log;
                                  3: struct dexct_gn_options - tolerance stop, results in the reference's order; 256 material ids;
-                                 4: dexct_gn_options.pass / .iterations - the two launches of the two-level Newton solve */
+                                 4: dexct_gn_options.pass / .iterations / .start - the Newton short cut (tabulated fixed points) */
 
 #define DEXCT_OK 0
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
