@@ -276,7 +276,7 @@ def test_config4_2000x1024_view_shard(hip):
     250 views (750..1000) at full size.  (The gather itself: tests/test_shard_gloo.py, bench.py --gpus 2.)"""
     from dex_ct_sim_amd import _shard
     assert _shard.split(2000, 3, 8) == (750, 1000)
-    res = _dual_energy_shard(512, 2000, 1024, (750, 1000), sample_views=[750, 875, 999], rows_at=(100, 300))
+    res = _dual_energy_shard(512, 2000, 1024, (750, 1000), sample_views=[750, 875, 999], rows_at=(100, 300), compare_exact=True)
     assert all(n_live > 1000 for _, n_live in res)
 
 
