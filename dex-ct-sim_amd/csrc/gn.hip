@@ -440,13 +440,31 @@ __device__ __forceinline__ long long gn_out_index(const GnTiling& tl, long long 
 // nearly singular Hessian, a wild transient far from the solution where steps are small only relative to a huge |a|) or
 // whose steps grow is NOT stopped and runs on to the exact repeated-state exit or to n_iters, as in the reference.  prev0 /
 // prev1: the state before (a0, a1) (history slot 0), valid when it >= 1; no stop after the very first step.
-__device__ __forceinline__ bool gn_converged(double stop_tol, double a0, double a1, double n0, double n1, double prev0,
-                                             double prev1, int it) {
-  if (!(stop_tol > 0.0) || it < 1) return false;
+__device__ __forceinline__ bool gn_rule(double stop_tol, double a0, double a1, double n0, double n1, double prev0, double prev1) {
   const double dk = fmax(fabs(n0 - a0), fabs(n1 - a1));
   const double size = fmax(fmax(fabs(n0), fabs(n1)), 1.0);
   const double dprev = fmax(fabs(a0 - prev0), fabs(a1 - prev1));
   return dk < dprev && dk * dk <= (0.25 * stop_tol) * size * (dprev - dk) && dprev < __builtin_huge_val();   // NaN compares false
+}
+
+// prev2: the state before prev (history slot 1), valid when it >= 2.  `confirm`: the walk from the reference's start value ends
+// only when the step BEFORE contracted as well (d_(k-1) < d_(k-2): three steps in decreasing order).  A wandering pixel -
+// photon-starved counts that no thicknesses reproduce, drifting towards |a| ~ 1e3 - takes a step now and then that happens
+// to be tiny next to its predecessor and was stopped there, where the reference walks on (to NaN, mostly): 481 + 48 of the
+// 4.7e7 pixels of a noisy 2e4-photon scan differed from the exact count (profiles/r04_gn_two_level.md).  A converging pixel's
+// steps decrease anyway: it pays nothing.  (Asking the previous step to meet the whole rule would: a quadratically
+// converging pixel meets it once, at its last step above the rounding floor.)  Not asked of a pixel that starts next to a
+// tabulated, isolated fixed point (the short cut): its first step has no predecessor.
+__device__ __forceinline__ bool gn_converged(double stop_tol, double a0, double a1, double n0, double n1, double prev0,
+                                             double prev1, int it, bool confirm = false, double prev2_0 = 0.0, double prev2_1 = 0.0) {
+  if (!(stop_tol > 0.0) || it < 1) return false;
+  bool ok = gn_rule(stop_tol, a0, a1, n0, n1, prev0, prev1);
+  if (confirm) {
+    const double dprev = fmax(fabs(a0 - prev0), fabs(a1 - prev1));
+    const double dprev2 = fmax(fabs(prev0 - prev2_0), fabs(prev1 - prev2_1));
+    ok = ok && it >= 2 && dprev < dprev2;
+  }
+  return ok;
 }
 
 // MIXED: n_iters - n_polish iterations in float32, then n_polish in float64.
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
   for (; it < n_iters; ++it) {
     double n0 = a0, n1 = a1;
     newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);
-    if (exact_exit) {
+    if (exact_exit & 1) {
       const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
       if (b0 == __double_as_longlong(a0) && b1 == __double_as_longlong(a1)) hit = -1;
 #pragma unroll
@@ -557,7 +575,8 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
         if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
       if (hit != -2) break;
       // the tolerance stop (float64 loop only; see gn_converged)
-      if (gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it)) {
+      if (gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it, (exact_exit & 4) != 0,
+                       __longlong_as_double(h0[1]), __longlong_as_double(h1[1]))) {
         a0 = n0;
         a1 = n1;
         break;
@@ -699,7 +718,7 @@ __global__ __launch_bounds__(256) void gn_tile_scatter_kernel(int n_tiles, int* 
 // the pixel with (a0, a1) = what all n_iters iterations would return (repeated state) / the converged state (tolerance).
 __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_iters, int exact_exit, double stop_tol,
                                                    double& a0, double& a1, int& it, long long (&h0)[kGnHistory],
-                                                   long long (&h1)[kGnHistory], bool* by_rule = nullptr) {
+                                                   long long (&h1)[kGnHistory], bool* by_rule = nullptr, bool confirm = false) {
   int hit = -2;
   if (exact_exit) {
     const long long b0 = __double_as_longlong(n0), b1 = __double_as_longlong(n1);
@@ -708,7 +727,8 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
     for (int k = kGnHistory - 1; k >= 0; --k)
       if (k < it && b0 == h0[k] && b1 == h1[k] && hit != -1) hit = k;
   }
-  const bool converged = gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it);
+  const bool converged = gn_converged(stop_tol, a0, a1, n0, n1, __longlong_as_double(h0[0]), __longlong_as_double(h1[0]), it, confirm,
+                                      __longlong_as_double(h0[1]), __longlong_as_double(h1[1]));
   if (by_rule) *by_rule = converged;
   const bool advance = hit == -2 && !converged;
   // the state a cycle holds at iteration n_iters: s_m = s_{base + (m - base) mod period} for m >= base = it-1-hit,
@@ -1044,8 +1064,11 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
     // through it too and are ignored.
     bool by_rule = false;
+    // (flags bit 2: the walk from 1e-6 must have contracted over the step before as well; pixels on the short cut - PASS 2 with the warm bit, PASS 1
+    // from start values - are not: they start next to an isolated fixed point)
+    const bool confirm = (flags & 4) != 0 && (PASS == 0 || (PASS == 2 && (ent & kWarmBit) == 0) || (PASS == 1 && start == nullptr));
     const bool advance = gn_exit_or_advance(n0, n1, PASS == 2 ? budget : n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1,
-                                            PASS == 1 ? &by_rule : nullptr);
+                                            PASS == 1 ? &by_rule : nullptr, confirm);
     bool fin = ent >= 0 && (!advance || it >= (PASS == 2 ? budget : n_iters));
     if (PASS == 2) {
       // a pixel started from the coarse result that used up its budget or ran into NaN: the reference's own solve instead
@@ -1197,7 +1220,7 @@ __global__ __launch_bounds__(kCoopWaves * kWave, 3) void gn_coop_kernel(const vo
     const GnSums s{{tot[0], tot[1]}, {tot[2], tot[3]}, {tot[4], tot[5]}, {tot[6], tot[7]}, {tot[8], tot[9]}, {tot[10], tot[11]}};
     double n0 = a0, n1 = a1;
     newton_solve_f64(s, gd0, gd1, n0, n1);
-    const bool advance = gn_exit_or_advance(n0, n1, n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1);
+    const bool advance = gn_exit_or_advance(n0, n1, n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1, nullptr, (flags & 4) != 0);
     if (pout >= 0 && (!advance || it >= n_iters)) {
       if (writer) store_a(out_a, pout, a0, a1);
       pout = -1;
@@ -1312,11 +1335,15 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     if (!(tol >= 0.0)) tol = 0.0;
   }
   if (!exact_exit) tol = 0.0;                         // the full loop is the full loop
+  // a walk from the reference's start value ends by the tolerance rule only when the step before contracted too (gn_converged);
+  // DEXCT_GN_CONFIRM=0: the rule as first shipped this round
+  const char* cfe = getenv("DEXCT_GN_CONFIRM");
+  const int confirm_flag = (cfe && cfe[0] == '0') ? 0 : 4;
   if (pass != 0 && !(tol > 0.0)) return DEXCT_EINVAL;  // both passes end pixels by the tolerance rule
   const dim3 grid((unsigned)nblk), block(kGnBlock);
   if (n_bins > 1) {
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
-                       n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit, tol, tl, out_a);
+                       n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit | confirm_flag, tol, tl, out_a);
   } else if (precision == 0) {
     // Lane refill from a queue of 64-pixel tiles; no more workgroups than can be resident: 28 KB of LDS and the registers allow 4 - 5 per CU
     // (those beyond would start when the queue is already empty).  Round 3 measured the fetch size: 64 / 128 / 256 / 512 /
@@ -1379,22 +1406,22 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     const int qflags = (tiles_per_fetch << 8) | (refill_min << 20);
     if (pass == 1)
       hipLaunchKernelGGL((gn_refill_kernel<4, 1>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
     else if (pass == 2)
       hipLaunchKernelGGL((gn_refill_kernel<4, 2>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
     else if (which == 2 || (which == 0 && n_pix < coop_below)) {
       int64_t ncb = tl.n_tiles;
       const int64_t ccap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : 3);
       if (ncb > ccap) ncb = ccap;
       hipLaunchKernelGGL(gn_coop_kernel, dim3((unsigned)ncb), dim3(kCoopWaves * kWave), 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0), tol, out_a, counters);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag, tol, out_a, counters);
     } else if (minw == 4)
       hipLaunchKernelGGL((gn_refill_kernel<4, 0>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
     else
       hipLaunchKernelGGL((gn_refill_kernel<5, 0>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | qflags, tol, out_a, counters, iters, start);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, 0.0, tl, out_a);
