@@ -451,8 +451,8 @@ __device__ __forceinline__ bool gn_rule(double stop_tol, double a0, double a1, d
 // only when the step BEFORE contracted as well (d_(k-1) < d_(k-2): three steps in decreasing order).  A wandering pixel -
 // photon-starved counts that no thicknesses reproduce, drifting towards |a| ~ 1e3 - takes a step now and then that happens
 // to be tiny next to its predecessor and was stopped there, where the reference walks on (to NaN, mostly): 481 + 48 of the
-// 4.7e7 pixels of a noisy 2e4-photon scan differed from the exact count (profiles/r04_gn_two_level.md).  A converging pixel's
-// steps decrease anyway: it pays nothing.  (Asking the previous step to meet the whole rule would: a quadratically
+// 4.7e7 pixels of a noisy 2e4-photon scan differed from the exact count (profiles/r04_gn.md section 1).  A converging pixel's
+// steps decrease anyway.  (Asking the previous step to meet the whole rule would: a quadratically
 // converging pixel meets it once, at its last step above the rounding floor.)  Not asked of a pixel that starts next to a
 // tabulated, isolated fixed point (the short cut): its first step has no predecessor.
 __device__ __forceinline__ bool gn_converged(double stop_tol, double a0, double a1, double n0, double n1, double prev0,
@@ -460,9 +460,14 @@ __device__ __forceinline__ bool gn_converged(double stop_tol, double a0, double 
   if (!(stop_tol > 0.0) || it < 1) return false;
   bool ok = gn_rule(stop_tol, a0, a1, n0, n1, prev0, prev1);
   if (confirm) {
+    // ... and the distance still to go is estimated with the WORSE of the last two contraction ratios (a creeping pixel's
+    // ratio fluctuates: one good step does not make a geometric series): d_k r / (1 - r) <= stop_tol / 4 * size with
+    // r = d_(k-1) / d_(k-2) as well, i.e. d_k d_(k-1) <= stop_tol / 4 * size * (d_(k-2) - d_(k-1))
+    const double dk = fmax(fabs(n0 - a0), fabs(n1 - a1));
+    const double size = fmax(fmax(fabs(n0), fabs(n1)), 1.0);
     const double dprev = fmax(fabs(a0 - prev0), fabs(a1 - prev1));
     const double dprev2 = fmax(fabs(prev0 - prev2_0), fabs(prev1 - prev2_1));
-    ok = ok && it >= 2 && dprev < dprev2;
+    ok = ok && it >= 2 && dprev < dprev2 && dk * dprev <= (0.25 * stop_tol) * size * (dprev2 - dprev);
   }
   return ok;
 }

@@ -253,8 +253,10 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *   stop_tol    >= 0: taken as given.  0 = the reference's fixed iteration count, bit for bit (matdecomp.py:114: `for
  *               i in range(n_iters)`).  > 0 = tolerance stop: a float64 pixel also ends, with the state after the step, when
  *               the distance it still has to go - estimated from its last two steps d_k < d_(k-1) as d_k r / (1 - r), r =
- *               d_k / d_(k-1) - is at most stop_tol / 4 * max(|a0|, |a1|, 1), and the step before contracted as well (d_(k-1) <
- *               d_(k-2): a wandering pixel's accidental tiny step does not end it; DEXCT_GN_CONFIRM=0 drops this).  A creeping
+ *               d_k / d_(k-1) - is at most stop_tol / 4 * max(|a0|, |a1|, 1), the step before contracted as well (d_(k-1) <
+ *               d_(k-2)) and the estimate also holds with the ratio of THAT step (the worse of the two ratios counts): a wandering
+ *               pixel's accidental tiny step does not end it, a creeping one is not trusted after one good step
+ *               (DEXCT_GN_CONFIRM=0 drops both).  A creeping
  *               (r near 1) or wandering pixel is not stopped and runs to n_iters as in the reference.
  *               < 0: the library default = DEXCT_GN_DEFAULT_STOP_TOL (1e-12: seven orders inside the 1e-5 the results
  *               are specified to, three inside the 1e-9 the kernel keeps to the reference's own outputs), or the value of

@@ -381,10 +381,8 @@ def test_noisy_scan_default_mode_against_the_exact_count(hip, counts_per_ray):
         e = ((d - x).abs() / x.abs().clamp(min=1.0)).amax(-1)[fin & (x.abs().amax(-1) < 1e6)]
         worst = max(worst, float(e.max()))
         beyond += int((e > 1e-12).sum())
-    # every pixel the exact count leaves finite is finite here and vice versa; and all but a handful (creeping pixels of
-    # photon-starved rays whose two counts no thicknesses reproduce: the rule's estimate of the distance still to go is
-    # optimistic there) are within 1e-12 - those within 1e-8
-    assert bad_pattern == 0 and beyond <= 64 and worst <= 1e-8, (bad_pattern, beyond, worst)
-    if counts_per_ray >= 1e6:
-        assert beyond == 0
+    # every pixel the exact count leaves finite is finite here and vice versa, and every one of them is within 1e-12 (before
+    # the tolerance rule asked the walk from 1e-6 for two contracting steps and the worse of their ratios: 481 wandering pixels
+    # of the 2e4-photon scan ended finite where the reference ends NaN, 48 creeping ones up to 2e-5 away)
+    assert bad_pattern == 0 and beyond == 0 and worst <= 1e-12, (bad_pattern, beyond, worst)
     assert st['pixel_iterations'] < (0.35 if counts_per_ray >= 1e6 else 0.8) * n_exact
