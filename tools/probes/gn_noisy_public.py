@@ -12,11 +12,12 @@ from conftest import small_scan, INPUT
 import dex_ct_sim_amd as dx
 from dex_ct_sim_amd import matdecomp as md
 
+PAIR = tuple(sys.argv[1:3]) if len(sys.argv) > 2 else ('140kV_1mGy_float32.bin', '80kV_1mGy_float32.bin')
 for n, nz, views, chans, rows in ((512, 1, 1200, 800, 1), (256, 64, 360, 512, 64)):
     ct, ph = small_scan(n=n, nz=nz, n_views=views, n_channels=chans, n_rows=rows)
     for dose in (5.0, 0.5, 0.02):                      # mGy-like scale factors of main.py:68 (A_iso * dose / N_proj)
         specs = []
-        for name in ('140kV_1mGy_float32.bin', '80kV_1mGy_float32.bin'):
+        for name in PAIR:
             s = dx.xRaySpectrum(os.path.join(INPUT, 'spectrum', name), name[:5])
             s.rescale_counts(ct.A_iso * dose / ct.N_proj)
             specs.append(s)
