@@ -60,10 +60,11 @@ DEFAULT_STOP_TOL = None
 # reference's ~17 Newton steps per pixel are the walk from its start value 1e-6 to the neighbourhood of the solution; what it
 # returns is the fixed point its walk ends at.  That is a function of the pixel's two counts alone, so it is tabulated once
 # per pair of spectra: the library's own single launch (full tables, from 1e-6) is run on the counts at the corners of a
-# 128 x 128 cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / 16 (quadrature.newton_start_grid / assemble_start: where
-# does the walk end, after how many steps, how smoothly does that vary).  A pixel whose counts fall in an open cell - the
-# walk ends by the tolerance rule within n_iters steps at all corners around it, and the fixed points vary smoothly (no
-# boundary between two basins) - starts from the Catmull-Rom interpolant of those fixed points (1e-6 of |a| from its own)
+# 128 x 128 cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / 16, and once more on the cell centres as a check
+# (quadrature.newton_start_grid / assemble_start / validate_start: where does the walk end, after how many steps, is that an
+# isolated root of the two equations, how smoothly does it vary).  A pixel whose counts fall in an open cell - the walk ends by
+# the tolerance rule within n_iters steps at all corners around it, at well-conditioned roots that vary smoothly (no boundary
+# between two basins), the attenuation is not beyond exp(-12) - starts from the Catmull-Rom interpolant of those fixed points (1e-6 of |a| from its own)
 # and takes TWO steps on the full tables: the second is the tolerance rule's evidence that the FULL model has converged to
 # stop_tol.  The result is accepted only within the cell's radius of the interpolant (the reference's branch); a pixel
 # without that evidence or acceptance, or in a closed cell (few steps asked for, an ill-conditioned pair, counts outside the
@@ -139,9 +140,11 @@ def _host_tables(x):
 
 
 def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12, want_short=False):
-    """(i0_d [2, nBins, nE], mus_d [2, nE], coarse) for host or device tables, cached by content; coarse = (i0_short_d
-    [2, 1, n] or None, mus_short_d [2, n] or None, start array) or None; ``cal_tol``: the tolerance the gate is calibrated for.  Tables given as device tensors are used as they are (and read back once
-    per call only when the short tables are wanted: pass host arrays to avoid that synchronisation)."""
+    """(i0_d [2, nBins, nE], mus_d [2, nE], tabs) for host or device tables, cached by content; ``want_coarse``: prepare the
+    short cut - tabs = [i0_short_d [2, 1, n] or None, mus_short_d [2, n] or None (``want_short``: the 'coarse' mode's short
+    spectra), start array (the gate's table, csrc/gn.hip gn_start)] or None when the spectra allow no short cut;
+    ``cal_tol``: the tolerance the gate is calibrated for.  Tables given as device tensors are used as they are - and read
+    back once per call when the short cut is wanted: pass host arrays to avoid that synchronisation."""
     if isinstance(i0, torch.Tensor) and isinstance(mus, torch.Tensor) and not want_coarse:
         i0_d, mus_d = to_dev(i0, torch.float64, dev), to_dev(mus, torch.float64, dev)
         return (i0_d[:, None, :].contiguous() if i0_d.dim() == 2 else i0_d), mus_d, None
