@@ -512,18 +512,18 @@ def main():
     n_one = int(((i0[0] != 0) ^ (i0[1] != 0)).sum())
     hw_share = (29.0 * n_both + 17.0 * n_one) / (29.0 * i0.shape[1])
     gstats = md.last_gn_stats()            # of the last timed step's launches (the default mode)
-    two_level = bool(gstats) and gstats.get('mode') in ('coarse', 'start')
-    gn_name = ('gn_refill_kernel<4, 2> (start values from the table of the reference\'s fixed points + full-table steps)' if two_level
-               else 'gn_refill_kernel<4, 0>') if precision == 'f64' else 'gn_kernel<true,false>'
+    two_level = bool(gstats) and gstats.get('mode') == 'start'
+    gn_name = ('gn_shortcut_kernel (start values from the table of the reference\'s fixed points + full-table steps)' if two_level
+               else 'gn_refill_kernel<false>') if precision == 'f64' else 'gn_kernel<true,false>'
     main_ms = gstats['main_ms'] if gstats else gn_ms      # HIP events around the launch, on its stream, last timed step
     roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
             'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': main_ms, 'gn_ms_all_launches': gn_ms,
             'traffic': ((prof.get('gn_fetch_bytes_raw', 0) if prof.get('gn_fetch_counted_in_full') else prof.get('gn_fetch_bytes_x2_corrected', 0))
                         + prof.get('gn_write_bytes', 0)) or None,
-            'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': (24 + (17 if two_level and gstats.get('mode') == 'coarse' else 0)) * n_rays,
+            'traffic_source': traffic_src, 'algorithmic_bytes_per_launch': 24 * n_rays,
             'traffic_note': 'HBM-side bytes (FETCH_SIZE + WRITE_SIZE) of this kernel from the rocprofv3 --pmc passes of the same command '
                             'recorded in traffic_source (counters cannot be read from inside the timed run); algorithmic: 8 B of counts '
-                            'in and 16 B of results out per pixel (mode coarse: plus 16 B of coarse result and 1 B of step count in)',
+                            'in and 16 B of results out per pixel',
             'bound_note': 'neither HBM (24 - 41 B/pixel against >= 2e4 flops/pixel) nor MFMA (no dense contraction; FP64 MFMA and '
                           'FP64 VALU do not overlap on gfx950, DESIGN.md 4.4): bound = FP64 vector issue'}
     if gstats and gstats.get('pixel_iterations'):
@@ -551,9 +551,6 @@ def main():
                 'mode': gstats['mode'], 'launch_ms': main_ms, 'full_energies': int(i0.shape[1]),
                 'table_preparation_s_once_per_pair_of_spectra': gate_prep_s,
                 'full_steps_per_unmasked_pixel': gstats['pixel_iterations'] / live,
-                'coarse_launch_ms': gstats.get('coarse_ms') if gstats['mode'] == 'coarse' else None,
-                'coarse_energies': gstats.get('coarse_energies') if gstats['mode'] == 'coarse' else None,
-                'coarse_steps_per_unmasked_pixel': (gstats.get('coarse_pixel_iterations', 0) / live) if gstats['mode'] == 'coarse' else None,
                 'note': 'what the reference returns is the fixed point its walk from 1e-6 ends at - a function of the two counts, '
                         'tabulated once per pair of spectra by running the single launch on a 129 x 129 grid of counts.  A pixel '
                         'in a cell where that walk ends by the tolerance rule within n_iters steps, smoothly, starts from the '
@@ -594,16 +591,12 @@ def main():
         elapsed_ex = time.perf_counter() - t0
         ex_stats = md.last_gn_stats()
         a_exact = a_out.clone()
-        os.environ['DEXCT_GN_FULL_LOOP'] = '1'
-        try:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'f64', out=a_out, out_rc=out_rc, mask_max=gmax,
-                         mask_frac=0.95)
-            e1.record()
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop('DEXCT_GN_FULL_LOOP', None)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        md.gn_device(counts_nat[0], counts_nat[1], i0_d, mus_d, args.iters, 'f64', out=a_out, out_rc=out_rc, mask_max=gmax,
+                     mask_frac=0.95, full_loop=True)             # DEXCT_GN_FLAG_FULL_LOOP: every iteration executed
+        e1.record()
+        torch.cuda.synchronize()
         full_ms = e0.elapsed_time(e1)
         exact_is_full = bool(torch.equal(a_out.view(torch.int64), a_exact.view(torch.int64)))
         diff = float(torch.nan_to_num((a_default - a_exact).abs() / a_exact.abs().clamp(min=1.0), nan=0.0).max().item())

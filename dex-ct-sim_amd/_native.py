@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libdexct_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every entry point include/dexct.h declares
 SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
@@ -13,7 +13,7 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_reduce_max', 'dexct_transpose_batched', 'dexct_fbp_filter', 'dexct_fbp_backproject',
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
            'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
-           'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather',
+           'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather', 'dexct_sino_gather',
            'dexct_volume_ids', 'dexct_volume_remap', 'dexct_fbp_parker', 'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
 
 
@@ -41,20 +41,24 @@ def log_out(sino_log_ptr, air):
 
 
 class GnOptions(C.Structure):
-    """dexct_gn_options (ABI 4)"""
+    """dexct_gn_options (ABI 5)"""
     _fields_ = [('stop_tol', C.c_double), ('out_rows', C.c_int32), ('out_channels', C.c_int32), ('kernel', C.c_int32),
-                ('gn_pass', C.c_int32), ('iterations', C.c_void_p), ('start', C.c_void_p)]
+                ('gn_pass', C.c_int32), ('iterations', C.c_void_p), ('start', C.c_void_p), ('flags', C.c_int32),
+                ('blocks_per_cu', C.c_int32)]
 
 
-GN_PASS_COARSE, GN_PASS_REFINE = 1, 2
+GN_PASS_COUNT, GN_PASS_SHORTCUT = 1, 2
+GN_FLAG_FULL_LOOP, GN_FLAG_NATURAL_ORDER = 1, 2
 
 
-def gn_options(stop_tol=None, out_rows=0, out_channels=0, kernel=0, gn_pass=0, iterations=None, start=None):
+def gn_options(stop_tol=None, out_rows=0, out_channels=0, kernel=0, gn_pass=0, iterations=None, start=None, flags=0,
+               blocks_per_cu=0):
     """byref-able dexct_gn_options; ``stop_tol=None`` asks for the library default (a negative value in the struct).
-    ``gn_pass`` / ``iterations`` (device address of n_pix bytes) / ``start`` (device address of the table of the reference's fixed points): the
-    Newton short cut (include/dexct.h)."""
+    ``gn_pass`` / ``iterations`` (device address of n_pix bytes: the step counts of GN_PASS_COUNT) / ``start`` (device address of
+    the table of the reference's fixed points: GN_PASS_SHORTCUT): the Newton short cut; ``flags``: GN_FLAG_*;
+    ``blocks_per_cu``: workgroups per CU of the queue kernels, 0 = default (include/dexct.h)."""
     o = GnOptions(-1.0 if stop_tol is None else float(stop_tol), int(out_rows), int(out_channels), int(kernel), int(gn_pass),
-                  iterations, start)
+                  iterations, start, int(flags), int(blocks_per_cu))
     return C.byref(o)
 
 
@@ -98,6 +102,7 @@ def load():
     lib.dexct_vmi.argtypes = [vp, vp, i64, f64, f64, f64, i32, vp, vp]
     lib.dexct_label_moments.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     lib.dexct_sino_allgather.argtypes = [vp, vp, i64, vp, vp]
+    lib.dexct_sino_gather.argtypes = [vp, vp, C.POINTER(i64), C.POINTER(i64), i32, i32, i32, vp, vp]
     lib.dexct_fdk_backproject.argtypes = [vp, vp, vp, i32, i32, i32, f64, f64, f64, f64, f64, f64, f64, i32, f64, i32,
                                           f64, f64, vp, vp]
     lib.dexct_poisson_detect.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp]

@@ -771,32 +771,53 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
   return advance;
 }
 
-// Start values of the two-level solve (dexct_gn_options.start): nothing ties the coarse pass - or a refining pass that runs
-// without one - to the reference's start value 1e-6, because what is returned is decided by the tolerance rule of the full
-// model (or, failing that, by the reference's own solve from 1e-6).
+// ---- THE SHORT CUT past the reference's walk from 1e-6 (dexct_gn_options.pass = DEXCT_GN_PASS_SHORTCUT, .start) ---------------
 //
 // THE GATE.  What the reference returns is a function of a pixel's two counts alone: the state its iteration reaches from
 // 1e-6 in n_iters steps - the fixed point only if it gets there in time, and, where noisy counts admit several fixed
 // points, the one ITS walk ends at.  So the short cut is laid out in DATA space.  When the tables of a pair of spectra are
-// prepared, the host runs the reference's iteration (this library's single launch, full tables, from 1e-6) on the counts at
-// the corners of a cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / log_range, and records where it ends and after
-// how many steps.  The start array carries, per corner, that fixed point; per cell, the number of steps a pixel needs (the
-// largest count among the corners of the cell and of its eight neighbours, plus a margin; infinity where a corner did not end
-// by the tolerance rule, or where the corners' fixed points do not vary smoothly - a boundary between two basins crosses the
-// cell) and an acceptance radius (the spread of the corners' fixed points).  A pixel takes the short cut iff its counts fall
-// in a cell with n_iters >= that number; it starts from the bilinear interpolant s of the corners' fixed points - a point on
-// the REFERENCE'S branch - and its result is accepted only within the radius of s.  Every other pixel (few steps asked for,
-// an ill-conditioned pair of spectra, counts outside the grid, another fixed point, NaN) is solved the reference's way.
+// prepared, the host runs the reference's iteration (this library's single launch, full tables, from 1e-6, counting steps:
+// DEXCT_GN_PASS_COUNT) on the counts at the corners of a cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / log_range,
+// and records where it ends and after how many steps.  The start array carries, per corner, that fixed point; per cell, the
+// number of steps a pixel needs (the largest count among the corners of the cell and of its eight neighbours, plus a margin;
+// infinity where a corner did not end by the tolerance rule, or where the corners' fixed points do not vary smoothly - a
+// boundary between two basins crosses the cell) and an acceptance radius (a hundredth of the spread of the corners' fixed
+// points).  A pixel takes the short cut iff its counts fall in a cell with n_iters >= that number; it starts from the
+// Catmull-Rom interpolant s of the corners' fixed points - a point on the REFERENCE'S branch, 1e-6 of |a| from the pixel's own
+// fixed point - and its result is accepted only within the radius of s.  Every other pixel (few steps asked for, counts
+// outside the grid, another fixed point, NaN) is solved the reference's way.
 // Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] cells per axis n; [4] ln of the smallest u0 of the grid;
-// [5] cells per unit of ln u0; [6] smallest ratio u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] reserved; then
-// the corners' fixed points as pairs (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair (need, radius)[n^2];
-// the array is 16-byte aligned (pairs are read with one load).
+// [5] cells per unit of ln u0; [6] smallest ratio u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] ln of [0],[1];
+// then the corners' fixed points as pairs (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair
+// (need, radius)[n^2]; the array is 16-byte aligned (pairs are read with one load).
 constexpr int kStartHeader = 10;
-__device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n_iters, double g0, double g1, double& s0,
-                                         double& s1, double& radius) {
+
+// ln(x) for a positive, normal double: the hardware's float32 logarithm as a first guess y0 (|error| < 1e-5), then one
+// Newton step on the table-driven exponential above: ln x = y0 + ln(x e^-y0) = y0 + r - r^2 / 2 with r = x e^-y0 - 1, |r| <
+// 1e-5 (r^3 / 3 < 1e-16).  About 22 instructions against the 90 of the library logarithm; absolute error ~2e-16 + 1 ulp.
+// Zero, negative, subnormal-in-float32, infinite or NaN arguments return NaN or +-inf (the gate then closes: every comparison
+// with them is false).
+__device__ __forceinline__ double log_pos(double x, const double* __restrict__ lds_pow) {
+#ifdef DEXCT_GN_LIBM_LOG
+  return log(x);
+#else
+  const double y0 = (double)(__builtin_amdgcn_logf((float)x) * 0.693147180559945309f);
+  const double r = fma(x, exp_tab(-y0 * kExpScale, lds_pow), -1.0);
+  return y0 + fma(-0.5 * r, r, r);
+#endif
+}
+
+__device__ __forceinline__ bool gn_start(const double* __restrict__ start, const double* __restrict__ lds_pow, int n_iters,
+                                         double g0, double g1, double& s0, double& s1, double& radius) {
+#ifdef DEXCT_GN_LIBM_LOG          // (round 4's arithmetic, kept for one bit-for-bit comparison of the two kernels)
   const double u0 = log(start[0] / g0) * start[2], u1 = log(start[1] / g1) * start[2];
+  const double t = u1 / u0;
+#else
+  const double u0 = (start[8] - log_pos(g0, lds_pow)) * start[2], u1 = (start[9] - log_pos(g1, lds_pow)) * start[2];
+  const double t = u1 * rcp_f64(u0);
+#endif
   const int n = (int)start[3];
-  const double fx = (log(u0) - start[4]) * start[5], fy = (u1 / u0 - start[6]) * start[7];
+  const double fx = (log_pos(u0, lds_pow) - start[4]) * start[5], fy = (t - start[6]) * start[7];
   bool ok = fx >= 0.0 && fy >= 0.0 && fx < (double)n && fy < (double)n;        // (NaN compares false)
   const int i = ok ? (int)fx : 0, j = ok ? (int)fy : 0;
   typedef double d2 __attribute__((ext_vector_type(2)));
@@ -808,11 +829,11 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n
   // cells the step table vouches for; cells on the border of the grid are closed by the host): 1e-6 of |a| where the
   // bilinear interpolant is 6e-4 off - the difference between two and three steps of the full tables per pixel
   const double wx = fx - (double)i, wy = fy - (double)j;
-  auto weights = [](double t, double (&w)[4]) {
-    const double t2 = t * t, t3 = t2 * t;
-    w[0] = -0.5 * t3 + t2 - 0.5 * t;
+  auto weights = [](double t_, double (&w)[4]) {
+    const double t2 = t_ * t_, t3 = t2 * t_;
+    w[0] = -0.5 * t3 + t2 - 0.5 * t_;
     w[1] = 1.5 * t3 - 2.5 * t2 + 1.0;
-    w[2] = -1.5 * t3 + 2.0 * t2 + 0.5 * t;
+    w[2] = -1.5 * t3 + 2.0 * t2 + 0.5 * t_;
     w[3] = 0.5 * t3 - 0.5 * t2;
   };
   double cx[4], cy[4];
@@ -838,51 +859,35 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, int n
   return ok;
 }
 
-// float64, one shared spectrum - the benchmark's path - with lane refill.  The exits end pixels at very different
-// iterations (from 10 to all of n_iters), and a wave is as slow as its slowest lane.  Here every lane whose pixel has ended
-// takes the next pixel of the wave's current tile, and a wave whose tile is handed out fetches the next tile from a global
-// counter at once, while its other lanes still iterate: all 64 lanes keep iterating until the sinogram is used up, the load
-// balances itself over CUs and XCDs.  The energy loops stay wave-uniform (scalar table loads) because the tables do not
-// depend on the pixel.  Pixels are independent problems: results are bit-identical to gn_kernel's in any order.
-// MINW: minimum waves per SIMD the register allocation must allow (4, the default: 110 VGPRs, no scratch; 5: 96 VGPRs + 48 B).
+// float64, one shared spectrum - the single launch from the reference's start value - with lane refill.  The exits end
+// pixels at very different iterations (from 10 to all of n_iters), and a wave is as slow as its slowest lane.  Here every
+// lane whose pixel has ended takes the next pixel of the wave's current tile, and a wave whose tile is handed out fetches the
+// next tile from a global counter at once, while its other lanes still iterate: all 64 lanes keep iterating until the
+// sinogram is used up, the load balances itself over CUs and XCDs.  The energy loops stay wave-uniform (scalar table loads)
+// because the tables do not depend on the pixel.  Pixels are independent problems: results are bit-identical to gn_kernel's
+// in any order.  Register allocation: 4 waves per SIMD, 110 VGPRs, no scratch.
 //
-// PASS (dexct_gn_options.pass; the short cut past the reference's walk from 1e-6: gn_start above, matdecomp.gn_device):
-//   0  one launch from 1e-6, everything above.
-//   1  the same iteration on whatever tables it is given, counting steps: besides the result, `iters` receives per pixel
-//      (result order) the number of steps after which the tolerance rule ended it, or 255 when it ended any other way
-//      (n_iters reached, repeated state, NaN).  Run by the host on a grid of counts with the full tables to tabulate where the
-//      reference's walk ends (the gate), and - "coarse" mode - on short tables from the gate's start values.
-//   2  the short cut, on the full tables.  With `start` and without `iters` (the default): a pixel in an open cell starts from
-//      the interpolated fixed point of the reference's walk.  With `iters` (coarse mode): a pixel whose byte k is not 255 and
-//      leaves at least two steps of the budget starts from the coarse result in out_a - if that lies within the cell's radius
-//      of the interpolant - with n_iters - k steps left (the coarse steps count against the budget, so no pixel gets more
-//      iterations than the reference gives it).  Either way it ends by the same tolerance rule - i.e. only after a step of
-//      the FULL model has been seen to contract to within stop_tol - or at a repeated state, and is accepted only within the
-//      radius.  A pixel that does not (budget used up, NaN, another fixed point), every pixel in a closed cell and every pixel
-//      marked 255 is solved from the reference's start value with all n_iters steps, exactly as PASS 0 does: the result is
-//      either a verified fixed point of the full model on the reference's branch or the reference's own trajectory.
-template <int MINW, int PASS>
-__global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
+// COUNT (dexct_gn_options.pass = DEXCT_GN_PASS_COUNT): the same iteration, counting steps: besides the result, `iters` receives
+// per pixel (result order) the number of steps after which the tolerance rule ended it, or 255 when it ended any other way
+// (n_iters reached, repeated state, NaN).  Run by the host on a grid of counts to tabulate where the reference's walk ends
+// (the gate of the short cut, above).
+template <bool COUNT>
+__global__ __launch_bounds__(kGnBlock, 4) void gn_refill_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                              int g_is_f64, long long n_pix, const double* __restrict__ ws,
                                                              int n_e, int n_iters, GnTiling tl,
                                                              const double* __restrict__ mask_max, double mask_frac,
-                                                             int flags, double stop_tol,      // flags: bit 0 exact repeated-state exit, bit 1 sorted hand-out, bits 8..19: tiles per queue reservation, 20..26: lanes waiting before a hand-out
+                                                             int flags, double stop_tol,      // flags: bit 0 exact repeated-state exit, bit 1 sorted hand-out, bit 2 the rule asks for two contracting steps, bits 8..19: tiles per queue reservation
                                                              double* __restrict__ out_a,
                                                              unsigned long long* __restrict__ counters,
-                                                             unsigned char* __restrict__ iters,
-                                                             const double* __restrict__ start) {
+                                                             unsigned char* __restrict__ iters) {
   typedef double d2 __attribute__((ext_vector_type(2)));
-  constexpr int kWarmBit = 1 << 20;       // PASS 2, in `ent`: this lane's pixel started from the coarse result
   // `counters` = the workspace words 9.. (executed, progress, queue head, stalls): ONE pointer, and the tile order is found
   // from it too (the table pointer `ws` stays read-only for the compiler: its loads are scalar loads)
   auto counter = [&](int k) { return counters + (k - 9); };
   __shared__ double lds_pow[kPowN];                                      // 16 KB
-  __shared__ d2 lds_out[kGnBlock / kWave][kSlots * kTilePix];            // 16 KB: with the table 32 KB = 5 workgroups per CU
-  __shared__ unsigned char lds_it[PASS == 1 ? kGnBlock / kWave : 1][PASS == 1 ? kSlots * kTilePix : 1];
-  unsigned char* __restrict__ my_it = lds_it[PASS == 1 ? (threadIdx.x >> 6) : 0];
-  // PASS 2: the acceptance radius of a pixel on the short cut (its start value waits in the pixel's result slot of lds_out)
-  __shared__ double lds_rad[PASS == 2 ? kGnBlock / kWave : 1][PASS == 2 ? kSlots * kTilePix : 1];
-  double* __restrict__ my_rad = lds_rad[PASS == 2 ? (threadIdx.x >> 6) : 0];
+  __shared__ d2 lds_out[kGnBlock / kWave][kSlots * kTilePix];            // 12 KB: with the table 28 KB = 5 workgroups per CU
+  __shared__ unsigned char lds_it[COUNT ? kGnBlock / kWave : 1][COUNT ? kSlots * kTilePix : 1];
+  unsigned char* __restrict__ my_it = lds_it[COUNT ? (threadIdx.x >> 6) : 0];
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves leave the loop below independently
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
@@ -904,14 +909,12 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   bool exhausted = false;
   unsigned n_exec = 0, n_stall = 0;       // Newton steps executed; lane-steps spent waiting for a free slot (diagnostic)
   const int batch = ((flags >> 8) & 0xFFF) > 0 ? ((flags >> 8) & 0xFFF) : 1;      // queue positions reserved per atomic (flags bits 8..19)
-  const int refill_min = (flags >> 20) & 0x7F;                // lanes that must be waiting before pixels are handed out (bits 20..26)
   int q_next = 0, q_end = 0;              // the reserved positions not yet handed out (n_tiles < 2^31)
   unsigned handed = 0u;                   // pixels of the tiles handed out since the last reservation (progress word)
 
   int ent = -1;                           // slot * 64 + place of this lane's result in the slot, -1: no pixel
   double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
   int it = 0;
-  int budget = n_iters;                   // PASS 2: steps this lane's pixel may still take (PASS 0 / 1: n_iters, uniform)
   long long h0[kGnHistory], h1[kGnHistory];
 #pragma unroll
   for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
@@ -938,24 +941,17 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
       __builtin_amdgcn_wave_barrier();
       const GnTile d = gn_decode_tile(tl, n_pix, (long long)tile);
       const int c_off = tl.transposed ? (lane & (kTileC - 1)) : lane, r_off = tl.transposed ? (lane >> kTileCLog2) : 0;
-#ifndef DEXCT_GN_DIRECT
       if (c_off < d.nc && r_off < d.nr) {
         const d2 v = my_out[k * kTilePix + lane];
         __builtin_nontemporal_store(v, reinterpret_cast<d2*>(out_a) + (d.out_base + (long long)r_off * out_stride + c_off));
-        if (PASS == 1) iters[d.out_base + (long long)r_off * out_stride + c_off] = my_it[k * kTilePix + lane];
+        if (COUNT) iters[d.out_base + (long long)r_off * out_stride + c_off] = my_it[k * kTilePix + lane];
       }
-#endif
       __builtin_amdgcn_wave_barrier();
     }
   };
 
   for (;;) {
     unsigned long long want = __ballot(ent < 0);
-    // The hand-out below runs for the whole wave whenever one lane wants a pixel.  With ~17 steps per pixel that is cheap
-    // next to a step; on the short cut a pixel takes two steps and its hand-out includes gn_start (three float64 logarithms,
-    // 16 table loads, the interpolation: a third of a step), and the one pixel in 60 that needs a third step would pull its
-    // whole wave through it once more per step.  So a few waiting lanes wait until `refill_min` of them do (or nobody iterates).
-    if (PASS != 0 && (int)__popcll(want) < refill_min && __ballot(ent >= 0) != 0ull) want = 0ull;
     while (want != 0ull) {
       if (next_j >= kTilePix) {
         if (exhausted) break;
@@ -965,9 +961,7 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
         if (s < 0) { n_stall += (unsigned)__popcll(want); break; }     // every slot still waits for a straggler
         if (q_next >= q_end) {
           // reserve the next `batch` queue positions: ONE atomic on the queue head for `batch` tiles, and one for the progress
-          // word (the pixels of the tiles handed out since the last reservation).  All waves of the chip hit these two words:
-          // at one tile per atomic a launch of two steps per pixel spends more time queueing for them than iterating
-          // (profiles/r04_gn_two_level.md: about 12 ns per atomic on one address, 6.4e6 tiles per pass at the benchmark's size).
+          // word (the pixels of the tiles handed out since the last reservation)
           long long t = 0;
           if (lane == 0) {
             t = (long long)atomicAdd(counter(11), (unsigned long long)batch);
@@ -1003,52 +997,15 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
           gd0 = load_g<double>(g1, g_is_f64, np);
           gd1 = load_g<double>(g2, g_is_f64, np);
           if (has_mask && gd0 >= thresh) {             // air (matdecomp.py:195-196, :204-205): 0, not iterated
-#ifdef DEXCT_GN_DIRECT
-            store_a(out_a, np, 0.0, 0.0);
-#else
             my_out[place] = d2{0.0, 0.0};
-#endif
-            if (PASS == 1) my_it[place] = 255;
+            if (COUNT) my_it[place] = 255;
             done_now = true;
           } else if (n_iters <= 0) {
             my_out[place] = d2{1e-6, 1e-6};
-            if (PASS == 1) my_it[place] = 255;
+            if (COUNT) my_it[place] = 255;
             done_now = true;
           } else {
             ent = place; a0 = 1e-6; a1 = 1e-6; it = 0;
-            if (PASS == 1 && start != nullptr) {
-              double s0, s1, rad;
-              if (gn_start(start, n_iters, gd0, gd1, s0, s1, rad)) {
-                a0 = s0; a1 = s1;
-              } else {             // not a pixel for the short cut: marked for the reference's own solve, no coarse steps
-                my_out[place] = d2{1e-6, 1e-6};
-                my_it[place] = 255;
-                ent = -1;
-                done_now = true;
-              }
-            }
-            if (PASS == 2) {
-              budget = n_iters;
-              double s0 = 0.0, s1 = 0.0, rad = __builtin_huge_val();
-              const bool open = start == nullptr || gn_start(start, n_iters, gd0, gd1, s0, s1, rad);
-              if (iters == nullptr) {                      // no coarse pass: straight from the gate's start value
-                if (open) { a0 = s0; a1 = s1; ent = place | kWarmBit; }
-              } else {
-                const long long po = ct.out_base + (long long)r_off * out_stride + c_off;
-                const int k = iters[po];
-                if (open && k != 255 && n_iters - k >= 2) { // from the coarse result, the coarse steps paid for ...
-                  const d2 v = reinterpret_cast<const d2*>(out_a)[po];
-                  // ... if it lies on the reference's branch (without a start array: unchecked, s = the coarse result itself)
-                  if (start == nullptr) { s0 = v.x; s1 = v.y; }
-                  if (fmax(fabs(v.x - s0), fabs(v.y - s1)) <= rad) {
-                    a0 = v.x; a1 = v.y;
-                    budget = n_iters - k;
-                    ent = place | kWarmBit;
-                  }
-                }
-              }
-              if (ent & kWarmBit) { my_out[place] = d2{s0, s1}; my_rad[place] = rad; }
-            }
           }
         }
       }
@@ -1069,36 +1026,13 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
     // k + 2 states) determines every later iterate.  Written with selects instead of branches; idle lanes run
     // through it too and are ignored.
     bool by_rule = false;
-    // (flags bit 2: the walk from 1e-6 must have contracted over the step before as well; pixels on the short cut - PASS 2 with the warm bit, PASS 1
-    // from start values - are not: they start next to an isolated fixed point)
-    const bool confirm = (flags & 4) != 0 && (PASS == 0 || (PASS == 2 && (ent & kWarmBit) == 0) || (PASS == 1 && start == nullptr));
-    const bool advance = gn_exit_or_advance(n0, n1, PASS == 2 ? budget : n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1,
-                                            PASS == 1 ? &by_rule : nullptr, confirm);
-    bool fin = ent >= 0 && (!advance || it >= (PASS == 2 ? budget : n_iters));
-    if (PASS == 2) {
-      // a pixel started from the coarse result that used up its budget or ran into NaN: the reference's own solve instead
-      // ... or that ended away from the reference's branch (farther from its start value s than the cell's acceptance radius)
-      bool redo = false;
-      if (fin && (ent & kWarmBit) != 0) {
-        const d2 sv = my_out[ent & ~kWarmBit];
-        redo = advance || !(fmax(fabs(a0 - sv.x), fabs(a1 - sv.y)) <= my_rad[ent & ~kWarmBit]);        // (NaN: redo)
-      }
-      if (redo) { a0 = 1e-6; a1 = 1e-6; it = 0; budget = n_iters; ent &= ~kWarmBit; fin = false; }
-      if (fin) ent &= ~kWarmBit;
-    }
+    const bool advance = gn_exit_or_advance(n0, n1, n_iters, flags & 1, stop_tol, a0, a1, it, h0, h1,
+                                            COUNT ? &by_rule : nullptr, (flags & 4) != 0);
+    const bool fin = ent >= 0 && (!advance || it >= n_iters);
     const unsigned long long fb = __ballot(fin);
     if (fb != 0ull) {
-      if (PASS == 1 && fin) my_it[ent] = (unsigned char)(by_rule ? (it + 1 < 255 ? it + 1 : 254) : 255);
-#ifdef DEXCT_GN_DIRECT
-      if (fin) {                                     // experiment (plain order only): every result stored by itself
-        int tile = tid[0];
-#pragma unroll
-        for (int q = 1; q < kSlots; ++q) tile = (ent >> 6) == q ? tid[q] : tile;
-        store_a(out_a, (long long)tile * kTilePix + (ent & 63), a0, a1);
-      }
-#else
+      if (COUNT && fin) my_it[ent] = (unsigned char)(by_rule ? (it + 1 < 255 ? it + 1 : 254) : 255);
       if (fin) my_out[ent] = d2{a0, a1};
-#endif
       const int my_slot = ent >> 6;                  // (-1 for lanes without a pixel: matches no slot)
       if (fin) ent = -1;
       settle(fb, my_slot);
@@ -1107,6 +1041,230 @@ __global__ __launch_bounds__(kGnBlock, MINW) void gn_refill_kernel(const void* _
   if (lane == 0) {
     atomicAdd(counter(9), (unsigned long long)n_exec);            // one atomic per wave
     if (n_stall) atomicAdd(counter(12), (unsigned long long)n_stall);
+    if (handed) atomicAdd(counter(10), (unsigned long long)handed);
+  }
+}
+
+// THE SHORT-CUT KERNEL (dexct_gn_options.pass = DEXCT_GN_PASS_SHORTCUT; the default of get_basismat_sinos since round 4, this
+// form since round 5).  On the short cut a pixel takes exactly two steps - all of them do, so there is nothing to balance and
+// the machinery of the refill kernel (result slots, hand-out loop, repeated-state history: a fifth of round 4's launch) is in the
+// way.  Here a wave works through tiles in lock step:
+//   FAST PATH, straight-line code for the 64 pixels of a tile at once: counts in (the next tile's loads are issued before this
+//     tile's arithmetic), air mask, gate + start value (gn_start), two steps on the full tables, the tolerance rule on the
+//     second (its evidence that the FULL model has converged to stop_tol), the acceptance radius, results out through LDS as
+//     whole 64-byte runs in the reference's order.
+//   STASH: a pixel the fast path does not finish - closed cell (walk from the reference's start value 1e-6 with all n_iters
+//     steps), rule not yet met after two steps (one in 60: it continues where it is), result outside the radius (walk) - is
+//     put aside in LDS (96 entries per wave) and the wave moves on.
+//   DRAIN: when 32 entries have gathered (and at the end) the wave solves them with the general iteration - one lane per
+//     entry, refilled from the stash, every exit of gn_exit_or_advance, the acceptance test for continued pixels - and stores
+//     those results pixel by pixel.
+// Per pixel the sequence of states and the exit taken are those of round 4's refill kernel with start values (bit-identical
+// results, tools/probes/gn_shortcut_ab.py); only who computes them when has changed.
+constexpr int kStashCap = 96, kStashDrain = 32;
+constexpr long long kStashCont = 1ll << 62;          // entry: the pixel continues from the stored states (else: walks from 1e-6)
+
+__global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
+                                                               int g_is_f64, long long n_pix, const double* __restrict__ ws,
+                                                               int n_e, int n_iters, GnTiling tl,
+                                                               const double* __restrict__ mask_max, double mask_frac,
+                                                               int flags, double stop_tol, double* __restrict__ out_a,
+                                                               unsigned long long* __restrict__ counters,
+                                                               const double* __restrict__ start) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  auto counter = [&](int k) { return counters + (k - 9); };
+  __shared__ double lds_pow[kPowN];                                      // 16 KB
+  __shared__ d2 lds_out[kGnBlock / kWave][kTilePix];                     // 4 KB: one tile of results per wave
+  __shared__ long long lds_snp[kGnBlock / kWave][kStashCap];             // 3 KB: the stash - input index of the pixel | kind,
+  __shared__ d2 lds_sa[kGnBlock / kWave][kStashCap];                     // 6 KB: its state,
+  __shared__ d2 lds_sp[kGnBlock / kWave][kStashCap];                     // 6 KB: the state before,
+  __shared__ double lds_srad[kGnBlock / kWave][kStashCap];               // 3 KB: what is left of its acceptance radius  (38 KB: 4 workgroups per CU)
+  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
+  __syncthreads();                        // the only barrier: waves work independently from here on
+  const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
+  const double* __restrict__ tab = ws + kWsHeader;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  d2* __restrict__ my_out = lds_out[wv];
+  long long* __restrict__ snp = lds_snp[wv];
+  d2* __restrict__ sa = lds_sa[wv];
+  d2* __restrict__ sp = lds_sp[wv];
+  double* __restrict__ srad = lds_srad[wv];
+  const bool has_mask = mask_max != nullptr;
+  const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
+  const int in_stride = tl.transposed ? tl.rows : 1, out_stride = tl.transposed ? tl.channels : 0;
+  // this lane's pixel of a tile on the input side (consecutive lanes: consecutive rows of a channel / consecutive pixels),
+  // where its result goes in the tile's LDS image, and the pixel this lane WRITES (consecutive lanes: consecutive channels)
+  const int ci = tl.transposed ? lane / kTileR : lane, ri = tl.transposed ? lane % kTileR : 0;
+  const int place = tl.transposed ? ri * kTileC + ci : lane;
+  const int co = tl.transposed ? (lane & (kTileC - 1)) : lane, ro = tl.transposed ? (lane >> kTileCLog2) : 0;
+  const int lane_in_of_out = tl.transposed ? co * kTileR + ro : lane;    // the input-side lane that computed what this lane writes
+  const bool exact_exit = (flags & 1) != 0, confirm_walk = (flags & 4) != 0;
+  const int batch = ((flags >> 8) & 0xFFF) > 0 ? ((flags >> 8) & 0xFFF) : 1;
+  int q_next = 0, q_end = 0;
+  bool exhausted = false;
+  unsigned handed = 0u;
+  unsigned long long n_exec = 0ull;
+  int n_stash = 0;                        // wave-uniform
+
+  // the next tile of this wave, -1 when the queue is used up (one atomic per `batch` tiles, as in gn_refill_kernel)
+  auto next_tile = [&]() -> long long {
+    if (exhausted) return -1;
+    if (q_next >= q_end) {
+      long long t = 0;
+      if (lane == 0) {
+        t = (long long)atomicAdd(counter(11), (unsigned long long)batch);
+        if (handed) atomicAdd(counter(10), (unsigned long long)handed);
+      }
+      handed = 0u;
+      t = ((long long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+          (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+      if (t >= tl.n_tiles) { exhausted = true; return -1; }
+      q_next = (int)t;
+      q_end = t + batch < tl.n_tiles ? (int)t + batch : (int)tl.n_tiles;
+    }
+    return (long long)q_next++;
+  };
+
+  // DRAIN: the general iteration on the entries of the stash.  A continued pixel (states: s the start value, n after one step,
+  // m after two) goes on from m with n as the state before; it is accepted within srad = radius - |m - s| of m (hence within
+  // the radius of s; neither s nor the table is touched here: registers).  s is not entered into the history: a cycle through
+  // it is found one period later, with the same result.
+  auto drain = [&]() {
+    int head = 0;
+    long long po = -1;                    // where this lane's result goes, -1: no pixel
+    double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
+    int it = 0, warm = -1;                // warm >= 0: a continued pixel, its entry
+    long long h0[kGnHistory], h1[kGnHistory];
+#pragma unroll
+    for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
+    for (;;) {
+      const unsigned long long want = __ballot(po < 0);
+      if (head < n_stash && want != 0ull) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+        const int idx = head + rank;
+        if (po < 0 && idx < n_stash) {
+          const long long e = snp[idx];
+          const long long np = e & ~kStashCont;
+          gd0 = load_g<double>(g1, g_is_f64, np);
+          gd1 = load_g<double>(g2, g_is_f64, np);
+          po = gn_out_index(tl, np);
+          it = 0; a0 = 1e-6; a1 = 1e-6; warm = -1;
+          if (e & kStashCont) {
+            const d2 va = sa[idx], vp = sp[idx];
+            a0 = va.x; a1 = va.y;
+            h0[0] = __double_as_longlong(vp.x); h1[0] = __double_as_longlong(vp.y);
+            it = 1;                       // (as if m followed n directly: history of one state)
+            warm = idx;
+          }
+        }
+        const int taken = (int)__popcll(want);
+        head = head + taken < n_stash ? head + taken : n_stash;
+      }
+      const unsigned long long busy = __ballot(po >= 0);
+      if (busy == 0ull) break;            // (head == n_stash here: an idle wave with entries left takes them above)
+      n_exec += (unsigned long long)__popcll(busy);
+      double n0 = a0, n1 = a1;
+      newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);
+      // a continued pixel has taken two steps already: its budget is n_iters - 1 at it = 1
+      const bool advance = gn_exit_or_advance(n0, n1, warm >= 0 ? n_iters - 1 : n_iters, exact_exit ? 1 : 0, stop_tol, a0, a1, it, h0, h1,
+                                              nullptr, confirm_walk && warm < 0);
+      bool fin = po >= 0 && (!advance || it >= (warm >= 0 ? n_iters - 1 : n_iters));
+      if (fin && warm >= 0) {
+        // a continued pixel that used up its budget, ran into NaN or ended away from the reference's branch: the reference's
+        // own solve instead
+        const d2 vm = sa[warm];
+        const bool redo = advance || !(fmax(fabs(a0 - vm.x), fabs(a1 - vm.y)) <= srad[warm]);
+        if (redo) { a0 = 1e-6; a1 = 1e-6; it = 0; fin = false; }
+        warm = -1;
+      }
+      if (fin) {
+        store_a(out_a, po, a0, a1);
+        po = -1;
+      }
+    }
+    n_stash = 0;
+  };
+
+  // (No software prefetch of the next tile's counts: the registers it holds across the arithmetic cost more - spills - than the
+  // three other waves of the SIMD leave uncovered of one load's latency.)
+  for (long long t = next_tile(); t >= 0; t = next_tile()) {
+    const GnTile d = gn_decode_tile(tl, n_pix, t);
+    handed += (unsigned)(d.nr * d.nc);
+    const bool valid = ci < d.nc && ri < d.nr;
+    const long long np = d.in_base + (long long)ci * in_stride + ri;
+    const double gd0 = valid ? load_g<double>(g1, g_is_f64, np) : 1.0, gd1 = valid ? load_g<double>(g2, g_is_f64, np) : 1.0;
+    const bool air = has_mask && gd0 >= thresh;             // (matdecomp.py:195-196, :204-205): 0, not iterated
+    const bool act = valid && !air && n_iters > 0;
+    d2 res = air ? d2{0.0, 0.0} : d2{1e-6, 1e-6};
+    bool done = valid && !act;
+    bool to_walk = false, to_cont = false;
+    d2 st_a = d2{1e-6, 1e-6}, st_p = d2{0.0, 0.0};
+    double st_rad = 0.0;
+    if (__ballot(act) != 0ull) {
+      double s0, s1, rad;
+      const bool open = gn_start(start, lds_pow, n_iters, gd0, gd1, s0, s1, rad) && n_iters >= 3;
+      const bool fast = act && open;
+      to_walk = act && !open;
+      const unsigned long long fm = __ballot(fast);
+      if (fm != 0ull) {
+        n_exec += 2ull * (unsigned long long)__popcll(fm);
+        double n0 = s0, n1 = s1, m0 = s0, m1 = s1;
+#pragma nounroll
+        for (int k = 0; k < 2; ++k) {                                        // step 1: from s to n, step 2: from n to m
+          n0 = m0; n1 = m1;
+          newton_step_f64(tab, lds_pow, ec, gd0, gd1, m0, m1);
+        }
+        // the exits of gn_exit_or_advance for these two steps (no history yet: a fixed point at either step, the tolerance
+        // rule at the second); anything else - the rule not met, a cycle through s - continues in the drain
+        const bool fixed1 = exact_exit && __double_as_longlong(n0) == __double_as_longlong(s0) &&
+                            __double_as_longlong(n1) == __double_as_longlong(s1);
+        const bool fixed2 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(n0) &&
+                            __double_as_longlong(m1) == __double_as_longlong(n1);
+        const bool cycle2 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(s0) &&
+                            __double_as_longlong(m1) == __double_as_longlong(s1);
+        const bool conv = gn_converged(stop_tol, n0, n1, m0, m1, s0, s1, 1);
+        const bool ended = fixed1 || ((fixed2 || conv) && !cycle2);
+        const double f0 = fixed1 ? s0 : (conv ? m0 : n0), f1 = fixed1 ? s1 : (conv ? m1 : n1);
+        const bool accept = fmax(fabs(f0 - s0), fabs(f1 - s1)) <= rad;        // (NaN: no)
+        if (fast) {
+          if (ended && accept) { res = d2{f0, f1}; done = true; }
+          else if (ended) to_walk = true;                                     // another fixed point: the reference's own solve
+          else {                                                              // goes on from m if m is well inside the radius of s
+            st_rad = rad - fmax(fabs(m0 - s0), fabs(m1 - s1));
+            if (st_rad > 0.0) { to_cont = true; st_a = d2{m0, m1}; st_p = d2{n0, n1}; }
+            else to_walk = true;                                              // (NaN included)
+          }
+        }
+      }
+    }
+    // the stash takes what is left
+    const unsigned long long pm = __ballot(to_walk || to_cont);
+    if (pm != 0ull) {
+      const int idx = n_stash + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+      if (to_walk || to_cont) {
+        snp[idx] = np | (to_cont ? kStashCont : 0ll);
+        sa[idx] = st_a;
+        sp[idx] = st_p;
+        srad[idx] = st_rad;
+      }
+      n_stash += (int)__popcll(pm);
+    }
+    // results of the tile: through LDS into the order of the output, whole 64-byte runs
+    const unsigned long long dm = __ballot(done);
+    if (dm != 0ull) {
+      if (done) my_out[place] = res;
+      __builtin_amdgcn_wave_barrier();
+      if (co < d.nc && ro < d.nr && ((dm >> lane_in_of_out) & 1ull) != 0ull) {
+        const d2 v = my_out[lane];
+        __builtin_nontemporal_store(v, reinterpret_cast<d2*>(out_a) + (d.out_base + (long long)ro * out_stride + co));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (n_stash > kStashDrain) drain();
+  }
+  if (n_stash > 0) drain();
+  if (lane == 0) {
+    atomicAdd(counter(9), n_exec);                                // one atomic per wave
     if (handed) atomicAdd(counter(10), (unsigned long long)handed);
   }
 }
@@ -1275,6 +1433,45 @@ __global__ __launch_bounds__(256) void max_kernel(const void* __restrict__ g1, i
   }
 }
 
+// The environment is read ONCE per process (first call): tuning and checking knobs only - what a call computes is decided by its
+// arguments (dexct_gn_options), never by a variable that changes between two calls.
+struct GnEnv {
+  int full_loop;            // DEXCT_GN_FULL_LOOP=1: every call executes every iteration
+  double default_tol;       // options->stop_tol < 0: DEXCT_GN_EXACT=1 -> 0, DEXCT_GN_STOP_TOL=<t>, else DEXCT_GN_DEFAULT_STOP_TOL
+  int blocks_per_cu;        // DEXCT_GN_BLOCKS_PER_CU=<n>: workgroups per CU of the queue kernels (0: what is resident)
+  long long coop_below;     // DEXCT_GN_COOP_BELOW=<pixels>
+  int sort;                 // DEXCT_GN_SORT=0: natural order of the hand-out on small sinograms
+  int tiles_per_fetch;      // DEXCT_GN_TILES_PER_FETCH=<n>: queue positions per reservation (0: by size)
+};
+
+static const GnEnv& gn_env() {
+  static const GnEnv env = [] {
+    GnEnv e{0, DEXCT_GN_DEFAULT_STOP_TOL, 0, kCoopBelowDefault, 1, 0};
+    auto flag = [](const char* name, char c) { const char* v = getenv(name); return v && v[0] == c; };
+    auto number = [](const char* name, long long lo, long long hi, long long dflt) {
+      const char* v = getenv(name);
+      if (!v || !*v) return dflt;
+      char* end = nullptr;
+      const long long x = strtoll(v, &end, 10);
+      return (end && *end == 0 && x >= lo && x <= hi) ? x : dflt;
+    };
+    e.full_loop = flag("DEXCT_GN_FULL_LOOP", '1');
+    if (flag("DEXCT_GN_EXACT", '1')) {
+      e.default_tol = 0.0;
+    } else if (const char* t = getenv("DEXCT_GN_STOP_TOL")) {
+      char* end = nullptr;
+      const double x = strtod(t, &end);
+      if (end && end != t && *end == 0 && x >= 0.0) e.default_tol = x;      // anything else: ignored (the default stays)
+    }
+    e.blocks_per_cu = (int)number("DEXCT_GN_BLOCKS_PER_CU", 1, 64, 0);
+    e.coop_below = number("DEXCT_GN_COOP_BELOW", 0, 1ll << 62, kCoopBelowDefault);
+    e.sort = !flag("DEXCT_GN_SORT", '0');
+    e.tiles_per_fetch = (int)number("DEXCT_GN_TILES_PER_FETCH", 1, 1024, 0);
+    return e;
+  }();
+  return env;
+}
+
 }  // namespace dexct
 
 using namespace dexct;
@@ -1315,44 +1512,42 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   }
   if (tl.n_tiles > 0x7FFFFFFFll) return DEXCT_ERANGE;
   if (options && (options->kernel < 0 || options->kernel > 2)) return DEXCT_EINVAL;
-  // the two launches of the two-level solve (see gn_refill_kernel): lane kernel, one shared spectrum, float64, counts in a byte
+  // the step-counting launch and the short cut (see gn_refill_kernel<true>, gn_shortcut_kernel): lane kernels, one shared
+  // spectrum, float64, step counts in a byte
   const int pass = options ? options->pass : 0;
   if (pass < 0 || pass > 2) return DEXCT_EINVAL;
   if (pass != 0 && (n_bins > 1 || precision != 0 || n_iters > 254 || options->kernel == 2)) return DEXCT_EINVAL;
-  const double* start = (pass != 0) ? options->start : nullptr;
-  if (pass == 1 && !options->iterations) return DEXCT_EINVAL;
-  if (pass == 2 && !options->iterations && !start) return DEXCT_EINVAL;      // start from the coarse result or from the table
+  if (pass == DEXCT_GN_PASS_COUNT && (!options->iterations || options->start)) return DEXCT_EINVAL;
+  if (pass == DEXCT_GN_PASS_SHORTCUT && (!options->start || options->iterations)) return DEXCT_EINVAL;
+  const double* start = (pass == DEXCT_GN_PASS_SHORTCUT) ? options->start : nullptr;
   if (start && (reinterpret_cast<uintptr_t>(start) & 15u)) return DEXCT_EINVAL;   // its pairs are read with 16-byte loads
+  if (options && (options->flags & ~(DEXCT_GN_FLAG_FULL_LOOP | DEXCT_GN_FLAG_NATURAL_ORDER))) return DEXCT_EINVAL;
+  if (options && options->blocks_per_cu < 0) return DEXCT_EINVAL;
   hipStream_t st = as_stream(stream);
   double* ws = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(gn_tables_kernel, dim3(n_bins), dim3(256), 0, st, i0, mus, n_energies, n_bins, ws);
   DEXCT_LAUNCH_CHECK();
-  // DEXCT_GN_FULL_LOOP=1 runs every iteration (to check that the repeated-state exit changes no bit)
-  const char* full = getenv("DEXCT_GN_FULL_LOOP");
-  const int exact_exit = (full && full[0] == '1') ? 0 : 1;
+  const GnEnv& env = gn_env();
+  const int oflags = options ? options->flags : 0;
+  // DEXCT_GN_FLAG_FULL_LOOP (or DEXCT_GN_FULL_LOOP=1 at process start) runs every iteration: the check that the repeated-state
+  // exit changes no bit
+  const int exact_exit = ((oflags & DEXCT_GN_FLAG_FULL_LOOP) || env.full_loop) ? 0 : 1;
   // The tolerance stop.  options->stop_tol >= 0 is taken as given (0 = the reference's fixed count, bit for bit);
-  // negative or no options = the library default: 1e-12, or DEXCT_GN_STOP_TOL, or 0 with DEXCT_GN_EXACT=1.
+  // negative or no options = the library default: 1e-12, or DEXCT_GN_STOP_TOL, or 0 with DEXCT_GN_EXACT=1 (read once).
   double tol = options ? options->stop_tol : -1.0;
-  if (!(tol >= 0.0)) {
-    const char* xe = getenv("DEXCT_GN_EXACT");
-    const char* te = getenv("DEXCT_GN_STOP_TOL");
-    tol = (xe && xe[0] == '1') ? 0.0 : (te ? atof(te) : DEXCT_GN_DEFAULT_STOP_TOL);
-    if (!(tol >= 0.0)) tol = 0.0;
-  }
+  if (!(tol >= 0.0)) tol = env.default_tol;
   if (!exact_exit) tol = 0.0;                         // the full loop is the full loop
-  // a walk from the reference's start value ends by the tolerance rule only when the step before contracted too (gn_converged);
-  // DEXCT_GN_CONFIRM=0: the rule as first shipped this round
-  const char* cfe = getenv("DEXCT_GN_CONFIRM");
-  const int confirm_flag = (cfe && cfe[0] == '0') ? 0 : 4;
+  // a walk from the reference's start value ends by the tolerance rule only when the step before contracted too (gn_converged)
+  const int confirm_flag = 4;
   if (pass != 0 && !(tol > 0.0)) return DEXCT_EINVAL;  // both passes end pixels by the tolerance rule
   const dim3 grid((unsigned)nblk), block(kGnBlock);
   if (n_bins > 1) {
     hipLaunchKernelGGL((gn_kernel<false, true>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, 0, n_bins, bin_div, mask_max, mask_frac, exact_exit | confirm_flag, tol, tl, out_a);
   } else if (precision == 0) {
-    // Lane refill from a queue of 64-pixel tiles; no more workgroups than can be resident: 28 KB of LDS and the registers allow 4 - 5 per CU
-    // (those beyond would start when the queue is already empty).  Round 3 measured the fetch size: 64 / 128 / 256 / 512 /
-    // 1024 pixels = 766 / 764 / 769 / 771 / 773 ms on the benchmark sinograms and 64 ahead below 1e8 pixels
+    // Lane refill from a queue of 64-pixel tiles; no more workgroups than can be resident: 28 - 35 KB of LDS and the registers
+    // allow 4 per CU (those beyond would start when the queue is already empty).  Round 3 measured the fetch size: 64 / 128 /
+    // 256 / 512 / 1024 pixels = 766 / 764 / 769 / 771 / 773 ms on the benchmark sinograms and 64 ahead below 1e8 pixels
     // (tools/probes/gn_small2.py): the tail of a launch is the last fetches' slowest pixels.
     static const int n_cu = [] {             // queried once per process (one GPU per process)
       int dev_id = 0, n = 0;
@@ -1361,24 +1556,16 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
         n = 256;
       return n;
     }();
-    const char* be = getenv("DEXCT_GN_BLOCKS_PER_CU");          // tuning knob
-    // Register allocation: 4 waves per SIMD with 110 VGPRs and NO scratch (the default since round 4), or 5 with 96 VGPRs
-    // and 48 B of scratch per lane (DEXCT_GN_MINW=5).  Same speed within 1 % (profiles/r04_gn.md), but the spill traffic of
-    // the 5-wave form is written back to HBM: WRITE_SIZE 1.45 x the results against 1.06 - 1.09 x.
-    const char* ve = getenv("DEXCT_GN_MINW");
-    const int minw = (ve && atoi(ve) == 5) ? 5 : 4;
-    const int64_t cap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : minw);
+    const int per_cu = (options && options->blocks_per_cu > 0) ? options->blocks_per_cu : env.blocks_per_cu;
+    const int64_t cap = (int64_t)n_cu * (per_cu > 0 ? per_cu : 4);
     int64_t nb = (tl.n_tiles + kGnBlock / kWave - 1) / (kGnBlock / kWave);
     if (nb > cap) nb = cap;
     unsigned long long* counters = reinterpret_cast<unsigned long long*>(ws) + 9;
     // the cooperative kernel below DEXCT_GN_COOP_BELOW pixels (options->kernel: 1 / 2 force one or the other)
-    const char* cbe = getenv("DEXCT_GN_COOP_BELOW");
-    const int64_t coop_below = cbe ? atoll(cbe) : kCoopBelowDefault;
     const int which = options ? options->kernel : 0;
-    // small sinograms: thick tiles first (DEXCT_GN_SORT=0 keeps the natural order)
+    // small sinograms: thick tiles first (DEXCT_GN_FLAG_NATURAL_ORDER / DEXCT_GN_SORT=0 keep the natural order)
     const int* order = nullptr;
-    const char* se = getenv("DEXCT_GN_SORT");
-    if (pass == 0 && tl.n_tiles <= kMaxSortTiles && tl.n_tiles > 1 && !(se && se[0] == '0')) {    // (the passes: ~2 steps a pixel)
+    if (pass == 0 && tl.n_tiles <= kMaxSortTiles && tl.n_tiles > 1 && env.sort && !(oflags & DEXCT_GN_FLAG_NATURAL_ORDER)) {
       char* base = reinterpret_cast<char*>(workspace) + gn_ws_tables_bytes(n_energies, n_bins);
       int* hist = reinterpret_cast<int*>(base);
       int* ord = hist + kSortBuckets;
@@ -1393,40 +1580,31 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
       DEXCT_LAUNCH_CHECK();
       order = ord;
     }
-    unsigned char* iters = options ? options->iterations : nullptr;
     // tiles a wave reserves per atomic on the queue head: 1 for the single launch (measured in round 3: larger fetches gain
-    // nothing at ~17 steps per pixel and lengthen the tail).  On the short-cut passes (two steps per pixel) the one word all
+    // nothing at ~17 steps per pixel and lengthen the tail).  On the short cut (two steps per pixel) the one word all
     // waves of the chip queue for is the limit (12 ns per atomic): 2 / 4 / 8 tiles per reservation once a wave gets 3 / 8 / 128
     // tiles on average (tools/probes/gn_tpf_small.py, 1 / 2 / 4 / 8 tiles: 1200 x 800: 0.69 / 0.57 / 0.60 / 0.74 ms; 2.6e6 pixels:
     // 1.29 / 0.85 / 0.82 / 0.84; 1.2e7: 4.75 / 2.62 / 2.49 / 2.55; 250 views of the benchmark: 38.7 / 20.4 / 17.7 / 17.6);
     // DEXCT_GN_TILES_PER_FETCH overrides
-    const char* tfe = getenv("DEXCT_GN_TILES_PER_FETCH");
     const int64_t tiles_per_wave = tl.n_tiles / (nb * (kGnBlock / kWave));
-    int tiles_per_fetch = pass == 0 ? 1 : (tiles_per_wave >= 128 ? 8 : tiles_per_wave >= 8 ? 4 : tiles_per_wave >= 3 ? 2 : 1);
-    if (tfe && atoi(tfe) >= 1 && atoi(tfe) <= 1024) tiles_per_fetch = atoi(tfe);
-    // lanes that must be waiting before the hand-out runs (short-cut passes only; see the loop head of gn_refill_kernel)
-    const char* rme = getenv("DEXCT_GN_REFILL_MIN");
-    int refill_min = pass != 0 ? 32 : 0;
-    if (rme && atoi(rme) >= 0 && atoi(rme) <= 64) refill_min = atoi(rme);
-    const int qflags = (tiles_per_fetch << 8) | (refill_min << 20);
-    if (pass == 1)
-      hipLaunchKernelGGL((gn_refill_kernel<4, 1>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
-    else if (pass == 2)
-      hipLaunchKernelGGL((gn_refill_kernel<4, 2>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
-    else if (which == 2 || (which == 0 && n_pix < coop_below)) {
+    int tiles_per_fetch = pass != DEXCT_GN_PASS_SHORTCUT ? 1 : (tiles_per_wave >= 128 ? 8 : tiles_per_wave >= 8 ? 4 : tiles_per_wave >= 3 ? 2 : 1);
+    if (env.tiles_per_fetch >= 1) tiles_per_fetch = env.tiles_per_fetch;
+    const int kflags = exact_exit | (order ? 2 : 0) | confirm_flag | (tiles_per_fetch << 8);
+    if (pass == DEXCT_GN_PASS_COUNT)
+      hipLaunchKernelGGL((gn_refill_kernel<true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, options->iterations);
+    else if (pass == DEXCT_GN_PASS_SHORTCUT)
+      hipLaunchKernelGGL(gn_shortcut_kernel, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, start);
+    else if (which == 2 || (which == 0 && n_pix < env.coop_below)) {
       int64_t ncb = tl.n_tiles;
-      const int64_t ccap = (int64_t)n_cu * (be && atoi(be) > 0 ? atoi(be) : 3);
+      const int64_t ccap = (int64_t)n_cu * (per_cu > 0 ? per_cu : 3);
       if (ncb > ccap) ncb = ccap;
       hipLaunchKernelGGL(gn_coop_kernel, dim3((unsigned)ncb), dim3(kCoopWaves * kWave), 0, st, g1, g2, g_is_f64, (long long)n_pix,
                          (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag, tol, out_a, counters);
-    } else if (minw == 4)
-      hipLaunchKernelGGL((gn_refill_kernel<4, 0>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
-    else
-      hipLaunchKernelGGL((gn_refill_kernel<5, 0>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, exact_exit | (order ? 2 : 0) | confirm_flag | qflags, tol, out_a, counters, iters, start);
+    } else
+      hipLaunchKernelGGL((gn_refill_kernel<false>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, nullptr);
   } else {
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, 0.0, tl, out_a);

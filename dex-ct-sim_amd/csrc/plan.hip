@@ -214,30 +214,79 @@ int dexct_abi_version(void) { return DEXCT_ABI_VERSION; }
 // copy the process has already loaded (the host framework's, e.g. torch's) or, failing that, from librccl.so.1 -
 // two RCCL instances in one process must not happen.
 typedef int (*dexct_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*dexct_send_fn)(const void*, size_t, int, int, void*, hipStream_t);
+typedef int (*dexct_recv_fn)(void*, size_t, int, int, void*, hipStream_t);
+typedef int (*dexct_group_fn)(void);
 
-static dexct_allgather_fn find_allgather() {
-  static dexct_allgather_fn fn = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+struct RcclSymbols {
+  dexct_allgather_fn all_gather = nullptr;
+  dexct_send_fn send = nullptr;
+  dexct_recv_fn recv = nullptr;
+  dexct_group_fn group_start = nullptr, group_end = nullptr;
+};
+
+static const RcclSymbols& rccl() {
+  static const RcclSymbols sym = [] {
+    RcclSymbols r;
     const char* names[] = {"librccl.so.1", "librccl.so"};
     void* h = nullptr;
     for (const char* n : names)
       if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
     for (const char* n : names)
       if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (h) fn = reinterpret_cast<dexct_allgather_fn>(dlsym(h, "ncclAllGather"));
-  }
-  return fn;
+    if (h) {
+      r.all_gather = reinterpret_cast<dexct_allgather_fn>(dlsym(h, "ncclAllGather"));
+      r.send = reinterpret_cast<dexct_send_fn>(dlsym(h, "ncclSend"));
+      r.recv = reinterpret_cast<dexct_recv_fn>(dlsym(h, "ncclRecv"));
+      r.group_start = reinterpret_cast<dexct_group_fn>(dlsym(h, "ncclGroupStart"));
+      r.group_end = reinterpret_cast<dexct_group_fn>(dlsym(h, "ncclGroupEnd"));
+    }
+    return r;
+  }();
+  return sym;
 }
 
 int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_rank, void* rccl_comm, void* stream) {
   if (!local || !gathered || !rccl_comm || count_per_rank <= 0) return DEXCT_EINVAL;
-  dexct_allgather_fn fn = find_allgather();
+  dexct_allgather_fn fn = rccl().all_gather;
   if (!fn) return DEXCT_ERCCL;
   const int rc = fn(local, gathered, (size_t)count_per_rank, /* ncclFloat32 */ 7, rccl_comm, as_stream(stream));
   if (rc != 0) {
     g_last_hip_error = rc;          // ncclResult_t of the failed call
+    return DEXCT_ERCCL;
+  }
+  return DEXCT_OK;
+}
+
+// The same assembly as point-to-point transfers, one per peer, all inside ONE RCCL group (they run concurrently, each over
+// the direct xGMI link of its pair of GPUs): what the step costs does not depend on which algorithm RCCL picks for an
+// all-gather (a ring is bound by one link).  Ragged shards need no padding.
+int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts, const int64_t* offsets, int32_t rank,
+                      int32_t world, int32_t root, void* rccl_comm, void* stream) {
+  if (!local || !counts || !offsets || !rccl_comm || world < 1 || rank < 0 || rank >= world || root < -1 || root >= world)
+    return DEXCT_EINVAL;
+  const bool receives = root < 0 || root == rank;
+  if (receives && !gathered) return DEXCT_EINVAL;
+  for (int k = 0; k < world; ++k)
+    if (counts[k] < 0 || offsets[k] < 0) return DEXCT_EINVAL;
+  const RcclSymbols& r = rccl();
+  if (!r.send || !r.recv || !r.group_start || !r.group_end) return DEXCT_ERCCL;
+  hipStream_t st = as_stream(stream);
+  if (receives && counts[rank] > 0 && gathered + offsets[rank] != local)         // this rank's own shard: a device copy
+    DEXCT_HIP_TRY(hipMemcpyAsync(gathered + offsets[rank], local, (size_t)counts[rank] * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (world == 1) return DEXCT_OK;
+  int rc = r.group_start();
+  for (int k = 0; k < world && rc == 0; ++k) {
+    if (k == rank) continue;
+    if ((root < 0 || root == k) && counts[rank] > 0)                             // my shard goes to peer k
+      rc = r.send(local, (size_t)counts[rank], /* ncclFloat32 */ 7, k, rccl_comm, st);
+    if (rc == 0 && receives && counts[k] > 0)                                    // peer k's shard lands where it belongs
+      rc = r.recv(gathered + offsets[k], (size_t)counts[k], 7, k, rccl_comm, st);
+  }
+  const int rc_end = r.group_end();                                              // (always closed, also after a failed call)
+  if (rc == 0) rc = rc_end;
+  if (rc != 0) {
+    g_last_hip_error = rc;
     return DEXCT_ERCCL;
   }
   return DEXCT_OK;

@@ -68,6 +68,10 @@ def main(argv=None):
     ap.add_argument('--gn-exact', action='store_true',
                     help='run the fixed iteration count of matdecomp.py:114 bit for bit (stop_tol = 0) instead of ending a '
                          'pixel once the distance it still has to go is below 1e-12 relative (the default)')
+    ap.add_argument('--gn-audit', default='100', metavar='PPM[,strict]',
+                    help='sampled audit of the Newton short cut: that many pixels per million are solved again with the fixed '
+                         'iteration count in the same call and compared (<= 1e-12, same NaN pattern); a difference warns, or '
+                         'raises with ",strict"; 0 = off (the library default; this script switches it on)')
     ap.add_argument('--show', action='store_true')
     ap.add_argument('--noise', default='off', choices=['off', 'gaussian', 'poisson'],
                     help='quantum noise for the dose of each spectrum (default off: the noise-free expectation); '
@@ -124,7 +128,9 @@ def main(argv=None):
             print('Decomposing into basis material sinograms!')
             matsino1, matsino2 = get_basismat_sinos(ct, sinos[0][0], sinos[1][0], specs[0], specs[1],
                                                     n_iters=args.n_iters, verbose=True,     # progress lines of :111-112
-                                                    stop_tol=0.0 if args.gn_exact else None)
+                                                    stop_tol=0.0 if args.gn_exact else None,
+                                                    audit=float(args.gn_audit.split(',')[0]),
+                                                    audit_strict=args.gn_audit.endswith(',strict'))
             if rank == 0:
                 os.makedirs(sub_dir, exist_ok=True)
                 print(f'\n*** {sub_dir} ***')

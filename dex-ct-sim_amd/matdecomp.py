@@ -52,44 +52,88 @@ def _as_device_counts(x, dev):
     return to_dev(a.astype(np.float32 if dt == torch.float32 else np.float64, copy=False), dt, dev)
 
 
-# Tolerance stop of the Newton iteration (include/dexct.h, dexct_gn_options).  None = the library default: 1e-12 unless the
-# environment says otherwise (DEXCT_GN_STOP_TOL=<t>, DEXCT_GN_EXACT=1).  0 = the reference's fixed count, bit for bit.
-DEFAULT_STOP_TOL = None
+# Tolerance stop of the Newton iteration (include/dexct.h, dexct_gn_options).  None = the default below; 0 = the reference's
+# fixed count, bit for bit.  The default is resolved ONCE, here, from the environment (DEXCT_GN_EXACT=1 -> 0,
+# DEXCT_GN_STOP_TOL=<t>, else 1e-12) and every call hands the library an explicit value: one parser, no drift between what the
+# host calibrates the short cut for and what the library runs.
+def _default_stop_tol():
+    if os.environ.get('DEXCT_GN_EXACT', '')[:1] == '1':
+        return 0.0
+    t = os.environ.get('DEXCT_GN_STOP_TOL')
+    if t is None or t.strip() == '':
+        return 1.0e-12
+    try:
+        v = float(t)
+    except ValueError:
+        raise ValueError(f'DEXCT_GN_STOP_TOL={t!r} is not a number') from None
+    if not v >= 0.0:
+        raise ValueError(f'DEXCT_GN_STOP_TOL={t!r} must be >= 0')
+    return v
 
-# The short cut of the Newton solve (include/dexct.h, dexct_gn_options.pass / .start; csrc/gn.hip gn_start).  Most of the
-# reference's ~17 Newton steps per pixel are the walk from its start value 1e-6 to the neighbourhood of the solution; what it
-# returns is the fixed point its walk ends at.  That is a function of the pixel's two counts alone, so it is tabulated once
-# per pair of spectra: the library's own single launch (full tables, from 1e-6) is run on the counts at the corners of a
-# 128 x 128 cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / 16, and once more on the cell centres as a check
-# (quadrature.newton_start_grid / assemble_start / validate_start: where does the walk end, after how many steps, is that an
-# isolated root of the two equations, how smoothly does it vary).  A pixel whose counts fall in an open cell - the walk ends by
-# the tolerance rule within n_iters steps at all corners around it, at well-conditioned roots that vary smoothly (no boundary
-# between two basins), the attenuation is not beyond exp(-12) - starts from the Catmull-Rom interpolant of those fixed points (1e-6 of |a| from its own)
-# and takes TWO steps on the full tables: the second is the tolerance rule's evidence that the FULL model has converged to
-# stop_tol.  The result is accepted only within the cell's radius of the interpolant (the reference's branch); a pixel
-# without that evidence or acceptance, or in a closed cell (few steps asked for, an ill-conditioned pair, counts outside the
-# grid, NaN), is solved from 1e-6 with all n_iters steps in the same launch.  What comes out is, per pixel, a fixed point of
-# the full model verified to stop_tol on the reference's branch, or the reference's own trajectory: the contract of the
-# single launch with the tolerance stop, asserted against the exact count on every pixel of the benchmark (bench.py,
-# tests/test_gpu_full_scale.py), on the reference goldens at 1 / 2 / 5 / 50 iterations and in tools/soak_gn.py.
+
+DEFAULT_STOP_TOL = _default_stop_tol()
+
+# The short cut of the Newton solve (include/dexct.h, dexct_gn_options.pass / .start; csrc/gn.hip gn_start, gn_shortcut_kernel).
+# Most of the reference's ~17 Newton steps per pixel are the walk from its start value 1e-6 to the neighbourhood of the
+# solution; what it returns is the fixed point its walk ends at.  That is a function of the pixel's two counts alone, so it is
+# tabulated once per pair of spectra: the library's own single launch (full tables, from 1e-6, counting steps) is run on the
+# counts at the corners of a 128 x 128 cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / 16, and once more on the cell
+# centres as a check (quadrature.newton_start_grid / assemble_start / validate_start: where does the walk end, after how many
+# steps, is that an isolated root of the two equations, how smoothly does it vary).  A pixel whose counts fall in an open cell
+# - the walk ends by the tolerance rule within n_iters steps at all corners around it, at well-conditioned roots that vary
+# smoothly (no boundary between two basins), the attenuation is not beyond exp(-12) - starts from the Catmull-Rom interpolant
+# of those fixed points (1e-6 of |a| from its own) and takes TWO steps on the full tables: the second is the tolerance rule's
+# evidence that the FULL model has converged to stop_tol.  The result is accepted only within the cell's radius of the
+# interpolant (the reference's branch); a pixel without that evidence or acceptance, or in a closed cell (few steps asked
+# for, counts outside the grid, NaN), is solved from 1e-6 with all n_iters steps in the same launch.  What comes out is, per
+# pixel, a fixed point of the full model verified to stop_tol on the reference's branch, or the reference's own trajectory:
+# the contract of the single launch with the tolerance stop, asserted against the exact count on every pixel of the benchmark
+# (bench.py, tests/test_gpu_full_scale.py), on the reference goldens at 1 / 2 / 5 / 50 iterations and in tools/soak_gn.py.
 # 2.0 full-table steps per pixel instead of ~17.
+#
+# ILL-POSED PAIRS run the reference's fixed count.  Where the calibration itself shows that the pair of spectra does not
+# determine two thicknesses (quadrature.pair_is_ill_posed: the walk ends non-finite or without the rule on a measurable share
+# of the corner grid - the MV / kV pairs, the class of the reference's live pair, main.py:101) the default is stop_tol = 0 for
+# that pair: the tolerance rule on the wandering pixels of such a pair was the only place where the default ever differed from
+# the exact count (profiles/r04_gn_noisy_public.log), and it saved 15 % there.  An explicit stop_tol > 0 is honoured.
+#
 # Modes (``two_level=`` of the calls below; DEXCT_GN_TWO_LEVEL in the environment; DEFAULT_TWO_LEVEL):
 #   None / True / 'start'   the above (one launch)
-#   'coarse'     two launches: ~2 steps on a SHORT quadrature of the spectra (quadrature.coarse_newton_tables: ~23 of 140
-#                energies) from the same start values, then the full tables from there.  The first form of the short cut, when
-#                start values came from a polynomial and cost three full steps; with the interpolated fixed points it is 15 %
-#                slower than 'start' (profiles/r04_gn_two_level.md) and kept as an option
-#   False / '0'  the single launch from 1e-6
+#   False / '0'             the single launch from 1e-6
 # It applies to float64 with one shared spectrum, the tolerance stop on, 4 <= n_iters <= 254 and >= 48 energies; anything
 # else runs the single launch.
-DEFAULT_TWO_LEVEL = None
+DEFAULT_TWO_LEVEL = {'0': False, '1': True, 'start': 'start'}.get(os.environ.get('DEXCT_GN_TWO_LEVEL', ''), None)
+
+# Sampled audit of the short cut (``audit=`` of the calls below; DEXCT_GN_AUDIT=<ppm>[,strict] in the environment): that many
+# pixels per million, chosen by the device's Philox generator, are solved again with the reference's fixed count in the same
+# call and compared (<= 1e-12 relative, same finite / NaN pattern); a difference warns (GnAuditWarning) or, strict, raises
+# (GnAuditError) with the worst pixel's counts.  Off by default; main.py switches it on.
+def _default_audit():
+    v = os.environ.get('DEXCT_GN_AUDIT', '')
+    if not v:
+        return 0.0, False
+    parts = v.split(',')
+    return float(parts[0]), (len(parts) > 1 and parts[1].strip() == 'strict')
+
+
+DEFAULT_AUDIT_PPM, DEFAULT_AUDIT_STRICT = _default_audit()
+AUDIT_TOL = 1.0e-12
+
+
+class GnAuditWarning(UserWarning):
+    pass
+
+
+class GnAuditError(RuntimeError):
+    pass
+
 
 _last_ws = []          # workspaces of the most recent call (one per view chunk of the pipelined boundary)
-_last_ws_coarse = []   # ... of its coarse launches ('coarse' mode of the short cut)
-_last_events = []      # (before, between, after) events of the launches of the most recent call(s)
+_last_events = []      # (before, after) events of the launches of the most recent call(s)
 _last_zeroed = None
+_last_mode = 'single'
+_last_audit = None
 _table_cache = {}
-COARSE_STOP_TOL = 1.0e-7     # tolerance of the coarse launch's stop rule (its model is ~1e-6 from the full one anyway)
 
 
 def last_gn_stats():
@@ -97,55 +141,146 @@ def last_gn_stats():
     get_basismat_sinos call - (synchronises): ``pixel_iterations`` = Newton steps the float64 shared-spectrum kernels
     actually executed (the exits end pixels before n_iters; masked air pixels run none), ``stalled_lane_steps`` = lane-steps
     a wave could not hand out because all its result slots waited for stragglers.  0 for the mixed-precision and
-    per-channel-spectrum kernels, which do not count."""
+    per-channel-spectrum kernels, which do not count.  ``mode``: 'start' (the short cut), 'single', or 'exact (ill-posed
+    pair)'; ``audit``: the last sampled audit, if any."""
     if not _last_ws:
         return None
     words = torch.stack([w[72:104].view(torch.int64) for w in _last_ws]).sum(dim=0).tolist()
-    st = {'pixel_iterations': int(words[0]), 'stalled_lane_steps': int(words[3]), 'launches': len(_last_ws)}
-    if _last_ws_coarse:
-        # 'coarse' mode: 'pixel_iterations' are the steps on the FULL tables, these the steps on the short ones
-        cw = torch.stack([w[72:104].view(torch.int64) for w in _last_ws_coarse]).sum(dim=0).tolist()
-        st['coarse_pixel_iterations'] = int(cw[0])
-        st['coarse_energies'] = _last_coarse_ne
-    st['mode'] = _last_mode
+    st = {'pixel_iterations': int(words[0]), 'stalled_lane_steps': int(words[3]), 'launches': len(_last_ws), 'mode': _last_mode}
     if _last_events:
         torch.cuda.synchronize()
-        st['coarse_ms'] = sum(e[0].elapsed_time(e[1]) for e in _last_events)
-        st['main_ms'] = sum(e[1].elapsed_time(e[2]) for e in _last_events)       # the single launch / the refining launch
+        st['main_ms'] = sum(e[0].elapsed_time(e[1]) for e in _last_events)
+    if _last_audit is not None:
+        st['audit'] = _last_audit
     return st
-
-
-_last_coarse_ne = 0
-_last_mode = 'single'
-
-
-def _effective_stop_tol(stop_tol):
-    """What the library will use (dexct_gn_decompose): an explicit value, else DEXCT_GN_EXACT / DEXCT_GN_STOP_TOL / 1e-12;
-    0 under DEXCT_GN_FULL_LOOP=1."""
-    if os.environ.get('DEXCT_GN_FULL_LOOP', '')[:1] == '1':
-        return 0.0
-    if stop_tol is not None and stop_tol >= 0:
-        return float(stop_tol)
-    if os.environ.get('DEXCT_GN_EXACT', '')[:1] == '1':
-        return 0.0
-    try:
-        t = float(os.environ.get('DEXCT_GN_STOP_TOL', '1e-12'))
-    except ValueError:
-        t = 0.0
-    return t if t >= 0 else 0.0
 
 
 def _host_tables(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
 
 
-def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12, want_short=False):
-    """(i0_d [2, nBins, nE], mus_d [2, nE], tabs) for host or device tables, cached by content; ``want_coarse``: prepare the
-    short cut - tabs = [i0_short_d [2, 1, n] or None, mus_short_d [2, n] or None (``want_short``: the 'coarse' mode's short
-    spectra), start array (the gate's table, csrc/gn.hip gn_start)] or None when the spectra allow no short cut;
-    ``cal_tol``: the tolerance the gate is calibrated for.  Tables given as device tensors are used as they are - and read
-    back once per call when the short cut is wanted: pass host arrays to avoid that synchronisation."""
-    if isinstance(i0, torch.Tensor) and isinstance(mus, torch.Tensor) and not want_coarse:
+def _walk(lib, dev, i0_d, mus_d, n_e, g, cal_tol):
+    """The reference's iteration (the library's own kernel, full tables, from 1e-6, counting steps) on counts g [n, 2]:
+    (steps until the tolerance rule fired | 255, where it ended)."""
+    g_d = to_dev(np.ascontiguousarray(g.T), torch.float64, dev)
+    n_c = g_d.shape[1]
+    a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
+    k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, 1), dtype=torch.uint8, device=dev)
+    _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(i0_d), ptr(mus_d), n_e, 1, 1, 254, 0, 0, None, 0.95,
+                                         ptr(a_c), _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COUNT, k_c.data_ptr()),
+                                         ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
+    return k_c.cpu().numpy(), a_c.cpu().numpy()
+
+
+def calibrate_gate(i0_h, mus_h, i0_d, mus_d, dev, cal_tol):
+    """THE GATE of the short cut (csrc/gn.hip, gn_start): the reference's iteration run on the counts at the corners of a cell
+    grid in data space; where it ends, after how many steps, and how smoothly that varies decides where pixels may take the
+    short cut and where they start; then the table is checked against what it stands for at every cell's centre.
+    Returns (start array or None, stats) - stats says what the calibration saw of the pair (quadrature.pair_is_ill_posed)."""
+    from . import quadrature
+    i0_2 = i0_h.reshape(2, -1)
+    pieces = quadrature.newton_start_grid(i0_2, mus_h)
+    if pieces is None:
+        return None, {'grid': False}
+    lib = _native.load()
+    n_e = i0_2.shape[1]
+    steps, roots = _walk(lib, dev, i0_d, mus_d, n_e, pieces['corner_g'], cal_tol)
+    start_h, share, stats = quadrature.assemble_start(pieces, steps, roots)
+    start_h, share, n_bad = quadrature.validate_start(start_h, pieces, *_walk(lib, dev, i0_d, mus_d, n_e, quadrature.cell_centres(pieces), cal_tol))
+    stats = dict(stats, grid=True, open_share=float(share), centres_failed=int(n_bad))
+    return start_h, stats
+
+
+def _lib_fingerprint():
+    """sha256 of the built library (once per process): a cached gate table is only as good as the kernel that made it."""
+    global _lib_hash
+    if _lib_hash is None:
+        import hashlib
+        h = hashlib.sha256()
+        with open(_native.LIB_PATH, 'rb') as f:
+            for blk in iter(lambda: f.read(1 << 20), b''):
+                h.update(blk)
+        _lib_hash = h.hexdigest()
+    return _lib_hash
+
+
+_lib_hash = None
+
+
+def _cache_dir():
+    d = os.environ.get('DEXCT_CACHE_DIR')
+    if d is not None and d.strip().lower() in ('', '0', 'off', 'none'):
+        return None
+    return d or os.path.join(os.path.expanduser('~'), '.cache', 'dexct')
+
+
+def _gate_cache_path(i0_h, mus_h, cal_tol):
+    d = _cache_dir()
+    if d is None:
+        return None
+    import hashlib
+    from . import quadrature
+    h = hashlib.sha256()
+    h.update(f'{_native.ABI_VERSION}|{quadrature.GATE_VERSION}|{cal_tol!r}|{i0_h.shape}|{_lib_fingerprint()}'.encode())
+    h.update(i0_h.tobytes())
+    h.update(mus_h.tobytes())
+    return os.path.join(d, f'gate_{h.hexdigest()[:32]}.npz')
+
+
+def _gate_from_disk(path, i0_h, mus_h):
+    """(start, stats) of an earlier process, or None: the file must be complete, carry its own checksum and agree with the
+    grid this process would lay out for the tables (a stale, truncated or foreign file is ignored, never trusted)."""
+    if path is None or not os.path.exists(path):
+        return None
+    try:
+        import hashlib
+        import json
+        from . import quadrature
+        with np.load(path, allow_pickle=False) as z:
+            start_h = np.ascontiguousarray(z['start'], dtype=np.float64) if z['start'].size else None
+            stats = json.loads(str(z['stats']))
+            digest = str(z['digest'])
+        blob = b'' if start_h is None else start_h.tobytes()
+        if hashlib.sha256(blob + json.dumps(stats, sort_keys=True).encode()).hexdigest() != digest:
+            return None
+        if start_h is not None:
+            pieces = quadrature.newton_start_grid(i0_h.reshape(2, -1), mus_h)
+            n = quadrature.GATE_CELLS
+            if (pieces is None or start_h.shape != (quadrature.START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n,)
+                    or not np.array_equal(start_h[:quadrature.START_HEADER], pieces['head'])):
+                return None
+        return start_h, stats
+    except Exception:
+        return None
+
+
+def _gate_to_disk(path, start_h, stats):
+    if path is None:
+        return
+    try:
+        import hashlib
+        import json
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        blob = b'' if start_h is None else start_h.tobytes()
+        digest = hashlib.sha256(blob + json.dumps(stats, sort_keys=True).encode()).hexdigest()
+        tmp = f'{path}.{os.getpid()}.tmp'
+        with open(tmp, 'wb') as f:
+            np.savez(f, start=np.zeros(0) if start_h is None else start_h, stats=json.dumps(stats, sort_keys=True), digest=digest)
+        os.replace(tmp, path)             # atomic: a reader sees the old file or the whole new one
+    except OSError:
+        pass                              # (a read-only home directory: the table is simply not kept)
+
+
+def _device_tables(i0, mus, dev, want_gate, cal_tol=1.0e-12):
+    """(i0_d [2, nBins, nE], mus_d [2, nE], gate) for host or device tables, cached by content; ``want_gate``: prepare the short
+    cut - gate = {'start': device array | None, 'ill_posed': bool, 'stats': ...} (None when not wanted); ``cal_tol``: the
+    tolerance the gate is calibrated for.  Tables given as device tensors are used as they are - and read back once per call
+    when the short cut is wanted: pass host arrays to avoid that synchronisation.  The gate comes from this process's cache,
+    else from DEXCT_CACHE_DIR (default ~/.cache/dexct; validated on load), else from a calibration (two launches + host NumPy,
+    ~0.1 s) whose result is stored in both - only after it succeeded: a calibration that raises leaves nothing behind and is
+    tried again by the next call."""
+    if isinstance(i0, torch.Tensor) and isinstance(mus, torch.Tensor) and not want_gate:
         i0_d, mus_d = to_dev(i0, torch.float64, dev), to_dev(mus, torch.float64, dev)
         return (i0_d[:, None, :].contiguous() if i0_d.dim() == 2 else i0_d), mus_d, None
     i0_h, mus_h = np.ascontiguousarray(_host_tables(i0), dtype=np.float64), np.ascontiguousarray(_host_tables(mus), dtype=np.float64)
@@ -158,61 +293,92 @@ def _device_tables(i0, mus, dev, want_coarse, cal_tol=1.0e-12, want_short=False)
         if i0_d.dim() == 2:
             i0_d = i0_d[:, None, :].contiguous()
         ent = _table_cache[key] = {'i0': i0_d, 'mus': mus_d}
-    if want_coarse and ('coarse', cal_tol) not in ent:
-        ent[('coarse', cal_tol)] = None
+    if want_gate and ('gate', cal_tol) not in ent:
+        gate = {'start': None, 'ill_posed': False, 'stats': {'grid': False}, 'source': 'none'}
         if i0_h.ndim == 2 or i0_h.shape[1] == 1:
             from . import quadrature
-            i0_2 = i0_h.reshape(2, -1)
-            pieces = quadrature.newton_start_grid(i0_2, mus_h)
-            start = None
-            if pieces is not None:
-                # THE GATE (csrc/gn.hip, gn_start): the reference's iteration - the library's own kernel, full tables, from
-                # 1e-6 - run on the counts at the corners of a cell grid in data space; where it ends, after how many steps,
-                # and how smoothly that varies decides where pixels may take the short cut and where they start
-                lib = _native.load()
+            path = _gate_cache_path(i0_h, mus_h, cal_tol)
+            got = _gate_from_disk(path, i0_h, mus_h)
+            if got is not None:
+                start_h, stats = got
+                gate['source'] = 'disk'
+            else:
+                start_h, stats = calibrate_gate(i0_h, mus_h, ent['i0'], ent['mus'], dev, cal_tol)     # (may raise: nothing is stored then)
+                _gate_to_disk(path, start_h, stats)
+                gate['source'] = 'calibration'
+            gate['stats'] = stats
+            gate['ill_posed'] = bool(quadrature.pair_is_ill_posed(stats))
+            if start_h is not None and not gate['ill_posed'] and stats.get('open_share', 0.0) >= 0.1:
+                gate['start'] = to_dev(start_h, torch.float64, dev)
+        ent[('gate', cal_tol)] = gate
+    return ent['i0'], ent['mus'], (ent.get(('gate', cal_tol)) if want_gate else None)
 
-                def walk(g):
-                    """the reference's iteration on counts g [n, 2]: (steps until the tolerance rule fired | 255, where)"""
-                    g_d = to_dev(np.ascontiguousarray(g.T), torch.float64, dev)
-                    n_c = g_d.shape[1]
-                    a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
-                    k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
-                    ws = torch.empty(lib.dexct_gn_workspace_bytes(i0_2.shape[1], 1), dtype=torch.uint8, device=dev)
-                    _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(ent['i0']), ptr(ent['mus']), i0_2.shape[1],
-                                                         1, 1, 254, 0, 0, None, 0.95, ptr(a_c),
-                                                         _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COARSE, k_c.data_ptr()),
-                                                         ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
-                    return k_c.cpu().numpy(), a_c.cpu().numpy()
 
-                start_h, share = quadrature.assemble_start(pieces, *walk(pieces['corner_g']))
-                # ... and the table is checked against what it stands for at every cell's centre
-                start_h, share, _ = quadrature.validate_start(start_h, pieces, *walk(quadrature.cell_centres(pieces)))
-                if share >= 0.1:                # (an ill-conditioned pair: the reference's iteration itself wanders)
-                    start = to_dev(start_h, torch.float64, dev)
-            if start is not None:
-                ent[('coarse', cal_tol)] = [None, None, start]
-    tabs = ent.get(('coarse', cal_tol)) if want_coarse else None
-    if tabs is not None and want_short and 'short' not in ent:
-        # the short tables of the 'coarse' mode (only when it is asked for: 40 ms of host time per pair of spectra)
-        from . import quadrature
-        red = quadrature.coarse_newton_tables(i0_h.reshape(2, -1), mus_h)
-        ent['short'] = None if red is None else (to_dev(np.ascontiguousarray(red[1])[:, None, :], torch.float64, dev),
-                                                 to_dev(np.ascontiguousarray(mus_h[:, red[0]]), torch.float64, dev))
-    if tabs is not None and want_short and ent.get('short') is not None:
-        tabs = [ent['short'][0], ent['short'][1], tabs[2]]
-    return ent['i0'], ent['mus'], tabs
+_audit_calls = 0
+
+
+def _audit(g1, g2, a, i0, mus, n_iters, ppm, strict, out_rc, mask_max, mask_frac, merge=False):
+    """Sampled audit of a default-mode result ``a`` (see DEFAULT_AUDIT_PPM): re-solve ~ppm pixels per million with the
+    reference's fixed count (stop_tol = 0, the single launch) and compare.  ``merge``: add to the record of the call's earlier
+    chunks."""
+    global _last_audit, _audit_calls
+    before = _last_audit if merge else None
+    n_pix = g1.numel()
+    m = int(min(max(round(n_pix * ppm * 1e-6), min(n_pix, 64)), n_pix, 1 << 22))
+    gen = torch.Generator(device=g1.device)           # Philox on the device; another sample in every call, the same in every run
+    gen.manual_seed(0x5EED + _audit_calls)
+    _audit_calls += 1
+    idx = torch.randint(n_pix, (m,), generator=gen, device=g1.device)
+    s1, s2 = g1.reshape(-1)[idx].contiguous(), g2.reshape(-1)[idx].contiguous()
+    if out_rc is not None:                             # where pixel (v, c, r) of the input went: [v][r][c]
+        rows, chans = out_rc
+        v, rem = idx // (rows * chans), idx % (rows * chans)
+        c, r = rem // rows, rem % rows
+        oidx = (v * rows + r) * chans + c
+    else:
+        oidx = idx
+    got = a.reshape(-1, 2)[oidx]
+    global _last_ws, _last_events, _last_mode
+    keep = (_last_ws, _last_events, _last_mode)
+    want = gn_device(s1, s2, i0, mus, n_iters, 'f64', mask_max=mask_max, mask_frac=mask_frac, stop_tol=0.0, kernel=1, two_level=False, audit=0)
+    _last_ws, _last_events, _last_mode = keep
+    rel = (got - want).abs() / want.abs().amax(dim=-1, keepdim=True).clamp(min=1.0)
+    same_nan = torch.isnan(got) == torch.isnan(want)
+    bad = (~same_nan.all(dim=-1)) | (torch.nan_to_num(rel, nan=0.0).amax(dim=-1) > AUDIT_TOL)
+    n_bad = int(bad.sum().item())
+    worst = float(torch.nan_to_num(rel, nan=0.0).max().item())
+    _last_audit = {'pixels': m + (before['pixels'] if before else 0), 'differing': n_bad + (before['differing'] if before else 0),
+                   'max_rel_diff': max(worst, before['max_rel_diff'] if before else 0.0), 'tolerance': AUDIT_TOL}
+    if before and 'worst' in before:
+        _last_audit['worst'] = before['worst']
+    if n_bad:
+        k = int(torch.nan_to_num(rel, nan=float('inf')).amax(dim=-1).argmax().item())
+        msg = (f'Newton short cut audit: {n_bad} of {m} sampled pixels differ from the reference\'s fixed iteration count by more than '
+               f'{AUDIT_TOL:g} (or in their NaN pattern); worst: pixel {int(idx[k])} counts ({float(s1[k])!r}, {float(s2[k])!r}) '
+               f'default {got[k].tolist()} exact {want[k].tolist()}.  Use stop_tol=0 / DEXCT_GN_EXACT=1 and report the tables.')
+        _last_audit['worst'] = {'pixel': int(idx[k]), 'counts': [float(s1[k]), float(s2[k])], 'default': got[k].tolist(), 'exact': want[k].tolist()}
+        if strict:
+            raise GnAuditError(msg)
+        import warnings
+        warnings.warn(msg, GnAuditWarning, stacklevel=3)
+    return _last_audit
 
 
 def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=None, bin_div=1, mask_max=None,
-              mask_frac=0.95, stop_tol=None, out_rc=None, kernel=0, accumulate_stats=False, two_level=None):
+              mask_frac=0.95, stop_tol=None, out_rc=None, kernel=0, accumulate_stats=False, two_level=None, full_loop=False,
+              natural_order=False, blocks_per_cu=0, audit=None, audit_strict=None):
     """g1, g2: device tensors of equal shape; mus: [2, nE] float64; i0: [2, nE] (one spectrum for all
     pixels) or [2, nBins, nE] (pixel p uses row (p // bin_div) % nBins: the reference's general layout).
     ``mask_max``: device float64 scalar (the global maximum of sinogram 1) - pixels with g1 >= mask_frac * max are
     the air pixels get_basismat_sinos zeroes (:204-205); they are written as 0 and not iterated.
-    ``stop_tol``: None = default (DEFAULT_STOP_TOL, else the library's 1e-12), 0 = the fixed iteration count exactly.
+    ``stop_tol``: None = default (DEFAULT_STOP_TOL = 1e-12 unless the environment said otherwise at import; the fixed count
+    for an ill-posed pair of spectra, see above), 0 = the fixed iteration count exactly.
     ``out_rc=(rows, channels)``: the sinograms are [..., channel, row] (row fastest) and the result is written as
     [..., row, channel, 2], the reference's order, by the kernel itself.  ``kernel``: 0 choose, 1 lane per pixel,
     2 cooperative (dexct_gn_options).  ``two_level``: None = DEFAULT_TWO_LEVEL (see there), True / False.
+    ``full_loop``, ``natural_order``, ``blocks_per_cu``: dexct_gn_options.flags / .blocks_per_cu (checking and tuning: results do
+    not depend on the last two, and on the first only through stop_tol = 0).  ``audit`` (pixels per million; None =
+    DEFAULT_AUDIT_PPM), ``audit_strict``: the sampled audit of the short cut (see DEFAULT_AUDIT_PPM).
     Returns a device tensor of shape g1.shape + (2,) float64 (with ``out_rc``: the last two sinogram dimensions swapped)."""
     lib = _native.load()
     dev = g1.device
@@ -221,8 +387,14 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
         raise ValueError(f'precision {precision!r}')
     if g1.shape != g2.shape or g1.dtype != g2.dtype:
         raise ValueError('the two sinograms must agree in shape and dtype')
+    explicit_tol = stop_tol is not None
     if stop_tol is None:
         stop_tol = DEFAULT_STOP_TOL
+    stop_tol = float(stop_tol)
+    if not stop_tol >= 0.0:
+        raise ValueError(f'stop_tol={stop_tol!r}')
+    if full_loop:
+        stop_tol = 0.0
     shp_i0, shp_mu = (tuple(x.shape) if hasattr(x, 'shape') else np.shape(x) for x in (i0, mus))
     if len(shp_i0) not in (2, 3) or shp_i0[0] != 2 or shp_mu != (2, shp_i0[-1]):
         raise ValueError('i0 must be [2, nE] or [2, nBins, nE] and mus [2, nE]')
@@ -231,24 +403,21 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
         precision = 'f64'               # mixed precision exists for the shared-spectrum fast path only
     if two_level is None:
         two_level = DEFAULT_TWO_LEVEL
-        env = os.environ.get('DEXCT_GN_TWO_LEVEL')
-        if env is not None:
-            two_level = {'0': False, '1': True, 'coarse': 'coarse', 'start': 'start'}.get(env, two_level)
     if two_level is None or two_level is True:
         two_level = 'start'
-    if two_level not in (False, 'coarse', 'start'):
+    if two_level not in (False, 'start'):
         raise ValueError(f'two_level={two_level!r}')
-    applies = (precision == 'f64' and n_bins == 1 and kernel != 2 and 4 <= int(n_iters) <= 254 and n_e >= 48
-               and _effective_stop_tol(stop_tol) > 0.0)
-    i0_d, mus_d, tabs = _device_tables(i0, mus, dev, bool(two_level and applies), min(_effective_stop_tol(stop_tol), 1.0e-12) or 1.0e-12,
-                                       want_short=two_level == 'coarse')
-    coarse = start_only = None
-    if tabs is not None:                    # (None: no start values with a usable gate for these spectra - the single launch)
-        i0_s, mus_s, start = tabs
-        if two_level == 'coarse' and i0_s is not None:
-            coarse = (i0_s, mus_s, start)
-        else:
-            start_only = start              # 'start', or 'coarse' for spectra that have no short tables
+    applies = (precision == 'f64' and n_bins == 1 and kernel != 2 and 4 <= int(n_iters) <= 254 and n_e >= 48 and stop_tol > 0.0)
+    # (the gate is consulted for the default tolerance even with two_level=False: an ill-posed pair runs the fixed count)
+    want_gate = applies and (bool(two_level) or not explicit_tol)
+    i0_d, mus_d, gate = _device_tables(i0, mus, dev, want_gate, min(stop_tol, 1.0e-12) or 1.0e-12)
+    start = None
+    mode = 'single'
+    if gate is not None:
+        if gate['ill_posed'] and not explicit_tol:
+            stop_tol, mode = 0.0, 'exact (ill-posed pair)'
+        elif two_level and gate['start'] is not None:
+            start, mode = gate['start'], 'start'
     shape = tuple(g1.shape)
     rows = chans = 0
     if out_rc is not None:
@@ -259,47 +428,34 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     a = out if out is not None else torch.empty(shape + (2,), dtype=torch.float64, device=dev)
     if out is not None and (a.numel() != 2 * g1.numel() or a.dtype != torch.float64 or not a.is_contiguous()):
         raise ValueError('out must be a contiguous float64 tensor with two values per pixel')
-    global _last_zeroed, _last_ws, _last_ws_coarse, _last_coarse_ne, _last_events, _last_mode
+    global _last_zeroed, _last_ws, _last_events, _last_mode, _last_audit
     is64 = int(g1.dtype == torch.float64)
-    ws_c = None
-    iters = None
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record()
-    if coarse is not None:
-        # COARSE launch: the same kernel on the short tables; per pixel, the steps it took (or 255) go to `iters`
-        i0_s, mus_s, start = coarse
-        n_s = int(mus_s.shape[1])
-        iters = torch.empty(g1.numel(), dtype=torch.uint8, device=dev)
-        ws_c = torch.empty(lib.dexct_gn_workspace_bytes(n_s, 1), dtype=torch.uint8, device=dev)
-        ws_c[72:104].zero_()
-        _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), is64, g1.numel(), ptr(i0_s), ptr(mus_s), n_s, 1, 1, int(n_iters),
-                                             0, 0, ptr(mask_max), float(mask_frac), ptr(a),
-                                             _native.gn_options(COARSE_STOP_TOL, rows, chans, 1, _native.GN_PASS_COARSE,
-                                                                iters.data_ptr(), None if start is None else start.data_ptr()),
-                                             ptr(ws_c), stream_ptr()),
-                      'dexct_gn_decompose (coarse pass)')
-        _last_coarse_ne = n_s
-    ev[1].record()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, n_bins), dtype=torch.uint8, device=dev)
     ws[72:104].zero_()       # executed-iteration, progress, queue and stall counters: defined before anybody polls them
     _last_zeroed = torch.cuda.Event()
     _last_zeroed.record()    # a progress poller on another stream waits for this (never reads uninitialised bytes)
-    if coarse is not None:
-        opts = _native.gn_options(stop_tol, rows, chans, 1, _native.GN_PASS_REFINE, iters.data_ptr(), coarse[2].data_ptr())
-    elif start_only is not None:
-        opts = _native.gn_options(stop_tol, rows, chans, 1, _native.GN_PASS_REFINE, None, start_only.data_ptr())
+    flags = (_native.GN_FLAG_FULL_LOOP if full_loop else 0) | (_native.GN_FLAG_NATURAL_ORDER if natural_order else 0)
+    if start is not None:
+        opts = _native.gn_options(stop_tol, rows, chans, 1, _native.GN_PASS_SHORTCUT, None, start.data_ptr(), flags, blocks_per_cu)
     else:
-        opts = _native.gn_options(stop_tol, rows, chans, kernel)
+        opts = _native.gn_options(stop_tol, rows, chans, kernel, 0, None, None, flags, blocks_per_cu)
+    ev[0].record()
     _native.check(lib.dexct_gn_decompose(ptr(g1), ptr(g2), is64, g1.numel(), ptr(i0_d),
                                          ptr(mus_d), n_e, n_bins, int(bin_div), int(n_iters),
                                          int(precision == 'mixed'), int(n_polish), ptr(mask_max), float(mask_frac), ptr(a),
                                          opts, ptr(ws), stream_ptr()),
                   'dexct_gn_decompose')
-    ev[2].record()
+    ev[1].record()
     _last_ws = (_last_ws + [ws]) if accumulate_stats else [ws]
-    _last_ws_coarse = ((_last_ws_coarse if accumulate_stats else []) + ([ws_c] if ws_c is not None else []))
     _last_events = (_last_events if accumulate_stats else []) + [ev]
-    _last_mode = 'coarse' if coarse is not None else ('start' if start_only is not None else 'single')
+    _last_mode = mode
+    if not accumulate_stats:
+        _last_audit = None
+    ppm = DEFAULT_AUDIT_PPM if audit is None else float(audit)
+    if ppm > 0.0 and mode == 'start':
+        _audit(g1, g2, a, i0, mus, n_iters, ppm, DEFAULT_AUDIT_STRICT if audit_strict is None else bool(audit_strict),
+               (rows, chans) if out_rc is not None else None, mask_max, mask_frac, merge=accumulate_stats)
     return a
 
 
@@ -331,7 +487,8 @@ def _progress_lines(ws, n_views, n_bins, done_event, t0, every=20, poll_s=0.05):
         time.sleep(poll_s)
 
 
-def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None, stop_tol=None, two_level=None):
+def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, precision=None, stop_tol=None, two_level=None, audit=None,
+                  audit_strict=None, **gn_knobs):
     """Newton iterations for every pixel (signature of matdecomp.py:20 / :87).
     ``verbose`` prints the reference's progress line every 20 views (:111-112) from the kernel's finished-pixel
     counter; the drop-in callers below pass verbose=False unless asked (a benchmark should not print).
@@ -350,7 +507,8 @@ def optimize_sino(Sino_gg, ee, i0, mus, n_iters, verbose=True, dtype=None, preci
     g = _as_device_counts(np.asarray(Sino_gg), dev)
     import time
     t0 = time.time()
-    a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision, stop_tol=stop_tol, two_level=two_level)
+    a = gn_device(g[0], g[1], i0, np.asarray(mus, dtype=np.float64), n_iters, precision, stop_tol=stop_tol, two_level=two_level, audit=audit,
+                  audit_strict=audit_strict, **gn_knobs)          # (kernel, full_loop, natural_order, blocks_per_cu: see gn_device)
     if verbose:
         done = torch.cuda.Event()
         done.record()
@@ -374,13 +532,13 @@ def decomposition_tables(ct, spec1, spec2):
     return ee, i0, mus
 
 
-def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None, stop_tol=None, two_level=None):
+def do_matdecomp_gn(ct, sino1, sino2, spec1, spec2, n_iters, precision=None, stop_tol=None, two_level=None, audit=None, audit_strict=None):
     """[N_proj, N_channels, 2] density line integrals (matdecomp.py:130-164)."""
     _, i0, mus = decomposition_tables(ct, spec1, spec2)
     dev = device()
     g1 = _as_device_counts(sino1, dev)
     g2 = _as_device_counts(sino2, dev).to(g1.dtype)
-    a = gn_device(g1, g2, i0, mus, n_iters, precision, stop_tol=stop_tol, two_level=two_level)
+    a = gn_device(g1, g2, i0, mus, n_iters, precision, stop_tol=stop_tol, two_level=two_level, audit=audit, audit_strict=audit_strict)
     return a if isinstance(sino1, torch.Tensor) else to_host(a)
 
 
@@ -391,7 +549,8 @@ _PIPE_CHUNKS = 8                 # view chunks of the pipelined host boundary (t
 _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinogram) the plain sequence is as fast
 
 
-def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level=None):
+def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level=None, audit=None,
+                              audit_strict=None):
     """get_basismat_sinos for NumPy sinograms of benchmark size: sinogram 1 goes to the device first (the mask needs its
     global maximum, matdecomp.py:195-196), then per view chunk: sinogram 2's chunk arrives on a copy stream, the Newton
     kernel runs on it, and the finished chunk leaves for page-locked host memory on the copy stream while the next chunk
@@ -431,12 +590,12 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
         t1 = torch.empty((n_views, nC, nR), dtype=dt, device=dev)
         t2 = torch.empty_like(t1)
         eb = 4 if dt == torch.float32 else 8
-    global _last_ws, _last_ws_coarse, _last_events
-    _last_ws, _last_ws_coarse, _last_events = [], [], []
+    global _last_ws, _last_events, _last_audit
+    _last_ws, _last_events, _last_audit = [], [], None
     for (b, e), ev in zip(bounds, arrived):
         main.wait_event(ev)
         kw = dict(out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol, accumulate_stats=True,
-                  two_level=two_level)
+                  two_level=two_level, audit=audit, audit_strict=audit_strict)
         if row_fastest:
             for src, dst in ((g1, t1), (g2, t2)):
                 _native.check(lib.dexct_transpose_batched(ptr(src[b:e]), ptr(dst[b:e]), e - b, nR, nC, eb, stream_ptr()),
@@ -464,7 +623,7 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
 
 
 def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mask_thresh=0.95, precision=None,
-                       strict=False, verbose=False, stop_tol=None, two_level=None):
+                       strict=False, verbose=False, stop_tol=None, two_level=None, audit=None, audit_strict=None):
     """Basis-material sinograms (matdecomp.py:167-207): air mask from sinogram 1
     (``>= mask_thresh * max``), Newton decomposition, masked pixels set to exactly 0.
 
@@ -475,8 +634,12 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     ``verbose=True`` prints the reference's progress line every 20 views (matdecomp.py:111-112; the reference always
     prints it) from the kernel's finished-pixel counter.
     ``stop_tol``: None = the default tolerance stop (1e-12 relative step with a contraction check, include/dexct.h
-    dexct_gn_options; DEXCT_GN_EXACT=1 in the environment makes the default exact); 0 = the reference's fixed iteration
+    dexct_gn_options; DEXCT_GN_EXACT=1 in the environment makes the default exact; a pair of spectra the calibration finds
+    ill-posed - the MV / kV pairs - runs the fixed count by default); 0 = the reference's fixed iteration
     count bit for bit (matdecomp.py:114); the two agree to ~1e-14 on converging pixels and are identical on the others.
+    ``audit`` (pixels per million; None = DEXCT_GN_AUDIT, 0 = off), ``audit_strict``: re-solve a Philox-chosen sample with the
+    fixed count in the same call and warn (GnAuditWarning) or raise (GnAuditError) when the default's result differs by more
+    than 1e-12 or in its NaN pattern.
     ``strict=True``: raise ``SingularHessianError`` (a ``numpy.linalg.LinAlgError``, what :125 raises) if a pixel
     outside the air mask ends non-finite; the default returns the inf/NaN in place, as documented above.
     """
@@ -495,7 +658,7 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
             and np.shape(sino_raw_1)[0] >= 2 * _PIPE_CHUNKS and np.size(sino_raw_1) >= _PIPE_MIN_PIXELS
             and np.shape(sino_raw_1) == np.shape(sino_raw_2)):
         return _basismat_sinos_pipelined(lib, dev, sino_raw_1, sino_raw_2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol,
-                                         two_level)
+                                         two_level, audit, audit_strict)
     g1 = _as_device_counts(sino_raw_1, dev)
     g2 = _as_device_counts(sino_raw_2, dev).to(g1.dtype)
     is64 = int(g1.dtype == torch.float64)
@@ -506,7 +669,7 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
     import time
     t0 = time.time()
     a = gn_device(g1, g2, i0, mus, n_iters, precision, mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol,
-                  two_level=two_level)
+                  two_level=two_level, audit=audit, audit_strict=audit_strict)
     if verbose and rank == 0 and g1.dim() >= 2:
         done = torch.cuda.Event()
         done.record()

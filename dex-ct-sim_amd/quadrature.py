@@ -3,11 +3,12 @@ no ray and no pixel is computed here):
 
 1. ``reduce_tables`` - a shorter energy quadrature for the DETECTION sum, with a verified error bound (opt-in:
    ``quadrature='reduced'``), described below;
-2. the tables of the Newton decomposition's short cut (matdecomp.gn_device; csrc/gn.hip gn_start; include/dexct.h,
+2. the table of the Newton decomposition's short cut (matdecomp.gn_device; csrc/gn.hip gn_start; include/dexct.h,
    dexct_gn_options.pass / .start): ``newton_start_grid`` lays a cell grid over the plane of the two counts,
    ``assemble_start`` / ``validate_start`` turn what the library's own kernel returns on its corners and centres - where the
    reference's walk from 1e-6 ends, after how many steps - into the table of start values, step budgets and acceptance radii
-   (profiles/r04_gn_two_level.md); ``coarse_newton_tables`` builds the short spectra of the optional 'coarse' mode.
+   (profiles/r04_gn_two_level.md); ``pair_is_ill_posed`` reads off the same calibration whether the pair of spectra determines
+   two thicknesses at all (the MV / kV pairs do not: they run the reference's fixed count).
 
 The detected signal of a ray is ``sum_e w[s][e] exp(-sum_m mu[m][e] L_m)`` over the spectrum's energy grid (the weighting the
 reference's decomposition assumes, matdecomp.py:146-150; 134 weighted bins for the 140 kVp spectrum).  As functions of the
@@ -182,89 +183,7 @@ def max_rel_error(mu, w, cols, w_red, L):
     return float(err.max())
 
 
-def _sparse_nonneg_fit(A, tol_inf, prefer=None, max_nodes=64):
-    """Lawson-Hanson non-negative least squares of A x = 1, stopped as soon as every row is met to ``tol_inf`` (or at
-    ``max_nodes`` columns): the active-set method adds one column per round, so stopping early IS the sparse solution.
-    ``prefer`` (boolean per column): columns that win ties - their gradient counts four-fold (nodes other spectra use).
-    Returns x (zeros outside the chosen columns) and the largest row residual."""
-    m, n = A.shape
-    b = np.ones(m)
-    x = np.zeros(n)
-    passive = np.zeros(n, dtype=bool)
-    r = b.copy()
-    boost = np.where(prefer, 4.0, 1.0) if prefer is not None else np.ones(n)
-    for _ in range(3 * max_nodes):
-        if np.abs(r).max() <= tol_inf or passive.sum() >= max_nodes:
-            break
-        g = (A.T @ r) * boost
-        g[passive] = -np.inf
-        j = int(np.argmax(g))
-        if not g[j] > 0.0:
-            break
-        passive[j] = True
-        while True:
-            idx = np.flatnonzero(passive)
-            z = np.linalg.lstsq(A[:, idx], b, rcond=None)[0]
-            if np.all(z > 0.0):
-                x[:] = 0.0
-                x[idx] = z
-                break
-            neg = z <= 0.0                                        # step towards z until the first weight reaches zero; drop it
-            alpha = np.min(x[idx][neg] / (x[idx][neg] - z[neg]))
-            x[idx] = x[idx] + alpha * (z - x[idx])
-            drop = idx[(x[idx] <= 1e-300) | (neg & (np.abs(x[idx]) <= 1e-14 * np.abs(x[idx]).max()))]
-            if drop.size == 0:
-                drop = idx[neg][:1]
-            passive[drop] = False
-            x[drop] = 0.0
-        r = b - A @ x
-    return x, float(np.abs(r).max())
-
-
-def coarse_newton_tables(i0, mus, log_range=16.0, max_err=2.0e-6):
-    """The short tables of the 'coarse' mode of the Newton short cut (matdecomp.gn_device; include/dexct.h, dexct_gn_options.pass):
-    i0 [2, nE] effective spectra, mus [2, nE] basis mass attenuation -> (cols, i0_short [2, n]) or None.
-
-    The decomposition's forward model ``sum_e i0[k][e] exp(-a0 mus[0][e] - a1 mus[1][e])`` is the same kind of sum as the
-    detection; its short quadrature is built for every (a0, a1) >= 0 whose attenuation at the most penetrating energy stays
-    below exp(-log_range) (1e-7 of the open beam: beyond any sinogram a detector delivers).  No guarantee is needed here and
-    none is claimed: the coarse pass only brings a pixel near its solution, the refining pass ends it on the full tables.
-    So the cheap builder is used - a non-negative least-squares fit stopped at ``max_err`` on its sample (some tens of
-    milliseconds; the linear programme of reduce_tables takes seconds) - and checked on fresh points only to decide whether
-    the short tables are used at all."""
-    i0 = np.asarray(i0, dtype=np.float64)
-    mus = np.asarray(mus, dtype=np.float64)
-    if i0.ndim != 2 or mus.shape != (2, i0.shape[1]) or np.any(i0 < 0.0) or not np.all(np.isfinite(mus)):
-        return None
-    used = np.any(i0 > 0.0, axis=0)
-    if not used.any():
-        return None
-    mu_min = mus[:, used].min(axis=1)
-    if np.any(mu_min <= 0.0):
-        return None
-    rng = np.random.default_rng(0)
-    l_max = log_range / mu_min
-    pts = _domain_points(l_max, log_range, 1500, 120, rng, mu_min)
-    chk = _domain_points(l_max, log_range, 6000, 300, rng, mu_min)
-    expo, expo_c = np.exp(-(pts @ mus)), np.exp(-(chk @ mus))
-    chosen = np.zeros(i0.shape[1], dtype=bool)
-    short = np.zeros_like(i0)
-    for s in np.argsort(-np.count_nonzero(i0, axis=1)):
-        cols = np.flatnonzero(i0[s])
-        F = expo @ i0[s]
-        A = expo[:, cols] * i0[s][cols][None, :] / F[:, None]
-        x, _ = _sparse_nonneg_fit(A, 0.5 * max_err, prefer=chosen[cols])
-        short[s, cols] = x * i0[s][cols]
-        Fc = expo_c @ i0[s]
-        if not np.abs(expo_c @ short[s] / Fc - 1.0).max() <= 4.0 * max_err:
-            return None
-        chosen |= short[s] > 0.0
-    keep = np.flatnonzero(chosen)
-    if keep.size * 2 > i0.shape[1]:
-        return None
-    return keep, short[:, keep]
-
-
+GATE_VERSION = 5           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
 START_HEADER = 10          # doubles before the tables (csrc/gn.hip, gn_start)
 GATE_CELLS = 128           # cells per axis of the grid over (ln u0, u1 / u0)
 GATE_U_MIN = 1.0e-4        # smallest u0 = ln(air_0 / g_0) / log_range of the grid: thinner rays walk from 1e-6 (a handful of steps)
@@ -323,7 +242,7 @@ def newton_start_grid(i0, mus, log_range=16.0):
     n = GATE_CELLS
     per_x = n / -np.log(GATE_U_MIN)
     per_t = n / (t_hi - t_lo)
-    head = np.array([air[0], air[1], 1.0 / log_range, float(n), np.log(GATE_U_MIN), per_x, t_lo, per_t, 0.0, 0.0])
+    head = np.array([air[0], air[1], 1.0 / log_range, float(n), np.log(GATE_U_MIN), per_x, t_lo, per_t, np.log(air[0]), np.log(air[1])])
     x = np.log(GATE_U_MIN) + np.arange(n + 1) / per_x
     tt = t_lo + np.arange(n + 1) / per_t
     u0 = np.exp(x)[:, None] * np.ones((1, n + 1))
@@ -365,12 +284,24 @@ def assemble_start(pieces, steps, roots):
     fixed points that vary smoothly over it and along the grid lines through its corners (mixed and axial second differences at
     most half the largest first difference: no boundary between two basins crosses or borders it); it needs the largest step count among its own corners and those of the eight cells around
     it plus GATE_MARGIN (infinity if any of those cells is closed); its acceptance radius is GATE_RADIUS x the spread of its
-    corners' fixed points.  Returns the array and the share of open cells."""
+    corners' fixed points.  Returns the array, the share of open cells, and what the walk did on the corner grid (``stats``,
+    for pair_is_ill_posed)."""
     n = int(pieces['head'][3])
     steps = np.asarray(steps).reshape(n + 1, n + 1).astype(np.float64)
     r = np.asarray(roots, dtype=np.float64).reshape(n + 1, n + 1, 2)
-    good = (steps < 255) & np.all(np.isfinite(r), axis=2) & np.all(np.isfinite(pieces['corner_g']), axis=1).reshape(n + 1, n + 1)
+    finite = np.all(np.isfinite(r), axis=2)
+    good = (steps < 255) & finite & np.all(np.isfinite(pieces['corner_g']), axis=1).reshape(n + 1, n + 1)
     resid, cond = _counts_and_condition(pieces, r.reshape(-1, 2), pieces['corner_g'])
+    # what the reference's walk did on the part of the grid a detector can deliver (attenuation up to exp(-12), GATE_U_MAX)
+    x_c = pieces['head'][4] + np.arange(n + 1) / pieces['head'][5]
+    dom = np.broadcast_to((x_c <= np.log(GATE_U_MAX))[:, None], (n + 1, n + 1))
+    root_ok = good & (resid.reshape(n + 1, n + 1) <= 1.0e-8)
+    cg = cond.reshape(n + 1, n + 1)[root_ok & dom]
+    stats = {'corners': int(dom.sum()), 'walk_nonfinite_share': float((~finite & dom).sum() / dom.sum()),
+             'walk_not_by_rule_share': float(((steps >= 255) & finite & dom).sum() / dom.sum()),
+             'not_a_root_share': float((good & dom & ~root_ok).sum() / dom.sum()),
+             'cond_median': float(np.median(cg)) if cg.size else float('inf'),
+             'cond_p90': float(np.percentile(cg, 90)) if cg.size else float('inf')}
     good &= (resid.reshape(n + 1, n + 1) <= 1.0e-8) & (cond.reshape(n + 1, n + 1) <= GATE_MAX_COND)
     c00, c01, c10, c11 = r[:-1, :-1], r[:-1, 1:], r[1:, :-1], r[1:, 1:]
     with np.errstate(invalid='ignore'):
@@ -403,7 +334,36 @@ def assemble_start(pieces, steps, roots):
     radius = np.where(cell_ok, GATE_RADIUS * spread + 1e-9, 0.0)
     r = np.where(good[:, :, None], r, 0.0)
     out = np.concatenate([pieces['head'], r.ravel(), np.stack([need, radius], axis=-1).ravel()])          # pairs: (a0, a1), (need, radius)
-    return out, float(np.isfinite(need).mean())
+    return out, float(np.isfinite(need).mean()), stats
+
+
+# A pair of spectra is ILL-POSED when it does not determine two thicknesses - MV against kV: above a few hundred keV both basis
+# materials attenuate by Compton scattering alone, their curves are parallel.  The calibration sees it in the reference's own
+# iteration, run on noise-free counts of its own forward model over the part of the data plane a detector can deliver
+# (profiles/r05_pair_classes.log - every pair of the bundled spectra, the benchmark's Kramers pair, the three golden cases):
+#                                 kV / kV (6 cases)      kV / MV (7 cases)      6MV / detunedMV
+#   open cells                    0.845 .. 0.944         0.23 .. 0.70           0.42
+#   walk rests where it does not  0.0001 .. 0.0019       0.17 .. 0.55           0.011
+#     reproduce its counts
+#   median cond of the log-       22 .. 69               31 .. 78               3674
+#     Jacobian at the roots
+# (the share of corners where the walk ends non-finite, 0.1 - 26 %, does not tell the classes apart: those are the corners in
+# the margin the grid adds around the physical ratios).  Ill-posed = the walk comes to rest at points that are no solutions on
+# more than ILL_POSED_NOT_A_ROOT of the plane, or fewer than ILL_POSED_OPEN of the cells are open, or the roots themselves
+# are ill-conditioned.  For such a pair the library runs the reference's fixed count (matdecomp.gn_device): its walk wanders on
+# noisy data, the tolerance rule is no safer there than anywhere on a wandering sequence (the only divergence from the exact
+# count ever seen, profiles/r04_gn_noisy_public.log), and the short cut saved 15 % there.  A false positive costs speed only.
+ILL_POSED_NOT_A_ROOT = 0.05
+ILL_POSED_OPEN = 0.78
+ILL_POSED_COND = 1.0e3
+
+
+def pair_is_ill_posed(stats):
+    """``stats`` of assemble_start + validate_start (via matdecomp.calibrate_gate)."""
+    if not stats or not stats.get('grid', True) or 'not_a_root_share' not in stats:
+        return False
+    return bool(stats['not_a_root_share'] > ILL_POSED_NOT_A_ROOT or stats.get('open_share', 1.0) < ILL_POSED_OPEN
+                or not stats['cond_median'] <= ILL_POSED_COND)
 
 
 def cell_centres(pieces):

@@ -21,9 +21,11 @@
 extern "C" {
 #endif
 
-#define DEXCT_ABI_VERSION 4   /* 2: log_out argument of the projection entry points, dexct_sino_log;
+#define DEXCT_ABI_VERSION 5   /* 2: log_out argument of the projection entry points, dexct_sino_log;
                                  3: struct dexct_gn_options - tolerance stop, results in the reference's order; 256 material ids;
-                                 4: dexct_gn_options.pass / .iterations / .start - the Newton short cut (tabulated fixed points) */
+                                 4: dexct_gn_options.pass / .iterations / .start - the Newton short cut (tabulated fixed points);
+                                 5: dexct_gn_options.flags / .blocks_per_cu (what the environment used to switch per call), the
+                                    two-launch form of the short cut removed, dexct_sino_gather (peer-to-peer assembly) */
 
 #define DEXCT_OK 0
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
@@ -249,18 +251,29 @@ int dexct_siddon_trace(const dexct_fan_geom* geom, const dexct_ray_plan* plan, c
  * torch.distributed (dex-ct-sim_amd/_shard.py). */
 int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_rank, void* rccl_comm, void* stream);
 
-/* Options of dexct_gn_decompose (ABI 3; pass and iterations: ABI 4).  A NULL pointer = every default.
+/* The same assembly as point-to-point transfers (ABI 5; SURVEY section 8e: "each GPU has a direct link to every peer, so
+ * gather-to-root uses 7 links concurrently"): rank r's shard is counts[r] float32 values and belongs at gathered + offsets[r]
+ * (shards may differ in size: no padding).  root >= 0: the gather of BASELINE.json's north star - every other rank sends its
+ * shard to `root`, which receives them in place (`gathered` may be NULL on the other ranks); root = -1: every rank sends its
+ * shard to every peer and receives every peer's (an all-gather made of world-1 sends and receives per rank, each pair over its
+ * own xGMI link).  One ncclGroupStart / ncclGroupEnd around all of them; the rank's own shard is copied on the device unless
+ * local == gathered + offsets[rank].  The Python host reaches the same transfers through torch.distributed
+ * (dex-ct-sim_amd/_shard.py, gather_views(mode='root' | 'direct')). */
+int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts, const int64_t* offsets, int32_t rank,
+                      int32_t world, int32_t root, void* rccl_comm, void* stream);
+
+/* Options of dexct_gn_decompose (ABI 3; pass, iterations, start: ABI 4; flags, blocks_per_cu: ABI 5).  A NULL pointer = every
+ * default.
  *   stop_tol    >= 0: taken as given.  0 = the reference's fixed iteration count, bit for bit (matdecomp.py:114: `for
  *               i in range(n_iters)`).  > 0 = tolerance stop: a float64 pixel also ends, with the state after the step, when
  *               the distance it still has to go - estimated from its last two steps d_k < d_(k-1) as d_k r / (1 - r), r =
  *               d_k / d_(k-1) - is at most stop_tol / 4 * max(|a0|, |a1|, 1), the step before contracted as well (d_(k-1) <
  *               d_(k-2)) and the estimate also holds with the ratio of THAT step (the worse of the two ratios counts): a wandering
  *               pixel's accidental tiny step does not end it, a creeping one is not trusted after one good step
- *               (DEXCT_GN_CONFIRM=0 drops both).  A creeping
- *               (r near 1) or wandering pixel is not stopped and runs to n_iters as in the reference.
+ *               A creeping (r near 1) or wandering pixel is not stopped and runs to n_iters as in the reference.
  *               < 0: the library default = DEXCT_GN_DEFAULT_STOP_TOL (1e-12: seven orders inside the 1e-5 the results
  *               are specified to, three inside the 1e-9 the kernel keeps to the reference's own outputs), or the value of
- *               the environment variable DEXCT_GN_STOP_TOL, or 0 when DEXCT_GN_EXACT=1.
+ *               the environment variable DEXCT_GN_STOP_TOL, or 0 when DEXCT_GN_EXACT=1 (read once per process).
  *   out_rows, out_channels   both 0: out_a[2*p + m] in the order of the pixels.  Both > 0 (n_pix a multiple of their
  *               product): the pixels are given as [..][channel][row] (row fastest - layout 1 of dexct_siddon_project, what
  *               the stacked-fan kernels write) and the results are written as [..][row][channel], the reference's order
@@ -273,42 +286,48 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
  *   pass, iterations, start   the short cut.  What the reference returns is the fixed point its walk from 1e-6 ends at, and
  *               most of its ~17 Newton steps per pixel are that walk.  The end of the walk is a function of the pixel's two
  *               counts alone; the caller tabulates it once per pair of spectra - by running THIS entry point (pass =
- *               DEXCT_GN_PASS_COARSE on the full tables, start = NULL: the reference's iteration, with step counts) on a grid of
- *               counts - and hands the table over as `start` (the Python host: dex-ct-sim_amd/quadrature.py newton_start_grid /
- *               assemble_start, matdecomp._device_tables).  Layout of `start` (doubles): [0],[1] the unattenuated signals
- *               sum_e i0[k][e]; [2] a scale s; [3] cells per axis n; [4] ln of the smallest u0 of the grid; [5] cells per
- *               unit of ln u0; [6] the smallest ratio u1 / u0 of the grid; [7] cells per unit of the ratio ([8],[9] reserved),
- *               where u_k = s ln(start[k] / g_k); then the fixed points at the (n+1)^2 cell corners as pairs (a0, a1) (row =
- *               index along ln u0); then per cell the pair (need, radius): need = the number of steps a pixel whose counts
- *               fall in the cell must be allowed for the reference's walk to be known to end by the tolerance rule (infinity:
- *               closed), radius = how far from the interpolated fixed point a result is accepted.  16-byte aligned.
- *                 pass = DEXCT_GN_PASS_REFINE, iterations = NULL, start != NULL (what the host runs by default): a pixel in a
+ *               DEXCT_GN_PASS_COUNT: the reference's iteration, with step counts) on a grid of counts - and hands the table over
+ *               as `start` (the Python host: dex-ct-sim_amd/quadrature.py newton_start_grid / assemble_start,
+ *               matdecomp._device_tables).
+ *                 pass = DEXCT_GN_PASS_COUNT, iterations != NULL, start = NULL: the usual iteration from 1e-6; besides the
+ *                   results, iterations[q] (q = the pixel's index in the RESULT order, n_pix bytes) receives the number of steps
+ *                   after which the tolerance rule ended the pixel, or 255 when it ended any other way.
+ *                 pass = DEXCT_GN_PASS_SHORTCUT, start != NULL, iterations = NULL (what the host runs by default): a pixel in a
  *                   cell with n_iters >= need starts from the Catmull-Rom interpolant of the corners' fixed points and ends by
  *                   the tolerance rule of the FULL tables (two steps; or at a repeated state), accepted only within the radius;
  *                   if any of this fails - and for every pixel in a closed cell - the pixel is solved from the reference's
  *                   start value with all n_iters steps, as a plain call does.  The call therefore returns, per pixel, either
  *                   a fixed point of the full model on the reference's branch verified to stop_tol, or the reference's own
  *                   trajectory; the table only decides how fast, never what.
- *                 Two calls on the same g1, g2, out_a, iterations (optional, "coarse" mode): pass = DEXCT_GN_PASS_COARSE with
- *                   SHORT tables (a quadrature of the spectra on a fifth of the energies: the i0, mus, n_energies of that
- *                   call) runs the usual iteration from the start values (from 1e-6 without `start`; pixels in closed cells
- *                   are not iterated) and writes to iterations[q] (q = the pixel's index in the RESULT order, n_pix bytes)
- *                   the number of steps after which the tolerance rule ended the pixel, or 255; then pass =
- *                   DEXCT_GN_PASS_REFINE with the full tables and the same iterations: a pixel with iterations[q] = k != 255
- *                   and n_iters - k >= 2 starts from out_a[q] - if that lies within the radius of the interpolant - with
- *                   n_iters - k steps left; everything else as above.
- *               All of this needs stop_tol > 0 (after defaults), n_bins == 1, precision 0, n_iters <= 254, kernel != 2;
- *               DEXCT_EINVAL otherwise.  pass = 0 (default): one launch from 1e-6; iterations and start are not used. */
+ *               Layout of `start` (doubles, 16-byte aligned): [0],[1] the unattenuated signals sum_e i0[k][e]; [2] a scale s;
+ *               [3] cells per axis n; [4] ln of the smallest u0 of the grid; [5] cells per unit of ln u0; [6] the smallest ratio
+ *               u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] ln of [0],[1]; where u_k = s ln(start[k] / g_k);
+ *               then the fixed points at the (n+1)^2 cell corners as pairs (a0, a1) (row = index along ln u0); then per cell
+ *               the pair (need, radius): need = the number of steps a pixel whose counts fall in the cell must be allowed for
+ *               the reference's walk to be known to end by the tolerance rule (infinity: closed), radius = how far from the
+ *               interpolated fixed point a result is accepted.
+ *               Both passes need stop_tol > 0 (after defaults), n_bins == 1, precision 0, n_iters <= 254, kernel != 2;
+ *               DEXCT_EINVAL otherwise.  pass = 0 (default): one launch from 1e-6; iterations and start must be NULL or are
+ *               not used.  (ABI 4 also had a two-launch "coarse" form of the short cut - a launch on a short quadrature of the
+ *               spectra in between; it was 15 % slower than this one and left the library in ABI 5.)
+ *   flags       DEXCT_GN_FLAG_FULL_LOOP: execute every iteration, no exit of any kind (stop_tol is then 0): the check that the
+ *               repeated-state exit changes no bit.  DEXCT_GN_FLAG_NATURAL_ORDER: hand the tiles of a small sinogram out in
+ *               their natural order instead of thick tiles first (results do not depend on it).
+ *   blocks_per_cu   > 0: workgroups per CU of the queue kernels (0: what is resident; results do not depend on it). */
 #define DEXCT_GN_DEFAULT_STOP_TOL 1e-12
-#define DEXCT_GN_PASS_COARSE 1
-#define DEXCT_GN_PASS_REFINE 2
+#define DEXCT_GN_PASS_COUNT 1
+#define DEXCT_GN_PASS_SHORTCUT 2
+#define DEXCT_GN_FLAG_FULL_LOOP 1
+#define DEXCT_GN_FLAG_NATURAL_ORDER 2
 typedef struct dexct_gn_options {
   double stop_tol;
   int32_t out_rows, out_channels;
   int32_t kernel;
-  int32_t pass;                /* 0, DEXCT_GN_PASS_COARSE, DEXCT_GN_PASS_REFINE */
-  uint8_t* iterations;         /* device, n_pix bytes; passes 1 and 2 only */
-  const double* start;         /* device, optional: the table of the reference's fixed points (above) */
+  int32_t pass;                /* 0, DEXCT_GN_PASS_COUNT, DEXCT_GN_PASS_SHORTCUT */
+  uint8_t* iterations;         /* device, n_pix bytes; DEXCT_GN_PASS_COUNT only */
+  const double* start;         /* device; DEXCT_GN_PASS_SHORTCUT only: the table of the reference's fixed points (above) */
+  int32_t flags;               /* DEXCT_GN_FLAG_* (ABI 5) */
+  int32_t blocks_per_cu;       /* (ABI 5) */
 } dexct_gn_options;
 
 /* Per-pixel Newton (Gauss-Newton) basis-material decomposition: replaces optimize_sino_cpu
@@ -344,12 +363,12 @@ typedef struct dexct_gn_options {
  * kernel stops a pixel at the first state that repeats bit for bit (fixed point or cycle of up to 9 states) and
  * returns the state the cycle holds at iteration n_iters: the result of all n_iters iterations, exactly; with a tolerance
  * stop (the default, see dexct_gn_options) a converging pixel ends a few iterations earlier still.
- * Environment (read per call, for checking and tuning only): DEXCT_GN_FULL_LOOP=1 executes every iteration (no exit of any
- * kind); DEXCT_GN_EXACT=1 / DEXCT_GN_STOP_TOL=<t> change the DEFAULT tolerance (an explicit options->stop_tol >= 0 wins);
- * DEXCT_GN_BLOCKS_PER_CU=<n> caps the grid of the queue kernel at n workgroups per CU (default = what is resident);
- * DEXCT_GN_MINW=5 selects the variant compiled for 5 waves per SIMD (96 registers per lane + scratch; default 4: no scratch);
- * DEXCT_GN_COOP_BELOW=<pixels> moves the size below which the cooperative kernel runs; DEXCT_GN_SORT=0 hands small sinograms
- * out in their natural order instead of thick tiles first. */
+ * Environment (read ONCE per process, at the first call; tuning only - what a call computes is decided by its arguments):
+ * DEXCT_GN_EXACT=1 / DEXCT_GN_STOP_TOL=<t> set the DEFAULT tolerance (an explicit options->stop_tol >= 0 wins; a value that is not
+ * a number >= 0 is ignored); DEXCT_GN_FULL_LOOP=1 = DEXCT_GN_FLAG_FULL_LOOP on every call; DEXCT_GN_BLOCKS_PER_CU=<n> = the
+ * default of options->blocks_per_cu; DEXCT_GN_COOP_BELOW=<pixels> moves the size below which the cooperative kernel runs;
+ * DEXCT_GN_SORT=0 = DEXCT_GN_FLAG_NATURAL_ORDER on every call; DEXCT_GN_TILES_PER_FETCH=<n> queue positions a wave reserves per
+ * atomic. */
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins);
 int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t n_pix, const double* i0,
                        const double* mus, int32_t n_energies, int32_t n_bins, int32_t bin_div, int32_t n_iters,

@@ -24,13 +24,19 @@ EPS_INIT = 1e-6          # matdecomp.py:98-99
 CLIP = 700.0             # matdecomp.py:116
 
 
-def newton_solve(sino_gg, i0, mus, n_iters):
+def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False, last=10):
     """Per-pixel Newton iterations on the Poisson negative log-likelihood.
 
     sino_gg : [2, nViews, nBins] measured counts
     i0      : [2, nBins, nE] (reference layout) or [2, nE] effective spectra
     mus     : [2, nE] basis mass-attenuation tables
     returns : [nViews, nBins, 2] density line integrals  (matdecomp.py:127)
+
+    ``return_sensitivity``: also return, per pixel, the largest value over the last ``last`` iterations of
+    cond(H_k) * |step_k| / max(|a_(k+1)|, 1) - times the machine epsilon, the relative uncertainty of the computed step itself:
+    any two float64 arithmetics (another order of the energy sums, another 2x2 solve) differ by about that much after the
+    step, and a pixel that is still moving at the end keeps the difference (a converged one sheds it: its last steps are 0).
+    The stability screen of tools/soak_gn.py (inf / NaN -> inf).
     """
     sino_gg = np.asarray(sino_gg, dtype=np.float64)
     mus = np.asarray(mus, dtype=np.float64)
@@ -46,7 +52,8 @@ def newton_solve(sino_gg, i0, mus, n_iters):
 
     a = np.full((n_views, n_bins, 2), EPS_INIT)
     g = np.moveaxis(sino_gg, 1, 0)                                          # [view, k, bin]
-    for _ in range(n_iters):
+    sens = np.zeros((n_views, n_bins))
+    for it in range(n_iters):
         expo = -(a[..., 0, None] * mus[0] + a[..., 1, None] * mus[1])       # [view, bin, e]
         att = np.exp(np.clip(expo, -CLIP, CLIP))
         nu = np.einsum('kbe,vbe->vkb', i0, att)                             # [view, k, bin]
@@ -62,7 +69,13 @@ def newton_solve(sino_gg, i0, mus, n_iters):
             s1 = (H[:, 0, 0] * dF[:, 1] - H[:, 1, 0] * dF[:, 0]) / det
         a[..., 0] -= s0
         a[..., 1] -= s1
-    return a
+        if return_sensitivity and it >= n_iters - last:
+            with np.errstate(all='ignore'):
+                fro2 = H[:, 0, 0] ** 2 + H[:, 1, 1] ** 2 + H[:, 0, 1] ** 2 + H[:, 1, 0] ** 2
+                cond = (fro2 + np.sqrt(np.maximum(fro2 * fro2 - 4.0 * det * det, 0.0))) / (2.0 * np.abs(det))     # sigma_max / sigma_min, 2 x 2
+                now = cond * np.maximum(np.abs(s0), np.abs(s1)) / np.maximum(np.abs(a).max(-1), 1.0)
+                sens = np.where(np.isfinite(now), np.maximum(sens, now), np.inf)
+    return (a, sens) if return_sensitivity else a
 
 
 def decomposition_tables(det_E, det_eta, eid, spec1_E, spec1_I0, spec2_E, spec2_I0):

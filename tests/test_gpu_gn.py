@@ -219,9 +219,8 @@ def test_entry_points_are_graph_capturable(hip):
 
 def test_repeated_state_exit_changes_no_bit(hip, golden):
     """The loop stops when an iterate repeats bit for bit (fixed point or a cycle of up to 9 states);
-    DEXCT_GN_FULL_LOOP=1 runs all iterations: both must agree in every bit, for iteration counts covering every
-    residue of every detectable period, incl. the ill-posed golden case."""
-    import os
+    DEXCT_GN_FLAG_FULL_LOOP (full_loop=True) runs all iterations: both must agree in every bit, for iteration counts covering
+    every residue of every detectable period, incl. the ill-posed golden case."""
     from dex_ct_sim_amd import matdecomp as md
     g = golden
     rng = np.random.default_rng(17)
@@ -230,26 +229,20 @@ def test_repeated_state_exit_changes_no_bit(hip, golden):
     ex = np.exp(-a_true @ mus)
     cnt = np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, 200000)))
     cases = [(cnt.reshape(2, 400, 500), i0, mus)] + [(g[f'gn{ci}_g'], g[f'gn{ci}_i0'], g[f'gn{ci}_mus']) for ci in range(3)]
-    try:
-        for data, ii, mm in cases:
-            for n_iters in (7, 23) + tuple(range(41, 52)):
-                for precision in ('f64', 'mixed'):       # mixed: the float32 bulk loop has the same exit
-                    os.environ['DEXCT_GN_FULL_LOOP'] = '1'
-                    full = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision, verbose=False)
-                    os.environ['DEXCT_GN_FULL_LOOP'] = '0'
-                    fast = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision, verbose=False, stop_tol=0.0)
-                    assert np.array_equal(full.view(np.int64), fast.view(np.int64)), (n_iters, precision)
-    finally:
-        os.environ.pop('DEXCT_GN_FULL_LOOP', None)
+    for data, ii, mm in cases:
+        for n_iters in (7, 23) + tuple(range(41, 52)):
+            for precision in ('f64', 'mixed'):       # mixed: the float32 bulk loop has the same exit
+                full = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision, verbose=False, full_loop=True)
+                fast = md.optimize_sino(data, None, ii, mm, n_iters, precision=precision, verbose=False, stop_tol=0.0)
+                assert np.array_equal(full.view(np.int64), fast.view(np.int64)), (n_iters, precision)
 
 
 def test_lane_refill_ragged_sizes_tiles_and_mask(hip, golden):
     """gn_refill_kernel: every pixel is solved exactly once and lands in its place - pixel counts around the wave and
-    tile boundaries, with and without the fused air mask, 0 and 1 iterations, any cap on the grid of the tile queue, the
-    5-waves-per-SIMD variant; and with the results written in the reference's [view][row][channel] order from
+    tile boundaries, with and without the fused air mask, 0 and 1 iterations, any cap on the grid of the tile queue;
+    and with the results written in the reference's [view][row][channel] order from
     [view][channel][row] input (4 x 16 tiles collected in LDS, ragged row / channel counts): the same bits as the plain
     order transposed.  Exact mode (stop_tol = 0) for the bit comparisons; the result matches the C oracle."""
-    import os
     from dex_ct_sim_amd import matdecomp as md
     g = golden
     i0, mus = g['gn0_i0'], g['gn0_mus']
@@ -262,66 +255,59 @@ def test_lane_refill_ragged_sizes_tiles_and_mask(hip, golden):
         cnt[0, rng.random(n_pix) < 0.3] = 2.0 * i0[0].sum()                    # above 0.95 * max: masked
         return cnt
 
-    try:
-        for n_pix in (1, 63, 64, 65, 127, 1000, 4097, 64 * 64 * 3 + 5):
-            cnt = problem(n_pix)
-            g1, g2 = (torch.tensor(cnt[k], device='cuda') for k in range(2))
-            gmax = g1.max().double()
-            air = cnt[0] >= 0.95 * cnt[0].max()                # what the mask rule selects (at least the maximum itself)
-            ref = co.gn_decompose(cnt[0], cnt[1], i0, mus, 30, n_threads=8)
-            results = {}
-            for masked in (False, True):
-                for env in ({}, {'DEXCT_GN_BLOCKS_PER_CU': '1'}, {'DEXCT_GN_BLOCKS_PER_CU': '3'}, {'DEXCT_GN_MINW': '5'}):
-                    os.environ.update(env)
-                    out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
-                    md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None, stop_tol=0.0, kernel=1)
-                    for k in env:
-                        os.environ.pop(k)
-                    results[(masked, tuple(env.items()))] = out.cpu().numpy()
-            base_m, base_u = results[(True, ())], results[(False, ())]
-            for (masked, env), r in results.items():
-                assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, env)
-            assert not np.isnan(base_m[air]).any() and np.all(base_m[air] == 0.0)
-            assert np.array_equal(base_m[~air].view(np.int64), base_u[~air].view(np.int64))
-            live_u = np.isfinite(ref).all(-1)                  # without the mask every pixel is solved
-            assert err(base_u[live_u], ref[live_u]) < TOL_F64
-            # the default mode (tolerance stop): within 1e-11 of the exact result wherever that is finite
-            out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
-            md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax, kernel=1)
-            fin = np.isfinite(base_m).all(-1)
-            assert err(out.cpu().numpy()[fin], base_m[fin]) < 1e-11
-            for n_iters, expect in ((0, 1e-6), (1, None)):
+    for n_pix in (1, 63, 64, 65, 127, 1000, 4097, 64 * 64 * 3 + 5):
+        cnt = problem(n_pix)
+        g1, g2 = (torch.tensor(cnt[k], device='cuda') for k in range(2))
+        gmax = g1.max().double()
+        air = cnt[0] >= 0.95 * cnt[0].max()                # what the mask rule selects (at least the maximum itself)
+        ref = co.gn_decompose(cnt[0], cnt[1], i0, mus, 30, n_threads=8)
+        results = {}
+        for masked in (False, True):
+            for env in ({}, {'blocks_per_cu': 1}, {'blocks_per_cu': 3}, {'natural_order': True}):
                 out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
-                md.gn_device(g1, g2, i0, mus, n_iters, 'f64', out=out, kernel=1)
-                o = out.cpu().numpy()
-                if expect is not None:
-                    assert np.all(o == expect)
-                else:
-                    one = co.gn_decompose(cnt[0], cnt[1], i0, mus, 1, n_threads=8)
-                    ok = np.isfinite(one).all(-1)
-                    assert err(o[ok], one[ok]) < TOL_F64
-        # results in the reference's order: [views][channels][rows] in, [views][rows][channels] out
-        for V, C, R in ((1, 1, 1), (2, 8, 8), (3, 5, 3), (2, 17, 9), (1, 64, 7), (5, 9, 70), (2, 40, 33)):
-            cnt = problem(V * C * R)
-            for dt in (torch.float64, torch.float32):
-                g1, g2 = (torch.tensor(cnt[k], device='cuda').to(dt).reshape(V, C, R) for k in range(2))
-                gmax = g1.max().double()
-                for masked in (False, True):
-                    plain = md.gn_device(g1, g2, i0, mus, 30, 'f64', mask_max=gmax if masked else None, stop_tol=0.0, kernel=1)
-                    out = torch.full((V, R, C, 2), float('nan'), dtype=torch.float64, device='cuda')
-                    got = md.gn_device(g1, g2, i0, mus, 30, 'f64', mask_max=gmax if masked else None, stop_tol=0.0,
-                                       out_rc=(R, C), out=out, kernel=1)
-                    assert got.shape == (V, R, C, 2)
-                    assert torch.equal(got.view(torch.int64), plain.permute(0, 2, 1, 3).contiguous().view(torch.int64)), (V, C, R)
-                    # the pixel-by-pixel kernels honour the same option (mixed precision: scattered stores)
-                    mix_p = md.gn_device(g1, g2, i0, mus, 30, 'mixed', mask_max=gmax if masked else None)
-                    mix_t = md.gn_device(g1, g2, i0, mus, 30, 'mixed', mask_max=gmax if masked else None, out_rc=(R, C))
-                    assert torch.equal(mix_t.view(torch.int64), mix_p.permute(0, 2, 1, 3).contiguous().view(torch.int64))
-        with pytest.raises(ValueError):
-            md.gn_device(g1, g2, i0, mus, 30, 'f64', out_rc=(C, R + 1))
-    finally:
-        for k in ('DEXCT_GN_BLOCKS_PER_CU', 'DEXCT_GN_MINW'):
-            os.environ.pop(k, None)
+                md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax if masked else None, stop_tol=0.0, kernel=1, **env)
+                results[(masked, tuple(env.items()))] = out.cpu().numpy()
+        base_m, base_u = results[(True, ())], results[(False, ())]
+        for (masked, env), r in results.items():
+            assert np.array_equal(r.view(np.int64), (base_m if masked else base_u).view(np.int64)), (n_pix, env)
+        assert not np.isnan(base_m[air]).any() and np.all(base_m[air] == 0.0)
+        assert np.array_equal(base_m[~air].view(np.int64), base_u[~air].view(np.int64))
+        live_u = np.isfinite(ref).all(-1)                  # without the mask every pixel is solved
+        assert err(base_u[live_u], ref[live_u]) < TOL_F64
+        # the default mode (tolerance stop): within 1e-11 of the exact result wherever that is finite
+        out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+        md.gn_device(g1, g2, i0, mus, 30, 'f64', out=out, mask_max=gmax, kernel=1)
+        fin = np.isfinite(base_m).all(-1)
+        assert err(out.cpu().numpy()[fin], base_m[fin]) < 1e-11
+        for n_iters, expect in ((0, 1e-6), (1, None)):
+            out = torch.full((n_pix, 2), float('nan'), dtype=torch.float64, device='cuda')
+            md.gn_device(g1, g2, i0, mus, n_iters, 'f64', out=out, kernel=1)
+            o = out.cpu().numpy()
+            if expect is not None:
+                assert np.all(o == expect)
+            else:
+                one = co.gn_decompose(cnt[0], cnt[1], i0, mus, 1, n_threads=8)
+                ok = np.isfinite(one).all(-1)
+                assert err(o[ok], one[ok]) < TOL_F64
+    # results in the reference's order: [views][channels][rows] in, [views][rows][channels] out
+    for V, C, R in ((1, 1, 1), (2, 8, 8), (3, 5, 3), (2, 17, 9), (1, 64, 7), (5, 9, 70), (2, 40, 33)):
+        cnt = problem(V * C * R)
+        for dt in (torch.float64, torch.float32):
+            g1, g2 = (torch.tensor(cnt[k], device='cuda').to(dt).reshape(V, C, R) for k in range(2))
+            gmax = g1.max().double()
+            for masked in (False, True):
+                plain = md.gn_device(g1, g2, i0, mus, 30, 'f64', mask_max=gmax if masked else None, stop_tol=0.0, kernel=1)
+                out = torch.full((V, R, C, 2), float('nan'), dtype=torch.float64, device='cuda')
+                got = md.gn_device(g1, g2, i0, mus, 30, 'f64', mask_max=gmax if masked else None, stop_tol=0.0,
+                                   out_rc=(R, C), out=out, kernel=1)
+                assert got.shape == (V, R, C, 2)
+                assert torch.equal(got.view(torch.int64), plain.permute(0, 2, 1, 3).contiguous().view(torch.int64)), (V, C, R)
+                # the pixel-by-pixel kernels honour the same option (mixed precision: scattered stores)
+                mix_p = md.gn_device(g1, g2, i0, mus, 30, 'mixed', mask_max=gmax if masked else None)
+                mix_t = md.gn_device(g1, g2, i0, mus, 30, 'mixed', mask_max=gmax if masked else None, out_rc=(R, C))
+                assert torch.equal(mix_t.view(torch.int64), mix_p.permute(0, 2, 1, 3).contiguous().view(torch.int64))
+    with pytest.raises(ValueError):
+        md.gn_device(g1, g2, i0, mus, 30, 'f64', out_rc=(C, R + 1))
 
 
 @pytest.mark.parametrize('seed', range(10))
@@ -372,13 +358,13 @@ def test_random_tables_against_numpy_oracle(hip, seed):
         assert err(got[ok], ref[ok]) < 1e-7, (seed, n_e, n_bins, n_iters, err(got[ok], ref[ok]))
 
 
-def test_cooperative_kernel_and_selection_by_size(hip, golden, monkeypatch):
+def test_cooperative_kernel_and_selection_by_size(hip, golden):
     """gn_coop_kernel (round 4): the four waves of a workgroup split the energies of the same 64 pixels and join their sums
     in LDS.  Another summation order than the one-lane kernel: the reference's goldens hold at the unchanged 1e-9, the two
     kernels agree to 1e-12 wherever the result is finite, exact mode equals ITS OWN full loop bit for bit (the update is
-    still a pure function of the state).  Selection: below DEXCT_GN_COOP_BELOW pixels (default 1e5) the cooperative
-    kernel runs, from there on the lane kernel - checked through bit-identity with the forced kernels on both sides of
-    the threshold (the two kernels differ in the last bits)."""
+    still a pure function of the state).  Selection: below 1e5 pixels (DEXCT_GN_COOP_BELOW at process start) the
+    cooperative kernel runs, from there on the lane kernel - checked through bit-identity with the forced kernels on both
+    sides of the threshold (the two kernels differ in the last bits)."""
     from dex_ct_sim_amd import matdecomp as md
     g = golden
     for ci in range(3):                                                   # reference goldens through the cooperative kernel
@@ -401,9 +387,7 @@ def test_cooperative_kernel_and_selection_by_size(hip, golden, monkeypatch):
         kw = dict(mask_max=gmax, out_rc=shape_rc)
         lane = md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=1, stop_tol=0.0, **kw)
         coop = md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=2, stop_tol=0.0, **kw)
-        monkeypatch.setenv('DEXCT_GN_FULL_LOOP', '1')
-        coop_full = md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=2, **kw)
-        monkeypatch.delenv('DEXCT_GN_FULL_LOOP')
+        coop_full = md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=2, full_loop=True, **kw)
         assert torch.equal(coop.view(torch.int64), coop_full.view(torch.int64))
         fin = torch.isfinite(lane).all(-1) & torch.isfinite(coop).all(-1)
         assert fin.float().mean() > 0.99
@@ -412,21 +396,17 @@ def test_cooperative_kernel_and_selection_by_size(hip, golden, monkeypatch):
         auto = md.gn_device(g1, g2, i0, mus, 50, 'f64', stop_tol=0.0, **kw)
         want = coop if n_pix < 100_000 else lane                            # the default threshold
         assert torch.equal(auto.view(torch.int64), want.view(torch.int64)), n_pix
-        monkeypatch.setenv('DEXCT_GN_COOP_BELOW', '5001')
-        auto = md.gn_device(g1, g2, i0, mus, 50, 'f64', stop_tol=0.0, **kw)
-        monkeypatch.delenv('DEXCT_GN_COOP_BELOW')
-        assert torch.equal(auto.view(torch.int64), (coop if n_pix < 5001 else lane).view(torch.int64)), n_pix
         # the order of the hand-out (thick tiles first for small sinograms) changes no bit
-        monkeypatch.setenv('DEXCT_GN_SORT', '0')
         for kern, ref in ((1, lane), (2, coop)):
-            assert torch.equal(md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=kern, stop_tol=0.0, **kw).view(torch.int64), ref.view(torch.int64))
-        monkeypatch.delenv('DEXCT_GN_SORT')
+            assert torch.equal(md.gn_device(g1, g2, i0, mus, 50, 'f64', kernel=kern, stop_tol=0.0, natural_order=True, **kw).view(torch.int64),
+                               ref.view(torch.int64))
 
 
 def test_default_tolerance_stop_and_exact_switches(hip, golden, monkeypatch):
     """Round 4: the tolerance stop (1e-12 relative step, contraction checked) is the DEFAULT of dexct_gn_decompose /
     get_basismat_sinos; the reference's fixed count is one switch away and every way of asking for it gives the same bits
-    as the full loop: stop_tol=0, DEXCT_GN_EXACT=1, DEXCT_GN_STOP_TOL=0.  The default stays within 1e-12 of the exact
+    as the full loop: stop_tol=0, and DEXCT_GN_EXACT=1 / DEXCT_GN_STOP_TOL=0 in the environment at import (resolved once by the
+    host, matdecomp._default_stop_tol - parsed on the CPU in tests/test_host.py).  The default stays within 1e-12 of the exact
     result on every finite pixel (measured ~1e-14); looser tolerances stay within a few tolerances; a pixel that never
     converges (non-finite or wandering in the exact run) is not cut short: it is bit-identical to the exact run."""
     from dex_ct_sim_amd import matdecomp as md
@@ -436,15 +416,12 @@ def test_default_tolerance_stop_and_exact_switches(hip, golden, monkeypatch):
     a_true = np.stack([rng.uniform(0, 40, 50000), rng.uniform(0, 8, 50000)], -1)
     ex = np.exp(-a_true @ mus)
     cnt = (np.stack([(i0[k] * ex).sum(-1) for k in range(2)]) * (1 + 0.002 * rng.standard_normal((2, 50000)))).reshape(2, 100, 500)
-    monkeypatch.setenv('DEXCT_GN_FULL_LOOP', '1')
-    full = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
-    monkeypatch.delenv('DEXCT_GN_FULL_LOOP')
+    full = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, full_loop=True)
     exact = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=0.0)
     assert np.array_equal(exact.view(np.int64), full.view(np.int64))
-    for var, val in (('DEXCT_GN_EXACT', '1'), ('DEXCT_GN_STOP_TOL', '0')):
-        monkeypatch.setenv(var, val)
-        assert np.array_equal(md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False).view(np.int64), exact.view(np.int64))
-        monkeypatch.delenv(var)
+    monkeypatch.setattr(md, 'DEFAULT_STOP_TOL', 0.0)                      # what DEXCT_GN_EXACT=1 / DEXCT_GN_STOP_TOL=0 resolve to
+    assert np.array_equal(md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False).view(np.int64), exact.view(np.int64))
+    monkeypatch.setattr(md, 'DEFAULT_STOP_TOL', 1e-12)
     ok = np.isfinite(exact).all(-1)
     default = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
     st_default = md.last_gn_stats()['pixel_iterations']
@@ -453,9 +430,9 @@ def test_default_tolerance_stop_and_exact_switches(hip, golden, monkeypatch):
     md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=0.0)
     st_exact = md.last_gn_stats()['pixel_iterations']
     assert st_default < 0.95 * st_exact                                   # and it is what saves the iterations (15 % on this noisy data)
-    monkeypatch.setenv('DEXCT_GN_EXACT', '1')                             # an explicit tolerance wins over the environment
+    monkeypatch.setattr(md, 'DEFAULT_STOP_TOL', 0.0)                      # an explicit tolerance wins over the environment's default
     explicit = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=1e-12)
-    monkeypatch.delenv('DEXCT_GN_EXACT')
+    monkeypatch.setattr(md, 'DEFAULT_STOP_TOL', 1e-12)
     assert np.array_equal(explicit.view(np.int64), default.view(np.int64))
     for tol in (1e-10, 1e-8):
         fast = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=tol)
@@ -702,64 +679,68 @@ def _noisy_counts(golden, n=60000, seed=77, noise=0.002, water=True):
 
 
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
-def test_two_level_solve_modes_against_the_exact_count(hip, golden, dtype):
-    """The short cut of the Newton solve (start values interpolated from the tabulated fixed points of the reference's walk;
-    'start': two steps on the full tables; 'coarse': ~2 steps on a short quadrature of the spectra in between) returns what the single launch returns: within 1e-12 of the exact count on every
-    pixel, bit-identical where the exact run has not converged - and spends a fraction of the full-table steps."""
+def test_short_cut_against_the_exact_count(hip, golden, dtype):
+    """The short cut of the Newton solve (start values interpolated from the tabulated fixed points of the reference's walk, two
+    steps on the full tables: gn_shortcut_kernel) returns what the single launch returns: within 1e-12 of the exact count on
+    every pixel, bit-identical where the exact run has not converged - and spends a fraction of the full-table steps.  Noisy
+    thin rays: closed cells (stash -> walk from 1e-6), continued pixels, NaN counts."""
     from dex_ct_sim_amd import matdecomp as md
     from dex_ct_sim_amd._device import to_dev, to_host
     cnt, i0, mus = _noisy_counts(golden)
     cnt = cnt.astype(dtype)
+    cnt[:, 3, ::97] = np.nan
     g = to_dev(cnt, torch.float32 if dtype == np.float32 else torch.float64, torch.device('cuda'))
-    # the lane kernel throughout (kernel=1; it is what the two launches use): at this size the single launch would otherwise
+    # the lane kernel throughout (kernel=1; it is what the short cut uses): at this size the single launch would otherwise
     # pick the cooperative kernel, whose different order of summation sends the one or two chaotic pixels of such noisy thin
     # rays - a step that lands far away through a nearly singular Hessian - somewhere else
-    exact = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', stop_tol=0.0, kernel=1, two_level='coarse'))
+    exact = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', stop_tol=0.0, kernel=1, two_level='start'))
     st_exact = md.last_gn_stats()
     assert st_exact['mode'] == 'single'                                  # the fixed count never takes a short cut
     ok = np.isfinite(exact).all(-1)
-    assert ok.mean() > 0.99
+    assert 0.98 < ok.mean() < 1.0
     steps = {}
-    for mode in (False, 'start', 'coarse'):
+    for mode in (False, 'start'):
         a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1, two_level=mode))
         st = md.last_gn_stats()
         assert st['mode'] == (mode or 'single')
         assert err(a[ok], exact[ok]) < 1e-12, mode
         assert np.array_equal(a[~ok].view(np.int64), exact[~ok].view(np.int64))
-        steps[mode] = (st['pixel_iterations'], st.get('coarse_pixel_iterations', 0))
-        if mode == 'coarse':
-            assert 16 <= st['coarse_energies'] <= i0.shape[1] // 3
+        steps[mode] = st['pixel_iterations']
     # (noisy thin rays whose solution has a negative component lie below the gate's grid and are solved the reference's way)
-    assert steps['start'][0] < 0.7 * steps[False][0] and steps['coarse'][0] < 0.7 * steps[False][0]
+    assert steps['start'] < 0.7 * steps[False]
     # without noise every pixel takes the short cut: two full-table steps each
     clean, _, _ = _noisy_counts(golden, n=30000, seed=3, noise=0.0)
     clean = clean.astype(dtype)
     n = clean[0].size
     md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level=False)
     one = md.last_gn_stats()['pixel_iterations']
-    md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level='coarse')
-    st = md.last_gn_stats()
-    assert 1.9 * n < st['pixel_iterations'] < 2.6 * n < 0.25 * one and 1.9 * n < st['coarse_pixel_iterations'] < 6.0 * n
     md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level='start')
-    assert md.last_gn_stats()['pixel_iterations'] < 8.0 * n      # (the reference's bundled spectra, weight down to 1 keV: more cells are closed)
-    # the default is 'start' (one launch), the environment overrides
+    assert md.last_gn_stats()['pixel_iterations'] < min(8.0 * n, 0.5 * one)    # (the reference's bundled spectra, weight down to 1 keV: more cells are closed)
+    # the default is 'start' (one launch); DEXCT_GN_TWO_LEVEL at import sets another default
     md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
     assert md.last_gn_stats()['mode'] == 'start'
-    import os
-    for env, want in (('0', 'single'), ('coarse', 'coarse'), ('start', 'start')):
-        os.environ['DEXCT_GN_TWO_LEVEL'] = env
-        try:
-            md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
-            assert md.last_gn_stats()['mode'] == want
-        finally:
-            del os.environ['DEXCT_GN_TWO_LEVEL']
+    # results in the reference's order from [view][channel][row] input, ragged tiles, float32 and float64 counts: the same bits
+    # as the plain order transposed (the fast path writes whole tiles, stashed pixels one by one)
+    V, C, R = 5, 50, 40
+    g3 = g.reshape(2, -1)[:, :V * C * R].reshape(2, V, C, R).contiguous()
+    plain = md.gn_device(g3[0], g3[1], i0, mus, 50, 'f64', kernel=1)
+    assert md.last_gn_stats()['mode'] == 'start'
+    got = md.gn_device(g3[0], g3[1], i0, mus, 50, 'f64', kernel=1, out_rc=(R, C))
+    assert got.shape == (V, R, C, 2)
+    assert torch.equal(got.view(torch.int64), plain.permute(0, 2, 1, 3).contiguous().view(torch.int64))
+    gmax = g3[0][torch.isfinite(g3[0])].max().double() * 0.6             # a mask that takes a third of the pixels
+    m_plain = md.gn_device(g3[0], g3[1], i0, mus, 50, 'f64', kernel=1, mask_max=gmax)
+    m_got = md.gn_device(g3[0], g3[1], i0, mus, 50, 'f64', kernel=1, mask_max=gmax, out_rc=(R, C), blocks_per_cu=1)
+    assert torch.equal(m_got.view(torch.int64), m_plain.permute(0, 2, 1, 3).contiguous().view(torch.int64))
+    air = g3[0] >= 0.95 * gmax
+    assert 0.1 < air.float().mean() < 0.9 and torch.all(m_plain[air] == 0)
+    assert torch.equal(m_plain[~air].view(torch.int64), plain[~air].view(torch.int64))
 
 
-@pytest.mark.parametrize('mode', ['start', 'coarse'])
-def test_two_level_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, golden, mode):
+def test_short_cut_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, golden):
     """The reference returns the state after n_iters steps from 1e-6 - the fixed point only if its iteration gets there in
-    time.  The gate (csrc/gn.hip gn_gate: step counts of the reference iteration itself over the (a0, a1) domain) lets a
-    pixel take the short cut only where it does: for every n_iters the two-level result is within 1e-12 of the exact count's
+    time.  The gate (csrc/gn.hip gn_start: step counts of the reference iteration itself over the data plane) lets a
+    pixel take the short cut only where it does: for every n_iters the result is within 1e-12 of the exact count's
     on every pixel - including those the exact count leaves far from their fixed point - and with very few steps nothing
     takes the short cut at all (bit-identical to the single launch)."""
     from dex_ct_sim_amd import matdecomp as md
@@ -775,9 +756,9 @@ def test_two_level_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, g
         exact = solve(n_iters, stop_tol=0.0, two_level=False)
         single = solve(n_iters, two_level=False)
         st1 = md.last_gn_stats()['pixel_iterations']
-        a = solve(n_iters, two_level=mode)
+        a = solve(n_iters, two_level='start')
         st = md.last_gn_stats()
-        assert st['mode'] == mode
+        assert st['mode'] == 'start'
         assert err(a, exact) < 1e-12, n_iters
         far = np.abs(exact - settled).max(-1) > 1e-6
         if n_iters <= 5:
@@ -788,32 +769,42 @@ def test_two_level_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, g
     assert warm_share[5] <= 0.0 and warm_share[50] > 0.6 and warm_share[12] < warm_share[30]
 
 
-def test_two_level_is_not_used_where_it_cannot_be_trusted(hip, golden):
-    """An ill-conditioned pair of spectra (golden case 1, the detuned MV pair: the reference's own iteration wanders over
-    much of the data plane) keeps the reference's results whichever mode is asked for - the gate's cells are closed where the
-    walk does not end by the rule or the fixed points jump; mixed precision, the fixed count, fewer than 48 energies and
-    fewer than 4 steps run the single launch."""
+def test_short_cut_is_not_used_where_it_cannot_be_trusted(hip, golden):
+    """An ill-posed pair of spectra (golden case 1, the detuned MV pair: the reference's own iteration wanders over much of
+    the data plane) runs the reference's FIXED COUNT by default (quadrature.pair_is_ill_posed: the calibration's own walk does
+    not settle on a measurable share of the corner grid) - bit-identical to stop_tol = 0 - and keeps the reference's results
+    whichever mode is asked for; an explicit tolerance is honoured.  Mixed precision, the fixed count, fewer than 48 energies
+    and fewer than 4 steps run the single launch."""
     from dex_ct_sim_amd import matdecomp as md
     g = golden
-    for mode in (None, 'start', 'coarse', False):
-        a = md.optimize_sino(g['gn1_g'], None, g['gn1_i0'], g['gn1_mus'], 50, verbose=False, precision='f64', two_level=mode)
+    exact = md.optimize_sino(g['gn1_g'], None, g['gn1_i0'], g['gn1_mus'], 50, verbose=False, precision='f64', stop_tol=0.0, kernel=1)
+    for mode in (None, 'start', False):
+        a = md.optimize_sino(g['gn1_g'], None, g['gn1_i0'], g['gn1_mus'], 50, verbose=False, precision='f64', two_level=mode, kernel=1)
+        assert md.last_gn_stats()['mode'] == 'exact (ill-posed pair)', mode
+        assert np.array_equal(a.view(np.int64), exact.view(np.int64))
         assert err(a, g['gn1_a_iters50']) < TOL_F64, mode
+    a = md.optimize_sino(g['gn1_g'], None, g['gn1_i0'], g['gn1_mus'], 50, verbose=False, precision='f64', stop_tol=1e-12)
+    assert md.last_gn_stats()['mode'] in ('single', 'start') and err(a, g['gn1_a_iters50']) < TOL_F64
+    for ci in (0, 2):                                                     # the kV pairs keep the short cut
+        md.optimize_sino(g[f'gn{ci}_g'], None, g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], 50, verbose=False, precision='f64')
+        assert md.last_gn_stats()['mode'] == 'start', ci
     cnt, i0, mus = _noisy_counts(golden, n=4000)
     for kw in (dict(precision='mixed'), dict(precision='f64', stop_tol=0.0)):
-        md.optimize_sino(cnt, None, i0, mus, 50, verbose=False, two_level='coarse', **kw)
+        md.optimize_sino(cnt, None, i0, mus, 50, verbose=False, two_level='start', **kw)
         assert md.last_gn_stats()['mode'] == 'single'
-    md.optimize_sino(cnt, None, i0[:, ::4], mus[:, ::4], 50, verbose=False, two_level='coarse')      # 35 energies
+    md.optimize_sino(cnt, None, i0[:, ::4], mus[:, ::4], 50, verbose=False, two_level='start')      # 35 energies
     assert md.last_gn_stats()['mode'] == 'single'
-    md.optimize_sino(cnt, None, i0, mus, 3, verbose=False, two_level='coarse')
+    md.optimize_sino(cnt, None, i0, mus, 3, verbose=False, two_level='start')
     assert md.last_gn_stats()['mode'] == 'single'
-    with pytest.raises(ValueError):
-        md.optimize_sino(cnt, None, i0, mus, 50, verbose=False, two_level='fast')
+    for bad in ('fast', 'coarse'):
+        with pytest.raises(ValueError):
+            md.optimize_sino(cnt, None, i0, mus, 50, verbose=False, two_level=bad)
 
 
-def test_two_level_passes_through_the_c_abi(hip, golden):
-    """dexct_gn_options.pass / .iterations / .start as include/dexct.h documents them: the coarse pass without start values
-    (from 1e-6) followed by the refining pass; argument errors."""
-    from dex_ct_sim_amd import _native, matdecomp as md, quadrature as q
+def test_short_cut_passes_through_the_c_abi(hip, golden):
+    """dexct_gn_options.pass / .iterations / .start / .flags / .blocks_per_cu as include/dexct.h documents them: the counting
+    pass (the reference's walk with step counts), the short cut from a table, argument errors."""
+    from dex_ct_sim_amd import _native, matdecomp as md
     from dex_ct_sim_amd._device import ptr, stream_ptr, to_dev
     lib = hip
     cnt, i0, mus = _noisy_counts(golden, n=20000, noise=0.0)
@@ -821,37 +812,46 @@ def test_two_level_passes_through_the_c_abi(hip, golden):
     g = to_dev(cnt.reshape(2, -1), torch.float64, dev)
     n = g.shape[1]
     i0_d, mus_d = to_dev(i0[:, None, :], torch.float64, dev), to_dev(mus, torch.float64, dev)
-    cols, i0_s = q.coarse_newton_tables(i0, mus)
-    i0_sd, mus_sd = to_dev(np.ascontiguousarray(i0_s)[:, None, :], torch.float64, dev), to_dev(np.ascontiguousarray(mus[:, cols]), torch.float64, dev)
     a = torch.empty((n, 2), dtype=torch.float64, device=dev)
     it = torch.full((n,), 7, dtype=torch.uint8, device=dev)
 
-    def call(i0t, mut, n_iters, opts):
-        ne = int(mut.shape[1])
+    def call(n_iters, opts):
+        ne = int(mus_d.shape[1])
         ws = torch.empty(lib.dexct_gn_workspace_bytes(ne, 1), dtype=torch.uint8, device=dev)
-        return lib.dexct_gn_decompose(ptr(g[0]), ptr(g[1]), 1, n, ptr(i0t), ptr(mut), ne, 1, 1, n_iters, 0, 0, None, 0.95, ptr(a),
+        return lib.dexct_gn_decompose(ptr(g[0]), ptr(g[1]), 1, n, ptr(i0_d), ptr(mus_d), ne, 1, 1, n_iters, 0, 0, None, 0.95, ptr(a),
                                       opts, ptr(ws), stream_ptr())
 
-    assert call(i0_sd, mus_sd, 50, _native.gn_options(1e-7, 0, 0, 1, _native.GN_PASS_COARSE, it.data_ptr())) == 0
-    k = it.cpu().numpy()
-    assert k.max() < 255 and 2 <= k.min() and 12 < k.mean() < 22          # from 1e-6: the reference's long walk, on a sixth of the energies
-    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == 0
     exact = md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False, stop_tol=0.0).reshape(-1, 2)
+    COUNT, SHORT = _native.GN_PASS_COUNT, _native.GN_PASS_SHORTCUT
+    assert call(50, _native.gn_options(1e-12, 0, 0, 1, COUNT, it.data_ptr())) == 0
+    k = it.cpu().numpy()
+    assert k.max() < 255 and 3 <= k.min() and 8 < k.mean() < 25           # from 1e-6: the reference's long walk
+    assert err(a.cpu().numpy(), exact) < 1e-12
+    gate = md._device_tables(i0, mus, dev, True)[2]
+    start = gate['start']
+    assert start is not None and not gate['ill_posed']
+    a.fill_(float('nan'))
+    assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, None, start.data_ptr())) == 0
+    assert err(a.cpu().numpy(), exact) < 1e-12
+    a.fill_(float('nan'))
+    assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, None, start.data_ptr(), 0, 2)) == 0         # blocks_per_cu
     assert err(a.cpu().numpy(), exact) < 1e-12
     EINVAL = -1
-    assert call(i0_sd, mus_sd, 50, _native.gn_options(1e-7, 0, 0, 1, _native.GN_PASS_COARSE, None)) == EINVAL        # nowhere to put the counts
-    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, None, None)) == EINVAL     # nothing to start from
-    assert call(i0_d, mus_d, 50, _native.gn_options(0.0, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL   # needs the tolerance rule
-    assert call(i0_d, mus_d, 255, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL  # counts are bytes
-    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 2, _native.GN_PASS_REFINE, it.data_ptr())) == EINVAL   # lane kernel only
-    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, 3, it.data_ptr())) == EINVAL
+    assert call(50, _native.gn_options(1e-7, 0, 0, 1, COUNT, None)) == EINVAL                         # nowhere to put the counts
+    assert call(50, _native.gn_options(1e-7, 0, 0, 1, COUNT, it.data_ptr(), start.data_ptr())) == EINVAL  # the counting pass walks from 1e-6
+    assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, None, None)) == EINVAL                   # nothing to start from
+    assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, it.data_ptr(), start.data_ptr())) == EINVAL   # (ABI 4's two-launch form is gone)
+    assert call(50, _native.gn_options(0.0, 0, 0, 1, SHORT, None, start.data_ptr())) == EINVAL        # needs the tolerance rule
+    assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, None, start.data_ptr(), _native.GN_FLAG_FULL_LOOP)) == EINVAL   # the full loop has no rule
+    assert call(255, _native.gn_options(None, 0, 0, 1, SHORT, None, start.data_ptr())) == EINVAL      # counts are bytes
+    assert call(50, _native.gn_options(None, 0, 0, 2, SHORT, None, start.data_ptr())) == EINVAL       # lane kernel only
+    assert call(50, _native.gn_options(None, 0, 0, 1, 3, it.data_ptr())) == EINVAL
+    assert call(50, _native.gn_options(None, 0, 0, 1, 0, None, None, 4)) == EINVAL                    # unknown flag
+    assert call(50, _native.gn_options(None, 0, 0, 1, 0, None, None, 0, -1)) == EINVAL
     # the table of fixed points must be 16-byte aligned (pairs are read with one load)
-    tabs = md._device_tables(i0, mus, dev, True)[2]
-    shifted = torch.empty(tabs[2].numel() + 1, dtype=torch.float64, device=dev)
-    shifted[1:].copy_(tabs[2])
-    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, None, shifted[1:].data_ptr())) == EINVAL
-    assert call(i0_d, mus_d, 50, _native.gn_options(None, 0, 0, 1, _native.GN_PASS_REFINE, None, tabs[2].data_ptr())) == 0
-    assert err(a.cpu().numpy(), exact) < 1e-12
+    shifted = torch.empty(start.numel() + 1, dtype=torch.float64, device=dev)
+    shifted[1:].copy_(start)
+    assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, None, shifted[1:].data_ptr())) == EINVAL
 
 
 @pytest.mark.parametrize('dose', [1e3, 1e5, 1e7])
@@ -898,9 +898,9 @@ def test_short_cut_tables_are_cached_by_content_and_accept_device_tensors(hip, g
     md._table_cache.clear()
     a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1))
     assert md.last_gn_stats()['mode'] == 'start' and len(md._table_cache) == 1
-    start0 = next(iter(md._table_cache.values()))[('coarse', 1e-12)][2]
+    start0 = next(iter(md._table_cache.values()))[('gate', 1e-12)]['start']
     b = to_host(md.gn_device(g[0], g[1], i0.copy(), mus.copy(), 50, 'f64', kernel=1))
-    assert len(md._table_cache) == 1 and next(iter(md._table_cache.values()))[('coarse', 1e-12)][2] is start0
+    assert len(md._table_cache) == 1 and next(iter(md._table_cache.values()))[('gate', 1e-12)]['start'] is start0
     c = to_host(md.gn_device(g[0], g[1], to_dev(i0, torch.float64, dev), to_dev(mus, torch.float64, dev), 50, 'f64', kernel=1))
     assert md.last_gn_stats()['mode'] == 'start' and len(md._table_cache) == 1
     assert np.array_equal(a.view(np.int64), b.view(np.int64)) and np.array_equal(a.view(np.int64), c.view(np.int64))
@@ -908,8 +908,8 @@ def test_short_cut_tables_are_cached_by_content_and_accept_device_tensors(hip, g
     assert len(md._table_cache) == 2
     # a tighter tolerance than the library's default gets a gate calibrated for it (more steps needed per cell)
     md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1, stop_tol=1e-14)
-    ent = [v for v in md._table_cache.values() if ('coarse', 1e-14) in v]
-    assert len(ent) == 1 and ('coarse', 1e-12) in ent[0]
+    ent = [v for v in md._table_cache.values() if ('gate', 1e-14) in v]
+    assert len(ent) == 1 and ('gate', 1e-12) in ent[0]
 
 
 def test_short_cut_through_the_public_boundary(hip):

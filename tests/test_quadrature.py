@@ -81,19 +81,6 @@ def newton_tables():
     return md.decomposition_tables(ct, synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80))
 
 
-def test_short_tables_of_the_coarse_newton_pass():
-    """quadrature.coarse_newton_tables: a sixth of the energies, non-negative weights on the spectra's own energies, the
-    forward model within a few 1e-6 over the decomposition's domain (attenuation down to exp(-16))."""
-    _, i0, mus = newton_tables()
-    cols, i0_s = q.coarse_newton_tables(i0, mus)
-    assert 16 <= len(cols) <= i0.shape[1] // 4 and np.all(i0_s >= 0) and not np.any((i0_s > 0) & (i0[:, cols] == 0))
-    rng = np.random.default_rng(3)
-    mu_min = mus[:, (i0 > 0).any(0)].min(1)
-    a = q._domain_points(16.0 / mu_min, 16.0, 40000, 600, rng, mu_min)
-    assert q.max_rel_error(mus, i0, cols, i0_s, a) < 1e-5
-    assert q.coarse_newton_tables(i0, -mus) is None and q.coarse_newton_tables(-i0, mus) is None
-
-
 def test_gate_grid_and_start_array():
     """quadrature.newton_start_grid: a cell grid in data space that holds every ray of the domain (incl. water in a tissue /
     bone basis, whose second component is slightly negative); assemble_start: a cell needs the largest step count among its
@@ -130,7 +117,9 @@ def test_gate_grid_and_start_array():
     roots = roots.copy()
     roots[45 * (n + 1) + 20] += [3.0, -2.0]
     roots[70 * (n + 1) + 60] += [1e-4, 0.0]
-    start, share = q.assemble_start(p, steps, roots)
+    start, share, stats = q.assemble_start(p, steps, roots)
+    assert stats['walk_nonfinite_share'] == 0.0 and 0.0 < stats['walk_not_by_rule_share'] < 1e-3 and not q.pair_is_ill_posed(stats)
+    assert np.allclose(start[8:10], np.log(start[0:2]), rtol=0, atol=0)          # ln of the open-beam signals, for the kernel's logarithm
     assert start.size == q.START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n
     r0 = start[q.START_HEADER:q.START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)[:, :, 0]          # pairs (a0, a1)
     cells = start[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)                                        # pairs (need, radius)
@@ -160,7 +149,7 @@ def test_gate_table_is_validated_at_the_cell_centres():
     xc, tc = h[4] + np.arange(n + 1) / h[5], h[6] + np.arange(n + 1) / h[7]
     roots = field(xc[:, None], tc[None, :]).reshape(-1, 2)
     p = dict(p, corner_g=np.exp(-(roots @ p['mus'])) @ p['i0'].T)
-    start, share = q.assemble_start(p, np.full((n + 1) ** 2, 17), roots)
+    start, share, _ = q.assemble_start(p, np.full((n + 1) ** 2, 17), roots)
     assert share > 0.85                                                    # (rows beyond GATE_U_MAX and the border are closed)
     xm, tm = h[4] + (np.arange(n) + 0.5) / h[5], h[6] + (np.arange(n) + 0.5) / h[7]
     centre_roots = field(xm[:, None], tm[None, :]).reshape(-1, 2)

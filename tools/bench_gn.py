@@ -1,7 +1,7 @@
 """Same-box A/B of the float64 Newton kernel's variants on the benchmark's sinograms (512^3, 1000 x 800 x 512):
-DEXCT_GN_MINW (4, the default: 110 VGPRs, no scratch; 5: 96 VGPRs + spills), grid caps, the full loop; exact mode,
-interleaved repetitions, results compared bit for bit with the default.  (Round 4: the history / ring / exponent / static-run
-variants of round 3 are gone from the kernel; their measurements are in profiles/r03_gn_isa.md.  Build variants: tools/probes/gn_ab.py.)"""
+grid caps (blocks_per_cu) and the full loop; exact mode, interleaved repetitions, results compared bit for bit with the
+default.  (The history / ring / exponent / static-run variants of round 3 and the 5-waves-per-SIMD register allocation of round
+4 are gone from the kernel; their measurements are in profiles/r03_gn_isa.md and r04_gn.md.  Build variants: tools/probes/gn_ab.py.)"""
 import os
 import sys
 
@@ -28,19 +28,16 @@ ref = torch.empty_like(a)
 
 
 def run(out, env):
-    for k in ('DEXCT_GN_MINW', 'DEXCT_GN_FULL_LOOP', 'DEXCT_GN_BLOCKS_PER_CU'):
-        os.environ.pop(k, None)
-    os.environ.update(env)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    md.gn_device(counts[0], counts[1], i0, mus, 50, 'f64', out=out, mask_max=gmax, stop_tol=0.0)      # exact mode: the variants agree bit for bit
+    md.gn_device(counts[0], counts[1], i0, mus, 50, 'f64', out=out, mask_max=gmax, stop_tol=0.0, **env)      # exact mode: the variants agree bit for bit
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1)
 
 
 run(ref, {})
-variants = [{}, {'DEXCT_GN_MINW': '5'}, {'DEXCT_GN_BLOCKS_PER_CU': '5'}, {'DEXCT_GN_BLOCKS_PER_CU': '8'}, {'DEXCT_GN_FULL_LOOP': '1'}]
+variants = [{}, {'blocks_per_cu': 3}, {'blocks_per_cu': 5}, {'blocks_per_cu': 8}, {'full_loop': True}]
 times = {i: [] for i in range(len(variants))}
 same = {}
 for rep in range(3):
