@@ -54,6 +54,13 @@ def parse():
                          'views [rank K-th] of the fixed scan; e.g. --workload config3 --shard-of 8 is the per-GPU work of '
                          'BASELINE configs[3]')
     ap.add_argument('--shard-rank', type=int, default=0)
+    ap.add_argument('--gather', default='root', choices=['root', 'direct', 'all'],
+                    help='N > 1: how the raw sinograms are assembled (dex-ct-sim_amd/_shard.py): root = the north star\'s gather to '
+                         'rank 0 (point-to-point, one transfer per peer link); direct = the same transfers to every rank (an '
+                         'all-gather that does not depend on RCCL\'s algorithm); all = one all_gather_into_tensor per spectrum')
+    ap.add_argument('--gather-chunks', type=int, default=0,
+                    help='N > 1: view chunks per rank; a chunk\'s transfer starts when its projection is done and overlaps the '
+                         'projection and the Newton launches of the following chunks (0: 4 for root / direct, 1 for all)')
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--gn-precision', default=None, choices=[None, 'f64', 'mixed'])
     ap.add_argument('--kernel', type=int, default=0, help='0 choose, 1 ray-parallel, 2 row-parallel')
@@ -292,7 +299,80 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     precision = args.gn_precision or md.DEFAULT_PRECISION
 
+    n_chunks = args.gather_chunks or (1 if args.gather == 'all' else 4)
+    n_chunks = max(1, min(n_chunks, nV))
+    if world > 1:
+        # the sharded step works chunk by chunk: per chunk a compact [2, views, channel, row] projection output (the kernel's
+        # own layout), its transposed copy [2, views, row, channel] (what travels), and the chunk of the results
+        cb = [_shard.split(nV, j, n_chunks) for j in range(n_chunks)]
+        cn = [torch.empty((2, e - b) + nat_shape[1:], dtype=torch.float32, device=dev) for b, e in cb]
+        cl = [torch.empty_like(t) for t in cn]
+        cr = [torch.empty((2, e - b, rows, args.channels), dtype=torch.float32, device=dev) if native == 1 else cn[j] for j, (b, e) in enumerate(cb)]
+        clr = [torch.empty_like(t) if native == 1 else cl[j] for j, t in enumerate(cr)]
+        cmax = torch.empty(n_chunks, dtype=torch.float64, device=dev)
+        # where the assembled sinogram lands: on every rank for 'direct' / 'all'; 'root' needs it on rank 0 only (the other ranks
+        # keep the buffer for the per-mode comparison below: gather_views ignores out= on ranks that receive nothing)
+        full_out = torch.empty((2, total_views, rows, args.channels), dtype=torch.float32, device=dev)
+        full_all = full_out
+
+    gather_mode = [args.gather]
+
+    def step_sharded(timed):
+        """N > 1.  Plan (whole shard, once); per chunk of this rank's views: projection (sino_raw and sino_log), its maximum,
+        transpose into the reference's order and - point-to-point modes - the START of the chunk's transfer; then the global
+        maximum (one scalar all-reduce), the Newton launches chunk by chunk, the log sinograms' transposes, and the wait for the
+        transfers.  Mode 'all': one all_gather_into_tensor per spectrum, started after the last chunk (rounds 1-4)."""
+        mode = gather_mode[0]
+        st = stream_ptr()
+        _native.check(lib.dexct_fan_plan(C.byref(pj.geom), ptr(pj.view_cs), ptr(pj.chan_cs), vb, ve, ptr(pj.plan), st), 'plan')
+        if timed:
+            ev[0].record()
+        finishes = []
+        for j, (b, e) in enumerate(cb):
+            pj.project_tables(mu_d, w_d, out=cn[j], layout=None, air=air, log_out=cl[j], views=(b, e))
+            _native.check(lib.dexct_reduce_max(ptr(cn[j][0]), 0, cn[j][0].numel(), ptr(cmax[j]), st), 'max')
+            if mode == 'all':                    # the whole shard in one buffer [2, views, row, channel]
+                for k in range(2):
+                    if native == 1:
+                        _native.check(lib.dexct_transpose_batched(ptr(cn[j][k]), ptr(counts[k, b:e]), e - b, args.channels, rows, 4, st),
+                                      'transpose counts')
+                    else:
+                        counts[k, b:e].copy_(cn[j][k])
+            else:
+                if native == 1:
+                    _native.check(lib.dexct_transpose_batched(ptr(cn[j]), ptr(cr[j]), 2 * (e - b), args.channels, rows, 4, st), 'transpose counts')
+                finishes.append(_shard.gather_views(cr[j], total_views, view_dim=1, async_op=True, out=full_out, mode=mode, root=0,
+                                                    part=(j, n_chunks), tag='bench'))
+        if mode == 'all':
+            finishes.append(_shard.gather_views(counts, total_views, view_dim=1, async_op=True, out=full_all, mode='all', tag='bench'))
+        if timed:
+            ev[1].record()
+        gmax.copy_(cmax.max())                   # NaN-propagating like np.max (torch.max returns NaN if any element is NaN)
+        gm = _shard.global_max(gmax)
+        if timed:
+            ev[2].record()
+        for j, (b, e) in enumerate(cb):
+            md.gn_device(cn[j][0], cn[j][1], i0, mus, args.iters, precision, out=a_out[b:e], out_rc=out_rc, mask_max=gm, mask_frac=0.95,
+                         stop_tol=gn_tol[0], two_level=gn_mode[0], accumulate_stats=j > 0)
+        if timed:
+            ev[3].record()
+        if native == 1:
+            for j, (b, e) in enumerate(cb):
+                _native.check(lib.dexct_transpose_batched(ptr(cl[j]), ptr(clr[j]), 2 * (e - b), args.channels, rows, 4, st), 'transpose log')
+        # basis-material sinograms stay view-sharded (each rank owns its angles, as a view-sharded back-projection would
+        # consume them); only the raw sinogram is assembled, as the north star says
+        if timed:
+            ev[4].record()
+        full = None
+        for f in finishes:
+            full = f()                           # the stream waits here for whatever of the transfers is not yet done
+        if timed:
+            ev[5].record()
+        return full, a_out
+
     def step(timed):
+        if world > 1:
+            return step_sharded(timed)
         st = stream_ptr()
         _native.check(lib.dexct_fan_plan(C.byref(pj.geom), ptr(pj.view_cs), ptr(pj.chan_cs), vb, ve, ptr(pj.plan), st),
                       'plan')
@@ -303,14 +383,6 @@ def main():
             ev[1].record()
         _native.check(lib.dexct_reduce_max(ptr(counts_nat[0]), 0, counts_nat[0].numel(), ptr(gmax), st), 'max')
         gm = _shard.global_max(gmax)
-        finish_gather = None
-        if world > 1:
-            # the one data-path collective: assemble the raw sinograms (reference order) on every rank; it is
-            # started here and overlaps the Newton kernel, which only needs the local shard
-            if native == 1:
-                _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
-                                                          4, st), 'transpose counts')
-            finish_gather = _shard.gather_views(counts, total_views, view_dim=1, async_op=True, tag='bench', reuse_out=True)
         if timed:
             ev[2].record()
         # air mask fused into the Newton kernel: threshold = 0.95 * (all-reduced) max, read from the device scalar
@@ -320,20 +392,10 @@ def main():
         if timed:
             ev[3].record()
         if native == 1:       # hand the sinograms over in the reference's [view][row][channel] order
-            if world == 1:
-                _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
-                                                          4, st), 'transpose counts')
+            _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
+                                                      4, st), 'transpose counts')
             _native.check(lib.dexct_transpose_batched(ptr(log_nat), ptr(log_ref), 2 * nV, args.channels, rows, 4, st),
                           'transpose log')
-        if world > 1:
-            # basis-material sinograms stay view-sharded (each rank owns its angles, as a view-sharded
-            # back-projection would consume them); only the raw sinogram is assembled, as the north star says
-            if timed:
-                ev[4].record()
-            full = finish_gather()          # the stream waits here for whatever of the gather is not yet done
-            if timed:
-                ev[5].record()
-            return full, a_out
         return counts, a_out
 
     def barrier():
@@ -348,24 +410,29 @@ def main():
         md._device_tables(i0, mus, dev, True)
         torch.cuda.synchronize()
     gate_prep_s = time.perf_counter() - t0
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t_sid, t_gn, t_exposed = [], [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-        torch.cuda.synchronize()
-        t_sid.append(ev[0].elapsed_time(ev[1]))
-        t_gn.append(ev[2].elapsed_time(ev[3]))
+    def timed_steps(n_steps, n_warm):
+        """n_warm untimed steps, then exactly n_steps bracketed by barrier + synchronize; the MAX over ranks of the wall time"""
+        for _ in range(n_warm):
+            step(False)
+        barrier()
+        ts, tg, tx = [], [], []
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(True)
+            torch.cuda.synchronize()
+            ts.append(ev[0].elapsed_time(ev[1]))
+            tg.append(ev[2].elapsed_time(ev[3]))
+            if world > 1:
+                tx.append(ev[4].elapsed_time(ev[5]))
+        barrier()
+        el = time.perf_counter() - t0
         if world > 1:
-            t_exposed.append(ev[4].elapsed_time(ev[5]))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor(elapsed, dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            t = torch.tensor(el, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ts, tg, tx
+
+    elapsed, t_sid, t_gn, t_exposed = timed_steps(args.steps, args.warmup)
     ms_per_step = 1e3 * elapsed / args.steps
     rays_all = total_views * rows * args.channels           # rays of all ranks together (ragged shards included)
     if args.shard_of > 1:
@@ -376,34 +443,57 @@ def main():
 
     multi = None
     if world > 1:
-        # the gather on its own (not overlapped with anything), outside the timed region
-        _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows, 4,
-                                                  stream_ptr()), 'transpose counts')
-        barrier()
-        n_alloc0 = torch.cuda.memory_stats().get('allocation.all.allocated', 0)
-        g0 = time.perf_counter()
-        for _ in range(3):
-            _shard.gather_views(counts, total_views, view_dim=1, tag='bench', reuse_out=True)
-            torch.cuda.synchronize()
-        gather_alone_ms = 1e3 * (time.perf_counter() - g0) / 3
-        gather_allocs = (torch.cuda.memory_stats().get('allocation.all.allocated', 0) - n_alloc0) / 3
+        # every mode of the assembly: its transfers alone (nothing else on the GPU), and the step with it - what the step still
+        # waits for after its last kernel (gather_exposed_ms) and the step time; the timed loop above ran args.gather
+        pj.project_tables(mu_d, w_d, out=counts_nat, layout=None, air=air, log_out=log_nat)          # the whole shard, for the statistics below
+        if native == 1:
+            _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows, 4, stream_ptr()), 'transpose counts')
+        by_mode = {}
+        gather_allocs = None
+        for mode in _shard.GATHER_MODES:
+            barrier()
+            _shard.gather_views(counts, total_views, view_dim=1, out=full_out, mode=mode, tag='bench')        # (buffers of the mode exist)
+            barrier()
+            n_alloc0 = torch.cuda.memory_stats().get('allocation.all.allocated', 0)
+            g0 = time.perf_counter()
+            for _ in range(3):
+                _shard.gather_views(counts, total_views, view_dim=1, out=full_out, mode=mode, tag='bench')
+                torch.cuda.synchronize()
+            alone_ms = 1e3 * (time.perf_counter() - g0) / 3
+            allocs = (torch.cuda.memory_stats().get('allocation.all.allocated', 0) - n_alloc0) / 3
+            if mode == args.gather:
+                gather_allocs = allocs
+                exposed, step_ms = float(np.mean(t_exposed)), ms_per_step
+            else:
+                gather_mode[0] = mode
+                el, _, _, tx = timed_steps(min(3, args.steps), 1)
+                gather_mode[0] = args.gather
+                exposed, step_ms = float(np.mean(tx)), 1e3 * el / min(3, args.steps)
+            t = torch.tensor([alone_ms, exposed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            recv_bytes = 2 * total_views * rows * args.channels * 4 * (world - 1) / world          # everybody else's views, both spectra
+            by_mode[mode] = {'gather_ms': float(t[0]), 'gather_exposed_ms': float(t[1]), 'ms_per_step': step_ms,
+                             'received_bytes_per_receiving_rank': recv_bytes, 'receiving_ranks': 1 if mode == 'root' else world,
+                             'GBps_into_a_receiving_rank': recv_bytes / (float(t[0]) * 1e-3) / 1e9}
+        step(False)                              # the selected mode's results are back in place
+        torch.cuda.synchronize()
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {'rank': rank, 'views': [vb, ve], 'siddon_ms': sid_ms, 'gn_ms': gn_ms,
-                                          'gather_exposed_ms': float(np.mean(t_exposed)),
-                                          'gather_alone_ms': gather_alone_ms})
-        gathered_bytes = 2 * total_views * rows * args.channels * 4
+                                          'gather_exposed_ms': float(np.mean(t_exposed))})
         multi = {'backend': 'nccl (RCCL)' if backend == 'nccl' else f'{backend} (REHEARSAL: ranks share devices, host-staged '
-                                                                      f'collectives; not an RCCL measurement)',
-                 'collectives_per_step': 'all_gather_into_tensor of the raw sinograms (reference order) + all_reduce(max) '
-                                         'of one float64',
-                 'gathered_bytes_per_rank_per_step': gathered_bytes,
-                 'gather_ms': max(r['gather_alone_ms'] for r in per_rank),
-                 'gather_exposed_ms': max(r['gather_exposed_ms'] for r in per_rank),
-                 'gather_device_allocations_per_call': gather_allocs,     # buffers are allocated once (_shard._buffers)
-                 'gather_GBps_per_rank': gathered_bytes * (world - 1) / world / (max(r['gather_alone_ms'] for r in per_rank) * 1e-3) / 1e9,
-                 'per_rank': per_rank,
-                 'note': 'gather_ms: the all-gather alone; gather_exposed_ms: what the step still waits for after the '
-                         'Newton kernel has finished (the collective is started before it and overlaps it)'}
+                                                                      f'transfers; not an RCCL measurement)',
+                 'gather': args.gather, 'view_chunks_per_rank': n_chunks if args.gather != 'all' else 1,
+                 'collectives_per_step': {'root': 'gather of the raw sinograms (reference order) to rank 0: one point-to-point transfer per peer '
+                                                  'and chunk in one RCCL group', 'direct': 'the same transfers to every rank (all-gather as '
+                                                  'world-1 sends + receives per rank)', 'all': 'all_gather_into_tensor per spectrum'}[args.gather]
+                                         + ' + all_reduce(max) of one float64',
+                 'gather_ms': by_mode[args.gather]['gather_ms'], 'gather_exposed_ms': by_mode[args.gather]['gather_exposed_ms'],
+                 'gather_device_allocations_per_call': gather_allocs,     # buffers are allocated once
+                 'by_mode': by_mode, 'per_rank': per_rank,
+                 'note': 'gather_ms: the assembly alone (whole shard, nothing else running); gather_exposed_ms: what the step still '
+                         'waits for after its last kernel (transfers start chunk by chunk during the projection and overlap the '
+                         'Newton launches); by_mode: the same two numbers and the step time for every mode, measured in this run '
+                         '(3 steps each for the modes that are not --gather)'}
 
     if rank != 0:
         if world > 1:

@@ -253,7 +253,7 @@ class Projector:
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 
     def project_tables(self, mu_d, w_d, want_pathlen=False, out=None, layout=0, w2_d=None, seed=0, air=None,
-                       log_out=None):
+                       log_out=None, views=None):
         """Device-side call: mu_d [M, nE], w_d [S, nE] float32 tensors -> counts.
 
         ``air`` (S unattenuated signals, sum_e w[s][e]) asks for get_sino's second output as well, the log sinogram
@@ -266,8 +266,15 @@ class Projector:
         dexct_transpose_batched converts (cheaper than scattered 4-byte stores).
         ``w2_d`` (variance weights, merged_tables(with_variance=True)) switches quantum noise on: the kernel also
         writes the signal variance and dexct_add_noise draws the sample (Philox, keyed by ``seed`` and by the
-        GLOBAL (view, row, channel, spectrum), so shards reproduce the unsharded sinogram)."""
+        GLOBAL (view, row, channel, spectrum), so shards reproduce the unsharded sinogram).
+        ``views=(a, b)``: only the local views [a, b) of this projector's range (outputs sized for b - a views): a step that
+        hands its sinogram on in chunks projects chunk by chunk (bench.py, the sharded step)."""
         S, nE = w_d.shape
+        sl0, sl1 = (0, self.n_local_views) if views is None else (int(views[0]), int(views[1]))
+        if not 0 <= sl0 < sl1 <= self.n_local_views:
+            raise ValueError(f'views={views}: a non-empty range within the {self.n_local_views} local views')
+        plan_ptr = self.plan.data_ptr() + sl0 * self.ct.N_channels * _native.PLAN_BYTES
+        vb, ve = self.view_begin + sl0, self.view_begin + sl1
         if mu_d.shape[0] != self.n_mat:
             if mu_d.shape[0] != self.phantom.n_materials:
                 raise ValueError(f'mu has {mu_d.shape[0]} rows; expected {self.n_mat} (compact ids, Projector.compact) or '
@@ -275,7 +282,7 @@ class Projector:
             mu_d = mu_d[torch.as_tensor(self.mat_rows, device=mu_d.device)].contiguous()
         M = self.n_mat
         ct = self.ct
-        nV, nR, nC = self.n_local_views, ct.N_rows, ct.N_channels
+        nV, nR, nC = sl1 - sl0, ct.N_rows, ct.N_channels
         native = self.native_layout
         want = native if layout is None else layout
         shape = {0: (S, nV, nR, nC), 1: (S, nV, nC, nR)}
@@ -302,13 +309,13 @@ class Projector:
             def cone_call(weights, out_counts, out_pathlen, out_log):
                 if self.cone_rows:
                     _native.check(self.lib.dexct_cone_project_rows(
-                        C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
-                        self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
+                        C.byref(self.geom), plan_ptr, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                        self.ct.src_z, max_dz, vb, ve, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
                         ptr(weights), ptr(out_counts), ptr(out_pathlen), out_log, stream_ptr()), 'dexct_cone_project_rows')
                 else:
                     _native.check(self.lib.dexct_cone_project(
-                        C.byref(self.geom), ptr(self.plan), ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
-                        self.ct.src_z, max_dz, self.view_begin, self.view_end, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
+                        C.byref(self.geom), plan_ptr, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                        self.ct.src_z, max_dz, vb, ve, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
                         ptr(mu_d), ptr(weights), ptr(out_counts), ptr(out_pathlen), out_log, stream_ptr()), 'dexct_cone_project')
 
             cone_call(w_d, counts, pathlen, lo)
@@ -319,7 +326,7 @@ class Projector:
                 cone_call(w2_d, variance, None, None)
         elif self.use_packed and w2_d is None:           # (with noise the byte-volume kernel below runs: it carries the variance)
             _native.check(self.lib.dexct_siddon_project_packed(
-                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_z2), M, nE, S,
+                C.byref(self.geom), plan_ptr, vb, ve, ptr(self.vol_z2), M, nE, S,
                 ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, lo, stream_ptr()), 'dexct_siddon_project_packed')
         elif self.grouped_packed or self.grouped:        # noise too: the detection pass carries the variance
             fn, what = ((self.lib.dexct_siddon_project_grouped_packed, 'dexct_siddon_project_grouped_packed') if self.grouped_packed
@@ -330,7 +337,7 @@ class Projector:
             n_chunk = max(1, min(nV, _GROUP_SCRATCH_BYTES // max(per_view, 1)))
             if n_chunk >= nV:
                 scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
-                _native.check(fn(C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.codes), M, nE, S,
+                _native.check(fn(C.byref(self.geom), plan_ptr, vb, ve, ptr(self.codes), M, nE, S,
                                  ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
                                  lo, stream_ptr()), what)
             else:
@@ -343,8 +350,8 @@ class Projector:
                     v_t = torch.empty_like(c_t) if variance is not None else None
                     l_t = torch.empty_like(c_t) if lo is not None else None
                     lo_t = _native.log_out(ptr(l_t), air) if lo is not None else None
-                    _native.check(fn(C.byref(self.geom), self.plan.data_ptr() + v0 * nC * _native.PLAN_BYTES, self.view_begin + v0,
-                                     self.view_begin + v1, ptr(self.codes), M, nE, S, ptr(mu_d), ptr(w_d), ptr(c_t), ptr(p_t),
+                    _native.check(fn(C.byref(self.geom), plan_ptr + v0 * nC * _native.PLAN_BYTES, vb + v0,
+                                     vb + v1, ptr(self.codes), M, nE, S, ptr(mu_d), ptr(w_d), ptr(c_t), ptr(p_t),
                                      ptr(scratch), run_layout, ptr(w2_d), ptr(v_t), lo_t, stream_ptr()), what)
                     counts[:, v0:v1].copy_(c_t)
                     if pathlen is not None:
@@ -355,13 +362,13 @@ class Projector:
                         log[:, v0:v1].copy_(l_t)
         else:
             _native.check(self.lib.dexct_siddon_project(
-                C.byref(self.geom), ptr(self.plan), self.view_begin, self.view_end, ptr(self.vol_yx),
+                C.byref(self.geom), plan_ptr, vb, ve, ptr(self.vol_yx),
                 ptr(self.vol_xy), ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
                 3 if self.kernel in (7, 8) else self.kernel, run_layout, ptr(w2_d), ptr(variance), lo, stream_ptr()),
                 'dexct_siddon_project')
         if variance is not None:
             _native.check(self.lib.dexct_add_noise(ptr(counts), ptr(variance), S, nV, nR, nC, run_layout,
-                                                   self.view_begin, int(seed) & (2 ** 64 - 1), stream_ptr()),
+                                                   vb, int(seed) & (2 ** 64 - 1), stream_ptr()),
                           'dexct_add_noise')
             if log is not None:
                 self.sino_log(counts, air, log)

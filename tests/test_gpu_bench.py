@@ -1,5 +1,6 @@
 """bench.py as the driver calls it: the plain command with --gpus N must start its own ranks (no launcher), run the
-sharded step (view shards, all-gather of the raw sinograms, all-reduced air-mask maximum) and print one JSON line."""
+sharded step (view shards projected in chunks, the raw sinograms assembled - gather to rank 0, point-to-point to every rank,
+or all-gather -, all-reduced air-mask maximum) and print one JSON line."""
 import json
 import os
 import subprocess
@@ -29,7 +30,7 @@ def run_bench(*extra, env=None):
 def test_plain_command_single_gpu(hip):
     out, _ = run_bench()
     assert out['n_gpus'] == 1 and out['scaling'] == 'strong' and out['value'] > 0
-    assert out['roofline']['kernel'].startswith('gn_refill_kernel') and 'roofline_siddon' in out
+    assert out['roofline']['kernel'].startswith('gn_shortcut_kernel') and 'roofline_siddon' in out
     for r in (out['roofline'], out['roofline_siddon']):
         assert r['frac'] is None or 0 < r['frac'] <= 1.0, r
     q = out['siddon_reduced_quadrature']         # opt-in shorter energy table: measured beside the step, bound checked on every ray
@@ -42,14 +43,19 @@ def test_plain_command_single_gpu(hip):
         assert case['bytes']['d2h_per_get_sino'] == 8 * case['rays']
 
 
-@pytest.mark.parametrize('scaling', ['strong', 'weak'])
-def test_plain_command_two_ranks(hip, scaling):
+@pytest.mark.parametrize('scaling,gather', [('strong', None), ('weak', 'direct'), ('strong', 'all')])
+def test_plain_command_two_ranks(hip, scaling, gather):
     """`python bench.py --gpus 2` (no torchrun): on a one-GPU box the two ranks share the device and rehearse over
-    gloo; with two devices the same command runs RCCL."""
-    out, err = run_bench('--gpus', '2', '--scaling', scaling)
+    gloo; with two devices the same command runs RCCL.  Every mode of the assembly (default: the gather to rank 0), with the
+    other two measured beside it."""
+    out, err = run_bench('--gpus', '2', '--scaling', scaling, *(('--gather', gather) if gather else ()))
     assert out['n_gpus'] == 2 and out['scaling'] == scaling
     m = out['multi_gpu']
+    assert m['gather'] == (gather or 'root') and m['view_chunks_per_rank'] == (1 if gather == 'all' else 4)
     assert len(m['per_rank']) == 2 and m['gather_ms'] > 0
+    assert sorted(m['by_mode']) == ['all', 'direct', 'root']
+    for mode, b in m['by_mode'].items():
+        assert b['gather_ms'] > 0 and b['gather_exposed_ms'] >= 0 and b['ms_per_step'] > 0 and b['receiving_ranks'] == (1 if mode == 'root' else 2)
     assert m['gather_device_allocations_per_call'] == 0          # preallocated send / receive / result buffers
     views = [r['views'] for r in sorted(m['per_rank'], key=lambda r: r['rank'])]
     total = 48 if scaling == 'strong' else 96
@@ -62,8 +68,8 @@ def test_plain_command_two_ranks(hip, scaling):
 
 def test_plain_command_four_ranks_ragged(hip):
     """Four ranks (gloo rehearsal on a one-GPU box) over a scan whose views do not divide evenly: 50 = 13+13+12+12."""
-    out, _ = run_bench('--gpus', '4', '--views', '50')
-    assert out['n_gpus'] == 4 and out['config']['rays_total'] == 50 * 64 * 96
+    out, _ = run_bench('--gpus', '4', '--views', '50', '--gather-chunks', '5')            # chunks of 3, 3, 3, 2, 2 / 3, 3, 2, 2, 2 views
+    assert out['n_gpus'] == 4 and out['multi_gpu']['view_chunks_per_rank'] == 5 and out['config']['rays_total'] == 50 * 64 * 96
     views = [r['views'] for r in sorted(out['multi_gpu']['per_rank'], key=lambda r: r['rank'])]
     assert views == [[0, 13], [13, 26], [26, 38], [38, 50]]
     assert out['multi_gpu']['gather_device_allocations_per_call'] == 0       # the ragged path too
@@ -83,7 +89,7 @@ def test_plain_command_three_ranks_config3_labels(hip):
     6 processes on the card and the test runner is one of them: the 4-rank test above is as far as a rehearsal here should
     go; the 8-rank launch is the driver's, on an 8-GPU node, and the 8-rank gather itself runs on CPU in
     tests/test_shard_gloo.py.)"""
-    out, _ = run_bench('--gpus', '3', '--views', '52', '--workload', 'config3')
+    out, _ = run_bench('--gpus', '3', '--views', '52', '--workload', 'config3', '--gather', 'direct')
     assert out['n_gpus'] == 3 and out['config']['rays_total'] == 52 * 64 * 96
     assert out['config']['baseline_config'] == 'configs[3]'
     views = [r['views'] for r in sorted(out['multi_gpu']['per_rank'], key=lambda r: r['rank'])]

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import oracle_geom, small_scan
+from conftest import INPUT, oracle_geom, small_scan
 from oracle import c_oracle as co
 
 pytestmark = pytest.mark.gpu
@@ -1111,3 +1111,45 @@ def test_reduced_quadrature_is_skipped_for_long_tables(hip):
     a, _ = pj.project(spectra())
     b, _ = pj.project(spectra(), quadrature='reduced')
     assert pj.quadrature_info is None and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('kind', ['single_row', 'stacked', 'packed', 'grouped', 'cone', 'cone_rows', 'noisy'])
+def test_projection_of_a_view_slice_is_the_slice_of_the_projection(hip, kind):
+    """Projector.project_tables(views=(a, b)) - what a step uses that hands its sinogram on in chunks (bench.py, sharded
+    runs): both outputs of every kernel family, projected slice by slice, are bit for bit the slices of the whole projection
+    (plans, Philox keys and view angles are indexed by the global view)."""
+    import os
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp, synthetic, system
+    n_views = 11
+    if kind in ('cone', 'cone_rows'):
+        _, ph = small_scan(n=48, nz=48 if kind == 'cone' else 24, n_views=n_views, n_channels=40)
+        ct = dx.FanBeamGeometry(N_channels=40, N_proj=n_views, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=0.5, eid=True,
+                                detector_file=os.path.join(INPUT, 'detector', 'eta_eid_mv.bin'), N_rows=6 if kind == 'cone' else 24, cone=True, src_z=0.2)
+    else:
+        nz = {'single_row': 1, 'stacked': 64, 'packed': 192, 'grouped': 64, 'noisy': 16}[kind]
+        ct, ph = small_scan(n=48, nz=nz, n_views=n_views, n_channels=40, n_rows=nz)
+        if kind == 'grouped':                                   # more than four table rows: material groups + detection pass
+            ph = ph_many(ph, 8)
+    specs = [synthetic.kramers_spectrum(120), synthetic.kramers_spectrum(80)]
+    pj = fp.Projector(ct, ph, view_range=(2, n_views))          # a shard that does not start at view 0
+    if kind == 'noisy':
+        _, mu, w, w2 = fp.merged_tables(ct, ph, specs, with_variance=True)
+        mu_d, w_d = (torch.tensor(x, dtype=torch.float32, device='cuda') for x in (pj.compact(mu), w))
+        kw = dict(w2_d=torch.tensor(w2, dtype=torch.float32, device='cuda'), seed=5)
+        air = [float(x) for x in w.sum(1)]
+    else:
+        _, mu_d, w_d, air = pj.upload_tables(specs)
+        kw = {}
+    whole_c, whole_l = pj.project_tables(mu_d, w_d, layout=None, air=air, **kw)
+    assert whole_c.shape[1] == n_views - 2 and torch.isfinite(whole_l).all()
+    for a, b in ((0, 4), (4, 5), (5, 9)):
+        c, l = pj.project_tables(mu_d, w_d, layout=None, air=air, views=(a, b), **kw)
+        assert c.shape[1] == b - a
+        assert torch.equal(c, whole_c[:, a:b]) and torch.equal(l, whole_l[:, a:b]), (kind, a, b)
+    c = pj.project_tables(mu_d, w_d, layout=0, views=(3, 7), **kw)              # the reference's order (a transpose pass for stacked fans)
+    assert torch.equal(c, pj.project_tables(mu_d, w_d, layout=0, **kw)[:, 3:7])
+    with pytest.raises(ValueError):
+        pj.project_tables(mu_d, w_d, views=(4, 4))
+    with pytest.raises(ValueError):
+        pj.project_tables(mu_d, w_d, views=(0, n_views))

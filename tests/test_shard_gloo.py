@@ -18,14 +18,44 @@ def _worker(rank, world, port, n_views, q):
     from dex_ct_sim_amd import _shard
     full = torch.arange(2 * n_views * 3 * 5, dtype=torch.float32).reshape(2, n_views, 3, 5)
     b, e = _shard.my_views(n_views)
-    got = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1)
-    # results of the public path are owned by the caller: a second gather of the same shape must not overwrite the first
-    # (advisor finding of round 3); only reuse_out=True hands out the cached buffer
-    again = _shard.gather_views((full[:, b:e] + 1.0).contiguous(), n_views, view_dim=1)
-    owned = bool(torch.equal(got, full) and torch.equal(again, full + 1.0) and got.data_ptr() != again.data_ptr())
-    r1 = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, tag='t', reuse_out=True)
-    r2 = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, tag='t', reuse_out=True)
-    owned = owned and r1.data_ptr() == r2.data_ptr() and bool(torch.equal(r2, full))
+    owned = _shard.DEFAULT_GATHER_MODE == 'direct'
+    for mode in _shard.GATHER_MODES:
+        root = (world - 1) if mode == 'root' else 0            # (not rank 0: the root is an argument, not a convention)
+        holds = mode != 'root' or rank == root
+        got = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, mode=mode, root=root)
+        # results of the public path are owned by the caller: a second gather of the same shape must not overwrite the first
+        # (advisor finding of round 3); only reuse_out=True hands out the cached buffer
+        again = _shard.gather_views((full[:, b:e] + 1.0).contiguous(), n_views, view_dim=1, mode=mode, root=root)
+        if holds:
+            owned = owned and bool(torch.equal(got, full) and torch.equal(again, full + 1.0) and got.data_ptr() != again.data_ptr())
+        else:
+            owned = owned and got is None and again is None    # gather to the root: the other ranks hold nothing
+        r1 = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, tag='t' + mode, reuse_out=True, mode=mode, root=root)
+        r2 = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, tag='t' + mode, reuse_out=True, mode=mode, root=root)
+        if holds:
+            owned = owned and r1.data_ptr() == r2.data_ptr() and bool(torch.equal(r2, full))
+        # views on dimension 0, asynchronous, into a tensor of the caller's
+        flat = full[0]
+        dst = torch.full_like(flat, -1.0) if holds else None
+        fin = _shard.gather_views(flat[b:e].clone(), n_views, view_dim=0, async_op=True, out=dst, mode=mode, root=root)
+        res = fin()
+        owned = owned and ((res is dst and bool(torch.equal(dst, flat))) if holds else res is None)
+        # the shard in pieces (a step that projects its views in chunks sends each chunk when it exists): all pieces started,
+        # then all awaited; ragged pieces included (3 pieces of 125 or 126 views)
+        n_parts = 3
+        fins = []
+        for j in range(n_parts):
+            pb, pe = _shard.part_bounds(n_views, world, (j, n_parts))[rank]
+            fins.append(_shard.gather_views((full[:, pb:pe] * 2.0).contiguous(), n_views, view_dim=1, async_op=True, tag='p' + mode, reuse_out=True,
+                                            mode=mode, root=root, part=(j, n_parts)))
+        outs = [f() for f in fins]
+        owned = owned and ((all(o is outs[0] for o in outs) and bool(torch.equal(outs[0], full * 2.0))) if holds else all(o is None for o in outs))
+    try:
+        _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, part=(0, 2))     # parts need a common destination
+        owned = False
+    except ValueError:
+        pass
+    got = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1)               # the default mode holds the result everywhere
     mx = _shard.global_max(torch.tensor(float(rank + 1), dtype=torch.float64))
     # np.max semantics over ranks (matdecomp.py:195-196): one rank's NaN makes the global maximum NaN on every rank;
     # -inf on a rank (an empty shard) does not disturb the others' values
