@@ -602,7 +602,7 @@ def main():
     n_one = int(((i0[0] != 0) ^ (i0[1] != 0)).sum())
     hw_share = (29.0 * n_both + 17.0 * n_one) / (29.0 * i0.shape[1])
     gstats = md.last_gn_stats()            # of the last timed step's launches (the default mode)
-    two_level = bool(gstats) and gstats.get('mode') == 'start'
+    two_level = bool(gstats) and gstats.get('mode') in md.SHORTCUT_MODES
     gn_name = ('gn_shortcut_kernel (start values from the table of the reference\'s fixed points + full-table steps)' if two_level
                else 'gn_refill_kernel<false>') if precision == 'f64' else 'gn_kernel<true,false>'
     main_ms = gstats['main_ms'] if gstats else gn_ms      # HIP events around the launch, on its stream, last timed step
@@ -642,18 +642,37 @@ def main():
                 'table_preparation_s_once_per_pair_of_spectra': gate_prep_s,
                 'full_steps_per_unmasked_pixel': gstats['pixel_iterations'] / live,
                 'note': 'what the reference returns is the fixed point its walk from 1e-6 ends at - a function of the two counts, '
-                        'tabulated once per pair of spectra by running the single launch on a 129 x 129 grid of counts.  A pixel '
+                        'tabulated once per pair of spectra by running the single launch on a 257 x 257 grid of counts.  A pixel '
                         'in a cell where that walk ends by the tolerance rule within n_iters steps, smoothly, starts from the '
-                        'interpolated fixed point and takes two full-table steps, the second being the tolerance rule\'s '
-                        'evidence of convergence of the FULL model; accepted only on the reference\'s branch; every other pixel '
-                        'is solved from 1e-6 with all n_iters steps in the same launch.  Compared with the exact count on every '
-                        'pixel below (gn_exact)'}
+                        'interpolated fixed point (2e-8 of |a| from its own) and takes ONE full-table step where the cell\'s '
+                        'tabulated kappa (Newton\'s contraction there, measured by the calibration with the library\'s own '
+                        'kernel) puts what is left below stop_tol / 4 - else two, the second being the tolerance rule\'s '
+                        'evidence of convergence of the FULL model (mode start: always two: value_two_step); accepted only on '
+                        'the reference\'s branch; every other pixel is solved from 1e-6 with all n_iters steps in the same '
+                        'launch.  Compared with the exact count on every pixel below (gn_exact)'}
     out['roofline'] = roof
     if precision == 'f64' and world == 1 and not args.skip_gn_full_loop:
         # ---- the reference's fixed iteration count, EXACTLY (stop_tol = 0): the same step timed the same way -> value_exact;
         # checked bit for bit against a launch that executes every iteration (DEXCT_GN_FULL_LOOP=1), and the default step's
         # results checked against it on every pixel
         a_default = a_out.clone()
+        if two_level and gstats.get('mode') == 'one':
+            # ---- the short cut with two steps and the tolerance rule for every pixel (round 4's form, 'start')
+            gn_mode[0] = 'start'
+            step(False)
+            torch.cuda.synchronize()
+            t_gn_2 = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(True)
+                torch.cuda.synchronize()
+                t_gn_2.append(ev[2].elapsed_time(ev[3]))
+            elapsed_2 = time.perf_counter() - t0
+            st2 = md.last_gn_stats()
+            a_two = a_out.clone()
+            gn_mode[0] = None
+        else:
+            a_two = None
         if two_level:
             # ---- the default tolerance stop in ONE launch from the reference's start value (round 4's first form of the default)
             gn_mode[0] = False
@@ -695,6 +714,22 @@ def main():
             raise SystemExit('bench.py: the exact launch (stop_tol = 0) differs from the full 50-iteration loop')
         if not (diff <= 1e-12 and same_nan):
             raise SystemExit(f'bench.py: the default mode moved a pixel by {diff:.3e} (> 1e-12) from the exact launch')
+        if a_two is not None:
+            diff2 = float(torch.nan_to_num((a_two - a_exact).abs() / a_exact.abs().clamp(min=1.0), nan=0.0).max().item())
+            if not (diff2 <= 1e-12 and bool(torch.equal(torch.isnan(a_two), torch.isnan(a_exact)))):
+                raise SystemExit(f'bench.py: the two-step short cut moved a pixel by {diff2:.3e} (> 1e-12) from the exact launch')
+            g2_ms = float(np.mean(t_gn_2))
+            out['value_two_step'] = integrals_per_step / (elapsed_2 / args.steps)
+            out['gn_two_step'] = {
+                'gn_ms': g2_ms, 'ms_per_step': 1e3 * elapsed_2 / args.steps, 'executed_pixel_iterations': st2['pixel_iterations'],
+                'mean_iterations_per_unmasked_pixel': st2['pixel_iterations'] / max((1.0 - masked) * n_rays, 1.0),
+                'achieved': st2['pixel_iterations'] * flops_per_pixel_iter / (g2_ms * 1e-3) / 1e12,
+                'frac': st2['pixel_iterations'] * flops_per_pixel_iter / (g2_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                'max_diff_vs_exact': diff2,
+                'note': "two_level='start' / DEXCT_GN_TWO_LEVEL=start: the short cut with two full-table steps and the tolerance rule for "
+                        'every pixel (the default of round 4, on round 5\'s kernel): the same launch doing twice the counted work - its '
+                        'frac is the kernel\'s rate with the per-pixel work (gate, start value, result) spread over two steps instead of one'}
+            del a_two
         if two_level:
             diff1 = float(torch.nan_to_num((a_single - a_exact).abs() / a_exact.abs().clamp(min=1.0), nan=0.0).max().item())
             if not (diff1 <= 1e-12 and bool(torch.equal(torch.isnan(a_single), torch.isnan(a_exact)))):

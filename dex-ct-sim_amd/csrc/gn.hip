@@ -788,9 +788,18 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // outside the grid, another fixed point, NaN) is solved the reference's way.
 // Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] cells per axis n; [4] ln of the smallest u0 of the grid;
 // [5] cells per unit of ln u0; [6] smallest ratio u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] ln of [0],[1];
-// then the corners' fixed points as pairs (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair
-// (need, radius)[n^2]; the array is 16-byte aligned (pairs are read with one load).
-constexpr int kStartHeader = 10;
+// [10] 1 if the array ends with kappa[n^2] (below), else 0; [11] reserved; then the corners' fixed points as pairs
+// (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair (need, radius)[n^2], then - optional - per cell kappa[n^2];
+// the array is 16-byte aligned (pairs are read with one load).
+//
+// ONE STEP INSTEAD OF TWO (kappa; DEXCT_GN_FLAG_ONE_STEP).  From a start value s at distance e0 from the pixel's fixed point,
+// Newton's step lands at distance e1 <= kappa e0^2, and the step itself measures e0: d1 = |n - s| = e0 (1 + O(kappa e0)).  kappa is
+// tabulated per cell by the calibration - the library's own kernel takes one step from the interpolant at every cell's centre
+// (DEXCT_GN_FLAG_PROBE), the host compares with where the reference's walk ends there: kappa = 4 x the largest e1 / d1^2 among the
+// cell and the eight around it (infinity where any of them is closed).  A pixel whose first step satisfies
+// kappa d1^2 <= stop_tol / 4 * max(|a|, 1) has the same evidence the tolerance rule asks of two steps - the distance it still
+// has to go is below stop_tol / 4 of its size - and ends there; every other pixel takes its second step and the rule, as before.
+constexpr int kStartHeader = 12;
 
 // ln(x) for a positive, normal double: the hardware's float32 logarithm as a first guess y0 (|error| < 1e-5), then one
 // Newton step on the table-driven exponential above: ln x = y0 + ln(x e^-y0) = y0 + r - r^2 / 2 with r = x e^-y0 - 1, |r| <
@@ -808,7 +817,7 @@ __device__ __forceinline__ double log_pos(double x, const double* __restrict__ l
 }
 
 __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const double* __restrict__ lds_pow, int n_iters,
-                                         double g0, double g1, double& s0, double& s1, double& radius) {
+                                         double g0, double g1, double& s0, double& s1, double& radius, double* kappa = nullptr) {
 #ifdef DEXCT_GN_LIBM_LOG          // (round 4's arithmetic, kept for one bit-for-bit comparison of the two kernels)
   const double u0 = log(start[0] / g0) * start[2], u1 = log(start[1] / g1) * start[2];
   const double t = u1 / u0;
@@ -843,7 +852,7 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const
   const int base = (i0c <= n - 3 ? i0c : n - 3) * (n + 1) + (j0c <= n - 3 ? j0c : n - 3);
   s0 = 0.0;
   s1 = 0.0;
-#pragma unroll
+#pragma unroll 2                      // (eight loads in flight, not sixteen: 16 registers less at the kernel's tightest spot)
   for (int p = 0; p < 4; ++p) {
     double ra = 0.0, rb = 0.0;
 #pragma unroll
@@ -856,6 +865,7 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const
     s1 = fma(cx[p], rb, s1);
   }
   radius = cell.y;
+  if (kappa) *kappa = start[10] != 0.0 ? reinterpret_cast<const double*>(cells + n * n)[i * n + j] : __builtin_huge_val();
   return ok;
 }
 
@@ -1046,29 +1056,31 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_refill_kernel(const void* __re
 }
 
 // THE SHORT-CUT KERNEL (dexct_gn_options.pass = DEXCT_GN_PASS_SHORTCUT; the default of get_basismat_sinos since round 4, this
-// form since round 5).  On the short cut a pixel takes exactly two steps - all of them do, so there is nothing to balance and
-// the machinery of the refill kernel (result slots, hand-out loop, repeated-state history: a fifth of round 4's launch) is in the
+// form since round 5).  On the short cut every pixel takes the same one or two steps, so there is nothing to balance and the
+// machinery of the refill kernel (result slots, hand-out loop, repeated-state history: a fifth of round 4's launch) is in the
 // way.  Here a wave works through tiles in lock step:
-//   FAST PATH, straight-line code for the 64 pixels of a tile at once: counts in (the next tile's loads are issued before this
-//     tile's arithmetic), air mask, gate + start value (gn_start), two steps on the full tables, the tolerance rule on the
-//     second (its evidence that the FULL model has converged to stop_tol), the acceptance radius, results out through LDS as
-//     whole 64-byte runs in the reference's order.
+//   FAST PATH, straight-line code for the 64 pixels of a tile at once: counts in, air mask, gate + start value (gn_start),
+//     STEPS steps on the full tables, the evidence of convergence - STEPS = 2: the tolerance rule on the second step (the FULL
+//     model has converged to stop_tol); STEPS = 1 (DEXCT_GN_FLAG_ONE_STEP): the cell's tabulated kappa, see gn_start - the
+//     acceptance radius, results out through LDS as whole 64-byte runs in the reference's order.
 //   STASH: a pixel the fast path does not finish - closed cell (walk from the reference's start value 1e-6 with all n_iters
-//     steps), rule not yet met after two steps (one in 60: it continues where it is), result outside the radius (walk) - is
-//     put aside in LDS (96 entries per wave) and the wave moves on.
+//     steps), no evidence yet (it continues where it is), result outside the radius (walk) - is put aside in LDS (96 entries
+//     per wave) and the wave moves on.
 //   DRAIN: when 32 entries have gathered (and at the end) the wave solves them with the general iteration - one lane per
 //     entry, refilled from the stash, every exit of gn_exit_or_advance, the acceptance test for continued pixels - and stores
 //     those results pixel by pixel.
-// Per pixel the sequence of states and the exit taken are those of round 4's refill kernel with start values (bit-identical
-// results, tools/probes/gn_shortcut_ab.py); only who computes them when has changed.
+// STEPS = 2: per pixel the sequence of states and the exit taken are those of round 4's refill kernel with start values
+// (bit-identical results, tools/probes/gn_shortcut_ab.py); only who computes them when has changed.
 constexpr int kStashCap = 96, kStashDrain = 32;
 constexpr long long kStashCont = 1ll << 62;          // entry: the pixel continues from the stored states (else: walks from 1e-6)
+constexpr long long kStashOne = 1ll << 61;           // ... after ONE step (states: sp = start value s, sa = after the step); else after two
 
+template <int STEPS>
 __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __restrict__ g1, const void* __restrict__ g2,
                                                                int g_is_f64, long long n_pix, const double* __restrict__ ws,
                                                                int n_e, int n_iters, GnTiling tl,
                                                                const double* __restrict__ mask_max, double mask_frac,
-                                                               int flags, double stop_tol, double* __restrict__ out_a,
+                                                               int flags, double stop_tol, double* __restrict__ out_a,     // flags: as gn_refill_kernel; bit 3: probe (STEPS = 1: every pixel of an open cell ends after its step)
                                                                unsigned long long* __restrict__ counters,
                                                                const double* __restrict__ start) {
   typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1078,7 +1090,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
   __shared__ long long lds_snp[kGnBlock / kWave][kStashCap];             // 3 KB: the stash - input index of the pixel | kind,
   __shared__ d2 lds_sa[kGnBlock / kWave][kStashCap];                     // 6 KB: its state,
   __shared__ d2 lds_sp[kGnBlock / kWave][kStashCap];                     // 6 KB: the state before,
-  __shared__ double lds_srad[kGnBlock / kWave][kStashCap];               // 3 KB: what is left of its acceptance radius  (38 KB: 4 workgroups per CU)
+  __shared__ double lds_srad[kGnBlock / kWave][kStashCap];               // 3 KB: its acceptance radius  (38 KB: 4 workgroups per CU)
   for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
   __syncthreads();                        // the only barrier: waves work independently from here on
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
@@ -1092,13 +1104,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
   const bool has_mask = mask_max != nullptr;
   const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
   const int in_stride = tl.transposed ? tl.rows : 1, out_stride = tl.transposed ? tl.channels : 0;
-  // this lane's pixel of a tile on the input side (consecutive lanes: consecutive rows of a channel / consecutive pixels),
-  // where its result goes in the tile's LDS image, and the pixel this lane WRITES (consecutive lanes: consecutive channels)
-  const int ci = tl.transposed ? lane / kTileR : lane, ri = tl.transposed ? lane % kTileR : 0;
-  const int place = tl.transposed ? ri * kTileC + ci : lane;
-  const int co = tl.transposed ? (lane & (kTileC - 1)) : lane, ro = tl.transposed ? (lane >> kTileCLog2) : 0;
-  const int lane_in_of_out = tl.transposed ? co * kTileR + ro : lane;    // the input-side lane that computed what this lane writes
-  const bool exact_exit = (flags & 1) != 0, confirm_walk = (flags & 4) != 0;
+  const bool exact_exit = (flags & 1) != 0, confirm_walk = (flags & 4) != 0, probe = (flags & 8) != 0;
   const int batch = ((flags >> 8) & 0xFFF) > 0 ? ((flags >> 8) & 0xFFF) : 1;
   int q_next = 0, q_end = 0;
   bool exhausted = false;
@@ -1125,15 +1131,16 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
     return (long long)q_next++;
   };
 
-  // DRAIN: the general iteration on the entries of the stash.  A continued pixel (states: s the start value, n after one step,
-  // m after two) goes on from m with n as the state before; it is accepted within srad = radius - |m - s| of m (hence within
-  // the radius of s; neither s nor the table is touched here: registers).  s is not entered into the history: a cycle through
-  // it is found one period later, with the same result.
+  // DRAIN: the general iteration on the entries of the stash.  A continued pixel goes on from its state sa with sp as the
+  // state before.  After ONE step (sp = the start value s, sa = n): exactly the refill kernel's pixel at it = 1, accepted within
+  // the radius of s.  After TWO (sp = n, sa = m; s not kept): it = 2 with the budget of n_iters; accepted within srad = radius -
+  // |m - s| of m (hence within the radius of s); s is not entered into the history - a cycle through it is found one period
+  // later, with the same result.  (Neither s nor the table is touched here: registers.)
   auto drain = [&]() {
     int head = 0;
     long long po = -1;                    // where this lane's result goes, -1: no pixel
     double a0 = 1e-6, a1 = 1e-6, gd0 = 1.0, gd1 = 1.0;
-    int it = 0, warm = -1;                // warm >= 0: a continued pixel, its entry
+    int it = 0, warm = -1;                // warm >= 0: a continued pixel: its entry, + 256 if it continues after ONE step
     long long h0[kGnHistory], h1[kGnHistory];
 #pragma unroll
     for (int k = 0; k < kGnHistory; ++k) { h0[k] = 0; h1[k] = 0; }
@@ -1144,7 +1151,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
         const int idx = head + rank;
         if (po < 0 && idx < n_stash) {
           const long long e = snp[idx];
-          const long long np = e & ~kStashCont;
+          const long long np = e & ~(kStashCont | kStashOne);
           gd0 = load_g<double>(g1, g_is_f64, np);
           gd1 = load_g<double>(g2, g_is_f64, np);
           po = gn_out_index(tl, np);
@@ -1153,8 +1160,8 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
             const d2 va = sa[idx], vp = sp[idx];
             a0 = va.x; a1 = va.y;
             h0[0] = __double_as_longlong(vp.x); h1[0] = __double_as_longlong(vp.y);
-            it = 1;                       // (as if m followed n directly: history of one state)
-            warm = idx;
+            it = 1;                       // (two steps taken: as if sa followed sp directly, one iteration less allowed)
+            warm = idx | ((e & kStashOne) ? 256 : 0);
           }
         }
         const int taken = (int)__popcll(want);
@@ -1165,15 +1172,14 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
       n_exec += (unsigned long long)__popcll(busy);
       double n0 = a0, n1 = a1;
       newton_step_f64(tab, lds_pow, ec, gd0, gd1, n0, n1);
-      // a continued pixel has taken two steps already: its budget is n_iters - 1 at it = 1
-      const bool advance = gn_exit_or_advance(n0, n1, warm >= 0 ? n_iters - 1 : n_iters, exact_exit ? 1 : 0, stop_tol, a0, a1, it, h0, h1,
-                                              nullptr, confirm_walk && warm < 0);
-      bool fin = po >= 0 && (!advance || it >= (warm >= 0 ? n_iters - 1 : n_iters));
+      const int bud = (warm >= 0 && (warm & 256) == 0) ? n_iters - 1 : n_iters;     // iterations allowed, counted like `it`
+      const bool advance = gn_exit_or_advance(n0, n1, bud, exact_exit ? 1 : 0, stop_tol, a0, a1, it, h0, h1, nullptr, confirm_walk && warm < 0);
+      bool fin = po >= 0 && (!advance || it >= bud);
       if (fin && warm >= 0) {
         // a continued pixel that used up its budget, ran into NaN or ended away from the reference's branch: the reference's
         // own solve instead
-        const d2 vm = sa[warm];
-        const bool redo = advance || !(fmax(fabs(a0 - vm.x), fabs(a1 - vm.y)) <= srad[warm]);
+        const d2 vc = (warm & 256) ? sp[warm & 255] : sa[warm & 255];
+        const bool redo = advance || !(fmax(fabs(a0 - vc.x), fabs(a1 - vc.y)) <= srad[warm & 255]);
         if (redo) { a0 = 1e-6; a1 = 1e-6; it = 0; fin = false; }
         warm = -1;
       }
@@ -1190,6 +1196,9 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
   for (long long t = next_tile(); t >= 0; t = next_tile()) {
     const GnTile d = gn_decode_tile(tl, n_pix, t);
     handed += (unsigned)(d.nr * d.nc);
+    // this lane's pixel of the tile on the input side (consecutive lanes: consecutive rows of a channel / consecutive pixels);
+    // (these lane constants are formed where they are used - a few shifts per tile - rather than held in registers)
+    const int ci = tl.transposed ? lane / kTileR : lane, ri = tl.transposed ? lane % kTileR : 0;
     const bool valid = ci < d.nc && ri < d.nr;
     const long long np = d.in_base + (long long)ci * in_stride + ri;
     const double gd0 = valid ? load_g<double>(g1, g_is_f64, np) : 1.0, gd1 = valid ? load_g<double>(g2, g_is_f64, np) : 1.0;
@@ -1201,34 +1210,47 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
     d2 st_a = d2{1e-6, 1e-6}, st_p = d2{0.0, 0.0};
     double st_rad = 0.0;
     if (__ballot(act) != 0ull) {
-      double s0, s1, rad;
-      const bool open = gn_start(start, lds_pow, n_iters, gd0, gd1, s0, s1, rad) && n_iters >= 3;
+      double s0, s1, rad, kap = __builtin_huge_val();
+      const bool open = gn_start(start, lds_pow, n_iters, gd0, gd1, s0, s1, rad, STEPS == 1 ? &kap : nullptr) && n_iters >= 3;
       const bool fast = act && open;
       to_walk = act && !open;
       const unsigned long long fm = __ballot(fast);
       if (fm != 0ull) {
-        n_exec += 2ull * (unsigned long long)__popcll(fm);
+        n_exec += (unsigned long long)(STEPS * (int)__popcll(fm));
         double n0 = s0, n1 = s1, m0 = s0, m1 = s1;
 #pragma nounroll
-        for (int k = 0; k < 2; ++k) {                                        // step 1: from s to n, step 2: from n to m
+        for (int k = 0; k < STEPS; ++k) {                                    // step 1: from s to n (STEPS = 1: m), step 2: from n to m
           n0 = m0; n1 = m1;
           newton_step_f64(tab, lds_pow, ec, gd0, gd1, m0, m1);
         }
-        // the exits of gn_exit_or_advance for these two steps (no history yet: a fixed point at either step, the tolerance
-        // rule at the second); anything else - the rule not met, a cycle through s - continues in the drain
-        const bool fixed1 = exact_exit && __double_as_longlong(n0) == __double_as_longlong(s0) &&
-                            __double_as_longlong(n1) == __double_as_longlong(s1);
-        const bool fixed2 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(n0) &&
-                            __double_as_longlong(m1) == __double_as_longlong(n1);
-        const bool cycle2 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(s0) &&
-                            __double_as_longlong(m1) == __double_as_longlong(s1);
-        const bool conv = gn_converged(stop_tol, n0, n1, m0, m1, s0, s1, 1);
-        const bool ended = fixed1 || ((fixed2 || conv) && !cycle2);
-        const double f0 = fixed1 ? s0 : (conv ? m0 : n0), f1 = fixed1 ? s1 : (conv ? m1 : n1);
+        bool ended;
+        double f0, f1;
+        if (STEPS == 1) {
+          // one step, from s to m: a fixed point, or the cell's kappa vouches that what is left is below the tolerance (gn_start)
+          const bool fixed1 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(s0) &&
+                              __double_as_longlong(m1) == __double_as_longlong(s1);
+          const double d1 = fmax(fabs(m0 - s0), fabs(m1 - s1)), size = fmax(fmax(fabs(m0), fabs(m1)), 1.0);
+          const bool conv1 = probe ? d1 < __builtin_huge_val() : kap * (d1 * d1) <= (0.25 * stop_tol) * size;      // (NaN, inf: no)
+          ended = fixed1 || conv1;
+          f0 = fixed1 ? s0 : m0; f1 = fixed1 ? s1 : m1;
+        } else {
+          // the exits of gn_exit_or_advance for these two steps (no history yet: a fixed point at either step, the tolerance
+          // rule at the second); anything else - the rule not met, a cycle through s - continues in the drain
+          const bool fixed1 = exact_exit && __double_as_longlong(n0) == __double_as_longlong(s0) &&
+                              __double_as_longlong(n1) == __double_as_longlong(s1);
+          const bool fixed2 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(n0) &&
+                              __double_as_longlong(m1) == __double_as_longlong(n1);
+          const bool cycle2 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(s0) &&
+                              __double_as_longlong(m1) == __double_as_longlong(s1);
+          const bool conv = gn_converged(stop_tol, n0, n1, m0, m1, s0, s1, 1);
+          ended = fixed1 || ((fixed2 || conv) && !cycle2);
+          f0 = fixed1 ? s0 : (conv ? m0 : n0); f1 = fixed1 ? s1 : (conv ? m1 : n1);
+        }
         const bool accept = fmax(fabs(f0 - s0), fabs(f1 - s1)) <= rad;        // (NaN: no)
         if (fast) {
           if (ended && accept) { res = d2{f0, f1}; done = true; }
           else if (ended) to_walk = true;                                     // another fixed point: the reference's own solve
+          else if (STEPS == 1) { to_cont = true; st_a = d2{m0, m1}; st_p = d2{s0, s1}; st_rad = rad; }
           else {                                                              // goes on from m if m is well inside the radius of s
             st_rad = rad - fmax(fabs(m0 - s0), fabs(m1 - s1));
             if (st_rad > 0.0) { to_cont = true; st_a = d2{m0, m1}; st_p = d2{n0, n1}; }
@@ -1242,7 +1264,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
     if (pm != 0ull) {
       const int idx = n_stash + __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
       if (to_walk || to_cont) {
-        snp[idx] = np | (to_cont ? kStashCont : 0ll);
+        snp[idx] = np | (to_cont ? (kStashCont | (STEPS == 1 ? kStashOne : 0ll)) : 0ll);
         sa[idx] = st_a;
         sp[idx] = st_p;
         srad[idx] = st_rad;
@@ -1252,6 +1274,11 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
     // results of the tile: through LDS into the order of the output, whole 64-byte runs
     const unsigned long long dm = __ballot(done);
     if (dm != 0ull) {
+      // where this lane's result goes in the tile's LDS image, and the pixel this lane WRITES (consecutive lanes: consecutive
+      // channels), computed by the input-side lane lane_in_of_out
+      const int place = tl.transposed ? (lane % kTileR) * kTileC + lane / kTileR : lane;
+      const int co = tl.transposed ? (lane & (kTileC - 1)) : lane, ro = tl.transposed ? (lane >> kTileCLog2) : 0;
+      const int lane_in_of_out = tl.transposed ? co * kTileR + ro : lane;
       if (done) my_out[place] = res;
       __builtin_amdgcn_wave_barrier();
       if (co < d.nc && ro < d.nr && ((dm >> lane_in_of_out) & 1ull) != 0ull) {
@@ -1521,7 +1548,9 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   if (pass == DEXCT_GN_PASS_SHORTCUT && (!options->start || options->iterations)) return DEXCT_EINVAL;
   const double* start = (pass == DEXCT_GN_PASS_SHORTCUT) ? options->start : nullptr;
   if (start && (reinterpret_cast<uintptr_t>(start) & 15u)) return DEXCT_EINVAL;   // its pairs are read with 16-byte loads
-  if (options && (options->flags & ~(DEXCT_GN_FLAG_FULL_LOOP | DEXCT_GN_FLAG_NATURAL_ORDER))) return DEXCT_EINVAL;
+  if (options && (options->flags & ~(DEXCT_GN_FLAG_FULL_LOOP | DEXCT_GN_FLAG_NATURAL_ORDER | DEXCT_GN_FLAG_ONE_STEP | DEXCT_GN_FLAG_PROBE)))
+    return DEXCT_EINVAL;
+  if (options && (options->flags & (DEXCT_GN_FLAG_ONE_STEP | DEXCT_GN_FLAG_PROBE)) && pass != DEXCT_GN_PASS_SHORTCUT) return DEXCT_EINVAL;
   if (options && options->blocks_per_cu < 0) return DEXCT_EINVAL;
   hipStream_t st = as_stream(stream);
   double* ws = reinterpret_cast<double*>(workspace);
@@ -1593,8 +1622,12 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     if (pass == DEXCT_GN_PASS_COUNT)
       hipLaunchKernelGGL((gn_refill_kernel<true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
                          (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, options->iterations);
+    else if (pass == DEXCT_GN_PASS_SHORTCUT && (oflags & (DEXCT_GN_FLAG_ONE_STEP | DEXCT_GN_FLAG_PROBE)))
+      hipLaunchKernelGGL(gn_shortcut_kernel<1>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags | ((oflags & DEXCT_GN_FLAG_PROBE) ? 8 : 0), tol,
+                         out_a, counters, start);
     else if (pass == DEXCT_GN_PASS_SHORTCUT)
-      hipLaunchKernelGGL(gn_shortcut_kernel, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
+      hipLaunchKernelGGL(gn_shortcut_kernel<2>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
                          (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, start);
     else if (which == 2 || (which == 0 && n_pix < env.coop_below)) {
       int64_t ncb = tl.n_tiles;

@@ -97,12 +97,21 @@ DEFAULT_STOP_TOL = _default_stop_tol()
 # that pair: the tolerance rule on the wandering pixels of such a pair was the only place where the default ever differed from
 # the exact count (profiles/r04_gn_noisy_public.log), and it saved 15 % there.  An explicit stop_tol > 0 is honoured.
 #
+# ONE STEP where the table vouches for it (the default since round 5; quadrature.attach_kappa, csrc/gn.hip gn_start).  From a start
+# value at distance e0 of the fixed point Newton's step leaves kappa e0^2, and the step's own length d1 measures e0.  The
+# calibration takes one step of the library's kernel from the interpolant at every cell's centre and compares with where the
+# reference's walk ends there: kappa per cell.  A pixel whose first step has kappa d1^2 <= stop_tol / 4 * size ends there - the
+# evidence the tolerance rule asks of two steps, from one; every other pixel takes the second step and the rule.  With 256 cells
+# per axis the interpolant is 2e-8 of |a| from the pixel's fixed point and one step lands at rounding level.
+#
 # Modes (``two_level=`` of the calls below; DEXCT_GN_TWO_LEVEL in the environment; DEFAULT_TWO_LEVEL):
-#   None / True / 'start'   the above (one launch)
+#   None / True / 'one'     the short cut, one step where kappa allows (one launch)
+#   'start'                 the short cut, always two steps and the tolerance rule (round 4's form)
 #   False / '0'             the single launch from 1e-6
 # It applies to float64 with one shared spectrum, the tolerance stop on, 4 <= n_iters <= 254 and >= 48 energies; anything
 # else runs the single launch.
-DEFAULT_TWO_LEVEL = {'0': False, '1': True, 'start': 'start'}.get(os.environ.get('DEXCT_GN_TWO_LEVEL', ''), None)
+SHORTCUT_MODES = ('one', 'start')
+DEFAULT_TWO_LEVEL = {'0': False, '1': True, 'start': 'start', 'one': 'one'}.get(os.environ.get('DEXCT_GN_TWO_LEVEL', ''), None)
 
 # Sampled audit of the short cut (``audit=`` of the calls below; DEXCT_GN_AUDIT=<ppm>[,strict] in the environment): that many
 # pixels per million, chosen by the device's Philox generator, are solved again with the reference's fixed count in the same
@@ -141,7 +150,7 @@ def last_gn_stats():
     get_basismat_sinos call - (synchronises): ``pixel_iterations`` = Newton steps the float64 shared-spectrum kernels
     actually executed (the exits end pixels before n_iters; masked air pixels run none), ``stalled_lane_steps`` = lane-steps
     a wave could not hand out because all its result slots waited for stragglers.  0 for the mixed-precision and
-    per-channel-spectrum kernels, which do not count.  ``mode``: 'start' (the short cut), 'single', or 'exact (ill-posed
+    per-channel-spectrum kernels, which do not count.  ``mode``: 'one' / 'start' (the short cut), 'single', or 'exact (ill-posed
     pair)'; ``audit``: the last sampled audit, if any."""
     if not _last_ws:
         return None
@@ -159,14 +168,21 @@ def _host_tables(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
 
 
-def _walk(lib, dev, i0_d, mus_d, n_e, g, cal_tol):
+def _walk(lib, dev, i0_d, mus_d, n_e, g, cal_tol, probe_from=None):
     """The reference's iteration (the library's own kernel, full tables, from 1e-6, counting steps) on counts g [n, 2]:
-    (steps until the tolerance rule fired | 255, where it ended)."""
+    (steps until the tolerance rule fired | 255, where it ended).  ``probe_from`` (a start table): instead, ONE step from the
+    table's interpolant for every pixel in an open cell (DEXCT_GN_FLAG_PROBE): where it lands."""
     g_d = to_dev(np.ascontiguousarray(g.T), torch.float64, dev)
     n_c = g_d.shape[1]
     a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
-    k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
     ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, 1), dtype=torch.uint8, device=dev)
+    if probe_from is not None:
+        t_d = to_dev(probe_from, torch.float64, dev)
+        opts = _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_SHORTCUT, None, t_d.data_ptr(), _native.GN_FLAG_PROBE)
+        _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(i0_d), ptr(mus_d), n_e, 1, 1, 254, 0, 0, None, 0.95,
+                                             ptr(a_c), opts, ptr(ws), stream_ptr()), 'dexct_gn_decompose (one-step probe)')
+        return a_c.cpu().numpy()
+    k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
     _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(i0_d), ptr(mus_d), n_e, 1, 1, 254, 0, 0, None, 0.95,
                                          ptr(a_c), _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COUNT, k_c.data_ptr()),
                                          ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
@@ -187,8 +203,14 @@ def calibrate_gate(i0_h, mus_h, i0_d, mus_d, dev, cal_tol):
     n_e = i0_2.shape[1]
     steps, roots = _walk(lib, dev, i0_d, mus_d, n_e, pieces['corner_g'], cal_tol)
     start_h, share, stats = quadrature.assemble_start(pieces, steps, roots)
-    start_h, share, n_bad = quadrature.validate_start(start_h, pieces, *_walk(lib, dev, i0_d, mus_d, n_e, quadrature.cell_centres(pieces), cal_tol))
-    stats = dict(stats, grid=True, open_share=float(share), centres_failed=int(n_bad))
+    centres = quadrature.cell_centres(pieces)
+    c_steps, c_roots = _walk(lib, dev, i0_d, mus_d, n_e, centres, cal_tol)
+    start_h, share, n_bad = quadrature.validate_start(start_h, pieces, c_steps, c_roots)
+    # ... and ONE step of the kernel from the interpolant at every centre against where the walk ends there: the kappa table
+    # of the one-step acceptance (quadrature.attach_kappa)
+    probe = _walk(lib, dev, i0_d, mus_d, n_e, centres, cal_tol, probe_from=start_h)
+    start_h, one_share = quadrature.attach_kappa(start_h, pieces, c_roots, probe, cal_tol)
+    stats = dict(stats, grid=True, open_share=float(share), centres_failed=int(n_bad), one_step_share=float(one_share))
     return start_h, stats
 
 
@@ -247,8 +269,11 @@ def _gate_from_disk(path, i0_h, mus_h):
         if start_h is not None:
             pieces = quadrature.newton_start_grid(i0_h.reshape(2, -1), mus_h)
             n = quadrature.GATE_CELLS
-            if (pieces is None or start_h.shape != (quadrature.START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n,)
-                    or not np.array_equal(start_h[:quadrature.START_HEADER], pieces['head'])):
+            head = None if pieces is None else pieces['head'].copy()
+            if head is not None:
+                head[10] = 1.0                # (the kappa table is attached)
+            if (head is None or start_h.shape != (quadrature.START_HEADER + 2 * (n + 1) ** 2 + 3 * n * n,)
+                    or not np.array_equal(start_h[:quadrature.START_HEADER], head)):
                 return None
         return start_h, stats
     except Exception:
@@ -404,8 +429,8 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     if two_level is None:
         two_level = DEFAULT_TWO_LEVEL
     if two_level is None or two_level is True:
-        two_level = 'start'
-    if two_level not in (False, 'start'):
+        two_level = 'one'
+    if two_level not in (False, 'one', 'start'):
         raise ValueError(f'two_level={two_level!r}')
     applies = (precision == 'f64' and n_bins == 1 and kernel != 2 and 4 <= int(n_iters) <= 254 and n_e >= 48 and stop_tol > 0.0)
     # (the gate is consulted for the default tolerance even with two_level=False: an ill-posed pair runs the fixed count)
@@ -417,7 +442,7 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
         if gate['ill_posed'] and not explicit_tol:
             stop_tol, mode = 0.0, 'exact (ill-posed pair)'
         elif two_level and gate['start'] is not None:
-            start, mode = gate['start'], 'start'
+            start, mode = gate['start'], (two_level if gate['stats'].get('one_step_share', 0.0) > 0.0 else 'start')
     shape = tuple(g1.shape)
     rows = chans = 0
     if out_rc is not None:
@@ -435,7 +460,8 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     ws[72:104].zero_()       # executed-iteration, progress, queue and stall counters: defined before anybody polls them
     _last_zeroed = torch.cuda.Event()
     _last_zeroed.record()    # a progress poller on another stream waits for this (never reads uninitialised bytes)
-    flags = (_native.GN_FLAG_FULL_LOOP if full_loop else 0) | (_native.GN_FLAG_NATURAL_ORDER if natural_order else 0)
+    flags = ((_native.GN_FLAG_FULL_LOOP if full_loop else 0) | (_native.GN_FLAG_NATURAL_ORDER if natural_order else 0)
+             | (_native.GN_FLAG_ONE_STEP if mode == 'one' else 0))
     if start is not None:
         opts = _native.gn_options(stop_tol, rows, chans, 1, _native.GN_PASS_SHORTCUT, None, start.data_ptr(), flags, blocks_per_cu)
     else:
@@ -453,7 +479,7 @@ def gn_device(g1, g2, i0, mus, n_iters, precision=None, n_polish=N_POLISH, out=N
     if not accumulate_stats:
         _last_audit = None
     ppm = DEFAULT_AUDIT_PPM if audit is None else float(audit)
-    if ppm > 0.0 and mode == 'start':
+    if ppm > 0.0 and mode in SHORTCUT_MODES:
         _audit(g1, g2, a, i0, mus, n_iters, ppm, DEFAULT_AUDIT_STRICT if audit_strict is None else bool(audit_strict),
                (rows, chans) if out_rc is not None else None, mask_max, mask_frac, merge=accumulate_stats)
     return a

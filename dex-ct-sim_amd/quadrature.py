@@ -183,9 +183,10 @@ def max_rel_error(mu, w, cols, w_red, L):
     return float(err.max())
 
 
-GATE_VERSION = 5           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
-START_HEADER = 10          # doubles before the tables (csrc/gn.hip, gn_start)
-GATE_CELLS = 128           # cells per axis of the grid over (ln u0, u1 / u0)
+GATE_VERSION = 6           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
+START_HEADER = 12          # doubles before the tables (csrc/gn.hip, gn_start)
+GATE_CELLS = 256           # cells per axis of the grid over (ln u0, u1 / u0): the Catmull-Rom interpolant of the fixed points is then ~2e-8 of |a|
+                           # from a pixel's own (128 cells: 3e-7) - close enough for ONE Newton step to land within the tolerance (attach_kappa)
 GATE_U_MIN = 1.0e-4        # smallest u0 = ln(air_0 / g_0) / log_range of the grid: thinner rays walk from 1e-6 (a handful of steps)
 GATE_U_MAX = 0.75          # largest u0 with open cells: attenuation exp(-12), six counts per million.  Beyond, the long walk from 1e-6 is
                            # fragile - photon-starved counts inside a cell whose corners all arrive have been seen to end at another
@@ -242,7 +243,7 @@ def newton_start_grid(i0, mus, log_range=16.0):
     n = GATE_CELLS
     per_x = n / -np.log(GATE_U_MIN)
     per_t = n / (t_hi - t_lo)
-    head = np.array([air[0], air[1], 1.0 / log_range, float(n), np.log(GATE_U_MIN), per_x, t_lo, per_t, np.log(air[0]), np.log(air[1])])
+    head = np.array([air[0], air[1], 1.0 / log_range, float(n), np.log(GATE_U_MIN), per_x, t_lo, per_t, np.log(air[0]), np.log(air[1]), 0.0, 0.0])
     x = np.log(GATE_U_MIN) + np.arange(n + 1) / per_x
     tt = t_lo + np.arange(n + 1) / per_t
     u0 = np.exp(x)[:, None] * np.ones((1, n + 1))
@@ -378,6 +379,53 @@ def cell_centres(pieces):
     return np.stack([h[0] * np.exp(-u0.ravel() / h[2]), h[1] * np.exp(-u1.ravel() / h[2])], axis=1)
 
 
+def centre_interpolant(start, n):
+    """The Catmull-Rom interpolant of the tabulated fixed points at the centre of every interior cell [n, n, 2] (what the kernel
+    starts a pixel from there; border cells: 0)."""
+    r = np.asarray(start)[START_HEADER:START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)
+    w = np.array([-1.0, 9.0, 9.0, -1.0]) / 16.0                      # Catmull-Rom weights at t = 1/2
+    s = np.zeros((n, n, 2))
+    for p in range(4):
+        for q_ in range(4):
+            s[1:-1, 1:-1] += w[p] * w[q_] * r[p:n - 2 + p, q_:n - 2 + q_]     # corner (i + p - 1, j + q - 1) of cell (i, j)
+    return s
+
+
+KAPPA_SAFETY = 4.0         # on the largest e1 / d1^2 seen at the centres of a cell and of the eight around it
+
+
+def attach_kappa(start, pieces, centre_roots, probe, stop_tol=1.0e-12):
+    """The ONE-STEP table of the short cut (csrc/gn.hip gn_start; include/dexct.h DEXCT_GN_FLAG_ONE_STEP).  ``centre_roots`` [n^2, 2]:
+    where the reference's walk ends on the counts at the cell centres (validate_start's input); ``probe`` [n^2, 2]: where the
+    library's kernel lands after ONE step from the interpolant there (DEXCT_GN_FLAG_PROBE).  Newton's step from a start value at
+    distance e0 of the fixed point leaves e1 <= kappa e0^2, and its own length d1 measures e0; per centre kappa_c = e1 / d1^2
+    with e1 = |probe - root| (not below the rounding floor, 8 eps of the size: the root itself is only known to that), per cell
+    KAPPA_SAFETY x the largest kappa_c among the cell and the eight around it - infinity where any of them is closed, where the
+    probe did not come back finite, or where the step at the centre did not itself land within stop_tol / 16 of the root.  The
+    interpolation error is largest at the centre of a cell, so a pixel anywhere in it has d1 <= the centre's or is turned away
+    by the kernel's test kappa d1^2 <= stop_tol / 4 * size.  Returns the array with kappa appended (header [10] = 1) and the
+    share of cells with a finite kappa."""
+    h = pieces['head']
+    n = int(h[3])
+    out = np.array(start, dtype=np.float64, copy=True)
+    cells = out[START_HEADER + 2 * (n + 1) ** 2:START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n].reshape(n, n, 2)
+    s = centre_interpolant(out, n)
+    rc = np.asarray(centre_roots, dtype=np.float64).reshape(n, n, 2)
+    pr = np.asarray(probe, dtype=np.float64).reshape(n, n, 2)
+    with np.errstate(all='ignore'):
+        size = np.maximum(np.abs(rc).max(axis=2), 1.0)
+        d1 = np.abs(pr - s).max(axis=2)
+        e1 = np.maximum(np.abs(pr - rc).max(axis=2), 8.0 * np.finfo(np.float64).eps * size)
+        kc = e1 / np.maximum(d1, 1.0e-300) ** 2
+        fine = np.isfinite(cells[:, :, 0]) & np.isfinite(kc) & np.all(np.isfinite(pr), axis=2) & (e1 <= stop_tol / 16.0 * size)
+    kc = np.where(fine, kc, np.inf)
+    pad = np.pad(kc, 1, mode='constant', constant_values=np.inf)
+    kappa = KAPPA_SAFETY * np.max([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
+    kappa = np.where(np.isfinite(cells[:, :, 0]), kappa, np.inf)
+    out[10] = 1.0
+    return np.concatenate([out, kappa.ravel()]), float(np.isfinite(kappa).mean())
+
+
 def validate_start(start, pieces, steps, roots):
     """The table checked against the thing it stands for, at one interior point per cell: the reference's walk run on the counts
     at the cell CENTRES (``steps``, ``roots`` as in assemble_start, n^2 of them).  An open cell stays open only if that walk
@@ -387,16 +435,10 @@ def validate_start(start, pieces, steps, roots):
     h = pieces['head']
     n = int(h[3])
     out = np.array(start, dtype=np.float64, copy=True)
-    r = out[START_HEADER:START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)
     cells = out[START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)
     steps = np.asarray(steps, dtype=np.float64).reshape(n, n)
     rc = np.asarray(roots, dtype=np.float64).reshape(n, n, 2)
-    w = np.array([-1.0, 9.0, 9.0, -1.0]) / 16.0                      # Catmull-Rom weights at t = 1/2
-    s = np.zeros((n, n, 2))
-    for p in range(4):
-        for q_ in range(4):
-            i0_, j0_ = p - 1, q_ - 1                                 # corner (i + p - 1, j + q - 1) of cell (i, j), interior cells
-            s[1:-1, 1:-1] += w[p] * w[q_] * r[1 + i0_:n - 1 + i0_, 1 + j0_:n - 1 + j0_]
+    s = centre_interpolant(out, n)
     g = cell_centres(pieces)
     resid, cond = _counts_and_condition(pieces, rc.reshape(-1, 2), g)
     with np.errstate(all='ignore'):

@@ -301,11 +301,13 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
  *                   trajectory; the table only decides how fast, never what.
  *               Layout of `start` (doubles, 16-byte aligned): [0],[1] the unattenuated signals sum_e i0[k][e]; [2] a scale s;
  *               [3] cells per axis n; [4] ln of the smallest u0 of the grid; [5] cells per unit of ln u0; [6] the smallest ratio
- *               u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] ln of [0],[1]; where u_k = s ln(start[k] / g_k);
+ *               u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] ln of [0],[1]; [10] 1 if the kappa array is present,
+ *               else 0; [11] reserved; where u_k = s ln(start[k] / g_k);
  *               then the fixed points at the (n+1)^2 cell corners as pairs (a0, a1) (row = index along ln u0); then per cell
  *               the pair (need, radius): need = the number of steps a pixel whose counts fall in the cell must be allowed for
  *               the reference's walk to be known to end by the tolerance rule (infinity: closed), radius = how far from the
- *               interpolated fixed point a result is accepted.
+ *               interpolated fixed point a result is accepted; then (optional, see [10] and DEXCT_GN_FLAG_ONE_STEP) per cell
+ *               kappa: e1 <= kappa d1^2 for a Newton step of length d1 from the interpolant (infinity: always two steps).
  *               Both passes need stop_tol > 0 (after defaults), n_bins == 1, precision 0, n_iters <= 254, kernel != 2;
  *               DEXCT_EINVAL otherwise.  pass = 0 (default): one launch from 1e-6; iterations and start must be NULL or are
  *               not used.  (ABI 4 also had a two-launch "coarse" form of the short cut - a launch on a short quadrature of the
@@ -313,12 +315,19 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
  *   flags       DEXCT_GN_FLAG_FULL_LOOP: execute every iteration, no exit of any kind (stop_tol is then 0): the check that the
  *               repeated-state exit changes no bit.  DEXCT_GN_FLAG_NATURAL_ORDER: hand the tiles of a small sinogram out in
  *               their natural order instead of thick tiles first (results do not depend on it).
+ *               DEXCT_GN_FLAG_ONE_STEP (DEXCT_GN_PASS_SHORTCUT only; `start` must end with the kappa array, below): a pixel whose
+ *               FIRST step from the interpolated fixed point has length d1 with kappa d1^2 <= stop_tol / 4 * max(|a|, 1) ends
+ *               there - kappa, tabulated per cell by the calibration, bounds what Newton's step leaves of a distance d1 - ;
+ *               every other pixel goes on to its second step and the tolerance rule.  DEXCT_GN_FLAG_PROBE (calibration only):
+ *               every pixel of an open cell takes exactly one step from the interpolant and returns where it lands.
  *   blocks_per_cu   > 0: workgroups per CU of the queue kernels (0: what is resident; results do not depend on it). */
 #define DEXCT_GN_DEFAULT_STOP_TOL 1e-12
 #define DEXCT_GN_PASS_COUNT 1
 #define DEXCT_GN_PASS_SHORTCUT 2
 #define DEXCT_GN_FLAG_FULL_LOOP 1
 #define DEXCT_GN_FLAG_NATURAL_ORDER 2
+#define DEXCT_GN_FLAG_ONE_STEP 4
+#define DEXCT_GN_FLAG_PROBE 8
 typedef struct dexct_gn_options {
   double stop_tol;
   int32_t out_rows, out_channels;

@@ -24,7 +24,7 @@ EPS_INIT = 1e-6          # matdecomp.py:98-99
 CLIP = 700.0             # matdecomp.py:116
 
 
-def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False, last=10):
+def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False):
     """Per-pixel Newton iterations on the Poisson negative log-likelihood.
 
     sino_gg : [2, nViews, nBins] measured counts
@@ -32,11 +32,12 @@ def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False, last=10):
     mus     : [2, nE] basis mass-attenuation tables
     returns : [nViews, nBins, 2] density line integrals  (matdecomp.py:127)
 
-    ``return_sensitivity``: also return, per pixel, the largest value over the last ``last`` iterations of
-    cond(H_k) * |step_k| / max(|a_(k+1)|, 1) - times the machine epsilon, the relative uncertainty of the computed step itself:
-    any two float64 arithmetics (another order of the energy sums, another 2x2 solve) differ by about that much after the
-    step, and a pixel that is still moving at the end keeps the difference (a converged one sheds it: its last steps are 0).
-    The stability screen of tools/soak_gn.py (inf / NaN -> inf).
+    ``return_sensitivity``: also return a dict of per-pixel arrays - the stability screen of tools/soak_gn.py:
+      'walk'       the largest value over ALL iterations of cond(H_k) * |step_k| / max(|a_(k+1)|, 1); times the machine epsilon it
+                   is the relative uncertainty of a computed step: any two float64 arithmetics (another order of the energy
+                   sums, another 2x2 solve) differ by about that much after the step (inf / NaN -> inf);
+      'last_step'  |step| / max(|a|, 1) of the last iteration;
+      'last_cond'  cond(H) at the last iteration.
     """
     sino_gg = np.asarray(sino_gg, dtype=np.float64)
     mus = np.asarray(mus, dtype=np.float64)
@@ -52,7 +53,7 @@ def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False, last=10):
 
     a = np.full((n_views, n_bins, 2), EPS_INIT)
     g = np.moveaxis(sino_gg, 1, 0)                                          # [view, k, bin]
-    sens = np.zeros((n_views, n_bins))
+    sens = {'walk': np.zeros((n_views, n_bins)), 'last_step': np.zeros((n_views, n_bins)), 'last_cond': np.ones((n_views, n_bins))}
     for it in range(n_iters):
         expo = -(a[..., 0, None] * mus[0] + a[..., 1, None] * mus[1])       # [view, bin, e]
         att = np.exp(np.clip(expo, -CLIP, CLIP))
@@ -69,12 +70,15 @@ def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False, last=10):
             s1 = (H[:, 0, 0] * dF[:, 1] - H[:, 1, 0] * dF[:, 0]) / det
         a[..., 0] -= s0
         a[..., 1] -= s1
-        if return_sensitivity and it >= n_iters - last:
+        if return_sensitivity:
             with np.errstate(all='ignore'):
                 fro2 = H[:, 0, 0] ** 2 + H[:, 1, 1] ** 2 + H[:, 0, 1] ** 2 + H[:, 1, 0] ** 2
                 cond = (fro2 + np.sqrt(np.maximum(fro2 * fro2 - 4.0 * det * det, 0.0))) / (2.0 * np.abs(det))     # sigma_max / sigma_min, 2 x 2
-                now = cond * np.maximum(np.abs(s0), np.abs(s1)) / np.maximum(np.abs(a).max(-1), 1.0)
-                sens = np.where(np.isfinite(now), np.maximum(sens, now), np.inf)
+                step = np.maximum(np.abs(s0), np.abs(s1)) / np.maximum(np.abs(a).max(-1), 1.0)
+                now = cond * step
+                sens['walk'] = np.where(np.isfinite(now), np.maximum(sens['walk'], now), np.inf)
+                sens['last_step'] = np.where(np.isfinite(step), step, np.inf)
+                sens['last_cond'] = np.where(np.isfinite(cond), cond, np.inf)
     return (a, sens) if return_sensitivity else a
 
 

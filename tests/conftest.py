@@ -8,6 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the on-disk copy of the Newton short cut's gate tables (matdecomp._gate_cache_path) stays inside the test session
+if 'DEXCT_CACHE_DIR' not in os.environ:
+    import tempfile
+    os.environ['DEXCT_CACHE_DIR'] = tempfile.mkdtemp(prefix='dexct_cache_')
+
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 INPUT = os.path.join(ROOT, 'dex-ct-sim_amd', 'input')
 

@@ -192,7 +192,7 @@ def _dual_energy_shard(n, n_views, n_channels, view_range, sample_views, rows_at
         # the default: start values from the gate's table of the reference's fixed points, then two full-table steps per
         # unmasked pixel (the second one is the tolerance rule's evidence of convergence)
         live = int((counts[0] < 0.95 * gmax).sum())
-        assert st_d['mode'] == 'start' and 1.99 * live <= st_default <= 2.2 * live
+        assert st_d['mode'] == 'one' and 0.99 * live <= st_default <= 1.2 * live
         a_single = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, two_level=False)
         assert md.last_gn_stats()['mode'] == 'single' and md.last_gn_stats()['pixel_iterations'] > 6 * st_default
         a_exact = md.gn_device(counts[0], counts[1], i0, mus, n_iters, 'f64', mask_max=gmax, mask_frac=0.95, stop_tol=0.0)
@@ -372,7 +372,7 @@ def test_noisy_scan_default_mode_against_the_exact_count(hip, counts_per_ray):
     n_exact = md.last_gn_stats()['pixel_iterations']
     a = md.gn_device(counts[0], counts[1], i0, mus, 50, 'f64', **kw)
     st = md.last_gn_stats()
-    assert st['mode'] == 'start'
+    assert st['mode'] == 'one'
     worst, bad_pattern, beyond = 0.0, 0, 0
     for v0 in range(0, 360, 60):
         d, x = a[v0:v0 + 60], exact[v0:v0 + 60]

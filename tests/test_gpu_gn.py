@@ -699,7 +699,7 @@ def test_short_cut_against_the_exact_count(hip, golden, dtype):
     ok = np.isfinite(exact).all(-1)
     assert 0.98 < ok.mean() < 1.0
     steps = {}
-    for mode in (False, 'start'):
+    for mode in (False, 'start', 'one'):
         a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1, two_level=mode))
         st = md.last_gn_stats()
         assert st['mode'] == (mode or 'single')
@@ -707,7 +707,7 @@ def test_short_cut_against_the_exact_count(hip, golden, dtype):
         assert np.array_equal(a[~ok].view(np.int64), exact[~ok].view(np.int64))
         steps[mode] = st['pixel_iterations']
     # (noisy thin rays whose solution has a negative component lie below the gate's grid and are solved the reference's way)
-    assert steps['start'] < 0.7 * steps[False]
+    assert steps['one'] < steps['start'] < 0.7 * steps[False]
     # without noise every pixel takes the short cut: two full-table steps each
     clean, _, _ = _noisy_counts(golden, n=30000, seed=3, noise=0.0)
     clean = clean.astype(dtype)
@@ -715,16 +715,19 @@ def test_short_cut_against_the_exact_count(hip, golden, dtype):
     md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level=False)
     one = md.last_gn_stats()['pixel_iterations']
     md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level='start')
-    assert md.last_gn_stats()['pixel_iterations'] < min(8.0 * n, 0.5 * one)    # (the reference's bundled spectra, weight down to 1 keV: more cells are closed)
-    # the default is 'start' (one launch); DEXCT_GN_TWO_LEVEL at import sets another default
+    two = md.last_gn_stats()['pixel_iterations']
+    assert two < min(8.0 * n, 0.5 * one)    # (the reference's bundled spectra, weight down to 1 keV: more cells are closed)
+    md.optimize_sino(clean, None, i0, mus, 50, precision='f64', verbose=False, two_level='one')
+    assert md.last_gn_stats()['pixel_iterations'] < 0.8 * two                  # one step where the table's kappa vouches for it
+    # the default is 'one' (one launch); DEXCT_GN_TWO_LEVEL at import sets another default
     md.optimize_sino(cnt, None, i0, mus, 50, precision='f64', verbose=False)
-    assert md.last_gn_stats()['mode'] == 'start'
+    assert md.last_gn_stats()['mode'] == 'one'
     # results in the reference's order from [view][channel][row] input, ragged tiles, float32 and float64 counts: the same bits
     # as the plain order transposed (the fast path writes whole tiles, stashed pixels one by one)
     V, C, R = 5, 50, 40
     g3 = g.reshape(2, -1)[:, :V * C * R].reshape(2, V, C, R).contiguous()
     plain = md.gn_device(g3[0], g3[1], i0, mus, 50, 'f64', kernel=1)
-    assert md.last_gn_stats()['mode'] == 'start'
+    assert md.last_gn_stats()['mode'] == 'one'
     got = md.gn_device(g3[0], g3[1], i0, mus, 50, 'f64', kernel=1, out_rc=(R, C))
     assert got.shape == (V, R, C, 2)
     assert torch.equal(got.view(torch.int64), plain.permute(0, 2, 1, 3).contiguous().view(torch.int64))
@@ -737,7 +740,8 @@ def test_short_cut_against_the_exact_count(hip, golden, dtype):
     assert torch.equal(m_plain[~air].view(torch.int64), plain[~air].view(torch.int64))
 
 
-def test_short_cut_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, golden):
+@pytest.mark.parametrize('mode', ['one', 'start'])
+def test_short_cut_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, golden, mode):
     """The reference returns the state after n_iters steps from 1e-6 - the fixed point only if its iteration gets there in
     time.  The gate (csrc/gn.hip gn_start: step counts of the reference iteration itself over the data plane) lets a
     pixel take the short cut only where it does: for every n_iters the result is within 1e-12 of the exact count's
@@ -756,9 +760,9 @@ def test_short_cut_gate_keeps_the_reference_trajectory_when_steps_are_few(hip, g
         exact = solve(n_iters, stop_tol=0.0, two_level=False)
         single = solve(n_iters, two_level=False)
         st1 = md.last_gn_stats()['pixel_iterations']
-        a = solve(n_iters, two_level='start')
+        a = solve(n_iters, two_level=mode)
         st = md.last_gn_stats()
-        assert st['mode'] == 'start'
+        assert st['mode'] == mode
         assert err(a, exact) < 1e-12, n_iters
         far = np.abs(exact - settled).max(-1) > 1e-6
         if n_iters <= 5:
@@ -778,16 +782,16 @@ def test_short_cut_is_not_used_where_it_cannot_be_trusted(hip, golden):
     from dex_ct_sim_amd import matdecomp as md
     g = golden
     exact = md.optimize_sino(g['gn1_g'], None, g['gn1_i0'], g['gn1_mus'], 50, verbose=False, precision='f64', stop_tol=0.0, kernel=1)
-    for mode in (None, 'start', False):
+    for mode in (None, 'one', 'start', False):
         a = md.optimize_sino(g['gn1_g'], None, g['gn1_i0'], g['gn1_mus'], 50, verbose=False, precision='f64', two_level=mode, kernel=1)
         assert md.last_gn_stats()['mode'] == 'exact (ill-posed pair)', mode
         assert np.array_equal(a.view(np.int64), exact.view(np.int64))
         assert err(a, g['gn1_a_iters50']) < TOL_F64, mode
     a = md.optimize_sino(g['gn1_g'], None, g['gn1_i0'], g['gn1_mus'], 50, verbose=False, precision='f64', stop_tol=1e-12)
-    assert md.last_gn_stats()['mode'] in ('single', 'start') and err(a, g['gn1_a_iters50']) < TOL_F64
+    assert md.last_gn_stats()['mode'] in ('single', 'one', 'start') and err(a, g['gn1_a_iters50']) < TOL_F64
     for ci in (0, 2):                                                     # the kV pairs keep the short cut
         md.optimize_sino(g[f'gn{ci}_g'], None, g[f'gn{ci}_i0'], g[f'gn{ci}_mus'], 50, verbose=False, precision='f64')
-        assert md.last_gn_stats()['mode'] == 'start', ci
+        assert md.last_gn_stats()['mode'] == 'one', ci
     cnt, i0, mus = _noisy_counts(golden, n=4000)
     for kw in (dict(precision='mixed'), dict(precision='f64', stop_tol=0.0)):
         md.optimize_sino(cnt, None, i0, mus, 50, verbose=False, two_level='start', **kw)
@@ -836,6 +840,9 @@ def test_short_cut_passes_through_the_c_abi(hip, golden):
     a.fill_(float('nan'))
     assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, None, start.data_ptr(), 0, 2)) == 0         # blocks_per_cu
     assert err(a.cpu().numpy(), exact) < 1e-12
+    a.fill_(float('nan'))
+    assert call(50, _native.gn_options(None, 0, 0, 1, SHORT, None, start.data_ptr(), _native.GN_FLAG_ONE_STEP)) == 0     # one step where kappa allows
+    assert err(a.cpu().numpy(), exact) < 1e-12
     EINVAL = -1
     assert call(50, _native.gn_options(1e-7, 0, 0, 1, COUNT, None)) == EINVAL                         # nowhere to put the counts
     assert call(50, _native.gn_options(1e-7, 0, 0, 1, COUNT, it.data_ptr(), start.data_ptr())) == EINVAL  # the counting pass walks from 1e-6
@@ -846,7 +853,8 @@ def test_short_cut_passes_through_the_c_abi(hip, golden):
     assert call(255, _native.gn_options(None, 0, 0, 1, SHORT, None, start.data_ptr())) == EINVAL      # counts are bytes
     assert call(50, _native.gn_options(None, 0, 0, 2, SHORT, None, start.data_ptr())) == EINVAL       # lane kernel only
     assert call(50, _native.gn_options(None, 0, 0, 1, 3, it.data_ptr())) == EINVAL
-    assert call(50, _native.gn_options(None, 0, 0, 1, 0, None, None, 4)) == EINVAL                    # unknown flag
+    assert call(50, _native.gn_options(None, 0, 0, 1, 0, None, None, 16)) == EINVAL                   # unknown flag
+    assert call(50, _native.gn_options(None, 0, 0, 1, 0, None, None, _native.GN_FLAG_ONE_STEP)) == EINVAL      # only on the short cut
     assert call(50, _native.gn_options(None, 0, 0, 1, 0, None, None, 0, -1)) == EINVAL
     # the table of fixed points must be 16-byte aligned (pairs are read with one load)
     shifted = torch.empty(start.numel() + 1, dtype=torch.float64, device=dev)
@@ -878,7 +886,7 @@ def test_short_cut_on_poisson_counts_of_physical_spectra(hip, dose):
     n_exact = md.last_gn_stats()['pixel_iterations']
     a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1))
     st = md.last_gn_stats()
-    assert st['mode'] == 'start'
+    assert st['mode'] == 'one'
     ok = np.isfinite(exact).all(-1) & (np.abs(exact).max(-1) < 1e6)
     assert ok.mean() > (0.5 if dose < 1e4 else 0.95)
     assert err(a[ok], exact[ok]) < 1e-12
@@ -897,12 +905,12 @@ def test_short_cut_tables_are_cached_by_content_and_accept_device_tensors(hip, g
     g = to_dev(cnt, torch.float64, dev)
     md._table_cache.clear()
     a = to_host(md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1))
-    assert md.last_gn_stats()['mode'] == 'start' and len(md._table_cache) == 1
+    assert md.last_gn_stats()['mode'] == 'one' and len(md._table_cache) == 1
     start0 = next(iter(md._table_cache.values()))[('gate', 1e-12)]['start']
     b = to_host(md.gn_device(g[0], g[1], i0.copy(), mus.copy(), 50, 'f64', kernel=1))
     assert len(md._table_cache) == 1 and next(iter(md._table_cache.values()))[('gate', 1e-12)]['start'] is start0
     c = to_host(md.gn_device(g[0], g[1], to_dev(i0, torch.float64, dev), to_dev(mus, torch.float64, dev), 50, 'f64', kernel=1))
-    assert md.last_gn_stats()['mode'] == 'start' and len(md._table_cache) == 1
+    assert md.last_gn_stats()['mode'] == 'one' and len(md._table_cache) == 1
     assert np.array_equal(a.view(np.int64), b.view(np.int64)) and np.array_equal(a.view(np.int64), c.view(np.int64))
     md.gn_device(g[0], g[1], 1.5 * i0, mus, 50, 'f64', kernel=1)                   # other spectra: another table
     assert len(md._table_cache) == 2
@@ -923,7 +931,7 @@ def test_short_cut_through_the_public_boundary(hip):
     specs = [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
     (r1, _), (r2, _) = dx.get_sinos(ct, ph, specs)
     m1, m2 = md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50)
-    assert md.last_gn_stats()['mode'] == 'start'
+    assert md.last_gn_stats()['mode'] == 'one'
     w1, w2 = md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50, two_level=False)
     assert md.last_gn_stats()['mode'] == 'single'
     x1, x2 = md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50, stop_tol=0.0)
@@ -931,3 +939,111 @@ def test_short_cut_through_the_public_boundary(hip):
     assert air.any() and np.all(m1[air] == 0) and np.all(m2[air] == 0) and np.all(w1[air] == 0)
     for got in ((m1, m2), (w1, w2)):
         assert err(np.stack(got, -1), np.stack([x1, x2], -1)) < 1e-12
+
+
+@pytest.mark.parametrize('pair', [('detunedMV', '80kV'), ('6MV', '80kV'), ('140kV', '80kV')])
+def test_default_mode_on_noisy_scans_of_the_bundled_pairs(hip, pair):
+    """The reference's LIVE spectrum pair (main.py:101: detunedMV / 80 kV) and its sibling 6MV / 80 kV are ill-posed - the
+    calibration of the short cut sees it (quadrature.pair_is_ill_posed) and the default runs the reference's fixed count for
+    them: get_sinos(noise=...) -> get_basismat_sinos default == stop_tol = 0 on EVERY pixel, bit for bit (hence the same finite
+    / NaN pattern and <= 1e-12), at the three doses and both noise models of profiles/r04_gn_noisy_public.log, where the
+    tolerance rule had left 1 - 27 of 9.6e5 pixels with another pattern.  The kV pair keeps the short cut (<= 0.16 of the
+    exact count's steps) and agrees with the exact count to 1e-12 with the same pattern.  1200 x 800 x 1, as the reference scans."""
+    import os
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import matdecomp as md
+    from conftest import INPUT, small_scan
+    ct, ph = small_scan(n=512, nz=1, n_views=1200, n_channels=800, n_rows=1)
+    ill = 'MV' in pair[0]
+    for dose in (5.0, 0.5, 0.02):                      # scale factors of main.py:68 (A_iso * dose / N_proj)
+        specs = []
+        for name in pair:
+            s = dx.xRaySpectrum(os.path.join(INPUT, 'spectrum', f'{name}_1mGy_float32.bin'), name)
+            s.rescale_counts(ct.A_iso * dose / ct.N_proj)
+            specs.append(s)
+        for noise in (True, 'poisson'):
+            (r1, _), (r2, _) = dx.get_sinos(ct, ph, specs, noise=noise, seed=3)
+            x = np.stack(md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50, stop_tol=0.0), -1)
+            n_exact = md.last_gn_stats()['pixel_iterations']
+            m = np.stack(md.get_basismat_sinos(ct, r1, r2, specs[0], specs[1], n_iters=50), -1)
+            st = md.last_gn_stats()
+            fin = np.isfinite(x).all(-1)
+            assert np.array_equal(np.isfinite(m).all(-1), fin), (pair, dose, noise)
+            if ill:
+                assert st['mode'] == 'exact (ill-posed pair)' and st['pixel_iterations'] == n_exact
+                assert np.array_equal(m.view(np.int64), x.view(np.int64)), (pair, dose, noise)
+                assert 0.85 < fin.mean() < 0.995           # (the pair is ill-posed: the reference itself ends NaN on 3 - 7 % of the pixels)
+            else:
+                assert st['mode'] == 'one' and st['pixel_iterations'] <= 0.16 * n_exact, (dose, noise, st['pixel_iterations'] / n_exact)
+                assert err(m[fin], x[fin]) < 1e-12, (dose, noise)
+
+
+def test_sampled_audit_of_the_short_cut(hip, golden, recwarn):
+    """get_basismat_sinos(..., audit=ppm) / DEXCT_GN_AUDIT / main.py --gn-audit: a Philox-chosen sample of the pixels is solved
+    again with the reference's fixed count in the same call; a healthy table passes silently, a deliberately corrupted one
+    (every open cell claims that 3 steps suffice, so pixels take the short cut when the reference's 5-step walk is nowhere near
+    its fixed point) is caught: a warning with the worst pixel's counts, an exception in strict mode."""
+    from dex_ct_sim_amd import matdecomp as md, quadrature as q
+    from dex_ct_sim_amd._device import to_dev
+    cnt, i0, mus = _noisy_counts(golden, n=60000, noise=0.0)
+    g = to_dev(cnt, torch.float64, torch.device('cuda'))
+    dev = g.device                                  # ('cuda:0': the key of the table cache carries the device)
+    gmax = g[0].max().double() * 0.9
+    for kw in (dict(), dict(mask_max=gmax), dict(out_rc=(20, 30))):
+        gg = g if 'out_rc' not in kw else g.reshape(2, 100, 30, 20)
+        md.gn_device(gg[0], gg[1], i0, mus, 50, 'f64', kernel=1, audit=2e4, audit_strict=True, **kw)      # 2 % of the pixels: passes
+        st = md.last_gn_stats()
+        assert st['mode'] == 'one' and st['audit']['pixels'] == 1200 and st['audit']['differing'] == 0 and st['audit']['max_rel_diff'] < 1e-12
+    assert not [w for w in recwarn.list if issubclass(w.category, md.GnAuditWarning)]
+    md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1)
+    assert 'audit' not in md.last_gn_stats()                                     # off by default
+    # corrupt the cached table of this pair: need = 3 in every open cell
+    gate = md._device_tables(i0, mus, dev, True)[2]
+    healthy = gate['start'].clone()
+    n = q.GATE_CELLS
+    cells = gate['start'][q.START_HEADER + 2 * (n + 1) ** 2:].view(n, n, 2)
+    cells[:, :, 0] = torch.where(torch.isfinite(cells[:, :, 0]), torch.full_like(cells[:, :, 0], 3.0), cells[:, :, 0])
+    try:
+        exact = md.gn_device(g[0], g[1], i0, mus, 5, 'f64', kernel=1, stop_tol=0.0)
+        with pytest.warns(md.GnAuditWarning, match='sampled pixels differ'):
+            bad = md.gn_device(g[0], g[1], i0, mus, 5, 'f64', kernel=1, audit=2e4)
+        st = md.last_gn_stats()
+        assert st['audit']['differing'] > 100 and st['audit']['max_rel_diff'] > 1e-3 and len(st['audit']['worst']['counts']) == 2
+        assert float(((bad - exact).abs() / exact.abs().clamp(min=1.0)).max()) > 1e-3       # (the corruption is real)
+        with pytest.raises(md.GnAuditError):
+            md.gn_device(g[0], g[1], i0, mus, 5, 'f64', kernel=1, audit=2e4, audit_strict=True)
+    finally:
+        gate['start'].copy_(healthy)
+    ok = md.gn_device(g[0], g[1], i0, mus, 5, 'f64', kernel=1, audit=2e4, audit_strict=True)
+    assert torch.equal(ok.view(torch.int64), exact.view(torch.int64))            # 5 steps: nothing takes the short cut
+
+
+def test_gate_table_survives_the_process_on_disk(hip, golden, tmp_path, monkeypatch):
+    """The reference's usage is one call per pair of spectra per run (main.py:153): the gate's table is kept under
+    DEXCT_CACHE_DIR and a fresh process (here: a cleared in-process cache) loads it instead of calibrating - same table, same
+    results bit for bit; a truncated file is ignored and replaced."""
+    from dex_ct_sim_amd import matdecomp as md
+    from dex_ct_sim_amd._device import to_dev
+    cnt, i0, mus = _noisy_counts(golden, n=20000, noise=0.0)
+    g = to_dev(cnt, torch.float64, torch.device('cuda'))
+    dev = g.device
+    monkeypatch.setenv('DEXCT_CACHE_DIR', str(tmp_path))
+    md._table_cache.clear()
+    a = md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1)
+    gate = md._device_tables(i0, mus, dev, True)[2]
+    assert gate['source'] == 'calibration' and md.last_gn_stats()['mode'] == 'one'
+    files = list(tmp_path.glob('gate_*.npz'))
+    assert len(files) == 1 and files[0].stat().st_size > 2_000_000
+    table = gate['start'].clone()
+    md._table_cache.clear()
+    b = md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1)
+    gate = md._device_tables(i0, mus, dev, True)[2]
+    assert gate['source'] == 'disk' and torch.equal(gate['start'], table) and torch.equal(a.view(torch.int64), b.view(torch.int64))
+    raw = files[0].read_bytes()
+    files[0].write_bytes(raw[: len(raw) // 3])
+    md._table_cache.clear()
+    c = md.gn_device(g[0], g[1], i0, mus, 50, 'f64', kernel=1)
+    gate = md._device_tables(i0, mus, dev, True)[2]
+    assert gate['source'] == 'calibration' and torch.equal(a.view(torch.int64), c.view(torch.int64))
+    assert files[0].stat().st_size == len(raw)                                 # written again, whole
+    md._table_cache.clear()

@@ -343,7 +343,9 @@ def test_gate_table_on_disk_is_validated_before_use(tmp_path, monkeypatch):
     p = q.newton_start_grid(i0, mus)
     n = q.GATE_CELLS
     rng = np.random.default_rng(0)
-    start = np.concatenate([p['head'], rng.random(2 * (n + 1) ** 2 + 2 * n * n)])
+    head = p['head'].copy()
+    head[10] = 1.0                                                        # (with the kappa table, as the calibration leaves it)
+    start = np.concatenate([head, rng.random(2 * (n + 1) ** 2 + 3 * n * n)])
     stats = {'grid': True, 'open_share': 0.9, 'walk_nonfinite_share': 0.0, 'walk_not_by_rule_share': 0.0}
     assert md._gate_from_disk(path, i0, mus) is None                      # nothing there yet
     md._gate_to_disk(path, start, stats)

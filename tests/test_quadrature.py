@@ -108,7 +108,7 @@ def test_gate_grid_and_start_array():
     # a smooth synthetic field of fixed points (made consistent: the corners' counts are set to the model's at those points),
     # one slow corner, one corner that did not end, one corner in another basin, one corner resting where it does not
     # reproduce its counts (a valley of the clipped likelihood)
-    ii, jj = np.meshgrid(np.arange(n + 1.0), np.arange(n + 1.0), indexing='ij')
+    ii, jj = np.meshgrid(np.arange(n + 1.0) * 128.0 / n, np.arange(n + 1.0) * 128.0 / n, indexing='ij')      # (the field of the 128-cell grid this test was written on)
     roots = np.stack([0.15 * ii + 0.005 * ii * jj / 4, 0.1 * jj - 0.025 * ii], -1).reshape(-1, 2)
     p = dict(p, corner_g=np.exp(-(roots @ p['mus'])) @ p['i0'].T)
     steps = np.full((n + 1) ** 2, 17)
@@ -196,3 +196,34 @@ def test_isolated_roots_are_told_from_families_of_them():
     far = np.array([[40.0, 5.0]])
     with np.errstate(all='ignore'):
         assert not np.isfinite(q._counts_and_condition(clipped, far, np.ones((1, 2)))[1][0]) or q._counts_and_condition(clipped, far, np.ones((1, 2)))[1][0] > 1e12
+
+
+def test_kappa_table_of_the_one_step_acceptance():
+    """quadrature.attach_kappa: per centre e1 / d1^2 (e1 = |probe - root|, not below 8 eps of the size; d1 = |probe - interpolant|),
+    per cell KAPPA_SAFETY x the largest among the cell and the eight around it; infinity in closed cells, around a centre whose
+    probe is not finite and around one whose single step does not land within stop_tol / 16; header [10] = 1, kappa appended."""
+    _, i0, mus = newton_tables()
+    p = q.newton_start_grid(i0, mus)
+    n = int(p['head'][3])
+    ii, jj = np.meshgrid(np.arange(n + 1.0) * 128.0 / n, np.arange(n + 1.0) * 128.0 / n, indexing='ij')
+    roots = np.stack([0.15 * ii + 0.005 * ii * jj / 4, 0.1 * jj - 0.025 * ii], -1).reshape(-1, 2)
+    p = dict(p, corner_g=np.exp(-(roots @ p['mus'])) @ p['i0'].T)
+    start, _, _ = q.assemble_start(p, np.full((n + 1) ** 2, 17), roots)
+    cells = start[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)
+    s = q.centre_interpolant(start, n)
+    probe = s + 1.0e-7                                                   # the step from the interpolant: d1 = 1e-7
+    size = np.maximum(np.abs(probe).max(-1), 1.0)
+    rc = probe + 1.0e-14 * size[:, :, None]                              # ... lands 1e-14 of the size from the root
+    rc[40, 40] = probe[40, 40] + 1.0e-12 * size[40, 40]                  # one centre where the step leaves too much (> stop_tol / 16)
+    probe[80, 80] = np.nan
+    out, share = q.attach_kappa(start, p, rc.reshape(-1, 2), probe.reshape(-1, 2), 1e-12)
+    assert out.size == start.size + n * n and out[10] == 1.0 and np.array_equal(out[:10], start[:10])
+    assert np.array_equal(out[q.START_HEADER:start.size], start[q.START_HEADER:])
+    kappa = out[start.size:].reshape(n, n)
+    open_ = np.isfinite(cells[:, :, 0])
+    assert np.all(np.isinf(kappa[~open_])) and 0.3 < share < open_.mean() + 1e-12
+    i, j = 60, 50
+    assert open_[i - 1:i + 2, j - 1:j + 2].all()
+    want = q.KAPPA_SAFETY * np.max(1.0e-14 * size[i - 1:i + 2, j - 1:j + 2] / 1.0e-14)
+    assert np.isclose(kappa[i, j], want, rtol=3e-2)                     # (1e-14 of the size is a dozen ulps: quantised)
+    assert np.all(np.isinf(kappa[39:42, 39:42])) and np.all(np.isinf(kappa[79:82, 79:82])) and np.isfinite(kappa[43, 43])

@@ -15,12 +15,16 @@ the cooperative kernel within 1e-9 of the lane kernel, on the pixels the NumPy r
 and agreement to 1e-9 with the NumPy restatement of the reference, all on the STABLE pixels.
 
 THE STABILITY SCREEN (version 2, round 5).  Two float64 arithmetics - another order of the energy sums, another 2x2 solve -
-differ after one Newton step by about eps * cond(H) * |step|, and a pixel that is still moving when the iterations run out keeps
-that difference (a converged one sheds it: its last steps are 0).  A pixel is compared only if
+differ after one Newton step by about eps * cond(H) * |step| / size, and what becomes of that difference depends on where the
+pixel goes: an iteration that converges to an ISOLATED root sheds it (Newton corrects itself), one that is still moving when
+the iterations run out, or rests on a line of solutions (one energy: the two attenuation vectors are parallel), keeps it, and
+a transient wild enough carries the two arithmetics into different basins.  With w = eps * the largest cond(H_k) |step_k| /
+max(|a_(k+1)|, 1) over all iterations of the restatement (gn_oracle.newton_solve(..., return_sensitivity=True)), a pixel is
+compared only if
   * the restatement's answer is finite, below 1e6, and its counts are finite and positive;
   * the answer moves by at most 1e-11 relative under a 1e-13 perturbation of the counts;
-  * eps * max over the last 10 iterations of cond(H_k) |step_k| / max(|a_(k+1)|, 1) <= 1e-11 (gn_oracle.newton_solve(...,
-    return_sensitivity=True)): the computed steps themselves are certain to well inside the 1e-9 / 1e-10 asked for.
+  * w <= 1e-11 (every step certain to well inside the 1e-9 / 1e-10 asked for), or: w <= 1e-6 and the iteration has converged
+    to an isolated root - last step <= 1e-12 of the size, eps * cond(H) <= 1e-11 there.
 Version 1 had the permutation of the energies in place of the last rule; with 2 or 3 energies a permutation changes little or
 nothing (seed 319's was a swap of two, 468's the identity) and photon-starved pixels still creeping at the last iteration through
 Hessians of condition 1e9 - 1e11 passed it: the cooperative kernel, the lane kernel and the restatement then part by 1e-9
@@ -97,6 +101,7 @@ def check_case(seed, stats=None):
         # the short cut: start values from the tabulated fixed points, gated by the reference iteration's own step counts -
         # same contract as the tolerance stop (an explicit tolerance: also on pairs the calibration calls ill-posed)
         short = run(g_d, i0, mus, n_iters, {}, stop_tol=md.DEFAULT_STOP_TOL or 1e-12, two_level='start')
+        short1 = run(g_d, i0, mus, n_iters, {}, stop_tol=md.DEFAULT_STOP_TOL or 1e-12, two_level='one')
         mode = md.last_gn_stats()['mode']
         stats[mode] = stats.get(mode, 0) + 1
         gmax = torch.tensor(float(np.nanmax(np.where(np.isfinite(g[0]), g[0], -np.inf))), dtype=torch.float64, device=dev)
@@ -110,17 +115,20 @@ def check_case(seed, stats=None):
             ref_p = gn_oracle.newton_solve(g * (1 + 1e-13), i0, mus, n_iters)
             size = np.maximum(np.abs(ref).max(-1), 1.0)
             ok = np.isfinite(ref).all(-1) & (np.abs(ref).max(-1) < 1e6) & np.isfinite(g).all(0) & (g > 0).all(0)
-            ok &= (np.abs(ref - ref_p).max(-1) <= 1e-11 * size) & (np.finfo(np.float64).eps * sens <= 1e-11)
+            eps = np.finfo(np.float64).eps
+            settled = (sens['last_step'] <= 1e-12) & (eps * sens['last_cond'] <= 1e-11)
+            ok &= (np.abs(ref - ref_p).max(-1) <= 1e-11 * size) & ((eps * sens['walk'] <= 1e-11) | (settled & (eps * sens['walk'] <= 1e-6)))
         stats['pixels'] = stats.get('pixels', 0) + n_v * n_c
         stats['stable'] = stats.get('stable', 0) + int(ok.sum())
         if ok.any():
             lane = base.cpu().numpy()
             for name, other, tol in (('NumPy restatement', ref, 1e-9), ('default tolerance stop', default.cpu().numpy(), 1e-10),
-                                     ('cooperative kernel', coop.cpu().numpy(), 1e-9), ('short cut', short.cpu().numpy(), 1e-10)):
+                                     ('cooperative kernel', coop.cpu().numpy(), 1e-9), ('short cut, two steps', short.cpu().numpy(), 1e-10),
+                                     ('short cut, one step', short1.cpu().numpy(), 1e-10)):
                 d = (np.abs(other - lane).max(-1) / size)[ok]
                 n_bad = int((~(d <= tol)).sum())
                 if n_bad:
-                    bad.append(f'{name}: {n_bad} of {int(ok.sum())} stable pixels beyond {tol:g} of the exact lane kernel (worst {np.nanmax(d):.2e})')
+                    bad.append(f'{name}: {n_bad} of {int(ok.sum())} stable pixels beyond {tol:g} of the exact lane kernel (worst {np.nanmax(d):.2e}, {int(np.isnan(d).sum())} not comparable)')
     except Exception as exc:
         bad = [f'{type(exc).__name__}: {exc}']
     return what, bad
@@ -137,7 +145,7 @@ if __name__ == '__main__':
             fails += 1
             print(f'FAIL seed {seed0 + case}: {what}: ' + '; '.join(bad), flush=True)
         if case % 100 == 99 or case == n_cases - 1:
-            print(f'{case + 1} cases from seed {seed0}, {fails} failed, {stats.get("pixels", 0):.3g} pixels x 14 launches, {stats.get("stable", 0):.3g} stable '
+            print(f'{case + 1} cases from seed {seed0}, {fails} failed, {stats.get("pixels", 0):.3g} pixels x 15 launches, {stats.get("stable", 0):.3g} stable '
                   f'pixels compared (screen v2); short-cut launches ended up as '
                   f'{ {k: v for k, v in stats.items() if k not in ("pixels", "stable")} }; {time.time() - t0:.0f} s', flush=True)
     sys.exit(1 if fails else 0)

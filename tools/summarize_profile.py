@@ -38,7 +38,7 @@ def pmc(which):
         out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']) * 1024.0)
     # (the step-counting instantiation of the Newton kernel is also dispatched once on the 16 641 pixels of the gate calibration:
     # the large dispatches are the ones of the steps)
-    return {k: (max(v) if 'gn_refill_kernel<4, 1>' in k else sum(v) / len(v)) for k, v in out.items()}
+    return {k: (max(v) if 'gn_refill_kernel<true>' in k else sum(v) / len(v)) for k, v in out.items()}
 
 
 fetch, write = pmc('fetch'), pmc('write')
@@ -69,19 +69,18 @@ if tl:
     trace = os.path.join(os.path.dirname(stats), os.path.basename(stats).replace('kernel_stats', 'kernel_trace'))
     big = {}
     for r in csv.DictReader(open(trace)):
-        for pat in ('gn_refill_kernel<4, 1>', 'gn_refill_kernel<4, 2>'):
+        for pat in ('gn_refill_kernel<true>', 'gn_shortcut_kernel'):
             if pat in r['Kernel_Name']:
                 big.setdefault(pat, []).append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e6)
     for pat, v in big.items():
-        if pat.endswith('1>') and tl.get('mode') != 'coarse':
+        if pat.endswith('<true>'):
             lines.append(f'`{pat}` (the step-counting instantiation): {len(v)} dispatches averaging {sum(v) / len(v):.2f} ms - the reference\'s walk on '
                          f'the gate\'s 16 641 cell corners and 16 384 cell centres, once per pair of spectra')
             continue
         step = [x for x in v if x > 0.25 * max(v)]
         lines.append(f'`{pat}`: {len(v)} dispatches, of which {len(step)} are step launches averaging {sum(step) / len(step):.2f} ms'
                      + (' (the others: the gate calibration, once per pair of spectra)' if len(step) < len(v) else ''))
-    lines += [f'Newton launch in bench.py (HIP events around it, last timed step; mode {tl["mode"]}): {tl["launch_ms"]:.2f} ms'
-              + (f', coarse launch {tl["coarse_launch_ms"]:.2f} ms' if tl.get('coarse_launch_ms') else ''), '']
+    lines += [f'Newton launch in bench.py (HIP events around it, last timed step; mode {tl["mode"]}): {tl["launch_ms"]:.2f} ms', '']
 cal = [k for k in fetch if 'transpose_xy' in k]
 traffic = {}
 if cal:
@@ -107,10 +106,10 @@ if cal:
             traffic['siddon_fetch_bytes'] = corr * fetch[k]
             traffic['siddon_write_bytes'] = write.get(k, 0.0)
             traffic['siddon_hbm_bytes_per_launch'] = corr * fetch[k] + write.get(k, 0.0)
-        # the Newton kernel of the step: the refining launch of the two-level solve (gn_refill_kernel<4, 2>) where it ran, else
-        # the single launch (<4, 0> / <5, 0>); the coarse launch (<4, 1>) is recorded beside it
-        is_main = ('gn_refill_kernel<4, 2>' in k) or (('gn_refill_kernel' in k or 'gn_kernel<false' in k) and 'gn_refill_kernel<4, 1>' not in k
-                                                      and not any('gn_refill_kernel<4, 2>' in kk for kk in fetch))
+        # the Newton kernel of the step: the short cut (gn_shortcut_kernel) where it ran, else the single launch
+        # (gn_refill_kernel<false>); the step-counting launches of the gate calibration (<true>) are recorded beside it
+        is_main = ('gn_shortcut_kernel' in k) or (('gn_refill_kernel' in k or 'gn_kernel<false' in k) and 'gn_refill_kernel<true>' not in k
+                                                  and not any('gn_shortcut_kernel' in kk for kk in fetch))
         if is_main:
             traffic['gn_kernel'] = k.split('(')[0].replace('void dexct::', '')
             traffic['gn_fetch_bytes_x2_corrected'] = 2 * fetch[k]
@@ -119,13 +118,13 @@ if cal:
             # runs, which FETCH_SIZE counts in full (tools/probes/gn_write2.py: 0.77 GB for 0.82 GB of input; the plain order's
             # dword-per-lane stream shows half): no doubling for the round-4 kernel
             traffic['gn_fetch_bytes_raw'] = fetch[k]
-            traffic['gn_fetch_counted_in_full'] = 'gn_refill_kernel<4' in k or 'gn_refill_kernel<5' in k
-        if 'gn_refill_kernel<4, 1>' in k:
-            traffic['gn_coarse_fetch_bytes_raw'] = fetch[k]
-            traffic['gn_coarse_write_bytes'] = write.get(k, 0.0)
+            traffic['gn_fetch_counted_in_full'] = 'gn_refill_kernel' in k or 'gn_shortcut_kernel' in k
+        if 'gn_refill_kernel<true>' in k:
+            traffic['gn_count_fetch_bytes_raw'] = fetch[k]
+            traffic['gn_count_write_bytes'] = write.get(k, 0.0)
     for k, d in sq.items():
-        if ('rows' in k and 'kernel' in k and 'cone_' not in k) or 'gn_refill_kernel' in k:
-            tag2 = 'siddon' if 'rows' in k else ('gn_coarse' if 'gn_refill_kernel<4, 1>' in k else 'gn')
+        if ('rows' in k and 'kernel' in k and 'cone_' not in k) or 'gn_refill_kernel' in k or 'gn_shortcut_kernel' in k:
+            tag2 = 'siddon' if 'rows' in k else ('gn_count' if 'gn_refill_kernel<true>' in k else 'gn')
             traffic[f'{tag2}_valu_insts'] = d.get('SQ_INSTS_VALU')
             if d.get('GRBM_GUI_ACTIVE'):
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's waves; GRBM_GUI_ACTIVE sums the 8 XCDs
