@@ -48,7 +48,7 @@ class GnOptions(C.Structure):
 
 
 GN_PASS_COUNT, GN_PASS_SHORTCUT = 1, 2
-GN_FLAG_FULL_LOOP, GN_FLAG_NATURAL_ORDER, GN_FLAG_ONE_STEP, GN_FLAG_PROBE = 1, 2, 4, 8
+GN_FLAG_FULL_LOOP, GN_FLAG_NATURAL_ORDER, GN_FLAG_ONE_STEP = 1, 2, 4
 
 
 def gn_options(stop_tol=None, out_rows=0, out_channels=0, kernel=0, gn_pass=0, iterations=None, start=None, flags=0,

@@ -783,7 +783,7 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // infinity where a corner did not end by the tolerance rule, or where the corners' fixed points do not vary smoothly - a
 // boundary between two basins crosses the cell) and an acceptance radius (a hundredth of the spread of the corners' fixed
 // points).  A pixel takes the short cut iff its counts fall in a cell with n_iters >= that number; it starts from the
-// Catmull-Rom interpolant s of the corners' fixed points - a point on the REFERENCE'S branch, 1e-6 of |a| from the pixel's own
+// sextic (6 x 6 Lagrange) interpolant s of the corners' fixed points - a point on the REFERENCE'S branch, 1e-10 of |a| from the pixel's own
 // fixed point - and its result is accepted only within the radius of s.  Every other pixel (few steps asked for, counts
 // outside the grid, another fixed point, NaN) is solved the reference's way.
 // Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] cells per axis n; [4] ln of the smallest u0 of the grid;
@@ -792,13 +792,15 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair (need, radius)[n^2], then - optional - per cell kappa[n^2];
 // the array is 16-byte aligned (pairs are read with one load).
 //
-// ONE STEP INSTEAD OF TWO (kappa; DEXCT_GN_FLAG_ONE_STEP).  From a start value s at distance e0 from the pixel's fixed point,
-// Newton's step lands at distance e1 <= kappa e0^2, and the step itself measures e0: d1 = |n - s| = e0 (1 + O(kappa e0)).  kappa is
-// tabulated per cell by the calibration - the library's own kernel takes one step from the interpolant at every cell's centre
-// (DEXCT_GN_FLAG_PROBE), the host compares with where the reference's walk ends there: kappa = 4 x the largest e1 / d1^2 among the
-// cell and the eight around it (infinity where any of them is closed).  A pixel whose first step satisfies
-// kappa d1^2 <= stop_tol / 4 * max(|a|, 1) has the same evidence the tolerance rule asks of two steps - the distance it still
-// has to go is below stop_tol / 4 of its size - and ends there; every other pixel takes its second step and the rule, as before.
+// ONE STEP INSTEAD OF TWO (kappa; DEXCT_GN_FLAG_ONE_STEP).  Newton's iteration on the likelihood F from a start value s at
+// distance e0 of the fixed point a* lands at n with  n - a* = 1/2 H(s)^-1 D3F(xi) [e0, e0]:  e1 <= kappa e0^2 in the max norm with
+// kappa = 1/2 max_i sum_j |H^-1_ij| sum_pq |D3F_jpq|, and the step itself measures e0: d1 = |n - s| >= e0 - e1.  The host tabulates
+// kappa per cell from the Hessian and the third derivatives of the Poisson likelihood at the tabulated fixed points
+// (quadrature.newton_kappa: 2.5 x the largest value at the corners of the cell and of the eight around it; infinity where one
+// does not count).  A pixel whose first step satisfies kappa d1^2 <= stop_tol / 4 * max(|a|, 1) has what the tolerance rule asks
+// of two steps - a bound on the distance it still has to go, below stop_tol / 4 of its size - from one, and ends there; every
+// other pixel takes its second step and the rule, as before.  With the sextic interpolant d1 is 1e-10 of |a| and the bound
+// holds with three orders to spare (kappa |a| is 600 on average, 1e4 at thick rays: profiles/r05_gn_one_step.md).
 constexpr int kStartHeader = 12;
 
 // ln(x) for a positive, normal double: the hardware's float32 logarithm as a first guess y0 (|error| < 1e-5), then one
@@ -834,29 +836,36 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const
   const d2* __restrict__ cells = roots + (n + 1) * (n + 1);                               // (need, radius) per cell
   const d2 cell = cells[i * n + j];
   ok = ok && (double)n_iters >= cell.x;
-  // Catmull-Rom interpolation of the corners' fixed points over the 4 x 4 corners around the cell (the corners of the 3 x 3
-  // cells the step table vouches for; cells on the border of the grid are closed by the host): 1e-6 of |a| where the
-  // bilinear interpolant is 6e-4 off - the difference between two and three steps of the full tables per pixel
+  // 6 x 6 Lagrange interpolation of the corners' fixed points (the corners of the 5 x 5 cells the step table vouches for; cells
+  // within two of the border of the grid are closed by the host).  The fixed point is an analytic function of (ln u0, u1 / u0);
+  // at 256 cells per axis the sextic interpolant is within 1e-10 of |a| of the pixel's own fixed point (the Catmull-Rom
+  // interpolant of round 4, third order: 2e-6; tools/probes/gn_interp_cpu.py) - close enough for ONE Newton step to land at
+  // rounding level with a proven bound (kappa, above), and it costs 36 loads and 100 FMAs against a step's 3 000.
   const double wx = fx - (double)i, wy = fy - (double)j;
-  auto weights = [](double t_, double (&w)[4]) {
-    const double t2 = t_ * t_, t3 = t2 * t_;
-    w[0] = -0.5 * t3 + t2 - 0.5 * t_;
-    w[1] = 1.5 * t3 - 2.5 * t2 + 1.0;
-    w[2] = -1.5 * t3 + 2.0 * t2 + 0.5 * t_;
-    w[3] = 0.5 * t3 - 0.5 * t2;
+  auto weights = [](double t_, double (&w)[6]) {
+    // nodes -2 .. 3: w_a = prod_(b != a) (t - x_b) / (x_a - x_b), by prefix and suffix products of p_b = t - x_b
+    const double p0 = t_ + 2.0, p1 = t_ + 1.0, p2 = t_, p3 = t_ - 1.0, p4 = t_ - 2.0, p5 = t_ - 3.0;
+    const double l1 = p0, l2 = l1 * p1, l3 = l2 * p2, l4 = l3 * p3, l5 = l4 * p4;          // prod_(b < a) p_b
+    const double r4 = p5, r3 = r4 * p4, r2 = r3 * p3, r1 = r2 * p2, r0 = r1 * p1;          // prod_(b > a) p_b
+    w[0] = r0 * (-1.0 / 120.0);
+    w[1] = l1 * r1 * (1.0 / 24.0);
+    w[2] = l2 * r2 * (-1.0 / 12.0);
+    w[3] = l3 * r3 * (1.0 / 12.0);
+    w[4] = l4 * r4 * (-1.0 / 24.0);
+    w[5] = l5 * (1.0 / 120.0);
   };
-  double cx[4], cy[4];
+  double cx[6], cy[6];
   weights(wx, cx);
   weights(wy, cy);
-  const int i0c = i > 0 ? i - 1 : 0, j0c = j > 0 ? j - 1 : 0;               // (closed border cells never get here with ok)
-  const int base = (i0c <= n - 3 ? i0c : n - 3) * (n + 1) + (j0c <= n - 3 ? j0c : n - 3);
+  const int i0c = i > 2 ? i - 2 : 0, j0c = j > 2 ? j - 2 : 0;               // (closed border cells never get here with ok)
+  const int base = (i0c <= n - 5 ? i0c : n - 5) * (n + 1) + (j0c <= n - 5 ? j0c : n - 5);
   s0 = 0.0;
   s1 = 0.0;
-#pragma unroll 2                      // (eight loads in flight, not sixteen: 16 registers less at the kernel's tightest spot)
-  for (int p = 0; p < 4; ++p) {
+#pragma unroll 2                      // (twelve loads in flight, not thirty-six: registers at the kernel's tightest spot)
+  for (int p = 0; p < 6; ++p) {
     double ra = 0.0, rb = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 6; ++q) {
       const d2 r = roots[base + p * (n + 1) + q];
       ra = fma(cy[q], r.x, ra);
       rb = fma(cy[q], r.y, rb);
@@ -1061,7 +1070,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_refill_kernel(const void* __re
 // way.  Here a wave works through tiles in lock step:
 //   FAST PATH, straight-line code for the 64 pixels of a tile at once: counts in, air mask, gate + start value (gn_start),
 //     STEPS steps on the full tables, the evidence of convergence - STEPS = 2: the tolerance rule on the second step (the FULL
-//     model has converged to stop_tol); STEPS = 1 (DEXCT_GN_FLAG_ONE_STEP): the cell's tabulated kappa, see gn_start - the
+//     model has converged to stop_tol); STEPS = 1 (DEXCT_GN_FLAG_ONE_STEP): the cell's tabulated kappa, see kStartHeader - the
 //     acceptance radius, results out through LDS as whole 64-byte runs in the reference's order.
 //   STASH: a pixel the fast path does not finish - closed cell (walk from the reference's start value 1e-6 with all n_iters
 //     steps), no evidence yet (it continues where it is), result outside the radius (walk) - is put aside in LDS (96 entries
@@ -1080,7 +1089,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
                                                                int g_is_f64, long long n_pix, const double* __restrict__ ws,
                                                                int n_e, int n_iters, GnTiling tl,
                                                                const double* __restrict__ mask_max, double mask_frac,
-                                                               int flags, double stop_tol, double* __restrict__ out_a,     // flags: as gn_refill_kernel; bit 3: probe (STEPS = 1: every pixel of an open cell ends after its step)
+                                                               int flags, double stop_tol, double* __restrict__ out_a,     // flags: as gn_refill_kernel
                                                                unsigned long long* __restrict__ counters,
                                                                const double* __restrict__ start) {
   typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1104,7 +1113,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
   const bool has_mask = mask_max != nullptr;
   const double thresh = has_mask ? mask_frac * mask_max[0] : 0.0;
   const int in_stride = tl.transposed ? tl.rows : 1, out_stride = tl.transposed ? tl.channels : 0;
-  const bool exact_exit = (flags & 1) != 0, confirm_walk = (flags & 4) != 0, probe = (flags & 8) != 0;
+  const bool exact_exit = (flags & 1) != 0, confirm_walk = (flags & 4) != 0;
   const int batch = ((flags >> 8) & 0xFFF) > 0 ? ((flags >> 8) & 0xFFF) : 1;
   int q_next = 0, q_end = 0;
   bool exhausted = false;
@@ -1230,7 +1239,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
           const bool fixed1 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(s0) &&
                               __double_as_longlong(m1) == __double_as_longlong(s1);
           const double d1 = fmax(fabs(m0 - s0), fabs(m1 - s1)), size = fmax(fmax(fabs(m0), fabs(m1)), 1.0);
-          const bool conv1 = probe ? d1 < __builtin_huge_val() : kap * (d1 * d1) <= (0.25 * stop_tol) * size;      // (NaN, inf: no)
+          const bool conv1 = kap * (d1 * d1) <= (0.25 * stop_tol) * size;      // (NaN, inf: no)
           ended = fixed1 || conv1;
           f0 = fixed1 ? s0 : m0; f1 = fixed1 ? s1 : m1;
         } else {
@@ -1548,9 +1557,8 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
   if (pass == DEXCT_GN_PASS_SHORTCUT && (!options->start || options->iterations)) return DEXCT_EINVAL;
   const double* start = (pass == DEXCT_GN_PASS_SHORTCUT) ? options->start : nullptr;
   if (start && (reinterpret_cast<uintptr_t>(start) & 15u)) return DEXCT_EINVAL;   // its pairs are read with 16-byte loads
-  if (options && (options->flags & ~(DEXCT_GN_FLAG_FULL_LOOP | DEXCT_GN_FLAG_NATURAL_ORDER | DEXCT_GN_FLAG_ONE_STEP | DEXCT_GN_FLAG_PROBE)))
-    return DEXCT_EINVAL;
-  if (options && (options->flags & (DEXCT_GN_FLAG_ONE_STEP | DEXCT_GN_FLAG_PROBE)) && pass != DEXCT_GN_PASS_SHORTCUT) return DEXCT_EINVAL;
+  if (options && (options->flags & ~(DEXCT_GN_FLAG_FULL_LOOP | DEXCT_GN_FLAG_NATURAL_ORDER | DEXCT_GN_FLAG_ONE_STEP))) return DEXCT_EINVAL;
+  if (options && (options->flags & DEXCT_GN_FLAG_ONE_STEP) && pass != DEXCT_GN_PASS_SHORTCUT) return DEXCT_EINVAL;
   if (options && options->blocks_per_cu < 0) return DEXCT_EINVAL;
   hipStream_t st = as_stream(stream);
   double* ws = reinterpret_cast<double*>(workspace);
@@ -1622,10 +1630,9 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     if (pass == DEXCT_GN_PASS_COUNT)
       hipLaunchKernelGGL((gn_refill_kernel<true>), dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
                          (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, options->iterations);
-    else if (pass == DEXCT_GN_PASS_SHORTCUT && (oflags & (DEXCT_GN_FLAG_ONE_STEP | DEXCT_GN_FLAG_PROBE)))
+    else if (pass == DEXCT_GN_PASS_SHORTCUT && (oflags & DEXCT_GN_FLAG_ONE_STEP))
       hipLaunchKernelGGL(gn_shortcut_kernel<1>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
-                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags | ((oflags & DEXCT_GN_FLAG_PROBE) ? 8 : 0), tol,
-                         out_a, counters, start);
+                         (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, start);
     else if (pass == DEXCT_GN_PASS_SHORTCUT)
       hipLaunchKernelGGL(gn_shortcut_kernel<2>, dim3((unsigned)nb), block, 0, st, g1, g2, g_is_f64, (long long)n_pix,
                          (const double*)ws, n_energies, n_iters, tl, mask_max, mask_frac, kflags, tol, out_a, counters, start);

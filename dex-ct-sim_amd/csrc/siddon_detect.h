@@ -402,96 +402,6 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
     }
 }
 
-// EXPERIMENT (review item 3 of round 2; DEXCT_P16_MFMA=1): the exponent contraction sum_m mu[m][e] L_m of 256 rays x 16
-// energies on the matrix pipe.  v_mfma_f32_16x16x4_f32: A[i][k] = mu[k][e0 + i] (rows = energies, K = 3 materials + a zero),
-// B[k][j] = L_k of ray j of a 16-ray tile, D[i][j] = the exponent - bit for bit the k-ordered fmaf chain of the vector
-// form (cdna_hip_programming.md, FP32-input MFMA).  Lane (h = lane >> 4, j = lane & 15) then holds energies e0 + 4h + r
-// (r = 0..3) of ray j: v_exp_f32 and the weighted sums stay on the vector pipe, each lane summing ITS energies; the four
-// partial sums of a ray (one per lane group) are added by a second MFMA with a 0/1 selector as A (k-ordered: ((p0 + p1) +
-// p2) + p3), which leaves every lane with the total of its OWN ray.  The counts differ from the vector form in the last
-// bits (other summation order); path lengths do not.  Tiles: (g, rr) = the rays (lane 16 g + j, row rr) of a round.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int NM>
-__device__ __forceinline__ void detect_mfma(const float (&L)[4][NM], const float* __restrict__ mu,
-                                            const float* __restrict__ w, int n_e, int n_spectra, float (&res)[2][4]) {
-  static_assert(NM == 3, "K = 3 materials + one zero column");
-  const int lane = threadIdx.x & (kWave - 1), h = lane >> 4, j = lane & 15;
-  auto load_a = [&](int e0) {
-    const int e = e0 + j;
-    return (h < NM && e < n_e) ? mu[h * n_e + e] : 0.0f;
-  };
-  auto load_w = [&](int e0, f32x2 (&wp)[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = e0 + 4 * h + r;
-      const bool ok = e < n_e;                                       // padded energies: weight 0 (and mu 0: 2^0 = 1, times 0)
-      wp[r] = f32x2{ok ? w[e] : 0.0f, (ok && n_spectra > 1) ? w[n_e + e] : 0.0f};
-    }
-  };
-  const int nblk = (n_e + 15) >> 4;
-  float sel[2];                     // selector of the second MFMA: A_g[i][k] = [i >> 2 == g], for the two groups of a half
-  // two halves of 8 tiles (lane groups 2 half, 2 half + 1): 16 accumulators and 8 B operands at a time instead of 32 + 16
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    // ---- B operands: lane (h, j) of tile (g, rr) needs L_h of the ray held by lane 16 g + j
-    float B[8];
-#pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-      const int addr = 4 * (16 * (2 * half + gg) + j);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float x[NM];
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-          x[m] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(L[rr][m] * kLog2e)));
-        B[4 * gg + rr] = h == 0 ? x[0] : (h == 1 ? x[1] : x[2]);     // h == 3: any finite value (its A column is 0)
-      }
-      sel[gg] = (j >> 2) == 2 * half + gg ? 1.0f : 0.0f;
-    }
-    f32x2 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = f32x2{0.0f, 0.0f};
-    float a_cur = load_a(0);
-    f32x2 w_cur[4];
-    load_w(0, w_cur);
-#pragma unroll 1
-    for (int b = 0; b < nblk; ++b) {
-      float a_nxt = 0.0f;
-      f32x2 w_nxt[4] = {f32x2{0, 0}, f32x2{0, 0}, f32x2{0, 0}, f32x2{0, 0}};
-      if (b + 1 < nblk) {                                            // uniform: the next block's operands are in flight
-        a_nxt = load_a(16 * (b + 1));                                // while this block is summed
-        load_w(16 * (b + 1), w_nxt);
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const f32x4 D = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, B[t], f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float te = __builtin_amdgcn_exp2f(-D[r]);
-          acc[t] = __builtin_elementwise_fma(w_cur[r], f32x2{te, te}, acc[t]);
-        }
-      }
-      a_cur = a_nxt;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w_cur[r] = w_nxt[r];
-    }
-    // ---- add the four partial sums of every ray of this half: after the chain over its two groups, row block h of T holds
-    // tile (h, rr) if group h belongs to the half: lane (h, j) then has the total of its OWN ray
-    const bool mine = (h >> 1) == half;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        f32x4 T = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg)
-          T = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[gg], s == 0 ? acc[4 * gg + rr].x : acc[4 * gg + rr].y, T, 0, 0, 0);
-        res[s][rr] = mine ? T[0] : res[s][rr];
-      }
-  }
-}
-
 template <int NM>
 __device__ __forceinline__ void detect_store1(const float (&L)[NM], const ProjArgs& a, const float* __restrict__ mu,
                                               const float* __restrict__ w, const float* __restrict__ w2, size_t ray) {

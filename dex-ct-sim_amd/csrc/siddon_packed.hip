@@ -117,7 +117,7 @@ struct Sliced {
 // GROUPED: a material-group pass (ids = codes 0..3 of one group of three materials): raw accumulators (units of u) go to
 // acc_out[(mat_base + code) * n_rays + ray], no detection (dexct_siddon_project_grouped_packed).
 // STAGED: results leave through LDS as whole lines (see below); the host picks it whenever it applies.
-template <int NM, int MINW = 4, bool GROUPED = false, bool STAGED = false, bool MFMA = false>      // MINW: waves per SIMD the register allocation must allow; MFMA: detect_mfma (experiment)
+template <int NM, int MINW = 4, bool GROUPED = false, bool STAGED = false>      // MINW: waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
                                                     const float* __restrict__ w2) {
   static_assert(NM >= 2 && NM <= 4, "ids 0..3");
@@ -360,20 +360,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
               for (int m = 0; m < NM; ++m) a.pathlen[rays[rr] * NM + m] = L[rr][m];
             }
         }
-        if constexpr (MFMA) {
-          // the air shortcut of detect_store decides first (same test): waves that saw nothing but air take the vector form
-          bool lane_air = true;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            lane_air = lane_air && L[q][0] == L[0][0];
-#pragma unroll
-            for (int m = 1; m < NM; ++m) lane_air = lane_air && L[q][m] == 0.0f;
-          }
-          if (__ballot(!lane_air) == 0ull) detect_store<NM, 4, false>(L, a, mu, w, w2, rays, valid, bm, &air_cache, &res);
-          else detect_mfma<NM>(L, mu, w, a.n_energies, a.n_spectra, res);
-        } else {
-          detect_store<NM, 4, false>(L, a, mu, w, w2, rays, valid, bm, &air_cache, &res);
-        }
+        detect_store<NM, 4, false>(L, a, mu, w, w2, rays, valid, bm, &air_cache, &res);
       } else {
         detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm, &air_cache);
       }
@@ -555,10 +542,6 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
     hipLaunchKernelGGL((rows16_kernel<4, 3, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (n_materials == 4)
     hipLaunchKernelGGL((rows16_kernel<4, 3>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
-  else if (staged && getenv("DEXCT_P16_MFMA") && atoi(getenv("DEXCT_P16_MFMA")) == 1)        // experiment, see detect_mfma
-    hipLaunchKernelGGL((rows16_kernel<3, 4, false, true, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
-  else if (staged && getenv("DEXCT_P16_MFMA") && atoi(getenv("DEXCT_P16_MFMA")) == 3)
-    hipLaunchKernelGGL((rows16_kernel<3, 3, false, true, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (staged && minw == 4)
     hipLaunchKernelGGL((rows16_kernel<3, 4, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (staged && minw == 5)

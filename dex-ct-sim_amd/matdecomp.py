@@ -97,12 +97,13 @@ DEFAULT_STOP_TOL = _default_stop_tol()
 # that pair: the tolerance rule on the wandering pixels of such a pair was the only place where the default ever differed from
 # the exact count (profiles/r04_gn_noisy_public.log), and it saved 15 % there.  An explicit stop_tol > 0 is honoured.
 #
-# ONE STEP where the table vouches for it (the default since round 5; quadrature.attach_kappa, csrc/gn.hip gn_start).  From a start
-# value at distance e0 of the fixed point Newton's step leaves kappa e0^2, and the step's own length d1 measures e0.  The
-# calibration takes one step of the library's kernel from the interpolant at every cell's centre and compares with where the
-# reference's walk ends there: kappa per cell.  A pixel whose first step has kappa d1^2 <= stop_tol / 4 * size ends there - the
-# evidence the tolerance rule asks of two steps, from one; every other pixel takes the second step and the rule.  With 256 cells
-# per axis the interpolant is 2e-8 of |a| from the pixel's fixed point and one step lands at rounding level.
+# ONE STEP where the table vouches for it (the default since round 5; quadrature.newton_kappa, csrc/gn.hip kStartHeader).  From a
+# start value at distance e0 of the fixed point Newton's step leaves at most kappa e0^2 - kappa from the Hessian and the third
+# derivatives of the likelihood at the tabulated fixed points - and the step's own length d1 measures e0.  A pixel whose first
+# step has kappa d1^2 <= stop_tol / 4 * size ends there: a bound on the distance it still has to go, which is what the tolerance
+# rule extracts from two steps; every other pixel takes the second step and the rule.  The kernel's sextic interpolant over the
+# 256-cell grid is within 1e-10 of |a| of the pixel's fixed point, so the bound holds with three orders to spare and the step
+# lands at rounding level.
 #
 # Modes (``two_level=`` of the calls below; DEXCT_GN_TWO_LEVEL in the environment; DEFAULT_TWO_LEVEL):
 #   None / True / 'one'     the short cut, one step where kappa allows (one launch)
@@ -168,21 +169,14 @@ def _host_tables(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
 
 
-def _walk(lib, dev, i0_d, mus_d, n_e, g, cal_tol, probe_from=None):
+def _walk(lib, dev, i0_d, mus_d, n_e, g, cal_tol):
     """The reference's iteration (the library's own kernel, full tables, from 1e-6, counting steps) on counts g [n, 2]:
-    (steps until the tolerance rule fired | 255, where it ended).  ``probe_from`` (a start table): instead, ONE step from the
-    table's interpolant for every pixel in an open cell (DEXCT_GN_FLAG_PROBE): where it lands."""
+    (steps until the tolerance rule fired | 255, where it ended)."""
     g_d = to_dev(np.ascontiguousarray(g.T), torch.float64, dev)
     n_c = g_d.shape[1]
     a_c = torch.empty((n_c, 2), dtype=torch.float64, device=dev)
-    ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, 1), dtype=torch.uint8, device=dev)
-    if probe_from is not None:
-        t_d = to_dev(probe_from, torch.float64, dev)
-        opts = _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_SHORTCUT, None, t_d.data_ptr(), _native.GN_FLAG_PROBE)
-        _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(i0_d), ptr(mus_d), n_e, 1, 1, 254, 0, 0, None, 0.95,
-                                             ptr(a_c), opts, ptr(ws), stream_ptr()), 'dexct_gn_decompose (one-step probe)')
-        return a_c.cpu().numpy()
     k_c = torch.empty(n_c, dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.dexct_gn_workspace_bytes(n_e, 1), dtype=torch.uint8, device=dev)
     _native.check(lib.dexct_gn_decompose(ptr(g_d[0]), ptr(g_d[1]), 1, n_c, ptr(i0_d), ptr(mus_d), n_e, 1, 1, 254, 0, 0, None, 0.95,
                                          ptr(a_c), _native.gn_options(cal_tol, 0, 0, 1, _native.GN_PASS_COUNT, k_c.data_ptr()),
                                          ptr(ws), stream_ptr()), 'dexct_gn_decompose (gate calibration)')
@@ -203,14 +197,8 @@ def calibrate_gate(i0_h, mus_h, i0_d, mus_d, dev, cal_tol):
     n_e = i0_2.shape[1]
     steps, roots = _walk(lib, dev, i0_d, mus_d, n_e, pieces['corner_g'], cal_tol)
     start_h, share, stats = quadrature.assemble_start(pieces, steps, roots)
-    centres = quadrature.cell_centres(pieces)
-    c_steps, c_roots = _walk(lib, dev, i0_d, mus_d, n_e, centres, cal_tol)
-    start_h, share, n_bad = quadrature.validate_start(start_h, pieces, c_steps, c_roots)
-    # ... and ONE step of the kernel from the interpolant at every centre against where the walk ends there: the kappa table
-    # of the one-step acceptance (quadrature.attach_kappa)
-    probe = _walk(lib, dev, i0_d, mus_d, n_e, centres, cal_tol, probe_from=start_h)
-    start_h, one_share = quadrature.attach_kappa(start_h, pieces, c_roots, probe, cal_tol)
-    stats = dict(stats, grid=True, open_share=float(share), centres_failed=int(n_bad), one_step_share=float(one_share))
+    start_h, share, n_bad = quadrature.validate_start(start_h, pieces, *_walk(lib, dev, i0_d, mus_d, n_e, quadrature.cell_centres(pieces), cal_tol))
+    stats = dict(stats, grid=True, open_share=float(share), centres_failed=int(n_bad))
     return start_h, stats
 
 
@@ -271,7 +259,7 @@ def _gate_from_disk(path, i0_h, mus_h):
             n = quadrature.GATE_CELLS
             head = None if pieces is None else pieces['head'].copy()
             if head is not None:
-                head[10] = 1.0                # (the kappa table is attached)
+                head[10] = 1.0                # (the kappa table follows the cells)
             if (head is None or start_h.shape != (quadrature.START_HEADER + 2 * (n + 1) ** 2 + 3 * n * n,)
                     or not np.array_equal(start_h[:quadrature.START_HEADER], head)):
                 return None

@@ -183,10 +183,10 @@ def max_rel_error(mu, w, cols, w_red, L):
     return float(err.max())
 
 
-GATE_VERSION = 6           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
+GATE_VERSION = 7           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
 START_HEADER = 12          # doubles before the tables (csrc/gn.hip, gn_start)
-GATE_CELLS = 256           # cells per axis of the grid over (ln u0, u1 / u0): the Catmull-Rom interpolant of the fixed points is then ~2e-8 of |a|
-                           # from a pixel's own (128 cells: 3e-7) - close enough for ONE Newton step to land within the tolerance (attach_kappa)
+GATE_CELLS = 256           # cells per axis of the grid over (ln u0, u1 / u0): the kernel's 6 x 6 Lagrange interpolant of the fixed points is then
+                           # within 1e-10 of |a| of a pixel's own (128 cells: 7e-9; Catmull-Rom, round 4: 2e-6; tools/probes/gn_interp_cpu.py)
 GATE_U_MIN = 1.0e-4        # smallest u0 = ln(air_0 / g_0) / log_range of the grid: thinner rays walk from 1e-6 (a handful of steps)
 GATE_U_MAX = 0.75          # largest u0 with open cells: attenuation exp(-12), six counts per million.  Beyond, the long walk from 1e-6 is
                            # fragile - photon-starved counts inside a cell whose corners all arrive have been seen to end at another
@@ -284,9 +284,9 @@ def assemble_start(pieces, steps, roots):
     start value rests elsewhere on it, so there is nothing to tabulate.  A cell is open when all four corners count, at finite
     fixed points that vary smoothly over it and along the grid lines through its corners (mixed and axial second differences at
     most half the largest first difference: no boundary between two basins crosses or borders it); it needs the largest step count among its own corners and those of the eight cells around
-    it plus GATE_MARGIN (infinity if any of those cells is closed); its acceptance radius is GATE_RADIUS x the spread of its
-    corners' fixed points.  Returns the array, the share of open cells, and what the walk did on the corner grid (``stats``,
-    for pair_is_ill_posed)."""
+    it - and of the sixteen around those: the 5 x 5 cells whose corners the kernel interpolates over - plus GATE_MARGIN (infinity if any of those cells is closed); its acceptance radius is GATE_RADIUS x the spread of its
+    corners' fixed points; kappa (the one-step acceptance, newton_kappa) follows the cells.  Returns the array, the share of open
+    cells, and what the walk did on the corner grid (``stats``, for pair_is_ill_posed)."""
     n = int(pieces['head'][3])
     steps = np.asarray(steps).reshape(n + 1, n + 1).astype(np.float64)
     r = np.asarray(roots, dtype=np.float64).reshape(n + 1, n + 1, 2)
@@ -325,16 +325,26 @@ def assemble_start(pieces, steps, roots):
     cell_ok = good[:-1, :-1] & good[:-1, 1:] & good[1:, :-1] & good[1:, 1:] & (twist <= 0.5 * edges + 1e-12)
     k = np.max([steps[:-1, :-1], steps[:-1, 1:], steps[1:, :-1], steps[1:, 1:]], axis=0)
     k = np.where(cell_ok, k, np.inf)
-    pad = np.pad(k, 1, mode='edge')
-    need = np.max([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0) + GATE_MARGIN
-    # the kernel interpolates the fixed points over the 4 x 4 corners around a cell (Catmull-Rom): the cells on the border of
-    # the grid, which lack a ring of neighbours, are closed; so are the cells of photon-starved counts (GATE_U_MAX)
-    need[0, :] = need[-1, :] = need[:, 0] = need[:, -1] = np.inf
+    pad = np.pad(k, 2, mode='edge')
+    need = np.max([pad[2 + di:n + 2 + di, 2 + dj:n + 2 + dj] for di in (-2, -1, 0, 1, 2) for dj in (-2, -1, 0, 1, 2)], axis=0) + GATE_MARGIN
+    # the kernel interpolates the fixed points over the 6 x 6 corners around a cell (the corners of the 5 x 5 cells above): the
+    # cells within two of the border of the grid, which lack the rings of neighbours, are closed; so are the cells of
+    # photon-starved counts (GATE_U_MAX)
+    need[:2, :] = need[-2:, :] = need[:, :2] = need[:, -2:] = np.inf
     x_hi = pieces['head'][4] + (np.arange(n) + 1.0) / pieces['head'][5]            # ln u0 at the upper edge of each cell row
     need[x_hi > np.log(GATE_U_MAX), :] = np.inf
     radius = np.where(cell_ok, GATE_RADIUS * spread + 1e-9, 0.0)
+    # kappa of the one-step acceptance: KAPPA_SAFETY x the largest value at the corners of the cell and of the eight around it
+    kc = np.where(good, newton_kappa(pieces, r.reshape(-1, 2)).reshape(n + 1, n + 1), np.inf)
+    kcell = np.maximum.reduce([kc[:-1, :-1], kc[:-1, 1:], kc[1:, :-1], kc[1:, 1:]])
+    padk = np.pad(kcell, 1, mode='edge')
+    kappa = KAPPA_SAFETY * np.max([padk[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
+    kappa = np.where(np.isfinite(need), kappa, np.inf)
+    stats['one_step_share'] = float(np.isfinite(kappa).mean())
     r = np.where(good[:, :, None], r, 0.0)
-    out = np.concatenate([pieces['head'], r.ravel(), np.stack([need, radius], axis=-1).ravel()])          # pairs: (a0, a1), (need, radius)
+    head = pieces['head'].copy()
+    head[10] = 1.0                        # the kappa table follows the cells
+    out = np.concatenate([head, r.ravel(), np.stack([need, radius], axis=-1).ravel(), kappa.ravel()])     # pairs (a0, a1), pairs (need, radius), kappa
     return out, float(np.isfinite(need).mean()), stats
 
 
@@ -379,63 +389,68 @@ def cell_centres(pieces):
     return np.stack([h[0] * np.exp(-u0.ravel() / h[2]), h[1] * np.exp(-u1.ravel() / h[2])], axis=1)
 
 
+def lagrange6(t):
+    """Weights of the 6-point Lagrange interpolation on the nodes -2 .. 3 at t (what csrc/gn.hip gn_start forms per axis)."""
+    nodes = np.arange(-2.0, 4.0)
+    w = np.ones(6)
+    for a in range(6):
+        for b in range(6):
+            if a != b:
+                w[a] *= (t - nodes[b]) / (nodes[a] - nodes[b])
+    return w
+
+
 def centre_interpolant(start, n):
-    """The Catmull-Rom interpolant of the tabulated fixed points at the centre of every interior cell [n, n, 2] (what the kernel
-    starts a pixel from there; border cells: 0)."""
+    """The 6 x 6 Lagrange interpolant of the tabulated fixed points at the centre of every cell that has its two rings of
+    neighbours [n, n, 2] (what the kernel starts a pixel from there; the others: 0)."""
     r = np.asarray(start)[START_HEADER:START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)
-    w = np.array([-1.0, 9.0, 9.0, -1.0]) / 16.0                      # Catmull-Rom weights at t = 1/2
+    w = lagrange6(0.5)                                               # [3, -25, 150, 150, -25, 3] / 256
     s = np.zeros((n, n, 2))
-    for p in range(4):
-        for q_ in range(4):
-            s[1:-1, 1:-1] += w[p] * w[q_] * r[p:n - 2 + p, q_:n - 2 + q_]     # corner (i + p - 1, j + q - 1) of cell (i, j)
+    for p in range(6):
+        for q_ in range(6):
+            s[2:-2, 2:-2] += w[p] * w[q_] * r[p:n - 4 + p, q_:n - 4 + q_]     # corner (i + p - 2, j + q - 2) of cell (i, j)
     return s
 
 
-KAPPA_SAFETY = 4.0         # on the largest e1 / d1^2 seen at the centres of a cell and of the eight around it
+KAPPA_SAFETY = 2.5         # on the largest kappa at the corners of a cell and of the eight around it: covers its variation across the
+                           # cells (a few per cent) and the factor (1 - kappa e0)^-2 <= 1.25 between e0^2 and the measured d1^2
 
 
-def attach_kappa(start, pieces, centre_roots, probe, stop_tol=1.0e-12):
-    """The ONE-STEP table of the short cut (csrc/gn.hip gn_start; include/dexct.h DEXCT_GN_FLAG_ONE_STEP).  ``centre_roots`` [n^2, 2]:
-    where the reference's walk ends on the counts at the cell centres (validate_start's input); ``probe`` [n^2, 2]: where the
-    library's kernel lands after ONE step from the interpolant there (DEXCT_GN_FLAG_PROBE).  Newton's step from a start value at
-    distance e0 of the fixed point leaves e1 <= kappa e0^2, and its own length d1 measures e0; per centre kappa_c = e1 / d1^2
-    with e1 = |probe - root| (not below the rounding floor, 8 eps of the size: the root itself is only known to that), per cell
-    KAPPA_SAFETY x the largest kappa_c among the cell and the eight around it - infinity where any of them is closed, where the
-    probe did not come back finite, or where the step at the centre did not itself land within stop_tol / 16 of the root.  The
-    interpolation error is largest at the centre of a cell, so a pixel anywhere in it has d1 <= the centre's or is turned away
-    by the kernel's test kappa d1^2 <= stop_tol / 4 * size.  Returns the array with kappa appended (header [10] = 1) and the
-    share of cells with a finite kappa."""
-    h = pieces['head']
-    n = int(h[3])
-    out = np.array(start, dtype=np.float64, copy=True)
-    cells = out[START_HEADER + 2 * (n + 1) ** 2:START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n].reshape(n, n, 2)
-    s = centre_interpolant(out, n)
-    rc = np.asarray(centre_roots, dtype=np.float64).reshape(n, n, 2)
-    pr = np.asarray(probe, dtype=np.float64).reshape(n, n, 2)
+def newton_kappa(pieces, roots):
+    """The contraction constant of Newton's iteration on the Poisson likelihood F(a) = sum_k nu_k(a) - g_k ln nu_k(a) at the fixed
+    points ``roots`` [n, 2] of the counts they reproduce (g_k = nu_k there; csrc/gn.hip kStartHeader, DEXCT_GN_FLAG_ONE_STEP): a step
+    from a0 lands at a1 with a1 - a* = 1/2 H^-1 D3F [e0, e0], hence |e1| <= kappa |e0|^2 in the max norm with
+    kappa = 1/2 max_i sum_j |H^-1_ij| sum_pq |D3F_jpq|.  With G_km = sum_e i0_k mu_m att, S_kmp = sum_e i0_k mu_m mu_p att:
+    H_mp = sum_k G_km G_kp / nu_k and D3F_mpq = sum_k [2 G_km G_kp G_kq / nu_k^2 - (S_kpq G_km + S_kmq G_kp + S_kmp G_kq) / nu_k]
+    (the terms with g_k / nu_k - 1 vanish at a root that reproduces its counts).  inf where H is singular or anything overflows."""
     with np.errstate(all='ignore'):
-        size = np.maximum(np.abs(rc).max(axis=2), 1.0)
-        d1 = np.abs(pr - s).max(axis=2)
-        e1 = np.maximum(np.abs(pr - rc).max(axis=2), 8.0 * np.finfo(np.float64).eps * size)
-        kc = e1 / np.maximum(d1, 1.0e-300) ** 2
-        fine = np.isfinite(cells[:, :, 0]) & np.isfinite(kc) & np.all(np.isfinite(pr), axis=2) & (e1 <= stop_tol / 16.0 * size)
-    kc = np.where(fine, kc, np.inf)
-    pad = np.pad(kc, 1, mode='constant', constant_values=np.inf)
-    kappa = KAPPA_SAFETY * np.max([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
-    kappa = np.where(np.isfinite(cells[:, :, 0]), kappa, np.inf)
-    out[10] = 1.0
-    return np.concatenate([out, kappa.ravel()]), float(np.isfinite(kappa).mean())
+        a = np.where(np.isfinite(roots), roots, 0.0)
+        att = np.exp(-(a @ pieces['mus']))                                               # [n, e]
+        nu = att @ pieces['i0'].T                                                        # [n, k]
+        G = np.einsum('ke,me,ne->nkm', pieces['i0'], pieces['mus'], att)
+        S = np.einsum('ke,me,pe,ne->nkmp', pieces['i0'], pieces['mus'], pieces['mus'], att)
+        H = np.einsum('nk,nkm,nkp->nmp', 1.0 / nu, G, G)
+        T = (2.0 * np.einsum('nk,nkm,nkp,nkq->nmpq', 1.0 / nu ** 2, G, G, G)
+             - np.einsum('nk,nkpq,nkm->nmpq', 1.0 / nu, S, G) - np.einsum('nk,nkmq,nkp->nmpq', 1.0 / nu, S, G)
+             - np.einsum('nk,nkmp,nkq->nmpq', 1.0 / nu, S, G))
+        det = H[:, 0, 0] * H[:, 1, 1] - H[:, 0, 1] * H[:, 1, 0]
+        Hinv = np.stack([np.stack([H[:, 1, 1], -H[:, 0, 1]], -1), np.stack([-H[:, 1, 0], H[:, 0, 0]], -1)], -2) / det[:, None, None]
+        kap = 0.5 * np.einsum('nij,nj->ni', np.abs(Hinv), np.abs(T).sum(axis=(2, 3))).max(axis=1)
+    return np.where(np.isfinite(kap) & np.all(np.isfinite(roots), axis=1), kap, np.inf)
 
 
 def validate_start(start, pieces, steps, roots):
     """The table checked against the thing it stands for, at one interior point per cell: the reference's walk run on the counts
     at the cell CENTRES (``steps``, ``roots`` as in assemble_start, n^2 of them).  An open cell stays open only if that walk
     ended by the rule within the cell's step budget (need - 1) at a fixed point that reproduces the centre's counts and lies
-    within the cell's acceptance radius of the Catmull-Rom interpolant the kernel would start from; a cell that fails is closed
-    together with the eight around it.  Returns the array and the share of open cells."""
+    within the cell's acceptance radius of the interpolant the kernel would start from; a cell that fails is closed
+    together with the two rings of cells around it (every cell whose interpolation uses its corners).  Returns the array and the share of open cells."""
     h = pieces['head']
     n = int(h[3])
     out = np.array(start, dtype=np.float64, copy=True)
-    cells = out[START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)
+    c0 = START_HEADER + 2 * (n + 1) ** 2
+    cells = out[c0:c0 + 2 * n * n].reshape(n, n, 2)
+    kappa = out[c0 + 2 * n * n:].reshape(n, n)
     steps = np.asarray(steps, dtype=np.float64).reshape(n, n)
     rc = np.asarray(roots, dtype=np.float64).reshape(n, n, 2)
     s = centre_interpolant(out, n)
@@ -446,7 +461,8 @@ def validate_start(start, pieces, steps, roots):
         fine = ((steps < 255) & np.all(np.isfinite(rc), axis=2) & (resid.reshape(n, n) <= 1.0e-8) & (cond.reshape(n, n) <= GATE_MAX_COND)
                 & (off <= cells[:, :, 1]) & (steps <= cells[:, :, 0] - 1.0))
     bad = np.isfinite(cells[:, :, 0]) & ~fine
-    pad = np.pad(bad, 1, mode='constant')
-    near = np.any([pad[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
+    pad = np.pad(bad, 2, mode='constant')
+    near = np.any([pad[2 + di:n + 2 + di, 2 + dj:n + 2 + dj] for di in (-2, -1, 0, 1, 2) for dj in (-2, -1, 0, 1, 2)], axis=0)
     cells[near, 0] = np.inf
+    kappa[near] = np.inf
     return out, float(np.isfinite(cells[:, :, 0]).mean()), int(bad.sum())

@@ -293,7 +293,8 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
  *                   results, iterations[q] (q = the pixel's index in the RESULT order, n_pix bytes) receives the number of steps
  *                   after which the tolerance rule ended the pixel, or 255 when it ended any other way.
  *                 pass = DEXCT_GN_PASS_SHORTCUT, start != NULL, iterations = NULL (what the host runs by default): a pixel in a
- *                   cell with n_iters >= need starts from the Catmull-Rom interpolant of the corners' fixed points and ends by
+ *                   cell with n_iters >= need starts from the 6 x 6 Lagrange interpolant of the corners' fixed points (the cell's
+ *                   corners and two rings around them: cells within two of the grid's border must be closed) and ends by
  *                   the tolerance rule of the FULL tables (two steps; or at a repeated state), accepted only within the radius;
  *                   if any of this fails - and for every pixel in a closed cell - the pixel is solved from the reference's
  *                   start value with all n_iters steps, as a plain call does.  The call therefore returns, per pixel, either
@@ -307,7 +308,8 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
  *               the pair (need, radius): need = the number of steps a pixel whose counts fall in the cell must be allowed for
  *               the reference's walk to be known to end by the tolerance rule (infinity: closed), radius = how far from the
  *               interpolated fixed point a result is accepted; then (optional, see [10] and DEXCT_GN_FLAG_ONE_STEP) per cell
- *               kappa: e1 <= kappa d1^2 for a Newton step of length d1 from the interpolant (infinity: always two steps).
+ *               kappa: a Newton step of length d1 from the interpolant lands within kappa d1^2 of the fixed point (infinity:
+ *               always two steps).
  *               Both passes need stop_tol > 0 (after defaults), n_bins == 1, precision 0, n_iters <= 254, kernel != 2;
  *               DEXCT_EINVAL otherwise.  pass = 0 (default): one launch from 1e-6; iterations and start must be NULL or are
  *               not used.  (ABI 4 also had a two-launch "coarse" form of the short cut - a launch on a short quadrature of the
@@ -317,9 +319,9 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
  *               their natural order instead of thick tiles first (results do not depend on it).
  *               DEXCT_GN_FLAG_ONE_STEP (DEXCT_GN_PASS_SHORTCUT only; `start` must end with the kappa array, below): a pixel whose
  *               FIRST step from the interpolated fixed point has length d1 with kappa d1^2 <= stop_tol / 4 * max(|a|, 1) ends
- *               there - kappa, tabulated per cell by the calibration, bounds what Newton's step leaves of a distance d1 - ;
- *               every other pixel goes on to its second step and the tolerance rule.  DEXCT_GN_FLAG_PROBE (calibration only):
- *               every pixel of an open cell takes exactly one step from the interpolant and returns where it lands.
+ *               there - kappa bounds what Newton's step leaves of a distance d1 (from the Hessian and the third derivatives of
+ *               the likelihood at the tabulated fixed points) - ; every other pixel goes on to its second step and the
+ *               tolerance rule.
  *   blocks_per_cu   > 0: workgroups per CU of the queue kernels (0: what is resident; results do not depend on it). */
 #define DEXCT_GN_DEFAULT_STOP_TOL 1e-12
 #define DEXCT_GN_PASS_COUNT 1
@@ -327,7 +329,6 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
 #define DEXCT_GN_FLAG_FULL_LOOP 1
 #define DEXCT_GN_FLAG_NATURAL_ORDER 2
 #define DEXCT_GN_FLAG_ONE_STEP 4
-#define DEXCT_GN_FLAG_PROBE 8
 typedef struct dexct_gn_options {
   double stop_tol;
   int32_t out_rows, out_channels;

@@ -1001,7 +1001,8 @@ def test_sampled_audit_of_the_short_cut(hip, golden, recwarn):
     gate = md._device_tables(i0, mus, dev, True)[2]
     healthy = gate['start'].clone()
     n = q.GATE_CELLS
-    cells = gate['start'][q.START_HEADER + 2 * (n + 1) ** 2:].view(n, n, 2)
+    c0 = q.START_HEADER + 2 * (n + 1) ** 2
+    cells = gate['start'][c0:c0 + 2 * n * n].view(n, n, 2)
     cells[:, :, 0] = torch.where(torch.isfinite(cells[:, :, 0]), torch.full_like(cells[:, :, 0], 3.0), cells[:, :, 0])
     try:
         exact = md.gn_device(g[0], g[1], i0, mus, 5, 'f64', kernel=1, stop_tol=0.0)

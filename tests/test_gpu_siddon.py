@@ -1024,25 +1024,6 @@ def test_integration_md_get_sino_stub_runs(hip):
     assert np.array_equal(raw, raw0) and np.allclose(log, log0, rtol=0, atol=1e-6)
 
 
-def test_mfma_detection_experiment(hip, monkeypatch):
-    """The opt-in matrix-pipe form of the detection (DEXCT_P16_MFMA=1, profiles/r03_kernels.md: measured slower, kept as the
-    record): path lengths bit-identical, counts and log sinogram within float32 rounding of the vector form (its sums run
-    in another order); 134-bin dual spectrum (padded to 144), a 7-bin single spectrum, air-only waves, idle lanes."""
-    from dex_ct_sim_amd import synthetic
-    for n_rows, n_ch, sp in ((512, 9, spectra()), (256, 21, spectra()[:1]), (200, 5, [synthetic.uniform_grid_spectrum(7)])):
-        ct, ph = small_scan(n=40, nz=-(-n_rows // 16) * 16, n_views=4, n_channels=n_ch, n_rows=n_rows)
-        pj = projector(ct, ph, kernel=7)
-        _, mu_d, w_d, air = pj.upload_tables(sp)
-        monkeypatch.delenv('DEXCT_P16_MFMA', raising=False)
-        c0, p0, l0 = pj.project_tables(mu_d, w_d, layout=None, air=air, want_pathlen=True)
-        monkeypatch.setenv('DEXCT_P16_MFMA', '1')
-        c1, p1, l1 = pj.project_tables(mu_d, w_d, layout=None, air=air, want_pathlen=True)
-        monkeypatch.delenv('DEXCT_P16_MFMA')
-        assert torch.equal(p1, p0)
-        assert float(((c1 - c0).abs() / c0).max()) < 3e-6
-        assert torch.allclose(l1, l0, rtol=0, atol=5e-6)
-
-
 @pytest.mark.parametrize('kind', ['single_row', 'stacked_256', 'rows_64', 'cone'])
 def test_reduced_quadrature_on_the_device(hip, kind, monkeypatch):
     """quadrature='reduced' (opt-in; dex-ct-sim_amd/quadrature.py): the same kernels on a shorter energy table.  Against the

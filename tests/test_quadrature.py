@@ -120,17 +120,23 @@ def test_gate_grid_and_start_array():
     start, share, stats = q.assemble_start(p, steps, roots)
     assert stats['walk_nonfinite_share'] == 0.0 and 0.0 < stats['walk_not_by_rule_share'] < 1e-3 and not q.pair_is_ill_posed(stats)
     assert np.allclose(start[8:10], np.log(start[0:2]), rtol=0, atol=0)          # ln of the open-beam signals, for the kernel's logarithm
-    assert start.size == q.START_HEADER + 2 * (n + 1) ** 2 + 2 * n * n
+    assert start.size == q.START_HEADER + 2 * (n + 1) ** 2 + 3 * n * n and start[10] == 1.0
     r0 = start[q.START_HEADER:q.START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)[:, :, 0]          # pairs (a0, a1)
-    cells = start[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)                                        # pairs (need, radius)
+    c0 = q.START_HEADER + 2 * (n + 1) ** 2
+    cells = start[c0:c0 + 2 * n * n].reshape(n, n, 2)                                                         # pairs (need, radius)
+    kappa = start[c0 + 2 * n * n:].reshape(n, n)                                                              # then kappa per cell
     need, radius = cells[:, :, 0], cells[:, :, 1]
     ok = np.ones((n + 1) ** 2, bool)
     ok[[30 * (n + 1) + 30, 45 * (n + 1) + 20, 70 * (n + 1) + 60]] = False
     assert np.array_equal(r0.ravel()[ok], roots[ok, 0]) and r0[30, 30] == 0.0 and r0[70, 60] == 0.0         # (corners that do not count: zeroed)
-    assert need[1, 1] == 17 + q.GATE_MARGIN and np.isinf(need[0, 5]) and np.isinf(need[7, n - 1]) and np.all(need[3:7, 5:9] == 30 + q.GATE_MARGIN) and need[2, 5] == need[7, 5] == 17 + q.GATE_MARGIN
+    # (the kernel interpolates over the 6 x 6 corners around a cell: a cell answers for the 5 x 5 cells around it, and the cells
+    # within two of the border are closed)
+    assert need[12, 30] == 17 + q.GATE_MARGIN and np.isinf(need[1, 5]) and np.isfinite(need[2, 20]) and np.isinf(need[7, n - 2])
+    assert np.all(need[2:8, 4:10] == 30 + q.GATE_MARGIN) and need[8, 5] == need[5, 10] == 17 + q.GATE_MARGIN
     for ci, cj in ((30, 30), (45, 20), (70, 60)):
-        assert np.all(np.isinf(need[ci - 2:ci + 2, cj - 2:cj + 2])) and np.isfinite(need[ci - 3, cj - 3]) and np.isfinite(need[ci + 2, cj])
+        assert np.all(np.isinf(need[ci - 3:ci + 3, cj - 3:cj + 3])) and np.isfinite(need[ci - 4, cj - 4]) and np.isfinite(need[ci + 3, cj])
     assert 0.93 < share < 1.0
+    assert np.array_equal(np.isfinite(kappa), np.isfinite(need)) and stats['one_step_share'] == share
     # the acceptance radius: a twentieth of the spread of the corners' fixed points
     c = roots.reshape(n + 1, n + 1, 2)
     want = max(np.abs(c[11, 11] - c[10, 10]).max(), np.abs(c[11, 10] - c[10, 11]).max(), np.abs(c[11, 10] - c[10, 10]).max(),
@@ -140,7 +146,8 @@ def test_gate_grid_and_start_array():
 
 def test_gate_table_is_validated_at_the_cell_centres():
     """quadrature.validate_start: the reference's walk at the centre of every cell must end, within the cell's step budget,
-    next to the Catmull-Rom interpolant the kernel would start from; a cell where it does not is closed with its neighbours."""
+    next to the interpolant the kernel would start from (6 x 6 Lagrange); a cell where it does not is closed with the two rings of
+    cells around it (those whose interpolation uses its corners)."""
     _, i0, mus = newton_tables()
     p = q.newton_start_grid(i0, mus)
     n = int(p['head'][3])
@@ -167,10 +174,12 @@ def test_gate_table_is_validated_at_the_cell_centres():
         out, share_bad, n_bad = q.validate_start(start, p, late.ravel(), moved.reshape(-1, 2))
     finally:
         q.cell_centres = orig
-    need = out[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)[:, :, 0]
+    c0 = q.START_HEADER + 2 * (n + 1) ** 2
+    need, kappa = out[c0:c0 + 2 * n * n].reshape(n, n, 2)[:, :, 0], out[c0 + 2 * n * n:].reshape(n, n)
     assert n_bad == 2 and share_bad < share
     for ci, cj in ((40, 50), (60, 70)):
-        assert np.all(np.isinf(need[ci - 1:ci + 2, cj - 1:cj + 2])) and np.isfinite(need[ci - 2, cj]) and np.isfinite(need[ci, cj + 2])
+        assert np.all(np.isinf(need[ci - 2:ci + 3, cj - 2:cj + 3])) and np.isfinite(need[ci - 3, cj]) and np.isfinite(need[ci, cj + 3])
+        assert np.all(np.isinf(kappa[ci - 2:ci + 3, cj - 2:cj + 3])) and np.isfinite(kappa[ci, cj + 3])
     # cell_centres itself: the counts at (x_i + 1/2, t_j + 1/2)
     g = q.cell_centres(p).reshape(n, n, 2)
     u = np.log(h[:2] / g[7, 9]) * h[2]
@@ -198,32 +207,43 @@ def test_isolated_roots_are_told_from_families_of_them():
         assert not np.isfinite(q._counts_and_condition(clipped, far, np.ones((1, 2)))[1][0]) or q._counts_and_condition(clipped, far, np.ones((1, 2)))[1][0] > 1e12
 
 
-def test_kappa_table_of_the_one_step_acceptance():
-    """quadrature.attach_kappa: per centre e1 / d1^2 (e1 = |probe - root|, not below 8 eps of the size; d1 = |probe - interpolant|),
-    per cell KAPPA_SAFETY x the largest among the cell and the eight around it; infinity in closed cells, around a centre whose
-    probe is not finite and around one whose single step does not land within stop_tol / 16; header [10] = 1, kappa appended."""
+def test_kappa_bounds_what_a_newton_step_leaves():
+    """quadrature.newton_kappa: |a1 - a*| <= kappa |a0 - a*|^2 for one Newton step on the Poisson likelihood from a0 next to a root
+    a* that reproduces its counts - checked by taking the step in NumPy (the restatement of the reference, one iteration from a
+    given start) in many directions; and the bound is not idle: the worst direction reaches a good part of it."""
+    from oracle import gn_oracle
     _, i0, mus = newton_tables()
     p = q.newton_start_grid(i0, mus)
-    n = int(p['head'][3])
-    ii, jj = np.meshgrid(np.arange(n + 1.0) * 128.0 / n, np.arange(n + 1.0) * 128.0 / n, indexing='ij')
-    roots = np.stack([0.15 * ii + 0.005 * ii * jj / 4, 0.1 * jj - 0.025 * ii], -1).reshape(-1, 2)
-    p = dict(p, corner_g=np.exp(-(roots @ p['mus'])) @ p['i0'].T)
-    start, _, _ = q.assemble_start(p, np.full((n + 1) ** 2, 17), roots)
-    cells = start[q.START_HEADER + 2 * (n + 1) ** 2:].reshape(n, n, 2)
-    s = q.centre_interpolant(start, n)
-    probe = s + 1.0e-7                                                   # the step from the interpolant: d1 = 1e-7
-    size = np.maximum(np.abs(probe).max(-1), 1.0)
-    rc = probe + 1.0e-14 * size[:, :, None]                              # ... lands 1e-14 of the size from the root
-    rc[40, 40] = probe[40, 40] + 1.0e-12 * size[40, 40]                  # one centre where the step leaves too much (> stop_tol / 16)
-    probe[80, 80] = np.nan
-    out, share = q.attach_kappa(start, p, rc.reshape(-1, 2), probe.reshape(-1, 2), 1e-12)
-    assert out.size == start.size + n * n and out[10] == 1.0 and np.array_equal(out[:10], start[:10])
-    assert np.array_equal(out[q.START_HEADER:start.size], start[q.START_HEADER:])
-    kappa = out[start.size:].reshape(n, n)
-    open_ = np.isfinite(cells[:, :, 0])
-    assert np.all(np.isinf(kappa[~open_])) and 0.3 < share < open_.mean() + 1e-12
-    i, j = 60, 50
-    assert open_[i - 1:i + 2, j - 1:j + 2].all()
-    want = q.KAPPA_SAFETY * np.max(1.0e-14 * size[i - 1:i + 2, j - 1:j + 2] / 1.0e-14)
-    assert np.isclose(kappa[i, j], want, rtol=3e-2)                     # (1e-14 of the size is a dozen ulps: quantised)
-    assert np.all(np.isinf(kappa[39:42, 39:42])) and np.all(np.isinf(kappa[79:82, 79:82])) and np.isfinite(kappa[43, 43])
+    rng = np.random.default_rng(4)
+    roots = np.stack([rng.uniform(0.5, 40.0, 300), rng.uniform(-0.2, 6.0, 300)], 1)
+    g = np.exp(-(roots @ p['mus'])) @ p['i0'].T
+    kap = q.newton_kappa(p, roots)
+    assert np.all(np.isfinite(kap)) and 1.0 < np.median(kap * np.abs(roots).max(1)) < 1e5
+    # one Newton step from a* + e0 (gn_oracle's iteration is matdecomp.py:116-125; its start value is a module constant)
+    worst = 0.0
+    for _ in range(8):
+        e0 = rng.standard_normal((300, 2))
+        e0 *= (1e-4 * np.abs(roots).max(1) / np.abs(e0).max(1))[:, None]           # |e0| = 1e-4 of the size: e1 ~ kappa 1e-8 >> rounding
+        a1 = np.empty_like(roots)
+        for k in range(300):
+            a1[k] = _one_step(p['i0'], p['mus'], g[k], roots[k] + e0[k])
+        e1 = np.abs(a1 - roots).max(1)
+        ratio = e1 / (kap * np.abs(e0).max(1) ** 2)
+        assert ratio.max() <= 1.0 + 1e-3, ratio.max()
+        worst = max(worst, ratio.max())
+    assert worst > 0.02                                                    # the bound is within two orders of what directions reach
+    assert np.isinf(q.newton_kappa(p, np.array([[np.nan, 1.0]]))[0])
+    same = dict(p, mus=np.stack([p['mus'][0], 2.0 * p['mus'][0]]))         # parallel attenuation vectors: singular Hessian
+    assert not np.isfinite(q.newton_kappa(same, roots[:5])).any() or q.newton_kappa(same, roots[:5]).min() > 1e10
+
+
+def _one_step(i0, mus, g, a):
+    """One iteration of matdecomp.py:116-125 from the state a (NumPy, float64)."""
+    att = np.exp(np.clip(-(a @ mus), -700, 700))
+    nu = i0 @ att
+    G = np.einsum('ke,me,e->km', i0, mus, att)
+    Hs = np.einsum('ke,me,pe,e->kmp', i0, mus, mus, att)
+    c, qq = g / nu - 1.0, g / nu ** 2
+    dF = -(c[:, None] * -G).sum(0)
+    H = -(c[:, None, None] * Hs - qq[:, None, None] * G[:, :, None] * G[:, None, :]).sum(0)
+    return a - np.linalg.solve(H, dF)

@@ -1,6 +1,7 @@
-"""Kernel times on one MI355X for the per-GPU share of every GPU configuration BASELINE.json lists
-(configs[1..4]); bench.py itself times configs[2].  Rows = Nz (stacked fan) as in bench.py, and the reference's
-single-row form next to it.  Prints one markdown table row per line."""
+"""Kernel times on one MI355X for the per-GPU share of every configuration BASELINE.json lists (configs[0..4]); bench.py
+itself times configs[2].  Rows = Nz (stacked fan) as in bench.py, and the reference's single-row form next to it; the Newton
+decomposition in its four modes (default: the short cut with one step where the table vouches for it; two steps; every pixel
+walked from 1e-6 in one launch; the reference's fixed count).  Prints one markdown table row per line."""
 import os
 import sys
 
@@ -28,17 +29,20 @@ def timed(fn, reps=3):
 
 CONFIGS = [
     # name, n, total views, channels, GPUs sharing the views, spectra, decomposition
+    ('configs[0] input/params.txt geometry: 512^2 slice, 1200 x 800, 140/80 kVp + GN', 512, 1200, 800, 1, [140, 80], True),
     ('configs[1] 256^3, 360 x 512, 120 kVp, forward only', 256, 360, 512, 1, [120], False),
     ('configs[2] 512^3, 1000 x 800, 140/80 kVp + GN', 512, 1000, 800, 1, [140, 80], True),
     ('configs[3] 512^3, 2000 x 1024, 140/80 kVp + GN, 1/8 of the views', 512, 2000, 1024, 8, [140, 80], True),
     ('configs[4] 1024^3, 128 bins, 2000 x 1024, forward only, 1/8 of the views', 1024, 2000, 1024, 8, ['grid128'], False),
 ]
-print('| configuration (per-GPU share) | rows | rays | projection ms | rays/s | ray-energy integrals/s | Newton ms (50 it) |')
+GN_MODES = [('default', {}), ('two steps', dict(two_level='start')), ('single launch', dict(two_level=False)), ('exact', dict(stop_tol=0.0))]
+print('| configuration (per-GPU share) | rows | rays | projection ms | rays/s | ray-energy integrals/s | Newton ms, 50 it: '
+      + ' / '.join(m for m, _ in GN_MODES) + ' (full-table steps per unmasked pixel) |')
 print('|---|---|---|---|---|---|---|')
 for name, n, views, chans, gpus, kvs, gn in CONFIGS:
     specs = [synthetic.uniform_grid_spectrum(128) if kv == 'grid128' else synthetic.kramers_spectrum(kv) for kv in kvs]
     ph = synthetic.make_phantom(n, n, extent=51.2, seed=1234)
-    for rows in (n, 1):
+    for rows in ((1,) if name.startswith('configs[0]') else (n, 1)):
         if rows == 1:
             ph.z_index = n // 2
         ct = dx.FanBeamGeometry(N_channels=chans, N_proj=views, gamma_fan=0.8230337, SID=60.0, SDD=100.0, eid=True,
@@ -53,8 +57,14 @@ for name, n, views, chans, gpus, kvs, gn in CONFIGS:
         if gn:
             _, i0, mus = md.decomposition_tables(ct, specs[0], specs[1])
             gmax = out[0].max().double()
-            a = torch.empty(tuple(out[0].shape) + (2,), dtype=torch.float64, device=out.device)
-            gn_ms = '%.1f' % timed(lambda: md.gn_device(out[0], out[1], i0, mus, 50, 'f64', out=a, mask_max=gmax), reps=2)
+            a = torch.empty(out[0].numel() * 2, dtype=torch.float64, device=out.device)
+            rc = (rows, chans) if pj.native_layout == 1 else None          # [view][channel][row] in, the reference's order out
+            live = float((out[0] < 0.95 * gmax).sum())
+            parts = []
+            for _, kw in GN_MODES:
+                t = timed(lambda: md.gn_device(out[0], out[1], i0, mus, 50, 'f64', out=a, mask_max=gmax, out_rc=rc, **kw), reps=2)
+                parts.append('%.2f (%.2f)' % (t, md.last_gn_stats()['pixel_iterations'] / live))
+            gn_ms = ' / '.join(parts)
             del a
         print(f'| {name} | {rows} | {n_rays:.3g} | {ms:.2f} | {n_rays / ms * 1e3:.3g} | {n_rays * n_e / ms * 1e3:.3g} | {gn_ms} |',
               flush=True)

@@ -49,9 +49,3 @@ for rep in range(2):
             print(f'staged={staged} log={int(want_log)}: {ms:.3f} ms   counts bit-identical: {same}', flush=True)
     ms = run('1', True, minw='5')
     print(f'staged=1 log=1 minw=5: {ms:.3f} ms   counts bit-identical: {bool(torch.equal(out, ref))}', flush=True)
-    for mode in ('1', '3'):          # experiment: exponent contraction on the matrix pipe (detect_mfma), 4 / 3 waves per SIMD
-        os.environ['DEXCT_P16_MFMA'] = mode
-        ms = run('1', True)
-        os.environ.pop('DEXCT_P16_MFMA')
-        rel = float(((out - ref).abs() / ref).max())
-        print(f'staged=1 log=1 MFMA={mode}: {ms:.3f} ms   counts max rel diff to the vector form: {rel:.2e}', flush=True)
