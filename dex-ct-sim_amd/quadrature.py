@@ -255,18 +255,32 @@ def newton_start_grid(i0, mus, log_range=16.0):
 GATE_MAX_COND = 1.0e4      # largest condition number of the forward model's log-Jacobian d ln nu_k / d a_m at a tabulated fixed point (physical tables: 15 - 140)
 
 
-def _counts_and_condition(pieces, a, g):
+def _model_sums(pieces, a, third=False):
+    """The energy sums of the forward model at the states a [n, 2] (with the reference's clip of the exponent, matdecomp.py:116):
+    nu [n, k], G [n, k, m] = sum_e i0_k mu_m att over the energies whose exponent is not clipped (the clipped exponent has no
+    slope), and with ``third`` S [n, k, m, p] = sum_e i0_k mu_m mu_p att - one exponential pass and one matrix product."""
+    i0, mus = pieces['i0'], pieces['mus']
+    a = np.where(np.isfinite(a), a, 0.0)
+    expo = -(a @ mus)
+    att = np.exp(np.clip(expo, -700.0, 700.0))
+    nu = att @ i0.T
+    live = att * (np.abs(expo) < 700.0)
+    w1 = (i0[:, None, :] * mus[None, :, :]).reshape(4, -1)                               # (k, m)
+    G = (live @ w1.T).reshape(-1, 2, 2)
+    if not third:
+        return nu, G, None
+    w2 = (i0[:, None, None, :] * mus[None, :, None, :] * mus[None, None, :, :]).reshape(8, -1)      # (k, m, p)
+    return nu, G, (live @ w2.T).reshape(-1, 2, 2, 2)
+
+
+def _counts_and_condition(pieces, a, g, sums=None):
     """For fixed points a [n, 2] and the counts g [n, 2] they belong to: how well the forward model (with the reference's clip of
     the exponent, matdecomp.py:116) reproduces the counts, and the condition number of its log-Jacobian there - an ISOLATED root
     of the two equations has a small one; where tables far from anything physical (attenuation x 30 at the low energies: clipped
     exponents) make the equations dependent, roots come in families and a start value next to one rests next to it, not on it."""
     with np.errstate(all='ignore'):
-        a = np.where(np.isfinite(a), a, 0.0)
-        expo = -(a @ pieces['mus'])
-        att = np.exp(np.clip(expo, -700.0, 700.0))
-        nu = att @ pieces['i0'].T                                                    # [n, 2]
-        live = att * (np.abs(expo) < 700.0)                                          # the clipped exponent has no slope
-        jac = -np.einsum('ke,me,ne->nkm', pieces['i0'], pieces['mus'], live) / nu[:, :, None]
+        nu, G, _ = sums if sums is not None else _model_sums(pieces, a)
+        jac = -G / nu[:, :, None]
         resid = np.abs(nu / g - 1.0).max(axis=1)
         fro2 = (jac ** 2).sum(axis=(1, 2))
         det = np.abs(jac[:, 0, 0] * jac[:, 1, 1] - jac[:, 0, 1] * jac[:, 1, 0])
@@ -292,7 +306,9 @@ def assemble_start(pieces, steps, roots):
     r = np.asarray(roots, dtype=np.float64).reshape(n + 1, n + 1, 2)
     finite = np.all(np.isfinite(r), axis=2)
     good = (steps < 255) & finite & np.all(np.isfinite(pieces['corner_g']), axis=1).reshape(n + 1, n + 1)
-    resid, cond = _counts_and_condition(pieces, r.reshape(-1, 2), pieces['corner_g'])
+    with np.errstate(all='ignore'):
+        sums = _model_sums(pieces, r.reshape(-1, 2), third=True)
+    resid, cond = _counts_and_condition(pieces, r.reshape(-1, 2), pieces['corner_g'], sums)
     # what the reference's walk did on the part of the grid a detector can deliver (attenuation up to exp(-12), GATE_U_MAX)
     x_c = pieces['head'][4] + np.arange(n + 1) / pieces['head'][5]
     dom = np.broadcast_to((x_c <= np.log(GATE_U_MAX))[:, None], (n + 1, n + 1))
@@ -335,7 +351,7 @@ def assemble_start(pieces, steps, roots):
     need[x_hi > np.log(GATE_U_MAX), :] = np.inf
     radius = np.where(cell_ok, GATE_RADIUS * spread + 1e-9, 0.0)
     # kappa of the one-step acceptance: KAPPA_SAFETY x the largest value at the corners of the cell and of the eight around it
-    kc = np.where(good, newton_kappa(pieces, r.reshape(-1, 2)).reshape(n + 1, n + 1), np.inf)
+    kc = np.where(good, newton_kappa(pieces, r.reshape(-1, 2), sums).reshape(n + 1, n + 1), np.inf)
     kcell = np.maximum.reduce([kc[:-1, :-1], kc[:-1, 1:], kc[1:, :-1], kc[1:, 1:]])
     padk = np.pad(kcell, 1, mode='edge')
     kappa = KAPPA_SAFETY * np.max([padk[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
@@ -416,7 +432,7 @@ KAPPA_SAFETY = 2.5         # on the largest kappa at the corners of a cell and o
                            # cells (a few per cent) and the factor (1 - kappa e0)^-2 <= 1.25 between e0^2 and the measured d1^2
 
 
-def newton_kappa(pieces, roots):
+def newton_kappa(pieces, roots, sums=None):
     """The contraction constant of Newton's iteration on the Poisson likelihood F(a) = sum_k nu_k(a) - g_k ln nu_k(a) at the fixed
     points ``roots`` [n, 2] of the counts they reproduce (g_k = nu_k there; csrc/gn.hip kStartHeader, DEXCT_GN_FLAG_ONE_STEP): a step
     from a0 lands at a1 with a1 - a* = 1/2 H^-1 D3F [e0, e0], hence |e1| <= kappa |e0|^2 in the max norm with
@@ -424,11 +440,7 @@ def newton_kappa(pieces, roots):
     H_mp = sum_k G_km G_kp / nu_k and D3F_mpq = sum_k [2 G_km G_kp G_kq / nu_k^2 - (S_kpq G_km + S_kmq G_kp + S_kmp G_kq) / nu_k]
     (the terms with g_k / nu_k - 1 vanish at a root that reproduces its counts).  inf where H is singular or anything overflows."""
     with np.errstate(all='ignore'):
-        a = np.where(np.isfinite(roots), roots, 0.0)
-        att = np.exp(-(a @ pieces['mus']))                                               # [n, e]
-        nu = att @ pieces['i0'].T                                                        # [n, k]
-        G = np.einsum('ke,me,ne->nkm', pieces['i0'], pieces['mus'], att)
-        S = np.einsum('ke,me,pe,ne->nkmp', pieces['i0'], pieces['mus'], pieces['mus'], att)
+        nu, G, S = sums if sums is not None else _model_sums(pieces, roots, third=True)
         H = np.einsum('nk,nkm,nkp->nmp', 1.0 / nu, G, G)
         T = (2.0 * np.einsum('nk,nkm,nkp,nkq->nmpq', 1.0 / nu ** 2, G, G, G)
              - np.einsum('nk,nkpq,nkm->nmpq', 1.0 / nu, S, G) - np.einsum('nk,nkmq,nkp->nmpq', 1.0 / nu, S, G)

@@ -75,7 +75,9 @@ def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False):
                 fro2 = H[:, 0, 0] ** 2 + H[:, 1, 1] ** 2 + H[:, 0, 1] ** 2 + H[:, 1, 0] ** 2
                 cond = (fro2 + np.sqrt(np.maximum(fro2 * fro2 - 4.0 * det * det, 0.0))) / (2.0 * np.abs(det))     # sigma_max / sigma_min, 2 x 2
                 step = np.maximum(np.abs(s0), np.abs(s1)) / np.maximum(np.abs(a).max(-1), 1.0)
-                now = cond * step
+                # (a 2 x 2 solve with eps * cond > 1e-4 is numerically singular: what it returns - even an exact 0, as with one energy,
+                # where the numerators cancel - is rounding residue, and another arithmetic returns another one)
+                now = np.where(cond * np.finfo(np.float64).eps > 1.0e-4, np.inf, cond * step)
                 sens['walk'] = np.where(np.isfinite(now), np.maximum(sens['walk'], now), np.inf)
                 sens['last_step'] = np.where(np.isfinite(step), step, np.inf)
                 sens['last_cond'] = np.where(np.isfinite(cond), cond, np.inf)

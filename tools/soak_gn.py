@@ -19,8 +19,9 @@ differ after one Newton step by about eps * cond(H) * |step| / size, and what be
 pixel goes: an iteration that converges to an ISOLATED root sheds it (Newton corrects itself), one that is still moving when
 the iterations run out, or rests on a line of solutions (one energy: the two attenuation vectors are parallel), keeps it, and
 a transient wild enough carries the two arithmetics into different basins.  With w = eps * the largest cond(H_k) |step_k| /
-max(|a_(k+1)|, 1) over all iterations of the restatement (gn_oracle.newton_solve(..., return_sensitivity=True)), a pixel is
-compared only if
+max(|a_(k+1)|, 1) over all iterations of the restatement (gn_oracle.newton_solve(..., return_sensitivity=True); infinite once
+eps * cond(H_k) > 1e-4: such a solve is numerically singular and even the exact 0 it may return - one energy: the numerators
+cancel - is one arithmetic's rounding residue), a pixel is compared only if
   * the restatement's answer is finite, below 1e6, and its counts are finite and positive;
   * the answer moves by at most 1e-11 relative under a 1e-13 perturbation of the counts;
   * w <= 1e-11 (every step certain to well inside the 1e-9 / 1e-10 asked for), or: w <= 1e-6 and the iteration has converged
@@ -128,7 +129,10 @@ def check_case(seed, stats=None):
                 d = (np.abs(other - lane).max(-1) / size)[ok]
                 n_bad = int((~(d <= tol)).sum())
                 if n_bad:
-                    bad.append(f'{name}: {n_bad} of {int(ok.sum())} stable pixels beyond {tol:g} of the exact lane kernel (worst {np.nanmax(d):.2e}, {int(np.isnan(d).sum())} not comparable)')
+                    k = np.flatnonzero(ok.ravel())[np.flatnonzero(~(d <= tol))[0]]
+                    first = (f'; first: pixel {k} counts {g.reshape(2, -1)[:, k].tolist()} lane {lane.reshape(-1, 2)[k].tolist()} other '
+                             f'{other.reshape(-1, 2)[k].tolist()} walk {float(np.finfo(np.float64).eps * sens["walk"].ravel()[k]):.1e}')
+                    bad.append(f'{name}: {n_bad} of {int(ok.sum())} stable pixels beyond {tol:g} of the exact lane kernel (worst {np.nanmax(d):.2e}, {int(np.isnan(d).sum())} not comparable{first})')
     except Exception as exc:
         bad = [f'{type(exc).__name__}: {exc}']
     return what, bad
