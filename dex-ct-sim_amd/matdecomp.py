@@ -563,6 +563,59 @@ _PIPE_CHUNKS = 8                 # view chunks of the pipelined host boundary (t
 _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinogram) the plain sequence is as fast
 
 
+def _pinned_bytes_in_reserve():
+    """Page-locked bytes torch's caching host allocator holds without a user (a result array of an earlier call that is
+    garbage by now): what pinned_empty can hand out at no cost.  None when the runtime does not say."""
+    try:
+        st = torch.cuda.host_memory_stats()
+        return int(st['allocated_bytes.current']) - int(st['active_bytes.current'])
+    except Exception:
+        return None
+
+
+class _LazyPinnedResult:
+    """The result array of a FIRST large call: a plain NumPy array whose view chunks are page-locked one after the other by a
+    helper thread (dexct_host_pin) while the kernels and the copies of the chunks before them run - instead of one page-locked
+    allocation of the whole result in front of everything (0.3 s for the 6.5 GB of the benchmark's size: what the reference's
+    one call per run, main.py:153, would always pay).  Unlocked again by the same thread after the last copy."""
+
+    def __init__(self, lib, shape, bounds, device_index):
+        import threading
+        self.lib, self.dev = lib, int(device_index)
+        self.array = np.empty(shape, dtype=np.float64)
+        row = int(np.prod(shape[1:])) * 8
+        self.pieces = [(self.array.ctypes.data + b * row, (e - b) * row) for b, e in bounds]
+        self.ready = [threading.Event() for _ in bounds]
+        self.failed = None
+        self.release = threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        pinned = []
+        for k, (addr, n) in enumerate(self.pieces):
+            rc = self.lib.dexct_host_pin(addr, n, self.dev)
+            if rc != 0:
+                self.failed = rc              # (a locked-memory limit): the copies below go through pageable memory, same result
+            else:
+                pinned.append(addr)
+            self.ready[k].set()
+        self.release.wait()
+        for addr in pinned:
+            self.lib.dexct_host_unpin(addr, self.dev)
+        self.array = None                     # (the thread held the array alive until its pages were unlocked)
+
+    def download(self, k, src, stream):
+        self.ready[k].wait()
+        addr, n = self.pieces[k]
+        _native.check(self.lib.dexct_download(addr, ptr(src), n, stream.cuda_stream), 'dexct_download')
+
+    def finish(self):
+        out = self.array
+        self.release.set()
+        return out
+
+
 def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level=None, audit=None,
                               audit_strict=None):
     """get_basismat_sinos for NumPy sinograms of benchmark size: sinogram 1 goes to the device first (the mask needs its
@@ -584,8 +637,16 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
     _native.check(lib.dexct_reduce_max(ptr(g1), int(dt == torch.float64), g1.numel(), ptr(gmax), stream_ptr()),
                   'dexct_reduce_max')
     a = torch.empty(tuple(g1.shape) + (2,), dtype=torch.float64, device=dev)
-    host = pinned_empty(tuple(g1.shape) + (2,), torch.float64)
     bounds = [_shard.split(n_views, k, _PIPE_CHUNKS) for k in range(_PIPE_CHUNKS)]
+    # where the results land: page-locked memory the allocator still holds from an earlier call - or, on a first call, a plain
+    # array locked chunk by chunk while the pipeline runs (_LazyPinnedResult)
+    out_bytes = 16 * g1.numel()
+    reserve = _pinned_bytes_in_reserve()
+    lazy = host = None
+    if reserve is not None and reserve < out_bytes and os.environ.get('DEXCT_LAZY_PIN', '1') != '0':
+        lazy = _LazyPinnedResult(lib, tuple(g1.shape) + (2,), bounds, dev.index or 0)
+    else:
+        host = pinned_empty(tuple(g1.shape) + (2,), torch.float64)
     arrived = []
     copy.wait_stream(main)
     with torch.cuda.stream(copy):                           # all of sinogram 2 is queued at once, chunk by chunk
@@ -606,7 +667,7 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
         eb = 4 if dt == torch.float32 else 8
     global _last_ws, _last_events, _last_audit
     _last_ws, _last_events, _last_audit = [], [], None
-    for (b, e), ev in zip(bounds, arrived):
+    for k, ((b, e), ev) in enumerate(zip(bounds, arrived)):
         main.wait_event(ev)
         kw = dict(out=a[b:e], mask_max=gmax, mask_frac=float(mask_thresh), stop_tol=stop_tol, accumulate_stats=True,
                   two_level=two_level, audit=audit, audit_strict=audit_strict)
@@ -621,10 +682,14 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
         done.record(main)
         with torch.cuda.stream(copy):
             copy.wait_event(done)
-            host[b:e].copy_(a[b:e], non_blocking=True)
+            if lazy is not None:
+                lazy.download(k, a[b:e], copy)
+            else:
+                host[b:e].copy_(a[b:e], non_blocking=True)
     main.wait_stream(copy)
     main.synchronize()
     copy.synchronize()
+    out = lazy.finish() if lazy is not None else host.numpy()          # (every copy has landed: the pages may be unlocked)
     if strict:
         bad = ~torch.isfinite(a).all(dim=-1)
         n_bad = int(bad.sum().item())
@@ -632,7 +697,6 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
             first = bad.flatten().nonzero()[:1].flatten().tolist()
             raise SingularHessianError(f'Singular matrix: {n_bad} pixel(s) outside the air mask ended non-finite '
                                        f'after {n_iters} Newton iterations (first flat index on this rank: {first})')
-    out = host.numpy()
     return out[..., 0], out[..., 1]
 
 

@@ -33,9 +33,10 @@ def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False):
     returns : [nViews, nBins, 2] density line integrals  (matdecomp.py:127)
 
     ``return_sensitivity``: also return a dict of per-pixel arrays - the stability screen of tools/soak_gn.py:
-      'walk'       the largest value over ALL iterations of cond(H_k) * |step_k| / max(|a_(k+1)|, 1); times the machine epsilon it
-                   is the relative uncertainty of a computed step: any two float64 arithmetics (another order of the energy
-                   sums, another 2x2 solve) differ by about that much after the step (inf / NaN -> inf);
+      'walk'       the SUM over all iterations of cond(H_k) * |step_k| / max(|a_(k+1)|, 1); times the machine epsilon, a term is
+                   the relative uncertainty of a computed step - any two float64 arithmetics (another order of the energy
+                   sums, another 2x2 solve) differ by about that much after the step - and the sum what has accumulated by
+                   the end if nothing amplifies it (inf / NaN -> inf; inf once eps * cond > 1e-4: a singular solve);
       'last_step'  |step| / max(|a|, 1) of the last iteration;
       'last_cond'  cond(H) at the last iteration.
     """
@@ -78,7 +79,7 @@ def newton_solve(sino_gg, i0, mus, n_iters, return_sensitivity=False):
                 # (a 2 x 2 solve with eps * cond > 1e-4 is numerically singular: what it returns - even an exact 0, as with one energy,
                 # where the numerators cancel - is rounding residue, and another arithmetic returns another one)
                 now = np.where(cond * np.finfo(np.float64).eps > 1.0e-4, np.inf, cond * step)
-                sens['walk'] = np.where(np.isfinite(now), np.maximum(sens['walk'], now), np.inf)
+                sens['walk'] = np.where(np.isfinite(now), sens['walk'] + now, np.inf)
                 sens['last_step'] = np.where(np.isfinite(step), step, np.inf)
                 sens['last_cond'] = np.where(np.isfinite(cond), cond, np.inf)
     return (a, sens) if return_sensitivity else a

@@ -1048,3 +1048,50 @@ def test_gate_table_survives_the_process_on_disk(hip, golden, tmp_path, monkeypa
     assert gate['source'] == 'calibration' and torch.equal(a.view(torch.int64), c.view(torch.int64))
     assert files[0].stat().st_size == len(raw)                                 # written again, whole
     md._table_cache.clear()
+
+
+def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
+    """matdecomp._LazyPinnedResult: a first large call (no page-locked memory in the allocator's reserve) returns a plain NumPy
+    array that was locked chunk by chunk while the pipeline ran (dexct_host_pin / dexct_download / dexct_host_unpin) - the same
+    bits as the path through one page-locked allocation, both results owned by the caller."""
+    from dex_ct_sim_amd import matdecomp as md
+    g = golden
+    ct = types.SimpleNamespace(det_E=g['gn0_det_E'], det_eta_E=g['gn0_det_eta'], eid=bool(g['gn0_eid']))
+    s1 = types.SimpleNamespace(E=g['gn0_spec1_E'], I0=g['gn0_spec1_I0'])
+    s2 = types.SimpleNamespace(E=g['gn0_spec2_E'], I0=g['gn0_spec2_I0'])
+    rng = np.random.default_rng(9)
+    base = np.tile(g['gn0_g'], (1, 30, 40)) * rng.uniform(0.7, 1.0, (120, 1280))          # [2, 120 views, 1280 bins]
+    a1, a2 = base[0].astype(np.float32), base[1].astype(np.float32)
+    monkeypatch.setattr(md, '_PIPE_MIN_PIXELS', 1)
+    used = []
+    real = md._LazyPinnedResult
+    monkeypatch.setattr(md, '_LazyPinnedResult', lambda *a, **k: (used.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(md, '_pinned_bytes_in_reserve', lambda: 0)                        # "a first call"
+    lazy = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert used == [1]
+    monkeypatch.setattr(md, '_pinned_bytes_in_reserve', lambda: 1 << 40)                  # plenty in reserve: one page-locked tensor
+    pinned = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert used == [1]
+    for k in range(2):
+        assert lazy[k].shape == (120, 1280) and np.array_equal(lazy[k].view(np.int64), pinned[k].view(np.int64))
+    assert lazy[0].base is lazy[1].base and 0 < (lazy[0] == 0).sum() < lazy[0].size      # two views of one buffer, like the reference's; air masked
+    monkeypatch.setenv('DEXCT_LAZY_PIN', '0')
+    monkeypatch.setattr(md, '_pinned_bytes_in_reserve', lambda: 0)
+    md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert used == [1]                                                                    # switched off
+
+
+@pytest.mark.parametrize('seed', [319, 525, 468, 1179, 4, 29, 126, 397])
+def test_soak_cases_that_were_flagged(hip, seed):
+    """tools/soak_gn.py cases that rounds 3-5 flagged (profiles/r04_soak_gn2.log, r05_soak_traj.log), through every invariant of the
+    campaign with the version-2 stability screen: 319 / 525 (3 energies, photon-starved pixels creeping through Hessians of
+    condition 1e9 - 1e11 at the last iteration: three arithmetics, three answers), 468 (2 energies, the same), 1179 (the
+    tolerance rule before it asked for two contracting steps), 4 (one energy: a line of solutions), 29 / 126 / 397 (a chaotic
+    transient that converges afterwards)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    from soak_gn import check_case
+    what, bad = check_case(seed)
+    assert not bad, (what, bad)

@@ -15,23 +15,23 @@ the cooperative kernel within 1e-9 of the lane kernel, on the pixels the NumPy r
 and agreement to 1e-9 with the NumPy restatement of the reference, all on the STABLE pixels.
 
 THE STABILITY SCREEN (version 2, round 5).  Two float64 arithmetics - another order of the energy sums, another 2x2 solve -
-differ after one Newton step by about eps * cond(H) * |step| / size, and what becomes of that difference depends on where the
-pixel goes: an iteration that converges to an ISOLATED root sheds it (Newton corrects itself), one that is still moving when
-the iterations run out, or rests on a line of solutions (one energy: the two attenuation vectors are parallel), keeps it, and
-a transient wild enough carries the two arithmetics into different basins.  With w = eps * the largest cond(H_k) |step_k| /
-max(|a_(k+1)|, 1) over all iterations of the restatement (gn_oracle.newton_solve(..., return_sensitivity=True); infinite once
-eps * cond(H_k) > 1e-4: such a solve is numerically singular and even the exact 0 it may return - one energy: the numerators
-cancel - is one arithmetic's rounding residue), a pixel is compared only if
+differ after one Newton step by about eps * cond(H) * |step| / size: the uncertainty of the computed step itself.  Over the
+iterations these add up, a creeping iteration (Jacobian of the Newton map near 1) keeps them, a wild transient amplifies them
+and can carry the two arithmetics into different basins of noisy counts that admit two fixed points.  With
+w = eps * SUM over all iterations of cond(H_k) |step_k| / max(|a_(k+1)|, 1) of the restatement (gn_oracle.newton_solve(...,
+return_sensitivity=True); infinite once eps * cond(H_k) > 1e-4: such a solve is numerically singular and even the exact 0 it may
+return - one energy: the numerators cancel - is one arithmetic's rounding residue), a pixel is compared only if
   * the restatement's answer is finite, below 1e6, and its counts are finite and positive;
   * the answer moves by at most 1e-11 relative under a 1e-13 perturbation of the counts;
-  * w <= 1e-11 (every step certain to well inside the 1e-9 / 1e-10 asked for), or: w <= 1e-6 and the iteration has converged
-    to an isolated root - last step <= 1e-12 of the size, eps * cond(H) <= 1e-11 there.
+  * w <= 1e-11: what the computed steps are uncertain by, all added up, is a hundredth of the tightest tolerance asked below.
 Version 1 had the permutation of the energies in place of the last rule; with 2 or 3 energies a permutation changes little or
 nothing (seed 319's was a swap of two, 468's the identity) and photon-starved pixels still creeping at the last iteration through
 Hessians of condition 1e9 - 1e11 passed it: the cooperative kernel, the lane kernel and the restatement then part by 1e-9
 at the iteration where cond(H) passes 1e7 (tools/probes/gn_soak_traj.py, profiles/r05_soak_traj.log: seeds 319, 525, 468 -
-three arithmetics, three answers, the differences of the same size).  With it every comparison below is exact: no pixel may
-exceed its tolerance.
+three arithmetics, three answers, the differences of the same size).  (A first form of version 2 took the largest term instead
+of the sum and forgave a rough transient to a pixel that converged afterwards: seeds 29 and 468 of profiles/r05_soak_gn.log - a
+transient uncertain by 2e-10 that ends in another basin, a creep of 61 iterations whose 5e-12 per step add up to 1e-9.)  With it
+every comparison below is exact: no pixel may exceed its tolerance.
 
     python tools/soak_gn.py [n_cases] [first_seed]
 """
@@ -117,8 +117,7 @@ def check_case(seed, stats=None):
             size = np.maximum(np.abs(ref).max(-1), 1.0)
             ok = np.isfinite(ref).all(-1) & (np.abs(ref).max(-1) < 1e6) & np.isfinite(g).all(0) & (g > 0).all(0)
             eps = np.finfo(np.float64).eps
-            settled = (sens['last_step'] <= 1e-12) & (eps * sens['last_cond'] <= 1e-11)
-            ok &= (np.abs(ref - ref_p).max(-1) <= 1e-11 * size) & ((eps * sens['walk'] <= 1e-11) | (settled & (eps * sens['walk'] <= 1e-6)))
+            ok &= (np.abs(ref - ref_p).max(-1) <= 1e-11 * size) & (eps * sens['walk'] <= 1e-11)
         stats['pixels'] = stats.get('pixels', 0) + n_v * n_c
         stats['stable'] = stats.get('stable', 0) + int(ok.sum())
         if ok.any():
