@@ -75,7 +75,7 @@ if tl:
     for pat, v in big.items():
         if pat.endswith('<true>'):
             lines.append(f'`{pat}` (the step-counting instantiation): {len(v)} dispatches averaging {sum(v) / len(v):.2f} ms - the reference\'s walk on '
-                         f'the gate\'s 16 641 cell corners and 16 384 cell centres, once per pair of spectra')
+                         f'the gate\'s 66 049 cell corners and 65 536 cell centres, once per pair of spectra (then from DEXCT_CACHE_DIR)')
             continue
         step = [x for x in v if x > 0.25 * max(v)]
         lines.append(f'`{pat}`: {len(v)} dispatches, of which {len(step)} are step launches averaging {sum(step) / len(step):.2f} ms'
