@@ -2,7 +2,7 @@
 (`bench.py --shard-of K`), for K = 1, 2, 4, 8 on BASELINE configs[2] (1000 x 800) and configs[3] (2000 x 1024) - the
 prediction the driver's first N-rank RCCL line is to be compared with.
 
-    python tools/shard_of_table.py > profiles/r04c_shard_of.md
+    python tools/shard_of_table.py > profiles/r05_shard_of.md
 """
 import json
 import os
@@ -39,10 +39,10 @@ for workload, views, chans in (('config2', 1000, 800), ('config3', 2000, 1024)):
             print(f'{workload} K={K} rank={rank}: step {j["ms_per_step"]:.1f} ms', file=sys.stderr, flush=True)
 
 print('# One rank\'s share of a K-GPU strong-scaling run, measured alone on one MI355X (`bench.py --shard-of K`)\n')
-print('Step = plan + fused dual-spectrum projection (sino_raw + sino_log) + global max + Newton (n_iters 50, default tolerance stop) + transposes, on the')
-print('rank\'s contiguous views of the FIXED scan; no collective runs here.  `gather` = bytes the rank RECEIVES in the one')
-print('all-gather of the raw sinograms (both spectra, float32, reference order).  The collective is started right after the')
-print('projection and overlaps the Newton kernel, so only `max(0, gather - Newton)` is exposed.  Two gather estimates at an')
+print('Step = plan + fused dual-spectrum projection (sino_raw + sino_log) + global max + Newton (n_iters 50, default mode: the short cut, one step) + transposes, on the')
+print('rank\'s contiguous views of the FIXED scan; no transfer runs here.  `gather` = bytes a rank RECEIVES when the raw sinograms (both')
+print('spectra, float32, reference order) are assembled on it (mode direct / all: every rank; mode root: rank 0 only).  The transfers start')
+print('chunk by chunk during the projection and overlap the Newton launches, so only `max(0, gather - Newton)` is exposed.  Two estimates at an')
 print(f'assumed {LINK_GBS:.0f} GB/s per xGMI link and direction: `ring` = (K-1)/K x total / link (a ring is per-link bound),')
 print('`direct` = one shard per peer link in parallel.  Predicted value = ray-energy integrals of the whole scan / (slowest')
 print('measured rank step + exposed ring gather).\n')
@@ -52,10 +52,10 @@ for r in rows:
     exposed = max(0.0, r['ring_ms'] - r['gn_ms'])
     print(f"| {r['workload']} | {r['K']} | {r['rank']} | {r['views']} | {r['step_ms']:.1f} | {r['sid_ms']:.2f} | {r['gn_ms']:.1f} | "
           f"{r['recv_gb']:.2f} | {r['ring_ms']:.1f} | {r['direct_ms']:.1f} | {exposed:.1f} |")
-print('\nSince the Newton share shrank to ~10 ms per rank at K = 8 (the short cut, profiles/r04_gn_two_level.md) the gather no longer')
-print('hides behind it by itself: what the driver measures will depend on how RCCL moves the 3.3 / 13.4 GB - bracketed here by the')
-print('ring-bound estimate (pessimistic: one link) and the direct one (every peer link in parallel, what a fully connected xGMI')
-print('mesh allows; RCCL all-gather bus bandwidths of ~300 GB/s reported for 8-GPU MI300X nodes correspond to it).\n')
+print('\nWith the Newton share at ~5 ms per rank at K = 8 (one step per pixel, profiles/r05_gn_one_step.md) nothing hides the assembly: the')
+print('step is what the transfers cost - bracketed here by the ring-bound estimate (one link: what an all-gather that RCCL runs as a ring')
+print('would cost; bench.py --gather all) and the direct one (one transfer per peer link in parallel: what bench.py --gather root / direct')
+print('issue, dexct_sino_gather; RCCL bus bandwidths of ~300 GB/s reported for 8-GPU xGMI meshes correspond to it).\n')
 print('| workload | K | rank compute ms | step ms, ring-bound gather | integrals/s | speed-up | step ms, direct gather | integrals/s | speed-up |')
 print('|---|---|---|---|---|---|---|---|---|')
 base = {}
