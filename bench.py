@@ -154,11 +154,23 @@ def segment_count(co, geom, view_cs, chan_cs, n_views_total, view_begin, view_en
 
 
 def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
-    """Wall seconds of the reference's own call sequence through the public NumPy boundary; 'cold' builds the device
-    state (volume upload, layouts, plans) and page-locks the result buffers, 'warm' is the second identical sequence."""
+    """Wall seconds of the reference's own call sequence through the public NumPy boundary.  'cold' = what a process's FIRST
+    sequence costs - the device state is built (volume upload, layouts, plans), no page-locked memory is in the allocator's
+    reserve (the result of get_basismat_sinos is locked chunk by chunk while the pipeline runs), the table of the Newton short
+    cut is not in the process - in two variants: with the table on disk from an earlier process (DEXCT_CACHE_DIR, the normal
+    case after a machine's first run) and without ('cold_no_disk_cache': the calibration runs inside the call).  'warm' is the
+    second identical sequence of the same process."""
     import gc
+    import tempfile
     import torch
     from dex_ct_sim_amd import synthetic
+
+    def fresh_process_state(cache_dir):
+        fp.invalidate()
+        md._table_cache.clear()
+        gc.collect()
+        torch._C._host_emptyCache()          # page-locked blocks of earlier results go back to the system
+        os.environ['DEXCT_CACHE_DIR'] = cache_dir
 
     def sequence(ct_, ph_, s1, s2):
         torch.cuda.synchronize()
@@ -195,14 +207,20 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
     cases = [('configs[0] size: 1200 views x 800 channels x 1 row, 512^2 slice', ct0, ph0)]
     if not args.skip_dropin_full:
         cases.append((f'this workload: {ct.N_proj} x {ct.N_channels} x {ct.N_rows} rows, {ph.Nx}^3', ct, ph))
+    keep_dir = os.environ.get('DEXCT_CACHE_DIR')
+    tmp = tempfile.mkdtemp(prefix='dexct_bench_cache_')
     for label, ct_, ph_ in cases:
-        fp.invalidate()
-        cold, n = sequence(ct_, ph_, specs[0], specs[1])
+        fresh_process_state(tmp)             # an empty directory: the calibration runs in the call and leaves its table there
+        for f in os.listdir(tmp):
+            os.remove(os.path.join(tmp, f))
+        cold_nodisk, n = sequence(ct_, ph_, specs[0], specs[1])
+        fresh_process_state(tmp)             # ... where the next "process" finds it
+        cold, _ = sequence(ct_, ph_, specs[0], specs[1])
         warm, _ = sequence(ct_, ph_, specs[0], specs[1])
         k_ms = kernel_ms(ct_, ph_, specs[0])
         d2h_sino = 2 * n * 4                       # sino_raw + sino_log, float32
         floor_s = k_ms * 1e-3 + d2h_sino / 50e9
-        res[label] = {'cold': cold, 'warm': warm, 'rays': n,
+        res[label] = {'cold': cold, 'cold_no_disk_cache': cold_nodisk, 'warm': warm, 'rays': n,
                       'bytes': {'h2d_volume_once': int(ph_.volume.size), 'd2h_per_get_sino': d2h_sino,
                                 'h2d_get_basismat_sinos': 2 * n * 4, 'd2h_get_basismat_sinos': n * 16},
                       'get_sino_kernels_ms': k_ms,
@@ -210,6 +228,12 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
                       'note': 'floor = projection kernels (single spectrum, both outputs) + its device-to-host bytes at '
                               '50 GB/s; warm get_sino / floor is the boundary overhead factor'}
     fp.invalidate()
+    if keep_dir is None:
+        os.environ.pop('DEXCT_CACHE_DIR', None)
+    else:
+        os.environ['DEXCT_CACHE_DIR'] = keep_dir
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     return res
 
 

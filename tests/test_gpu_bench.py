@@ -39,7 +39,7 @@ def test_plain_command_single_gpu(hip):
     e2e = out['dropin_e2e']                      # the public NumPy boundary, timed (get_sino x 2 + get_basismat_sinos)
     assert len(e2e) == 2
     for case in e2e.values():
-        assert case['cold']['ok'] and case['warm']['ok'] and case['warm']['total_s'] > 0
+        assert case['cold']['ok'] and case['cold_no_disk_cache']['ok'] and case['warm']['ok'] and case['warm']['total_s'] > 0
         assert case['bytes']['d2h_per_get_sino'] == 8 * case['rays']
 
 
