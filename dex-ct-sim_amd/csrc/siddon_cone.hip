@@ -40,7 +40,6 @@ struct ConeArgs {
   float* pathlen;          // optional [ray][M]
   float* sino_log;         // optional [S][view][row][channel]: ln(air[s] / counts)
   float air[DEXCT_MAX_SPECTRA];
-  int row_fastest;         // experiment (DEXCT_CONE_ROWFAST=1, row kernels only): outputs as [S][view][channel][row]
 };
 
 template <int NM, int CB = kConeBlock>   // CB: lanes per workgroup = width of the per-lane LDS columns (NM == 0)
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   const BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // a ballot: before dead rows leave
   if (!live) return;
   // ---- detection (same weighting as the other kernels)
-  const size_t ray = a.row_fastest ? ((size_t)v * a.g.n_channels + c) * a.g.n_rows + r : ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
+  const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   const int n_e = a.n_energies;
   float L2[NM];
@@ -705,7 +704,7 @@ void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const floa
   const BlockMasks bm = detect_block_masks(w, a.n_energies, a.n_spectra);      // a ballot: before dead rows leave
   if (!live) return;
   // ---- detection (same weighting as the other kernels)
-  const size_t ray = a.row_fastest ? ((size_t)v * a.g.n_channels + c) * a.g.n_rows + r : ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
+  const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   const int n_e = a.n_energies;
   float L2[NM];
@@ -782,7 +781,6 @@ extern "C" int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_pl
   const double dmax = geom->dx > geom->dy ? geom->dx : geom->dy;
   if (!(max_abs_dz >= 0) || max_abs_dz / geom->sdd / geom->dz * dmax * 1.4142135623730951 > 1.0) return DEXCT_ERANGE;
   ConeArgs a;
-  a.row_fastest = 0;
   a.g = *geom;
   a.plan = plan;
   a.view_cs = view_cs;
@@ -858,10 +856,6 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
   a.pathlen = pathlen;
   a.sino_log = log_out ? log_out->sino_log : nullptr;
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = log_out ? log_out->air[s] : 1.0f;
-  // experiment of round 5 (profiles/r05_notes_cone.md): lanes are rows, so row-fastest outputs are whole-line stores; the
-  // reference's order then needs a transpose pass (dexct_transpose_batched)
-  const char* rfe = getenv("DEXCT_CONE_ROWFAST");
-  a.row_fastest = (rfe && rfe[0] == '1') ? 1 : 0;
   const int n_chunks = (geom->n_rows + kConeRows - 1) / kConeRows;
   const size_t nblk = (size_t)a.n_local_views * geom->n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;

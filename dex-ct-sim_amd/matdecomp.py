@@ -590,6 +590,16 @@ class _LazyPinnedResult:
         self.array = np.empty(shape, dtype=np.float64)
         row = int(np.prod(shape[1:])) * 8
         self.pieces = [(self.array.ctypes.data + b * row, (e - b) * row) for b, e in bounds]
+        # the chunks as page-aligned spans that tile the array without overlap (a page shared by two chunks belongs to the earlier
+        # one: locking it twice is an error), each cut into _PIN_THREADS pieces on 2 MiB boundaries
+        small, big = 4096, 1 << 21
+        cuts = [self.pieces[0][0] // small * small] + [-(-(addr + n) // small) * small for addr, n in self.pieces]
+        self.spans = []
+        for k in range(len(self.pieces)):
+            lo, hi = cuts[k], cuts[k + 1]
+            inner = sorted({lo, hi} | {c for c in ((lo + (hi - lo) * j // self._PIN_THREADS) // big * big for j in range(1, self._PIN_THREADS))
+                                       if lo < c < hi})
+            self.spans.append([(x, y - x) for x, y in zip(inner[:-1], inner[1:])])
         self.ready = [threading.Event() for _ in bounds]
         self.release = threading.Event()
         self.thread = threading.Thread(target=self._run, daemon=True)
@@ -598,20 +608,12 @@ class _LazyPinnedResult:
     def _run(self):
         from concurrent.futures import ThreadPoolExecutor
         pinned = []
-        # the chunks as page-aligned spans that tile the array without overlap (a page shared by two chunks belongs to the earlier
-        # one: locking it twice is an error), each cut into _PIN_THREADS pieces on 2 MiB boundaries
-        small, big = 4096, 1 << 21
-        cuts = [self.pieces[0][0] // small * small] + [-(-(addr + n) // small) * small for addr, n in self.pieces]
 
         def lock(span):
             return span if self.lib.dexct_host_pin(span[0], span[1], self.dev) == 0 else None
 
         with ThreadPoolExecutor(self._PIN_THREADS) as pool:
-            for k in range(len(self.pieces)):
-                lo, hi = cuts[k], cuts[k + 1]
-                inner = sorted({lo, hi} | {c for c in ((lo + (hi - lo) * j // self._PIN_THREADS) // big * big for j in range(1, self._PIN_THREADS))
-                                           if lo < c < hi})
-                spans = [(x, y - x) for x, y in zip(inner[:-1], inner[1:])]
+            for k, spans in enumerate(self.spans):
                 # (a piece that cannot be locked - a locked-memory limit - is copied through pageable memory: same result)
                 pinned += [sp for sp in pool.map(lock, spans) if sp is not None]
                 self.ready[k].set()
@@ -625,9 +627,15 @@ class _LazyPinnedResult:
             pass
 
     def download(self, k, src, stream):
+        """chunk k of the result from device memory: one copy per locked span it touches (a copy must stay inside one locked
+        region; its first bytes may lie in the last page of the chunk before)"""
         self.ready[k].wait()
         addr, n = self.pieces[k]
-        _native.check(self.lib.dexct_download(addr, ptr(src), n, stream.cuda_stream), 'dexct_download')
+        src_ptr = ptr(src)
+        for lo, m in (self.spans[k - 1][-1:] if k else []) + self.spans[k]:
+            b, e = max(lo, addr), min(lo + m, addr + n)
+            if e > b:
+                _native.check(self.lib.dexct_download(b, src_ptr + (b - addr), e - b, stream.cuda_stream), 'dexct_download')
 
     def finish(self):
         out = self.array
