@@ -581,7 +581,7 @@ class _LazyPinnedResult:
     main.py:153, would always pay).  Unlocked again after the last copy; then the same thread puts a page-locked block of the
     result's size into the allocator's reserve, so that a SECOND call of the process takes the cheap path (pinned_empty)."""
 
-    _PIN_THREADS = 4
+    _PIN_THREADS = int(os.environ.get('DEXCT_PIN_THREADS', '8'))
 
     def __init__(self, lib, shape, bounds, device_index):
         import threading
