@@ -166,10 +166,12 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
     from dex_ct_sim_amd import synthetic
 
     def fresh_process_state(cache_dir):
+        time.sleep(1.0)                      # (a reserve of page-locked memory may still be on its way from the sequence before)
         fp.invalidate()
         md._table_cache.clear()
         gc.collect()
         torch._C._host_emptyCache()          # page-locked blocks of earlier results go back to the system
+        md._reserve['bytes'] = 0
         os.environ['DEXCT_CACHE_DIR'] = cache_dir
 
     def sequence(ct_, ph_, s1, s2):

@@ -50,84 +50,3 @@ def pinned_empty(shape, dtype):
         return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
     except RuntimeError:
         return torch.empty(tuple(shape), dtype=dtype)
-
-
-# ---- large results: device -> NumPy through a small ring of page-locked staging buffers ------------------------------------
-# Page-locking host memory costs the system 24 GB/s however many threads ask (tools/probes/pin_threads.py; torch's pinned
-# allocation: 11 GB/s), so a result of the benchmark's size (6.5 GB) that is to arrive by ONE DMA into page-locked memory of
-# its own costs 0.3 - 0.6 s before the first byte moves - on every first call of a process, which is all the reference's main.py
-# ever makes.  Here the result is a plain NumPy array; pieces of 128 MiB cross PCIe into two page-locked buffers (allocated once
-# per process: 20 ms) and a helper thread copies each into place - torch's parallel CPU copy - while the next piece is in
-# flight.  The first call of a process costs what every call costs.
-_STAGE_BYTES = 128 << 20
-_stage = []
-
-
-def _staging_ring():
-    if not _stage:
-        for _ in range(2):
-            _stage.append(pinned_empty((_STAGE_BYTES,), torch.uint8))
-    return _stage
-
-
-class StagedDownload:
-    """``out = StagedDownload(shape, np_dtype, copy_stream)``; ``push(src, byte_offset, after)`` for device tensors in the order of
-    their place in the result (``after``: an event of the producing stream); ``finish()`` -> the NumPy array (waits for everything).
-    One helper thread: it queues the DMA of piece k on ``copy_stream`` and, while that runs, copies piece k-1 from its staging
-    buffer into the array."""
-
-    def __init__(self, shape, np_dtype, copy_stream):
-        import queue
-        import threading
-        self.out = np.empty(shape, dtype=np_dtype)
-        self.flat = torch.from_numpy(self.out.reshape(-1).view(np.uint8))
-        self.stream = copy_stream
-        self.work = queue.Queue()
-        self.error = None
-        self.device = torch.cuda.current_device()
-        self.thread = threading.Thread(target=self._run, daemon=True)
-        self.thread.start()
-
-    def push(self, src, byte_offset, after=None):
-        self.work.put((src, int(byte_offset), after))
-
-    def _run(self):
-        try:
-            torch.cuda.set_device(self.device)
-            ring = _staging_ring()
-            pending = None                                    # (slot, offset, n, event) of the piece in flight
-            k = 0
-            while True:
-                item = self.work.get()
-                if item is None:
-                    break
-                src, off, after = item
-                flat = src.contiguous().view(-1).view(torch.uint8)
-                for p0 in range(0, flat.numel(), _STAGE_BYTES):
-                    n = min(_STAGE_BYTES, flat.numel() - p0)
-                    slot = ring[k % 2]
-                    with torch.cuda.stream(self.stream):
-                        if after is not None and p0 == 0:
-                            self.stream.wait_event(after)
-                        slot[:n].copy_(flat[p0:p0 + n], non_blocking=True)      # (the slot's last user was copied out two pieces ago)
-                        ev = torch.cuda.Event()
-                        ev.record(self.stream)
-                    if pending is not None:
-                        self._land(*pending)
-                    pending = (slot, off + p0, n, ev)
-                    k += 1
-            if pending is not None:
-                self._land(*pending)
-        except Exception as exc:                              # surfaced by finish()
-            self.error = exc
-
-    def _land(self, slot, off, n, ev):
-        ev.synchronize()
-        self.flat[off:off + n].copy_(slot[:n])
-
-    def finish(self):
-        self.work.put(None)
-        self.thread.join()
-        if self.error is not None:
-            raise self.error
-        return self.out

@@ -294,6 +294,30 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
 
 int dexct_last_hip_error(void) { return g_last_hip_error; }
 
+// Page-locking a piece of the CALLER'S host array and copying into it (the host boundary of get_basismat_sinos: the result
+// array of a first call is locked piece by piece by a helper thread while the kernels and the copies of the pieces before it
+// run, instead of in one 0.3 s allocation of page-locked memory in front of everything).  `device`: the HIP device of the
+// calling process - a helper thread has no current device of its own.
+int dexct_host_pin(void* host, int64_t n_bytes, int32_t device) {
+  if (!host || n_bytes <= 0 || device < 0) return DEXCT_EINVAL;
+  DEXCT_HIP_TRY(hipSetDevice(device));
+  DEXCT_HIP_TRY(hipHostRegister(host, (size_t)n_bytes, hipHostRegisterDefault));
+  return DEXCT_OK;
+}
+
+int dexct_host_unpin(void* host, int32_t device) {
+  if (!host || device < 0) return DEXCT_EINVAL;
+  DEXCT_HIP_TRY(hipSetDevice(device));
+  DEXCT_HIP_TRY(hipHostUnregister(host));
+  return DEXCT_OK;
+}
+
+int dexct_download(void* host, const void* device_src, int64_t n_bytes, void* stream) {
+  if (!host || !device_src || n_bytes <= 0) return DEXCT_EINVAL;
+  DEXCT_HIP_TRY(hipMemcpyAsync(host, device_src, (size_t)n_bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  return DEXCT_OK;
+}
+
 int dexct_volume_ids(const uint8_t* vol, int64_t n_voxels, uint64_t* counts256, void* stream) {
   if (!vol || !counts256 || n_voxels <= 0) return DEXCT_EINVAL;
   if (reinterpret_cast<uintptr_t>(vol) & 15u) return DEXCT_EINVAL;

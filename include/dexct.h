@@ -262,6 +262,14 @@ int dexct_sino_allgather(const float* local, float* gathered, int64_t count_per_
 int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts, const int64_t* offsets, int32_t rank,
                       int32_t world, int32_t root, void* rccl_comm, void* stream);
 
+/* The host boundary of the drop-in calls (NumPy out, main.py:153-155; ABI 5): lock `n_bytes` of the caller's host array at
+ * `host` for DMA (hipHostRegister; from any thread: `device` = the process's HIP device), copy device memory into it on a
+ * stream, unlock it again.  A result array is locked piece by piece while the kernels of the pieces before it run
+ * (dex-ct-sim_amd/matdecomp.py, _basismat_sinos_pipelined): a first call does not wait for one large page-locked allocation. */
+int dexct_host_pin(void* host, int64_t n_bytes, int32_t device);
+int dexct_host_unpin(void* host, int32_t device);
+int dexct_download(void* host, const void* device_src, int64_t n_bytes, void* stream);
+
 /* Options of dexct_gn_decompose (ABI 3; pass, iterations, start: ABI 4; flags, blocks_per_cu: ABI 5).  A NULL pointer = every
  * default.
  *   stop_tol    >= 0: taken as given.  0 = the reference's fixed iteration count, bit for bit (matdecomp.py:114: `for

@@ -1050,12 +1050,11 @@ def test_gate_table_survives_the_process_on_disk(hip, golden, tmp_path, monkeypa
     md._table_cache.clear()
 
 
-def test_large_results_arrive_through_the_staging_ring(hip, golden, monkeypatch):
-    """_device.StagedDownload: the result of a large get_basismat_sinos is a plain NumPy array filled piece by piece through two
-    page-locked staging buffers (no page-locked allocation of the result's size: a first call costs what every call costs) -
-    the same bits as the plain sequence, pieces smaller and larger than a staging buffer, two views of one buffer like the
-    reference's."""
-    from dex_ct_sim_amd import _device, matdecomp as md
+def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
+    """matdecomp._LazyPinnedResult: a first large call (no page-locked memory in the allocator's reserve) returns a plain NumPy
+    array that was locked chunk by chunk while the pipeline ran (dexct_host_pin / dexct_download / dexct_host_unpin) - the same
+    bits as the path through one page-locked allocation, both results owned by the caller."""
+    from dex_ct_sim_amd import matdecomp as md
     g = golden
     ct = types.SimpleNamespace(det_E=g['gn0_det_E'], det_eta_E=g['gn0_det_eta'], eid=bool(g['gn0_eid']))
     s1 = types.SimpleNamespace(E=g['gn0_spec1_E'], I0=g['gn0_spec1_I0'])
@@ -1063,16 +1062,23 @@ def test_large_results_arrive_through_the_staging_ring(hip, golden, monkeypatch)
     rng = np.random.default_rng(9)
     base = np.tile(g['gn0_g'], (1, 30, 40)) * rng.uniform(0.7, 1.0, (120, 1280))          # [2, 120 views, 1280 bins]
     a1, a2 = base[0].astype(np.float32), base[1].astype(np.float32)
-    plain = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
     monkeypatch.setattr(md, '_PIPE_MIN_PIXELS', 1)
-    for stage in (_device._STAGE_BYTES, 100_000):                                          # (a chunk is 245 760 bytes: one piece, then three)
-        monkeypatch.setattr(_device, '_STAGE_BYTES', stage)
-        monkeypatch.setattr(_device, '_stage', [])
-        got = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
-        for k in range(2):
-            assert got[k].shape == (120, 1280) and np.array_equal(got[k].view(np.int64), plain[k].view(np.int64))
-        assert got[0].base is got[1].base and 0 < (got[0] == 0).sum() < got[0].size
-    monkeypatch.setattr(_device, '_stage', [])
+    used = []
+    real = md._LazyPinnedResult
+    monkeypatch.setattr(md, '_LazyPinnedResult', lambda *a, **k: (used.append(1), real(*a, **k))[1])
+    monkeypatch.setitem(md._reserve, 'bytes', 0)                                          # "a first call"
+    lazy = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert used == [1]
+    monkeypatch.setitem(md._reserve, 'bytes', 1 << 40)                                    # plenty in reserve: one page-locked tensor
+    pinned = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert used == [1]
+    for k in range(2):
+        assert lazy[k].shape == (120, 1280) and np.array_equal(lazy[k].view(np.int64), pinned[k].view(np.int64))
+    assert lazy[0].base is lazy[1].base and 0 < (lazy[0] == 0).sum() < lazy[0].size      # two views of one buffer, like the reference's; air masked
+    monkeypatch.setenv('DEXCT_LAZY_PIN', '0')
+    monkeypatch.setitem(md._reserve, 'bytes', 0)
+    md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert used == [1]                                                                    # switched off
 
 
 @pytest.mark.parametrize('seed', [319, 525, 468, 1179, 4, 29, 126, 397])
