@@ -163,7 +163,7 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
     import gc
     import tempfile
     import torch
-    from dex_ct_sim_amd import synthetic
+    from dex_ct_sim_amd import _device, synthetic
 
     def fresh_process_state(cache_dir):
         time.sleep(1.0)                      # (a reserve of page-locked memory may still be on its way from the sequence before)
@@ -171,7 +171,7 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
         md._table_cache.clear()
         gc.collect()
         torch._C._host_emptyCache()          # page-locked blocks of earlier results go back to the system
-        md._reserve['bytes'] = 0
+        _device.empty_pool()
         os.environ['DEXCT_CACHE_DIR'] = cache_dir
 
     def sequence(ct_, ph_, s1, s2):

@@ -1,5 +1,7 @@
 """torch-ROCm as the device container: allocation, streams, pointers.  No compute happens here."""
 import os
+import threading
+import weakref
 
 import numpy as np
 import torch
@@ -50,3 +52,148 @@ def pinned_empty(shape, dtype):
         return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
     except RuntimeError:
         return torch.empty(tuple(shape), dtype=dtype)
+
+
+# ---- large results and large inputs: host memory made ready for DMA while the GPU works ---------------------------------------
+# Results cross PCIe by DMA into page-locked host memory that the returned arrays own.  A page-locked allocation (torch's, or
+# hipHostMalloc) of memory the process has never touched runs at 11 GB/s - 0.57 s for the 6.5 GB of the benchmark's
+# decomposition, 0.3 s for a sinogram pair - in front of everything, and one call of each kind is all the reference's main.py
+# makes (main.py:120, :153).  What costs is the first touch of the pages (the kernel hands them out zeroed): 29 GB/s for one
+# thread, 56 GB/s for two; memory that is RESIDENT locks at 500 GB/s and unlocks in microseconds (tools/probes/pin_resident.py,
+# touch_threads.py; profiles/r05_notes_boundary.md).  So a LazyPinnedResult is a plain block of host memory that a helper
+# thread, piece by piece and in the order the copies will come, touches (dexct_host_touch, new blocks only) and locks
+# (dexct_host_pin) while the kernels and the copies of the pieces before run; finish() unlocks it, and the caller gets an ordinary
+# NumPy array over ordinary memory (a block that stayed locked in several pieces would be a trap: one copy across two
+# separately locked regions is an error of the HIP runtime, also for the caller's own torch code).  When the last array that
+# views the block is garbage it goes to this module's pool - resident, so the next result of its size has nothing to touch.
+# Large INPUT arrays get the same treatment for the time of a call (locked_arrays): resident by nature, locked in milliseconds,
+# uploaded by DMA instead of through the runtime's staging buffers.
+LAZY_MIN_BYTES = 64 << 20       # smaller results: torch's page-locked allocation (milliseconds)
+POOL_MAX_BYTES = int(float(os.environ.get('DEXCT_HOST_POOL_GB', '64')) * (1 << 30))
+_pool = {}                      # bytes -> [free blocks (np.uint8 arrays, page aligned, resident)]
+_pool_lock = threading.Lock()
+_PAGE = 4096
+_TOUCH_THREADS = 2
+
+
+def pool_wanted(n_bytes):
+    """True when a result of n_bytes goes through LazyPinnedResult (large; DEXCT_LAZY_PIN=0 switches it off)."""
+    return n_bytes >= LAZY_MIN_BYTES and os.environ.get('DEXCT_LAZY_PIN', '1') != '0'
+
+
+def _give_back(buf):
+    with _pool_lock:
+        if sum(k * len(v) for k, v in _pool.items()) + buf.nbytes <= POOL_MAX_BYTES:
+            _pool.setdefault(buf.nbytes, []).append(buf)
+
+
+def empty_pool():
+    """Drop every pooled block (back to the system).  Returns the bytes let go."""
+    with _pool_lock:
+        n = sum(k * len(v) for k, v in _pool.items())
+        _pool.clear()
+    return n
+
+
+def _page_spans(ranges):
+    """[(address, bytes)] -> the page-aligned spans that cover them, merged where they share or touch a page"""
+    spans = sorted((addr // _PAGE * _PAGE, -(-(addr + n) // _PAGE) * _PAGE) for addr, n in ranges if n > 0)
+    out = []
+    for lo, hi in spans:
+        if out and lo <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], hi)
+        else:
+            out.append([lo, hi])
+    return [(lo, hi - lo) for lo, hi in out]
+
+
+class locked_arrays:
+    """``with locked_arrays(lib, [a1, a2], device_index): ...``: the memory of large contiguous NumPy arrays page-locked for the
+    time of the block (uploads inside it run as DMA).  Whatever cannot be locked - it is locked already (a torch page-locked
+    tensor's array), a file mapping, a limit - is left alone: the copy then goes the runtime's ordinary way."""
+
+    def __init__(self, lib, arrays, device_index, min_bytes=16 << 20):
+        self.lib, self.dev = lib, int(device_index)
+        self.spans = _page_spans([(a.ctypes.data, a.nbytes) for a in arrays
+                                  if isinstance(a, np.ndarray) and a.flags.c_contiguous and a.nbytes >= min_bytes])
+        self.locked = []
+
+    def __enter__(self):
+        self.locked = [sp for sp in self.spans if self.lib.dexct_host_pin(sp[0], sp[1], self.dev) == 0]
+        return self
+
+    def __exit__(self, *exc):
+        for addr, _ in self.locked:
+            self.lib.dexct_host_unpin(addr, self.dev)
+        self.locked = []
+        return False
+
+
+class LazyPinnedResult:
+    """``LazyPinnedResult(lib, shape, np_dtype, cuts, device_index)``: host memory for a result of ``shape`` whose byte ranges
+    [cuts[k], cuts[k + 1]) are filled in order.  ``download(k, device_address, stream)`` queues the copy of piece k (waits until
+    the piece is locked); ``finish()``, once the caller has synchronised the copies, unlocks and returns the NumPy array; the
+    block returns to the pool when that array and its views are garbage.  ``fresh``: the block was not in the pool."""
+
+    def __init__(self, lib, shape, np_dtype, cuts, device_index):
+        self.lib, self.dev, self.shape, self.dtype = lib, int(device_index), tuple(shape), np.dtype(np_dtype)
+        n_bytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        cuts = [int(c) for c in cuts]
+        assert cuts[0] == 0 and cuts[-1] == n_bytes and all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
+        with _pool_lock:
+            free = _pool.get(n_bytes)
+            self.buf = free.pop() if free else None
+        self.fresh = self.buf is None
+        if self.fresh:
+            raw = np.empty(n_bytes + 2 * _PAGE, dtype=np.uint8)
+            off = (-raw.ctypes.data) % _PAGE
+            self.buf = raw[off:off + n_bytes]
+        base = self.buf.ctypes.data
+        self.pieces = [(base + lo, hi - lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        # the pieces as page-aligned spans that tile the block without overlap (a page shared by two pieces belongs to the earlier
+        # one: locking it twice is an error)
+        edges = [base] + [-(-(addr + n) // _PAGE) * _PAGE for addr, n in self.pieces]
+        self.spans = [(lo, hi - lo) for lo, hi in zip(edges[:-1], edges[1:])]
+        self.locked = []
+        self.ready = [threading.Event() for _ in self.pieces]
+        threading.Thread(target=self._prepare, daemon=True).start()
+
+    def _prepare(self):
+        for k, (addr, n) in enumerate(self.spans):
+            if n > 0:
+                if self.fresh:
+                    self.lib.dexct_host_touch(addr, n, _TOUCH_THREADS)
+                # (a piece that cannot be locked - a locked-memory limit - is copied through the runtime's staging: same result)
+                if self.lib.dexct_host_pin(addr, n, self.dev) == 0:
+                    self.locked.append(addr)
+            self.ready[k].set()
+
+    def download(self, k, src_address, stream):
+        """piece k of the result from device memory at ``src_address``: one copy per locked span it touches (a copy must stay
+        inside one locked region; its first bytes may lie in the last page of a piece before)"""
+        from . import _native
+        self.ready[k].wait()
+        addr, n = self.pieces[k]
+        for lo, m in self.spans[:k + 1]:
+            b, e = max(lo, addr), min(lo + m, addr + n)
+            if e > b:
+                _native.check(self.lib.dexct_download(b, src_address + (b - addr), e - b, stream.cuda_stream), 'dexct_download')
+
+    def _unlock(self):
+        for ev in self.ready:
+            ev.wait()
+        for addr in self.locked:
+            self.lib.dexct_host_unpin(addr, self.dev)
+        self.locked = []
+
+    def __del__(self):                      # abandoned (an error between construction and finish): the block is still good
+        if getattr(self, 'buf', None) is not None:
+            self._unlock()
+            _give_back(self.buf)
+
+    def finish(self):
+        self._unlock()
+        owner = np.frombuffer(memoryview(self.buf), dtype=self.dtype)     # (views of it keep IT alive: its base is no ndarray)
+        weakref.finalize(owner, _give_back, self.buf).atexit = False
+        self.buf = None
+        return owner.reshape(self.shape)

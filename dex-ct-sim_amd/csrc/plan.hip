@@ -8,6 +8,9 @@
 // restates the same operations in the same order; build with -ffp-contract=off).
 #include "common.h"
 #include <dlfcn.h>
+#include <sys/mman.h>
+#include <thread>
+#include <vector>
 
 namespace dexct {
 
@@ -301,7 +304,41 @@ int dexct_last_hip_error(void) { return g_last_hip_error; }
 int dexct_host_pin(void* host, int64_t n_bytes, int32_t device) {
   if (!host || n_bytes <= 0 || device < 0) return DEXCT_EINVAL;
   DEXCT_HIP_TRY(hipSetDevice(device));
-  DEXCT_HIP_TRY(hipHostRegister(host, (size_t)n_bytes, hipHostRegisterDefault));
+  hipError_t e = hipHostRegister(host, (size_t)n_bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {                  // (memory that is locked already, a locked-memory limit: the caller copies without)
+    (void)hipGetLastError();              // do not leave the refusal behind for the next launch check of this thread
+    return ::dexct::hip_fail(e);
+  }
+  return DEXCT_OK;
+}
+
+int dexct_host_touch(void* host, int64_t n_bytes, int32_t threads) {
+  // make the pages of [host, host + n_bytes) resident, `threads` parts at a time: a page fault of fresh memory (zeroing included)
+  // is what page-locking it costs; memory that is resident locks in microseconds (tools/probes/pin_resident.py)
+  if (!host || n_bytes <= 0 || threads < 1 || threads > 64) return DEXCT_EINVAL;
+  const uintptr_t page = 4096, huge = (uintptr_t)1 << 21;
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(host) / page * page;
+  const uintptr_t hi = (reinterpret_cast<uintptr_t>(host) + (uintptr_t)n_bytes + page - 1) / page * page;
+  auto part = [](uintptr_t b, uintptr_t e) {
+    if (e <= b) return;
+#ifdef MADV_POPULATE_WRITE
+    if (madvise(reinterpret_cast<void*>(b), e - b, MADV_POPULATE_WRITE) == 0) return;
+#endif
+    for (uintptr_t a = b; a < e; a += 4096) {          // (kernels before 5.14: a read-modify-write of one byte per page)
+      volatile unsigned char* q = reinterpret_cast<volatile unsigned char*>(a);
+      *q = *q;
+    }
+  };
+  std::vector<uintptr_t> cut{lo};
+  for (int k = 1; k < threads; ++k) {
+    uintptr_t c = (lo + (hi - lo) / threads * k) / huge * huge;
+    if (c > cut.back() && c < hi) cut.push_back(c);
+  }
+  cut.push_back(hi);
+  std::vector<std::thread> pool;
+  for (size_t k = 1; k + 1 < cut.size(); ++k) pool.emplace_back(part, cut[k], cut[k + 1]);
+  part(cut[0], cut[1]);
+  for (auto& t : pool) t.join();
   return DEXCT_OK;
 }
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _native, _shard
-from ._device import device, pinned_empty, ptr, stream_ptr, to_dev
+from ._device import LazyPinnedResult, device, pinned_empty, pool_wanted, ptr, stream_ptr, to_dev
 
 
 def effective_weights(ct, spec):
@@ -547,6 +547,9 @@ def _projector(ct, phantom, view_range):
     return pj, bool(_verify_enabled() and pj.volume_hash is not None)
 
 
+_DOWNLOAD_PIECE = 128 << 20     # bytes of a large result per copy (and per step of the page-locking in front of it)
+
+
 def get_sinos(ct, phantom, specs, noise=False, seed=0, quadrature=None):
     """Several spectra from ONE traversal (path lengths are energy independent).
 
@@ -574,12 +577,27 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0, quadrature=None):
         counts, log = res
     # both results start towards page-locked host memory; the checksum of the volume is computed while the kernels and the
     # copies run; one wait for everything
-    h_raw, h_lg = pinned_empty(counts.shape, counts.dtype), pinned_empty(log.shape, log.dtype)
-    h_raw.copy_(counts, non_blocking=True)
-    h_lg.copy_(log, non_blocking=True)
-    stale = check and _hash64(phantom.volume) != pj.volume_hash
-    torch.cuda.current_stream().synchronize()
-    raw, lg = h_raw.numpy(), h_lg.numpy()
+    n_bytes = counts.numel() * 4
+    if pool_wanted(n_bytes):
+        # large results: blocks of the host pool - locked already, or (a process's first projections) locked piece by piece while
+        # the copies of the pieces before run (_device.LazyPinnedResult) - instead of two page-locked allocations in front of them
+        cuts = list(range(0, n_bytes, _DOWNLOAD_PIECE)) + [n_bytes]
+        lz = [LazyPinnedResult(pj.lib, tuple(t.shape), np.float32, cuts, pj.dev.index or 0) for t in (counts, log)]
+        cur = torch.cuda.current_stream()
+        for k in range(len(cuts) - 1):
+            for holder, t in zip(lz, (counts, log)):
+                holder.download(k, t.data_ptr() + cuts[k], cur)
+        stale = check and _hash64(phantom.volume) != pj.volume_hash
+        cur.synchronize()
+        raw, lg = lz[0].finish(), lz[1].finish()
+        h_raw = h_lg = None
+    else:
+        h_raw, h_lg = pinned_empty(counts.shape, counts.dtype), pinned_empty(log.shape, log.dtype)
+        h_raw.copy_(counts, non_blocking=True)
+        h_lg.copy_(log, non_blocking=True)
+        stale = check and _hash64(phantom.volume) != pj.volume_hash
+        torch.cuda.current_stream().synchronize()
+        raw, lg = h_raw.numpy(), h_lg.numpy()
     if stale:
         # phantom.volume was edited in place since the device state was built (no touch()): what was just computed is of
         # the old bytes.  Rebuild from the current ones and project again - the result is what the reference, which

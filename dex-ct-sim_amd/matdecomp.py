@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _native, _shard, xcompy as xc
-from ._device import device, pinned_empty, ptr, stream_ptr, to_dev, to_host
+from ._device import LazyPinnedResult, device, locked_arrays, pinned_empty, pool_wanted, ptr, stream_ptr, to_dev, to_host
 
 # Basis materials, as data (matdecomp.py:11-17).
 mat1 = 'ICRU tissue'
@@ -563,89 +563,6 @@ _PIPE_CHUNKS = 8                 # view chunks of the pipelined host boundary (t
 _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinogram) the plain sequence is as fast
 
 
-# Page-locked memory of a result's size that torch's caching host allocator holds without a user: what pinned_empty hands out at
-# no cost.  Kept by hand (the allocator's own statistics do not say: torch.cuda.host_memory_stats() never sees a block freed):
-# set by the thread that puts a block into the reserve after a first large call, and by the path that uses pinned_empty.
-_reserve = {'bytes': 0}
-
-
-class _LazyPinnedResult:
-    """The result array of a FIRST large call: a plain NumPy array whose view chunks are page-locked one after the other by helper
-    threads (dexct_host_pin; each chunk in _PIN_THREADS pieces at once: locking is the kernel faulting pages in, one thread does
-    16 GB/s) while the kernels and the copies of the chunks before them run - instead of one page-locked allocation of the whole
-    result in front of everything (0.3 s for the 6.5 GB of the benchmark's size: what the reference's one call per run,
-    main.py:153, would always pay; locking runs at 24 GB/s however many threads ask, tools/probes/pin_threads.py, and a page-locked
-    allocation of torch at 11).  Unlocked again after the last copy; then the same thread puts a page-locked block of the
-    result's size into the allocator's reserve, so that later calls of the process take the cheap path (pinned_empty: 0.175 s
-    against 0.36 here) - a second call that comes before the reserve is there is served like the first."""
-
-    _PIN_THREADS = 2
-
-    def __init__(self, lib, shape, bounds, device_index):
-        import threading
-        self.lib, self.dev = lib, int(device_index)
-        self.shape = tuple(shape)
-        self.array = np.empty(shape, dtype=np.float64)
-        row = int(np.prod(shape[1:])) * 8
-        self.pieces = [(self.array.ctypes.data + b * row, (e - b) * row) for b, e in bounds]
-        # the chunks as page-aligned spans that tile the array without overlap (a page shared by two chunks belongs to the earlier
-        # one: locking it twice is an error), each cut into _PIN_THREADS pieces on 2 MiB boundaries
-        small, big = 4096, 1 << 21
-        cuts = [self.pieces[0][0] // small * small] + [-(-(addr + n) // small) * small for addr, n in self.pieces]
-        self.spans = []
-        for k in range(len(self.pieces)):
-            lo, hi = cuts[k], cuts[k + 1]
-            inner = sorted({lo, hi} | {c for c in ((lo + (hi - lo) * j // self._PIN_THREADS) // big * big for j in range(1, self._PIN_THREADS))
-                                       if lo < c < hi})
-            self.spans.append([(x, y - x) for x, y in zip(inner[:-1], inner[1:])])
-        self.ready = [threading.Event() for _ in bounds]
-        self.release = threading.Event()
-        self.thread = threading.Thread(target=self._run, daemon=True)
-        self.thread.start()
-
-    def _run(self):
-        from concurrent.futures import ThreadPoolExecutor
-        pinned = []
-
-        def lock(span):
-            return span if self.lib.dexct_host_pin(span[0], span[1], self.dev) == 0 else None
-
-        with ThreadPoolExecutor(self._PIN_THREADS) as pool:
-            for k, spans in enumerate(self.spans):
-                # (a piece that cannot be locked - a locked-memory limit - is copied through pageable memory: same result)
-                pinned += [sp for sp in pool.map(lock, spans) if sp is not None]
-                self.ready[k].set()
-            self.release.wait()
-            list(pool.map(lambda sp: self.lib.dexct_host_unpin(sp[0], self.dev), pinned))
-        self.array = None                     # (the thread held the array alive until its pages were unlocked)
-        n_bytes = 8 * int(np.prod(self.shape))
-        if _reserve['bytes'] < n_bytes and not _reserve.get('filling'):
-            _reserve['filling'] = True
-            try:                              # the reserve for the process's later calls
-                del_me = torch.empty(self.shape, dtype=torch.float64, pin_memory=True)
-                del del_me
-                _reserve['bytes'] = n_bytes
-            except RuntimeError:
-                pass
-            _reserve['filling'] = False
-
-    def download(self, k, src, stream):
-        """chunk k of the result from device memory: one copy per locked span it touches (a copy must stay inside one locked
-        region; its first bytes may lie in the last page of the chunk before)"""
-        self.ready[k].wait()
-        addr, n = self.pieces[k]
-        src_ptr = ptr(src)
-        for lo, m in (self.spans[k - 1][-1:] if k else []) + self.spans[k]:
-            b, e = max(lo, addr), min(lo + m, addr + n)
-            if e > b:
-                _native.check(self.lib.dexct_download(b, src_ptr + (b - addr), e - b, stream.cuda_stream), 'dexct_download')
-
-    def finish(self):
-        out = self.array
-        self.release.set()
-        return out
-
-
 def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level=None, audit=None,
                               audit_strict=None):
     """get_basismat_sinos for NumPy sinograms of benchmark size: sinogram 1 goes to the device first (the mask needs its
@@ -654,29 +571,35 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
     computes.  Same kernels on the same pixels as the plain sequence: bit-identical results."""
     a1 = np.ascontiguousarray(s1)
     a2 = np.ascontiguousarray(s2)
+    npdt = np.float32 if a1.dtype == np.float32 else np.float64
+    a1, a2 = a1.astype(npdt, copy=False), a2.astype(npdt, copy=False)
+    # the inputs are locked for the time of the call: their uploads run as DMA, whoever allocated them
+    with locked_arrays(lib, [a1, a2], dev.index or 0):
+        return _pipeline(lib, dev, a1, a2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level, audit, audit_strict)
+
+
+def _pipeline(lib, dev, a1, a2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level, audit, audit_strict):
     dt = torch.float32 if a1.dtype == np.float32 else torch.float64
-    npdt = np.float32 if dt == torch.float32 else np.float64
-    h1 = torch.from_numpy(a1.astype(npdt, copy=False))
-    h2 = torch.from_numpy(a2.astype(npdt, copy=False))
+    h1 = torch.from_numpy(a1)
+    h2 = torch.from_numpy(a2)
     n_views = h1.shape[0]
     main = torch.cuda.current_stream()
     copy = torch.cuda.Stream()
-    g1 = h1.to(dev, non_blocking=True)                      # (one DMA when the array is page-locked, e.g. a get_sino result)
+    g1 = h1.to(dev, non_blocking=True)                      # (one DMA: the array is page-locked)
     g2 = torch.empty_like(g1)
     gmax = torch.empty((), dtype=torch.float64, device=dev)
     _native.check(lib.dexct_reduce_max(ptr(g1), int(dt == torch.float64), g1.numel(), ptr(gmax), stream_ptr()),
                   'dexct_reduce_max')
     a = torch.empty(tuple(g1.shape) + (2,), dtype=torch.float64, device=dev)
     bounds = [_shard.split(n_views, k, _PIPE_CHUNKS) for k in range(_PIPE_CHUNKS)]
-    # where the results land: page-locked memory the allocator still holds from an earlier call - or, on a first call, a plain
-    # array locked chunk by chunk while the pipeline runs (_LazyPinnedResult)
-    out_bytes = 16 * g1.numel()
+    # where the results land: a block of host memory that is touched (a new one) and locked chunk by chunk while the pipeline
+    # runs (_device.LazyPinnedResult)
     lazy = host = None
-    if _reserve['bytes'] < out_bytes and os.environ.get('DEXCT_LAZY_PIN', '1') != '0':
-        lazy = _LazyPinnedResult(lib, tuple(g1.shape) + (2,), bounds, dev.index or 0)
+    if pool_wanted(16 * g1.numel()):
+        row = 16 * int(np.prod(g1.shape[1:]))
+        lazy = LazyPinnedResult(lib, tuple(g1.shape) + (2,), np.float64, [b * row for b, _ in bounds] + [n_views * row], dev.index or 0)
     else:
         host = pinned_empty(tuple(g1.shape) + (2,), torch.float64)
-        _reserve['bytes'] = max(_reserve['bytes'], out_bytes)       # (back in the allocator's reserve once the caller lets go of it)
     arrived = []
     copy.wait_stream(main)
     with torch.cuda.stream(copy):                           # all of sinogram 2 is queued at once, chunk by chunk
@@ -713,13 +636,13 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
         with torch.cuda.stream(copy):
             copy.wait_event(done)
             if lazy is not None:
-                lazy.download(k, a[b:e], copy)
+                lazy.download(k, ptr(a[b:e]), copy)
             else:
                 host[b:e].copy_(a[b:e], non_blocking=True)
     main.wait_stream(copy)
     main.synchronize()
     copy.synchronize()
-    out = lazy.finish() if lazy is not None else host.numpy()          # (every copy has landed: the pages may be unlocked)
+    out = lazy.finish() if lazy is not None else host.numpy()          # (every copy has landed)
     if strict:
         bad = ~torch.isfinite(a).all(dim=-1)
         n_bad = int(bad.sum().item())

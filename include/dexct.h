@@ -267,6 +267,8 @@ int dexct_sino_gather(const float* local, float* gathered, const int64_t* counts
  * stream, unlock it again.  A result array is locked piece by piece while the kernels of the pieces before it run
  * (dex-ct-sim_amd/matdecomp.py, _basismat_sinos_pipelined): a first call does not wait for one large page-locked allocation. */
 int dexct_host_pin(void* host, int64_t n_bytes, int32_t device);
+/* make the pages of [host, host + n_bytes) resident with `threads` (1..64) threads; the bytes are left as they are */
+int dexct_host_touch(void* host, int64_t n_bytes, int32_t threads);
 int dexct_host_unpin(void* host, int32_t device);
 int dexct_download(void* host, const void* device_src, int64_t n_bytes, void* stream);
 

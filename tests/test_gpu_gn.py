@@ -1051,34 +1051,79 @@ def test_gate_table_survives_the_process_on_disk(hip, golden, tmp_path, monkeypa
 
 
 def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
-    """matdecomp._LazyPinnedResult: a first large call (no page-locked memory in the allocator's reserve) returns a plain NumPy
-    array that was locked chunk by chunk while the pipeline ran (dexct_host_pin / dexct_download / dexct_host_unpin) - the same
-    bits as the path through one page-locked allocation, both results owned by the caller."""
-    from dex_ct_sim_amd import matdecomp as md
+    """_device.LazyPinnedResult, its pool and locked_arrays: a large result lands in plain host memory that was touched and
+    page-locked piece by piece while the GPU worked (dexct_host_touch / _pin / dexct_download) and is unlocked again before the
+    caller sees it; when the arrays are garbage the block - resident - serves the next result of its size.  The same bits as
+    the path through torch's page-locked allocations, for get_basismat_sinos (chunks of the pipeline; inputs locked for the
+    call) and get_sino (one kernel, pieces of the copy); the results are the caller's alone and ordinary memory for torch."""
+    import gc
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import _device, forward_project as fp, matdecomp as md, synthetic
+    from conftest import small_scan
     g = golden
     ct = types.SimpleNamespace(det_E=g['gn0_det_E'], det_eta_E=g['gn0_det_eta'], eid=bool(g['gn0_eid']))
     s1 = types.SimpleNamespace(E=g['gn0_spec1_E'], I0=g['gn0_spec1_I0'])
     s2 = types.SimpleNamespace(E=g['gn0_spec2_E'], I0=g['gn0_spec2_I0'])
     rng = np.random.default_rng(9)
     base = np.tile(g['gn0_g'], (1, 30, 40)) * rng.uniform(0.7, 1.0, (120, 1280))          # [2, 120 views, 1280 bins]
-    a1, a2 = base[0].astype(np.float32), base[1].astype(np.float32)
+    both = base.astype(np.float32)
+    a1, a2 = both[0], both[1]                                                             # adjacent in memory: one locked span
+    bits = lambda x: x.view(np.int64)
     monkeypatch.setattr(md, '_PIPE_MIN_PIXELS', 1)
-    used = []
-    real = md._LazyPinnedResult
-    monkeypatch.setattr(md, '_LazyPinnedResult', lambda *a, **k: (used.append(1), real(*a, **k))[1])
-    monkeypatch.setitem(md._reserve, 'bytes', 0)                                          # "a first call"
-    lazy = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
-    assert used == [1]
-    monkeypatch.setitem(md._reserve, 'bytes', 1 << 40)                                    # plenty in reserve: one page-locked tensor
-    pinned = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
-    assert used == [1]
+    used, locks = [], []
+    real, real_locks = _device.LazyPinnedResult, _device.locked_arrays
+    monkeypatch.setattr(md, 'LazyPinnedResult', lambda *a, **k: (used.append(real(*a, **k)), used[-1])[1])
+    monkeypatch.setattr(fp, 'LazyPinnedResult', lambda *a, **k: (used.append(real(*a, **k)), used[-1])[1])
+    monkeypatch.setattr(md, 'locked_arrays', lambda lib, arrs, d: (locks.append(real_locks(lib, arrs, d, min_bytes=1)), locks[-1])[1])
+    monkeypatch.setattr(_device, 'LAZY_MIN_BYTES', 1)
+    _device.empty_pool()
+    first = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert [u.fresh for u in used] == [True] and not _device._pool and not used[0].locked
+    assert len(locks[0].spans) == 1 and not locks[0].locked                               # (locked inside, unlocked again)
+    second = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)                        # the first result is alive: a second block
+    assert [u.fresh for u in used] == [True, True]
     for k in range(2):
-        assert lazy[k].shape == (120, 1280) and np.array_equal(lazy[k].view(np.int64), pinned[k].view(np.int64))
-    assert lazy[0].base is lazy[1].base and 0 < (lazy[0] == 0).sum() < lazy[0].size      # two views of one buffer, like the reference's; air masked
-    monkeypatch.setenv('DEXCT_LAZY_PIN', '0')
-    monkeypatch.setitem(md._reserve, 'bytes', 0)
-    md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
-    assert used == [1]                                                                    # switched off
+        assert first[k].shape == (120, 1280) and np.array_equal(bits(first[k]), bits(second[k]))
+    assert 0 < (first[0] == 0).sum() < first[0].size                                      # (air masked)
+    on_device = torch.from_numpy(first[0]).to('cuda')                                     # ordinary memory for the caller's own copies
+    assert not torch.from_numpy(first[0]).is_pinned() and np.array_equal(bits(on_device.cpu().numpy()), bits(first[0]))
+    keep = first[1][5:7]                                                                  # a view of a view keeps the block out of the pool
+    address = first[0].ctypes.data
+    del first
+    gc.collect()
+    assert not _device._pool
+    copy_of_keep = keep.copy()
+    del keep
+    gc.collect()
+    assert [len(v) for v in _device._pool.values()] == [1]
+    third = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)                         # ... and now it is reused (nothing to touch)
+    assert [u.fresh for u in used] == [True, True, False] and third[0].ctypes.data == address and not any(_device._pool.values())
+    assert np.array_equal(bits(third[1]), bits(second[1])) and np.array_equal(bits(third[1][5:7]), bits(copy_of_keep))
+    pinned_in = torch.from_numpy(a1).pin_memory().numpy()                                 # an input that is locked already: left alone
+    fourth = md.get_basismat_sinos(ct, pinned_in, a2, s1, s2, n_iters=30)
+    assert np.array_equal(bits(fourth[0]), bits(second[0])) and len(locks[-1].spans) == 2
+    monkeypatch.setenv('DEXCT_LAZY_PIN', '0')                                             # switched off: torch's allocation
+    plain = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
+    assert len(used) == 4 and np.array_equal(bits(plain[0]), bits(second[0]))
+    # get_sino: both outputs
+    cts, ph = small_scan(n=64, nz=16, n_views=40, n_channels=96, n_rows=16)
+    spec = synthetic.kramers_spectrum(120)
+    fp.invalidate()
+    r_pin, l_pin = dx.get_sino(cts, ph, spec)
+    assert len(used) == 4
+    monkeypatch.delenv('DEXCT_LAZY_PIN')
+    monkeypatch.setattr(_device, 'LAZY_MIN_BYTES', 100 << 10)                             # two pieces of the 240 KiB
+    monkeypatch.setattr(fp, '_DOWNLOAD_PIECE', 128 << 10)
+    r_lazy, l_lazy = dx.get_sino(cts, ph, spec)
+    assert [u.fresh for u in used[4:]] == [True, True] and len(used[4].pieces) == 2       # raw and log
+    assert np.array_equal(r_lazy, r_pin) and np.array_equal(l_lazy, l_pin) and r_lazy.shape == (40, 16, 96)
+    del r_lazy, l_lazy
+    gc.collect()
+    r_again, l_again = dx.get_sino(cts, ph, spec)
+    assert [u.fresh for u in used[4:]] == [True, True, False, False] and np.array_equal(r_again, r_pin) and np.array_equal(l_again, l_pin)
+    del third, fourth, r_again, l_again, used
+    gc.collect()
+    assert _device.empty_pool() > 0 and not _device._pool
 
 
 @pytest.mark.parametrize('seed', [319, 525, 468, 1179, 4, 29, 126, 397])
