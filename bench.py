@@ -166,7 +166,6 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
     from dex_ct_sim_amd import _device, synthetic
 
     def fresh_process_state(cache_dir):
-        time.sleep(1.0)                      # (a reserve of page-locked memory may still be on its way from the sequence before)
         fp.invalidate()
         md._table_cache.clear()
         gc.collect()
@@ -218,8 +217,7 @@ def dropin_e2e(args, dx, fp, md, ct, ph, specs, det, dev):
         cold_nodisk, n = sequence(ct_, ph_, specs[0], specs[1])
         fresh_process_state(tmp)             # ... where the next "process" finds it
         cold, _ = sequence(ct_, ph_, specs[0], specs[1])
-        second, _ = sequence(ct_, ph_, specs[0], specs[1])        # (right behind the first: the page-locked reserve may still be on its way)
-        time.sleep(1.0)
+        second, _ = sequence(ct_, ph_, specs[0], specs[1])
         warm, _ = sequence(ct_, ph_, specs[0], specs[1])
         k_ms = kernel_ms(ct_, ph_, specs[0])
         d2h_sino = 2 * n * 4                       # sino_raw + sino_log, float32
@@ -318,6 +316,7 @@ def main():
     # decomposition directly from the Newton kernel (dexct_gn_options.out_rows / out_channels, ABI 3)
     counts = torch.empty((2, nV, rows, args.channels), dtype=torch.float32, device=dev) if native == 1 else counts_nat
     log_ref = torch.empty_like(counts) if native == 1 else log_nat
+    air_c = [(C.c_float * 2)(float(air[0]), float(air[1])), (C.c_float * 1)(float(air[1]))]      # host floats: both spectra / the second
     a_out = torch.empty((nV, rows, args.channels, 2), dtype=torch.float64, device=dev)
     out_rc = (rows, args.channels) if native == 1 else None
     # None: the default of get_basismat_sinos / dexct_gn_decompose (tolerance stop, 1e-12); 0.0: the fixed count exactly
@@ -346,10 +345,9 @@ def main():
     gather_mode = [args.gather]
 
     def step_sharded(timed):
-        """N > 1.  Plan (whole shard, once); per chunk of this rank's views: projection (sino_raw and sino_log), its maximum,
-        transpose into the reference's order and - point-to-point modes - the START of the chunk's transfer; then the global
-        maximum (one scalar all-reduce), the Newton launches chunk by chunk, the log sinograms' transposes, and the wait for the
-        transfers.  Mode 'all': one all_gather_into_tensor per spectrum, started after the last chunk (rounds 1-4)."""
+        """N > 1.  Plan (whole shard, once); per chunk of this rank's views: projection, its maximum,
+        transpose into the reference's order (sino_raw and, from the same pass, sino_log) and - point-to-point modes - the START of the chunk's transfer; then the global
+        maximum (one scalar all-reduce), the Newton launches chunk by chunk, and the wait for the transfers.  Mode 'all': one all_gather_into_tensor per spectrum, started after the last chunk (rounds 1-4)."""
         mode = gather_mode[0]
         st = stream_ptr()
         _native.check(lib.dexct_fan_plan(C.byref(pj.geom), ptr(pj.view_cs), ptr(pj.chan_cs), vb, ve, ptr(pj.plan), st), 'plan')
@@ -357,18 +355,23 @@ def main():
             ev[0].record()
         finishes = []
         for j, (b, e) in enumerate(cb):
-            pj.project_tables(mu_d, w_d, out=cn[j], layout=None, air=air, log_out=cl[j], views=(b, e))
+            # (row-parallel kernels: sino_log comes with the transpose into the reference's order, dexct_transpose_log)
+            if native == 1:
+                pj.project_tables(mu_d, w_d, out=cn[j], layout=None, views=(b, e))
+            else:
+                pj.project_tables(mu_d, w_d, out=cn[j], layout=None, air=air, log_out=cl[j], views=(b, e))
             _native.check(lib.dexct_reduce_max(ptr(cn[j][0]), 0, cn[j][0].numel(), ptr(cmax[j]), st), 'max')
             if mode == 'all':                    # the whole shard in one buffer [2, views, row, channel]
                 for k in range(2):
                     if native == 1:
-                        _native.check(lib.dexct_transpose_batched(ptr(cn[j][k]), ptr(counts[k, b:e]), e - b, args.channels, rows, 4, st),
-                                      'transpose counts')
+                        _native.check(lib.dexct_transpose_log(ptr(cn[j][k]), ptr(counts[k, b:e]), ptr(clr[j][k]), air_c[k], 1, e - b,
+                                                              args.channels, rows, st), 'transpose counts + log')
                     else:
                         counts[k, b:e].copy_(cn[j][k])
             else:
                 if native == 1:
-                    _native.check(lib.dexct_transpose_batched(ptr(cn[j]), ptr(cr[j]), 2 * (e - b), args.channels, rows, 4, st), 'transpose counts')
+                    _native.check(lib.dexct_transpose_log(ptr(cn[j]), ptr(cr[j]), ptr(clr[j]), air_c[0], 2, e - b, args.channels, rows, st),
+                                  'transpose counts + log')
                 finishes.append(_shard.gather_views(cr[j], total_views, view_dim=1, async_op=True, out=full_out, mode=mode, root=0,
                                                     part=(j, n_chunks), tag='bench'))
         if mode == 'all':
@@ -384,9 +387,6 @@ def main():
                          stop_tol=gn_tol[0], two_level=gn_mode[0], accumulate_stats=j > 0)
         if timed:
             ev[3].record()
-        if native == 1:
-            for j, (b, e) in enumerate(cb):
-                _native.check(lib.dexct_transpose_batched(ptr(cl[j]), ptr(clr[j]), 2 * (e - b), args.channels, rows, 4, st), 'transpose log')
         # basis-material sinograms stay view-sharded (each rank owns its angles, as a view-sharded back-projection would
         # consume them); only the raw sinogram is assembled, as the north star says
         if timed:
@@ -406,7 +406,10 @@ def main():
                       'plan')
         if timed:
             ev[0].record()
-        pj.project_tables(mu_d, w_d, out=counts_nat, layout=None, air=air, log_out=log_nat)      # sino_raw AND sino_log
+        if native == 1:       # sino_log comes with the transpose into the reference's order below (one pass for both outputs)
+            pj.project_tables(mu_d, w_d, out=counts_nat, layout=None)
+        else:
+            pj.project_tables(mu_d, w_d, out=counts_nat, layout=None, air=air, log_out=log_nat)      # sino_raw AND sino_log
         if timed:
             ev[1].record()
         _native.check(lib.dexct_reduce_max(ptr(counts_nat[0]), 0, counts_nat[0].numel(), ptr(gmax), st), 'max')
@@ -420,10 +423,8 @@ def main():
         if timed:
             ev[3].record()
         if native == 1:       # hand the sinograms over in the reference's [view][row][channel] order
-            _native.check(lib.dexct_transpose_batched(ptr(counts_nat), ptr(counts), 2 * nV, args.channels, rows,
-                                                      4, st), 'transpose counts')
-            _native.check(lib.dexct_transpose_batched(ptr(log_nat), ptr(log_ref), 2 * nV, args.channels, rows, 4, st),
-                          'transpose log')
+            _native.check(lib.dexct_transpose_log(ptr(counts_nat), ptr(counts), ptr(log_ref), air_c[0], 2, nV, args.channels, rows, st),
+                          'transpose counts + log')
         return counts, a_out
 
     def barrier():
@@ -563,7 +564,9 @@ def main():
     seg_vc, _ = segment_count(co, geom, ct.view_cs(), ct.chan_cs(), total_views, vb, ve)
     # algorithmic bytes: S_ray x bytes per stored voxel + outputs; the packed volume stores a voxel in 2 bits
     b_vox = 0.25 if getattr(pj, 'use_packed', False) else 1.0
-    alg_bytes = seg_vc * rows * b_vox + 4 * 4 * n_rays          # 4 floats out per ray: sino_raw and sino_log of both spectra
+    # outputs of the timed launch: sino_raw of both spectra; sino_log too where the kernel writes it itself (row-parallel kernels
+    # leave it to the pass that brings both outputs into the reference's order, dexct_transpose_log)
+    alg_bytes = seg_vc * rows * b_vox + (2 if native == 1 else 4) * 4 * n_rays
     alg_gbps = alg_bytes / (sid_ms * 1e-3) / 1e9
     kname = 'rows16_kernel' if getattr(pj, 'use_packed', False) else \
         {1: 'rays_kernel', 2: 'rows_kernel', 3: 'rows4_kernel', 5: 'rows4t_kernel', 6: 'wave_ray_kernel'}[args.kernel or (3 if native == 1 else 1)]
@@ -672,9 +675,10 @@ def main():
                 'note': 'what the reference returns is the fixed point its walk from 1e-6 ends at - a function of the two counts, '
                         'tabulated once per pair of spectra by running the single launch on a 257 x 257 grid of counts.  A pixel '
                         'in a cell where that walk ends by the tolerance rule within n_iters steps, smoothly, starts from the '
-                        'interpolated fixed point (2e-8 of |a| from its own) and takes ONE full-table step where the cell\'s '
-                        'tabulated kappa (Newton\'s contraction there, measured by the calibration with the library\'s own '
-                        'kernel) puts what is left below stop_tol / 4 - else two, the second being the tolerance rule\'s '
+                        '6 x 6 Lagrange interpolant of the tabulated fixed points (1e-10 of |a| from its own) and takes ONE '
+                        'full-table step where the cell\'s tabulated kappa - an analytic bound on Newton\'s quadratic constant '
+                        'from the Hessian and third derivatives of the likelihood at the tabulated fixed points - times the '
+                        'squared step puts what is left below stop_tol / 4; else two, the second being the tolerance rule\'s '
                         'evidence of convergence of the FULL model (mode start: always two: value_two_step); accepted only on '
                         'the reference\'s branch; every other pixel is solved from 1e-6 with all n_iters steps in the same '
                         'launch.  Compared with the exact count on every pixel below (gn_exact)'}
@@ -829,10 +833,13 @@ def main():
         else:
             c_red, l_red = torch.empty_like(counts_nat), torch.empty_like(log_nat)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # both grids' outputs in the kernel's own layout for the comparison below (untimed; the step takes its log with the
+            # transpose), then the reduced grid timed like the step's projection: counts only
+            pj.project_tables(mu_d, w_d, out=counts_nat, layout=None, air=air, log_out=log_nat)
             pj.project_tables(mu_r, w_r, out=c_red, layout=None, air=air, log_out=l_red)
             e0.record()
             for _ in range(5):
-                pj.project_tables(mu_r, w_r, out=c_red, layout=None, air=air, log_out=l_red)
+                pj.project_tables(mu_r, w_r, out=c_red, layout=None)
             e1.record()
             torch.cuda.synchronize()
             ms_r = e0.elapsed_time(e1) / 5

@@ -54,6 +54,23 @@ def pinned_empty(shape, dtype):
         return torch.empty(tuple(shape), dtype=dtype)
 
 
+# ---- the streams of the pipelined host boundary ---------------------------------------------------------------------------------
+# The runtime maps streams onto a few hardware queues in the order they are made, and two streams on one queue take turns.  A pair
+# of fresh streams per call beside the kernels on the default stream landed on the default stream's queue every other call:
+# get_basismat_sinos alternated between 0.157 and 0.180 s (tools/probes/boundary_streams.py, profiles/r05_notes_boundary.md).
+# Three streams made back to back, once per device - compute, upload, download - sit on three different queues whatever the
+# default stream shares; the pipelined calls run their kernels on the first and wait for the caller's stream at entry.
+_side = {}
+
+
+def side_streams(dev):
+    """(compute, upload, download) streams of ``dev`` for the pipelined boundary; the same three for every call."""
+    key = str(dev)
+    if key not in _side:
+        _side[key] = tuple(torch.cuda.Stream(dev) for _ in range(3))
+    return _side[key]
+
+
 # ---- large results and large inputs: host memory made ready for DMA while the GPU works ---------------------------------------
 # Results cross PCIe by DMA into page-locked host memory that the returned arrays own.  A page-locked allocation (torch's, or
 # hipHostMalloc) of memory the process has never touched runs at 11 GB/s - 0.57 s for the 6.5 GB of the benchmark's

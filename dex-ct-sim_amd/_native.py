@@ -13,7 +13,7 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_reduce_max', 'dexct_transpose_batched', 'dexct_fbp_filter', 'dexct_fbp_backproject',
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
            'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
-           'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather', 'dexct_sino_gather', 'dexct_host_pin', 'dexct_host_touch', 'dexct_host_unpin', 'dexct_download',
+           'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather', 'dexct_sino_gather', 'dexct_transpose_log', 'dexct_host_pin', 'dexct_host_touch', 'dexct_host_unpin', 'dexct_download',
            'dexct_volume_ids', 'dexct_volume_remap', 'dexct_fbp_parker', 'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
 
 
@@ -124,6 +124,7 @@ def load():
                                                  i32, vp, vp, vp, vp]
     lib.dexct_siddon_project_grouped_packed.argtypes = lib.dexct_siddon_project_grouped.argtypes
     lib.dexct_transpose_batched.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    lib.dexct_transpose_log.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i64, i32, i32, vp]
     lib.dexct_fbp_filter.argtypes = [vp, vp, vp, i64, i32, f64, vp, vp]
     lib.dexct_fbp_parker.argtypes = [vp, i32, i32, i32, f64, f64, i32, i32, vp, vp]
     lib.dexct_fbp_backproject.argtypes = [vp, vp, i32, i32, i32, f64, f64, f64, i32, f64, vp, vp]

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _native, _shard
-from ._device import LazyPinnedResult, device, pinned_empty, pool_wanted, ptr, stream_ptr, to_dev
+from ._device import LazyPinnedResult, device, pinned_empty, pool_wanted, ptr, side_streams, stream_ptr, to_dev
 
 
 def effective_weights(ct, spec):
@@ -297,10 +297,12 @@ class Projector:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
         variance = torch.empty_like(counts) if w2_d is not None else None
+        # the log sinogram: written by the detection store when the kernel's layout is the one wanted; else together with the
+        # transpose at the end (dexct_transpose_log: the counts are read once for both outputs)
+        fuse_log = air is not None and not direct
         log = None
-        if air is not None:
-            log = log_out if (log_out is not None and direct) else torch.empty(shape[run_layout], dtype=torch.float32,
-                                                                               device=self.dev)
+        if air is not None and not fuse_log:
+            log = log_out if log_out is not None else torch.empty(shape[run_layout], dtype=torch.float32, device=self.dev)
         # fused into the detection store, except for noisy sinograms (their counts exist after the sampling)
         lo = _native.log_out(ptr(log), air) if (log is not None and w2_d is None) else None
         if self.cone:
@@ -375,20 +377,25 @@ class Projector:
         if not direct:
             dst = out if out is not None else torch.empty(shape[want], dtype=torch.float32, device=self.dev)
             r, c = (nC, nR) if run_layout == 1 else (nR, nC)
-            _native.check(self.lib.dexct_transpose_batched(ptr(counts), ptr(dst), S * nV, r, c, 4, stream_ptr()),
-                          'dexct_transpose_batched')
+            if fuse_log:
+                log = log_out if log_out is not None else torch.empty(shape[want], dtype=torch.float32, device=self.dev)
+            self.transpose_log(counts, dst, log, air, r, c)
             counts = dst
-            if log is not None:
-                dst = log_out if log_out is not None else torch.empty(shape[want], dtype=torch.float32, device=self.dev)
-                _native.check(self.lib.dexct_transpose_batched(ptr(log), ptr(dst), S * nV, r, c, 4, stream_ptr()),
-                              'dexct_transpose_batched')
-                log = dst
             if pathlen is not None:
                 pathlen = pathlen.permute(0, 2, 1, 3).contiguous()      # test-only output
         res = (counts, pathlen) if want_pathlen else (counts,)
         if log is not None:
             res = res + (log,)
         return res if len(res) > 1 else res[0]
+
+    def transpose_log(self, src, dst, log_dst, air, rows, cols):
+        """src [S, n, rows, cols] -> dst [S, n, cols, rows] and (``log_dst`` not None) ln(air[s] / dst[s]) in the same pass
+        (dexct_transpose_log)."""
+        import ctypes as _C
+        S, n = int(src.shape[0]), int(src.shape[1])
+        arr = (_C.c_float * S)(*[float(x) for x in air[:S]]) if log_dst is not None else None
+        _native.check(self.lib.dexct_transpose_log(ptr(src), ptr(dst), ptr(log_dst), arr, S, n, rows, cols, stream_ptr()),
+                      'dexct_transpose_log')
 
     def sino_log(self, counts, air, out=None):
         """ln(air[s] / counts[s]) as a pass of its own (dexct_sino_log): noisy and gathered sinograms."""
@@ -547,6 +554,47 @@ def _projector(ct, phantom, view_range):
     return pj, bool(_verify_enabled() and pj.volume_hash is not None)
 
 
+_SINO_CHUNKS = 8                # view chunks of a large noise-free projection on one process: chunk k + 1 is projected while chunk k
+                                # crosses PCIe (3.3 GB of results take 58 ms, their kernels 12)
+
+
+def _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature):
+    """get_sinos for a large scan on one process: the views are projected in _SINO_CHUNKS chunks (Projector.project_tables,
+    views=) and every chunk's two outputs leave for host memory on a download stream while the next chunk is projected.  The same
+    kernels on the same rays as the single launch: the same bits.  One host block per spectrum and output (_device.LazyPinnedResult:
+    touched and locked chunk by chunk in front of the copies, unlocked before it is returned)."""
+    _, mu_d, w_d, air = pj.upload_tables(specs, quadrature)
+    S, nV, nR, nC = len(specs), pj.n_local_views, ct.N_rows, ct.N_channels
+    bounds = [_shard.split(nV, k, _SINO_CHUNKS) for k in range(_SINO_CHUNKS)]
+    row = nR * nC * 4
+    cuts = [b * row for b, _ in bounds] + [nV * row]
+    holders = [[LazyPinnedResult(pj.lib, (nV, nR, nC), np.float32, cuts, pj.dev.index or 0) for _ in range(2)] for _ in range(S)]
+    main, _, down = side_streams(pj.dev)      # (kernels and downloads on queues of their own, _device.side_streams)
+    main.wait_stream(torch.cuda.current_stream())
+    keep = []                                  # (the chunks' device tensors live until their copies are done)
+    with torch.cuda.stream(main):
+        for k, (b, e) in enumerate(bounds):
+            c_k, l_k = pj.project_tables(mu_d, w_d, layout=0, air=air, views=(b, e))
+            keep.append((c_k, l_k))
+            done = torch.cuda.Event()
+            done.record(main)
+            down.wait_event(done)
+            for s_i in range(S):
+                holders[s_i][0].download(k, c_k[s_i].data_ptr(), down)
+                holders[s_i][1].download(k, l_k[s_i].data_ptr(), down)
+    stale = check and _hash64(phantom.volume) != pj.volume_hash        # (computed while the GPU works, as in get_sinos)
+    down.synchronize()
+    out = [(h[0].finish(), h[1].finish()) for h in holders]
+    del keep
+    if stale:
+        del out
+        invalidate()
+        return get_sinos(ct, phantom, specs, noise=False, seed=seed, quadrature=quadrature)
+    if nR == 1:
+        out = [(r[:, 0, :], l[:, 0, :]) for r, l in out]
+    return out
+
+
 _DOWNLOAD_PIECE = 128 << 20     # bytes of a large result per copy (and per step of the page-locking in front of it)
 
 
@@ -569,6 +617,9 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0, quadrature=None):
     vb, ve = _shard.my_views(ct.N_proj)
     pj, check = _projector(ct, phantom, (vb, ve))
     sharded = _shard.world()[1] > 1
+    per_array = ct.N_proj * ct.N_rows * ct.N_channels * 4
+    if not sharded and not noise and pool_wanted(per_array) and ct.N_proj >= 4 * _SINO_CHUNKS:
+        return _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature)
     res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded, quadrature=quadrature)
     if sharded:
         counts = _shard.gather_views(res, ct.N_proj, view_dim=1, tag='get_sinos')

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _native, _shard, xcompy as xc
-from ._device import LazyPinnedResult, device, locked_arrays, pinned_empty, pool_wanted, ptr, stream_ptr, to_dev, to_host
+from ._device import LazyPinnedResult, device, locked_arrays, pinned_empty, pool_wanted, side_streams, ptr, stream_ptr, to_dev, to_host
 
 # Basis materials, as data (matdecomp.py:11-17).
 mat1 = 'ICRU tissue'
@@ -566,8 +566,8 @@ _PIPE_MIN_PIXELS = 1 << 24       # below 16.8 M pixels (64 MiB per float32 sinog
 def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level=None, audit=None,
                               audit_strict=None):
     """get_basismat_sinos for NumPy sinograms of benchmark size: sinogram 1 goes to the device first (the mask needs its
-    global maximum, matdecomp.py:195-196), then per view chunk: sinogram 2's chunk arrives on a copy stream, the Newton
-    kernel runs on it, and the finished chunk leaves for page-locked host memory on the copy stream while the next chunk
+    global maximum, matdecomp.py:195-196), then per view chunk: sinogram 2's chunk arrives on an upload stream, the Newton
+    kernel runs on it, and the finished chunk leaves for page-locked host memory on a download stream while the next chunk
     computes.  Same kernels on the same pixels as the plain sequence: bit-identical results."""
     a1 = np.ascontiguousarray(s1)
     a2 = np.ascontiguousarray(s2)
@@ -575,16 +575,21 @@ def _basismat_sinos_pipelined(lib, dev, s1, s2, i0, mus, n_iters, mask_thresh, p
     a1, a2 = a1.astype(npdt, copy=False), a2.astype(npdt, copy=False)
     # the inputs are locked for the time of the call: their uploads run as DMA, whoever allocated them
     with locked_arrays(lib, [a1, a2], dev.index or 0):
-        return _pipeline(lib, dev, a1, a2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level, audit, audit_strict)
+        comp, up, down = side_streams(dev)
+        comp.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comp):
+            return _pipeline(lib, dev, a1, a2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level, audit, audit_strict,
+                             up, down)
 
 
-def _pipeline(lib, dev, a1, a2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level, audit, audit_strict):
+def _pipeline(lib, dev, a1, a2, i0, mus, n_iters, mask_thresh, precision, strict, stop_tol, two_level, audit, audit_strict, copy, down):
     dt = torch.float32 if a1.dtype == np.float32 else torch.float64
     h1 = torch.from_numpy(a1)
     h2 = torch.from_numpy(a2)
     n_views = h1.shape[0]
     main = torch.cuda.current_stream()
-    copy = torch.cuda.Stream()
+    # (copy / down: the upload and the download stream - PCIe carries both directions at once, and a result chunk must not queue
+    # behind the uploads of ALL later input chunks; the kernels run on the current stream, _device.side_streams)
     g1 = h1.to(dev, non_blocking=True)                      # (one DMA: the array is page-locked)
     g2 = torch.empty_like(g1)
     gmax = torch.empty((), dtype=torch.float64, device=dev)
@@ -633,15 +638,16 @@ def _pipeline(lib, dev, a1, a2, i0, mus, n_iters, mask_thresh, precision, strict
             gn_device(g1[b:e], g2[b:e], i0, mus, n_iters, precision, **kw)
         done = torch.cuda.Event()
         done.record(main)
-        with torch.cuda.stream(copy):
-            copy.wait_event(done)
+        with torch.cuda.stream(down):
+            down.wait_event(done)
             if lazy is not None:
-                lazy.download(k, ptr(a[b:e]), copy)
+                lazy.download(k, ptr(a[b:e]), down)
             else:
                 host[b:e].copy_(a[b:e], non_blocking=True)
     main.wait_stream(copy)
+    main.wait_stream(down)
     main.synchronize()
-    copy.synchronize()
+    down.synchronize()
     out = lazy.finish() if lazy is not None else host.numpy()          # (every copy has landed)
     if strict:
         bad = ~torch.isfinite(a).all(dim=-1)

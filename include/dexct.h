@@ -234,6 +234,15 @@ int dexct_poisson_detect(const float* pathlen, const float* mu, const float* pho
 int dexct_transpose_batched(const void* src, void* dst, int64_t batch, int32_t rows, int32_t cols,
                             int32_t elem_bytes, void* stream);
 
+/* The two outputs of get_sino (main.py:120-122) in the reference's [view][row][channel] order from the row-parallel kernels'
+ * native [view][channel][row] counts, in one pass: dst[b][c][r] = src[b][r][c] for b < n_spectra * batch_per_spectrum
+ * (float32), and - log_dst not NULL - log_dst[b][c][r] = ln(air[b / batch_per_spectrum] / dst[b][c][r]) with the arithmetic
+ * of dexct_log_out / dexct_sino_log (air: n_spectra HOST floats).  The counts are read once and written twice; the
+ * projection then needs no log output of its own.  Any shape (16-byte accesses when rows and cols are multiples of 4 and
+ * the pointers are aligned).  src must not overlap dst / log_dst. */
+int dexct_transpose_log(const float* src, float* dst, float* log_dst, const float* air, int32_t n_spectra,
+                        int64_t batch_per_spectrum, int32_t rows, int32_t cols, void* stream);
+
 /* Trace of single rays for parity tests: voxel-index sequence and segment lengths.
  * For each of n_rays rays (view, row, channel given in ray_vrc[3*r + {0,1,2}], view relative to
  * the plan's view_begin) writes up to max_seg segments: seg_voxel[r*max_seg + k] = linear voxel

@@ -167,3 +167,24 @@ def test_oracles_on_poisson_noisy_goldens(n_iters):
         air = e['noisy_g'][0] >= 0.95 * e['noisy_g'][0].max()
         assert air.sum() >= 12 and np.all(e['noisy_mat1'][air] == 0) and np.all(e['noisy_mat2'][air] == 0)
         assert close(np.stack([e['noisy_mat1'], e['noisy_mat2']], -1)[~air], e['noisy_a50'][~air])
+
+
+def test_stability_screen_sees_a_wandering_pixel():
+    """The sensitivities newton_solve returns for tools/soak_gn.py's stability screen: a pixel that wanders for 35 iterations
+    before it settles (soak seed 1795, pixel 2221) passes the sum of per-step uncertainties ('walk') and is caught by the twin
+    trajectories; its converging neighbours pass both, and the result itself does not depend on asking for the sensitivities."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from soak_cases import draw
+    c = draw(1795)
+    v, ch = divmod(2221, c['n_c'])
+    g = c['g'][:, v:v + 1, ch - 3:ch + 4]
+    with np.errstate(all='ignore'):
+        a, sens = go.newton_solve(g, c['i0'], c['mus'], c['n_iters'], return_sensitivity=True)
+        plain = go.newton_solve(g, c['i0'], c['mus'], c['n_iters'])
+    assert np.array_equal(a, plain, equal_nan=True)
+    eps = np.finfo(np.float64).eps
+    assert eps * sens['walk'][0, 3] <= 1e-11 and not sens['twin'][0, 3] <= 1e-11
+    others = [k for k in range(7) if k != 3 and np.isfinite(a[0, k]).all() and eps * sens['walk'][0, k] <= 1e-11]
+    assert len(others) >= 3 and all(sens['twin'][0, k] <= 1e-11 for k in others)

@@ -1114,25 +1114,33 @@ def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
     monkeypatch.delenv('DEXCT_LAZY_PIN')
     monkeypatch.setattr(_device, 'LAZY_MIN_BYTES', 100 << 10)                             # two pieces of the 240 KiB
     monkeypatch.setattr(fp, '_DOWNLOAD_PIECE', 128 << 10)
-    r_lazy, l_lazy = dx.get_sino(cts, ph, spec)
-    assert [u.fresh for u in used[4:]] == [True, True] and len(used[4].pieces) == 2       # raw and log
+    r_lazy, l_lazy = dx.get_sino(cts, ph, spec)                                           # projected and copied in 8 view chunks
+    assert [u.fresh for u in used[4:]] == [True, True] and len(used[4].pieces) == fp._SINO_CHUNKS          # raw and log
     assert np.array_equal(r_lazy, r_pin) and np.array_equal(l_lazy, l_pin) and r_lazy.shape == (40, 16, 96)
     del r_lazy, l_lazy
     gc.collect()
     r_again, l_again = dx.get_sino(cts, ph, spec)
     assert [u.fresh for u in used[4:]] == [True, True, False, False] and np.array_equal(r_again, r_pin) and np.array_equal(l_again, l_pin)
-    del third, fourth, r_again, l_again, used
+    # a noisy projection is one launch, its results copied in pieces (two of them here)
+    n_lazy = dx.get_sino(cts, ph, spec, noise=True, seed=5)
+    assert len(used) == 10 and len(used[8].pieces) == 2
+    monkeypatch.setenv('DEXCT_LAZY_PIN', '0')
+    n_pin = dx.get_sino(cts, ph, spec, noise=True, seed=5)
+    monkeypatch.delenv('DEXCT_LAZY_PIN')
+    assert len(used) == 10 and np.array_equal(n_lazy[0], n_pin[0]) and np.array_equal(n_lazy[1], n_pin[1])
+    del third, fourth, r_again, l_again, n_lazy, used
     gc.collect()
     assert _device.empty_pool() > 0 and not _device._pool
 
 
-@pytest.mark.parametrize('seed', [319, 525, 468, 1179, 4, 29, 126, 397])
+@pytest.mark.parametrize('seed', [319, 525, 468, 1179, 4, 29, 126, 397, 1795])
 def test_soak_cases_that_were_flagged(hip, seed):
     """tools/soak_gn.py cases that rounds 3-5 flagged (profiles/r04_soak_gn2.log, r05_soak_traj.log), through every invariant of the
-    campaign with the version-2 stability screen: 319 / 525 (3 energies, photon-starved pixels creeping through Hessians of
+    campaign with the version-3 stability screen: 319 / 525 (3 energies, photon-starved pixels creeping through Hessians of
     condition 1e9 - 1e11 at the last iteration: three arithmetics, three answers), 468 (2 energies, the same), 1179 (the
     tolerance rule before it asked for two contracting steps), 4 (one energy: a line of solutions), 29 / 126 / 397 (a chaotic
-    transient that converges afterwards)."""
+    transient that converges afterwards), 1795 (a pixel that wanders for 35 iterations before it settles: the twin-trajectory
+    rule of version 3)."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

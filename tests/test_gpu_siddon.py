@@ -244,6 +244,38 @@ def test_native_layout_plus_transpose_equals_reference_layout(hip):
     assert torch.equal(b, a.permute(0, 2, 1, 3))
 
 
+@pytest.mark.parametrize('rows,cols', [(64, 64), (100, 72), (800, 512), (52, 16), (37, 16), (40, 50), (3, 5)])
+def test_transpose_with_the_log_sinogram_in_one_pass(hip, rows, cols):
+    """dexct_transpose_log: [S n][rows][cols] counts -> [S n][cols][rows] and ln(air[s] / counts) of the transposed counts from
+    the same registers - bit for bit the generic transpose followed by dexct_sino_log (the detection store's arithmetic), for
+    tile-aligned, ragged and non-vectorisable shapes, with and without the log, and on a misaligned view."""
+    import ctypes as C
+    from dex_ct_sim_amd import _native
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+    lib = _native.load()
+    S, n = 2, 3
+    gen = torch.Generator(device='cuda').manual_seed(rows * 1000 + cols)
+    src = torch.rand((S, n, rows, cols), generator=gen, device='cuda') * 1e5 + 1e-3
+    src[0, 0, 0, 0] = 0.0                                                    # counts == 0 -> +inf like the NumPy expression
+    air = (C.c_float * S)(3.0e5, 1.5e5)
+    want = src.permute(0, 1, 3, 2).contiguous()
+    want_log = torch.empty_like(want)
+    _native.check(lib.dexct_sino_log(ptr(want), air, S, n * rows * cols, ptr(want_log), stream_ptr()), 'dexct_sino_log')
+    dst, log = torch.zeros_like(want), torch.zeros_like(want)
+    _native.check(lib.dexct_transpose_log(ptr(src), ptr(dst), ptr(log), air, S, n, rows, cols, stream_ptr()), 'dexct_transpose_log')
+    assert torch.equal(dst, want) and torch.equal(log, want_log) and torch.isinf(log[0, 0, 0, 0])
+    only = torch.zeros_like(want)
+    _native.check(lib.dexct_transpose_log(ptr(src), ptr(only), None, None, S, n, rows, cols, stream_ptr()), 'dexct_transpose_log')
+    assert torch.equal(only, want)
+    # a view that starts 4 bytes into its buffer: the 16-byte path does not apply, the values are the same
+    buf = torch.zeros(src.numel() + 1, device='cuda')
+    off = buf[1:].view_as(src).copy_(src)
+    dst2, log2 = torch.zeros_like(want), torch.zeros_like(want)
+    _native.check(lib.dexct_transpose_log(ptr(off), ptr(dst2), ptr(log2), air, S, n, rows, cols, stream_ptr()), 'dexct_transpose_log')
+    assert torch.equal(dst2, want) and torch.equal(log2, want_log)
+    assert lib.dexct_transpose_log(ptr(src), ptr(dst), ptr(log), None, S, n, rows, cols, stream_ptr()) < 0      # a log without air values
+
+
 def test_more_than_512_slabs_per_ray(hip):
     """640 x 600 grid: rays cross up to 640 slabs, i.e. two staging passes of the packed-count kernel and
     more than 248 slabs between flushes of its byte counters; all kernels still equal the oracle bit for bit."""
