@@ -637,6 +637,9 @@ def main():
     gn_name = ('gn_shortcut_kernel (start values from the table of the reference\'s fixed points + full-table steps)' if two_level
                else 'gn_refill_kernel<false>') if precision == 'f64' else 'gn_kernel<true,false>'
     main_ms = gstats['main_ms'] if gstats else gn_ms      # HIP events around the launch, on its stream, last timed step
+    gn_form = two_level and gstats.get('mode') == 'one'    # the one step of the short cut is of the Gauss-Newton form: 6 of the 12 sums
+    if gn_form:
+        hw_share = (17.0 * n_both + 11.0 * n_one) / (29.0 * i0.shape[1])
     roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
             'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': main_ms, 'gn_ms_all_launches': gn_ms,
             'traffic': ((prof.get('gn_fetch_bytes_raw', 0) if prof.get('gn_fetch_counted_in_full') else prof.get('gn_fetch_bytes_x2_corrected', 0))
@@ -664,9 +667,16 @@ def main():
                              '(6 accumulations instead of 12) and %d none (dropped), so the FP64 flops the hardware issues are '
                              'hardware_fp64_flop_share = %.2f of that and hardware_fp64_utilisation = share x frac; the rest of '
                              'the fully busy vector pipe is integer / move work and the per-iteration 2x2 solve '
-                             '(profiles/r03_gn_isa.md).  exit_saving = share of the n_iters x pixels full-table iterations the '
+                             '(profiles/r03_gn_isa.md).%s  exit_saving = share of the n_iters x pixels full-table iterations the '
                              'two-level solve and the exits made unnecessary - reported separately, not as throughput'
-                             % (i0.shape[1], n_both, n_one, i0.shape[1] - n_both - n_one, hw_share)})
+                             % (i0.shape[1], n_both, n_one, i0.shape[1] - n_both - n_one, hw_share,
+                                '  The ONE step per pixel of the default short cut is of the Gauss-Newton form (the Hessian without '
+                                'its (g / nu - 1) x second-derivative term - a second-order effect the tabulated kappa includes): 6 of the 12 '
+                                'accumulations per energy, already taken out of hardware_fp64_flop_share; frac counts the unit of '
+                                'SURVEY 8d - one Newton iteration of one pixel - at the reference\'s 29 flops per energy as for '
+                                'every other mode' if gn_form else '')})
+        if gn_form:
+            roof['one_step_form'] = 'gauss-newton (6 of 12 sums per energy; the dropped term is second order and inside the tabulated kappa)'
         if two_level:
             roof['short_cut'] = {
                 'mode': gstats['mode'], 'launch_ms': main_ms, 'full_energies': int(i0.shape[1]),

@@ -86,7 +86,8 @@ __device__ __forceinline__ double rcp_f64(double x) {
 // (nB), only spectrum 1 (nC); energies no spectrum weights are dropped.  A zero weight contributes exactly
 // 0 to every sum (the attenuation factor is finite thanks to the clip), so skipping those FMAs changes no
 // term of the reference's sums - only their order.
-template <int KSEL, bool CLIP>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip
+template <int KSEL, bool CLIP, bool HESS = true>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip;
+                                                   // HESS: also the three second-derivative sums (false: the Gauss-Newton form of the step)
 __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 int e0, int e1, double a0, double a1, double (&nu)[2], double (&nuo)[2],
                                                 double (&G0)[2], double (&G1)[2], double (&H00)[2], double (&H01)[2],
@@ -108,9 +109,11 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
       nuk[k] = fma(tk[0], at, nuk[k]);
       G0[k] = fma(tk[1], at, G0[k]);
       G1[k] = fma(tk[2], at, G1[k]);
-      H00[k] = fma(tk[3], at, H00[k]);
-      H01[k] = fma(tk[4], at, H01[k]);
-      H11[k] = fma(tk[5], at, H11[k]);
+      if (HESS) {
+        H00[k] = fma(tk[3], at, H00[k]);
+        H01[k] = fma(tk[4], at, H01[k]);
+        H11[k] = fma(tk[5], at, H11[k]);
+      }
     }
   };
   int e = e0;
@@ -132,7 +135,7 @@ struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; }
 // split the energy loop of the same 64 pixels.
 struct GnSums { double nu[2], G0[2], G1[2], H00[2], H01[2], H11[2]; };
 
-template <int NPARTS>
+template <int NPARTS, bool HESS = true>
 __device__ __forceinline__ void newton_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 EnergyClasses ec, int part, double a0, double a1, GnSums& s) {
   double nu[2] = {0, 0}, nuo[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
@@ -140,21 +143,21 @@ __device__ __forceinline__ void newton_sums_f64(const double* __restrict__ tab, 
   auto lo = [&](int b, int e) { return NPARTS == 1 ? b : b + (e - b) * part / NPARTS; };
   auto hi = [&](int b, int e) { return NPARTS == 1 ? e : b + (e - b) * (part + 1) / NPARTS; };
   // the always-clipped heads of the three classes
-  energy_sums_f64<0, true>(tab, lds_pow, lo(bA, bA + ec.nAc), hi(bA, bA + ec.nAc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<1, true>(tab, lds_pow, lo(bB, bB + ec.nBc), hi(bB, bB + ec.nBc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<2, true>(tab, lds_pow, lo(bC, bC + ec.nCc), hi(bC, bC + ec.nCc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<0, true, HESS>(tab, lds_pow, lo(bA, bA + ec.nAc), hi(bA, bA + ec.nAc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<1, true, HESS>(tab, lds_pow, lo(bB, bB + ec.nBc), hi(bB, bB + ec.nBc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<2, true, HESS>(tab, lds_pow, lo(bC, bC + ec.nCc), hi(bC, bC + ec.nCc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
   const int tA0 = lo(bA + ec.nAc, bA + ec.nA), tA1 = hi(bA + ec.nAc, bA + ec.nA);
   const int tB0 = lo(bB + ec.nBc, bB + ec.nB), tB1 = hi(bB + ec.nBc, bB + ec.nB);
   const int tC0 = lo(bC + ec.nCc, bC + ec.nC), tC1 = hi(bC + ec.nCc, bC + ec.nC);
   if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 699.9) {
-    energy_sums_f64<0, false>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, false>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, false>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, false, HESS>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, false, HESS>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, false, HESS>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   } else {
-    energy_sums_f64<0, true>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, true>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, true>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, true, HESS>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, true, HESS>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, true, HESS>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -195,6 +198,37 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
   GnSums s;
   newton_sums_f64<1>(tab, lds_pow, ec, 0, a0, a1, s);
   newton_solve_f64(s, g0, g1, a0, a1);
+}
+
+// THE GAUSS-NEWTON FORM of the step, for the one step of the short cut (gn_shortcut_kernel<1>): the Hessian without its
+// (g / nu - 1) * hessian(nu) term (matdecomp.py:123, the first term), i.e. without the three second-derivative sums per
+// measurement - 6 of the 12 accumulations per energy.  Both forms have the same fixed points where the counts reproduce, and from
+// a start value at distance e0 of one the Gauss-Newton step leaves a1 - a* = Ht^-1 (X(a0) + 1/2 D3F [e0, .]) e0 with X = sum_k
+// c_k S_k the dropped term: c_k(a0) = (G_k . e0) / nu_k vanishes with e0 (the counts reproduce at a*), so X e0 is a SECOND-ORDER
+// term like Newton's own, with coefficients S_kjp G_kq / nu_k of the kind D3F is made of.  The table's kappa is the constant of
+// THIS step (quadrature.newton_kappa(gauss_newton=True): the third-derivative term plus max_i sum_j |H^-1_ij| sum_pqk S_kjp G_kq /
+// nu_k, from the same energy sums at the tabulated fixed points): |e1| <= kappa |e0|^2 as for the full step, about twice its
+// constant.
+__device__ __forceinline__ void newton_step_gn_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
+                                                   EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
+  GnSums s;
+  newton_sums_f64<1, false>(tab, lds_pow, ec, 0, a0, a1, s);
+  const double g[2] = {g0, g1};
+  double c[2], q[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {                                  // (as newton_solve_f64)
+    const double inv = rcp_f64(s.nu[k]), ratio = g[k] * inv;
+    c[k] = fabs(s.nu[k]) < __builtin_huge_val() ? (g[k] - s.nu[k]) * inv : ratio - 1.0;
+    q[k] = ratio * inv;
+  }
+  const double dF0 = c[0] * s.G0[0] + c[1] * s.G0[1];
+  const double dF1 = c[0] * s.G1[0] + c[1] * s.G1[1];
+  const double h00 = q[0] * (s.G0[0] * s.G0[0]) + q[1] * (s.G0[1] * s.G0[1]);
+  const double h01 = q[0] * (s.G0[0] * s.G1[0]) + q[1] * (s.G0[1] * s.G1[1]);
+  const double h11 = q[0] * (s.G1[0] * s.G1[0]) + q[1] * (s.G1[1] * s.G1[1]);
+  const double inv_det = rcp_f64(h00 * h11 - h01 * h01);
+  a0 -= (h11 * dF0 - h01 * dF1) * inv_det;
+  a1 -= (h00 * dF1 - h01 * dF0) * inv_det;
 }
 
 // float32 table layout per energy: [mu0*log2e, mu1*log2e, then for c in {1, mu0, mu1, mu0^2, mu0mu1, mu1^2}:
@@ -815,7 +849,8 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // does not count).  A pixel whose first step satisfies kappa d1^2 <= stop_tol / 4 * max(|a|, 1) has what the tolerance rule asks
 // of two steps - a bound on the distance it still has to go, below stop_tol / 4 of its size - from one, and ends there; every
 // other pixel takes its second step and the rule, as before.  With the sextic interpolant d1 is 1e-10 of |a| and the bound
-// holds with three orders to spare (kappa |a| is 600 on average, 1e4 at thick rays: profiles/r05_gn_one_step.md).
+// holds with orders to spare (kappa |a| is 600 on average, 1e4 at thick rays: profiles/r05_gn_one_step.md).  The one step is of
+// the Gauss-Newton form (newton_step_gn_f64, above: half the accumulations); kappa is tabulated for that form.
 constexpr int kStartHeader = 12;
 
 // ln(x) for a positive, normal double: the hardware's float32 logarithm as a first guess y0 (|error| < 1e-5), then one
@@ -1242,10 +1277,14 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
       if (fm != 0ull) {
         n_exec += (unsigned long long)(STEPS * (int)__popcll(fm));
         double n0 = s0, n1 = s1, m0 = s0, m1 = s1;
+        if (STEPS == 1) {                                                    // from s to m, Gauss-Newton form (newton_step_gn_f64)
+          newton_step_gn_f64(tab, lds_pow, ec, gd0, gd1, m0, m1);
+        } else {
 #pragma nounroll
-        for (int k = 0; k < STEPS; ++k) {                                    // step 1: from s to n (STEPS = 1: m), step 2: from n to m
-          n0 = m0; n1 = m1;
-          newton_step_f64(tab, lds_pow, ec, gd0, gd1, m0, m1);
+          for (int k = 0; k < STEPS; ++k) {                                  // step 1: from s to n, step 2: from n to m
+            n0 = m0; n1 = m1;
+            newton_step_f64(tab, lds_pow, ec, gd0, gd1, m0, m1);
+          }
         }
         bool ended;
         double f0, f1;

@@ -103,7 +103,9 @@ DEFAULT_STOP_TOL = _default_stop_tol()
 # step has kappa d1^2 <= stop_tol / 4 * size ends there: a bound on the distance it still has to go, which is what the tolerance
 # rule extracts from two steps; every other pixel takes the second step and the rule.  The kernel's sextic interpolant over the
 # 256-cell grid is within 1e-10 of |a| of the pixel's fixed point, so the bound holds with three orders to spare and the step
-# lands at rounding level.
+# lands at rounding level.  That one step is of the Gauss-Newton form - the Hessian without its (g / nu - 1) x second-derivative
+# term, half the accumulations per energy: the dropped term vanishes with the distance to the fixed point and leaves a second-
+# order remainder like Newton's own, which kappa (tabulated for this form) covers.
 #
 # Modes (``two_level=`` of the calls below; DEXCT_GN_TWO_LEVEL in the environment; DEFAULT_TWO_LEVEL):
 #   None / True / 'one'     the short cut, one step where kappa allows (one launch)

@@ -183,7 +183,7 @@ def max_rel_error(mu, w, cols, w_red, L):
     return float(err.max())
 
 
-GATE_VERSION = 7           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
+GATE_VERSION = 8           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
 START_HEADER = 12          # doubles before the tables (csrc/gn.hip, gn_start)
 GATE_CELLS = 256           # cells per axis of the grid over (ln u0, u1 / u0): the kernel's 6 x 6 Lagrange interpolant of the fixed points is then
                            # within 1e-10 of |a| of a pixel's own (128 cells: 7e-9; Catmull-Rom, round 4: 2e-6; tools/probes/gn_interp_cpu.py)
@@ -351,7 +351,7 @@ def assemble_start(pieces, steps, roots):
     need[x_hi > np.log(GATE_U_MAX), :] = np.inf
     radius = np.where(cell_ok, GATE_RADIUS * spread + 1e-9, 0.0)
     # kappa of the one-step acceptance: KAPPA_SAFETY x the largest value at the corners of the cell and of the eight around it
-    kc = np.where(good, newton_kappa(pieces, r.reshape(-1, 2), sums).reshape(n + 1, n + 1), np.inf)
+    kc = np.where(good, newton_kappa(pieces, r.reshape(-1, 2), sums, gauss_newton=True).reshape(n + 1, n + 1), np.inf)
     kcell = np.maximum.reduce([kc[:-1, :-1], kc[:-1, 1:], kc[1:, :-1], kc[1:, 1:]])
     padk = np.pad(kcell, 1, mode='edge')
     kappa = KAPPA_SAFETY * np.max([padk[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
@@ -432,13 +432,19 @@ KAPPA_SAFETY = 2.5         # on the largest kappa at the corners of a cell and o
                            # cells (a few per cent) and the factor (1 - kappa e0)^-2 <= 1.25 between e0^2 and the measured d1^2
 
 
-def newton_kappa(pieces, roots, sums=None):
+def newton_kappa(pieces, roots, sums=None, gauss_newton=False):
     """The contraction constant of Newton's iteration on the Poisson likelihood F(a) = sum_k nu_k(a) - g_k ln nu_k(a) at the fixed
     points ``roots`` [n, 2] of the counts they reproduce (g_k = nu_k there; csrc/gn.hip kStartHeader, DEXCT_GN_FLAG_ONE_STEP): a step
     from a0 lands at a1 with a1 - a* = 1/2 H^-1 D3F [e0, e0], hence |e1| <= kappa |e0|^2 in the max norm with
     kappa = 1/2 max_i sum_j |H^-1_ij| sum_pq |D3F_jpq|.  With G_km = sum_e i0_k mu_m att, S_kmp = sum_e i0_k mu_m mu_p att:
     H_mp = sum_k G_km G_kp / nu_k and D3F_mpq = sum_k [2 G_km G_kp G_kq / nu_k^2 - (S_kpq G_km + S_kmq G_kp + S_kmp G_kq) / nu_k]
-    (the terms with g_k / nu_k - 1 vanish at a root that reproduces its counts).  inf where H is singular or anything overflows."""
+    (the terms with g_k / nu_k - 1 vanish at a root that reproduces its counts).  inf where H is singular or anything overflows.
+
+    ``gauss_newton``: the constant of the step the short cut takes (csrc/gn.hip, newton_step_gn_f64) - the Hessian Ht without its
+    (g / nu - 1) x second-derivative term X = sum_k c_k S_k.  a1 - a* = Ht^-1 (Ht - Hbar) e0 with Hbar the Hessian averaged over
+    the segment: Ht - Hbar = X(a0) + 1/2 D3F [e0, .], and c_k(a0) = (G_k . e0) / nu_k (the counts reproduce at a*), so
+    (X e0)_j = sum_pq [sum_k S_kjp G_kq / nu_k] e0_p e0_q: a second-order term like Newton's own, with non-negative coefficients of
+    the kind D3F is made of.  kappa_GN = max_i sum_j |H^-1_ij| sum_pq (1/2 |D3F_jpq| + sum_k S_kjp G_kq / nu_k)."""
     with np.errstate(all='ignore'):
         nu, G, S = sums if sums is not None else _model_sums(pieces, roots, third=True)
         H = np.einsum('nk,nkm,nkp->nmp', 1.0 / nu, G, G)
@@ -447,7 +453,10 @@ def newton_kappa(pieces, roots, sums=None):
              - np.einsum('nk,nkmp,nkq->nmpq', 1.0 / nu, S, G))
         det = H[:, 0, 0] * H[:, 1, 1] - H[:, 0, 1] * H[:, 1, 0]
         Hinv = np.stack([np.stack([H[:, 1, 1], -H[:, 0, 1]], -1), np.stack([-H[:, 1, 0], H[:, 0, 0]], -1)], -2) / det[:, None, None]
-        kap = 0.5 * np.einsum('nij,nj->ni', np.abs(Hinv), np.abs(T).sum(axis=(2, 3))).max(axis=1)
+        per_row = 0.5 * np.abs(T).sum(axis=(2, 3))
+        if gauss_newton:
+            per_row = per_row + np.einsum('nk,nkjp,nkq->nj', 1.0 / np.abs(nu), np.abs(S), np.abs(G))
+        kap = np.einsum('nij,nj->ni', np.abs(Hinv), per_row).max(axis=1)
     return np.where(np.isfinite(kap) & np.all(np.isfinite(roots), axis=1), kap, np.inf)
 
 

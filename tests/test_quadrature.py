@@ -247,3 +247,44 @@ def _one_step(i0, mus, g, a):
     dF = -(c[:, None] * -G).sum(0)
     H = -(c[:, None, None] * Hs - qq[:, None, None] * G[:, :, None] * G[:, None, :]).sum(0)
     return a - np.linalg.solve(H, dF)
+
+
+def _gauss_newton_step(i0, mus, g, a):
+    """The step of csrc/gn.hip newton_step_gn_f64 from the state a (NumPy): the Hessian without its (g / nu - 1) x second-derivative
+    term."""
+    att = np.exp(np.clip(-(a @ mus), -700, 700))
+    nu = i0 @ att
+    G = np.einsum('ke,me,e->km', i0, mus, att)
+    c, qq = g / nu - 1.0, g / nu ** 2
+    dF = (c[:, None] * G).sum(0)
+    H = (qq[:, None, None] * G[:, :, None] * G[:, None, :]).sum(0)
+    return a - np.linalg.solve(H, dF)
+
+
+def test_gauss_newton_step_of_the_short_cut_is_bounded():
+    """The ONE step of the default short cut is of the Gauss-Newton form (csrc/gn.hip, newton_step_gn_f64): from a0 next to a root a*
+    that reproduces its counts it leaves |a1 - a*| <= kappa_GN |a0 - a*|^2 with quadrature.newton_kappa(gauss_newton=True) - the
+    constant the table carries - checked in NumPy in many directions at two distances; the bound is not idle, it is at most a few
+    times the full step's constant, and the Gauss-Newton step and the full step land within second order of each other."""
+    _, i0, mus = newton_tables()
+    p = q.newton_start_grid(i0, mus)
+    rng = np.random.default_rng(14)
+    roots = np.stack([rng.uniform(0.5, 40.0, 200), rng.uniform(-0.2, 6.0, 200)], 1)
+    g = np.exp(-(roots @ p['mus'])) @ p['i0'].T
+    kap = q.newton_kappa(p, roots, gauss_newton=True)
+    full = q.newton_kappa(p, roots)
+    assert np.all(kap >= full) and np.all(kap <= 6.0 * full)
+    worst = 0.0
+    for rel in (1e-4, 1e-6):
+        for _ in range(4):
+            e0 = rng.standard_normal((200, 2))
+            e0 *= (rel * np.abs(roots).max(1) / np.abs(e0).max(1))[:, None]
+            for k in range(200):
+                a1 = _gauss_newton_step(p['i0'], p['mus'], g[k], roots[k] + e0[k])
+                d0 = np.abs(e0[k]).max()
+                e1 = np.abs(a1 - roots[k]).max()
+                assert e1 <= kap[k] * d0 ** 2 * (1.0 + 1e-3) + 1e-13 * np.abs(roots[k]).max(), (k, e1, kap[k] * d0 ** 2)
+                if rel == 1e-4:
+                    worst = max(worst, e1 / (kap[k] * d0 ** 2))
+                    assert np.abs(a1 - _one_step(p['i0'], p['mus'], g[k], roots[k] + e0[k])).max() <= 2.0 * kap[k] * d0 ** 2
+    assert worst > 1e-3                                                    # (within three orders of what directions reach)
