@@ -327,8 +327,8 @@ int dexct_download(void* host, const void* device_src, int64_t n_bytes, void* st
  *               the pair (need, radius): need = the number of steps a pixel whose counts fall in the cell must be allowed for
  *               the reference's walk to be known to end by the tolerance rule (infinity: closed), radius = how far from the
  *               interpolated fixed point a result is accepted; then (optional, see [10] and DEXCT_GN_FLAG_ONE_STEP) per cell
- *               kappa: a Newton step of length d1 from the interpolant lands within kappa d1^2 of the fixed point (infinity:
- *               always two steps).
+ *               kappa: the step DEXCT_GN_FLAG_ONE_STEP takes - of the Gauss-Newton form, below - of length d1 from the
+ *               interpolant lands within kappa d1^2 of the fixed point (infinity: always two steps).
  *               Both passes need stop_tol > 0 (after defaults), n_bins == 1, precision 0, n_iters <= 254, kernel != 2;
  *               DEXCT_EINVAL otherwise.  pass = 0 (default): one launch from 1e-6; iterations and start must be NULL or are
  *               not used.  (ABI 4 also had a two-launch "coarse" form of the short cut - a launch on a short quadrature of the
@@ -338,9 +338,12 @@ int dexct_download(void* host, const void* device_src, int64_t n_bytes, void* st
  *               their natural order instead of thick tiles first (results do not depend on it).
  *               DEXCT_GN_FLAG_ONE_STEP (DEXCT_GN_PASS_SHORTCUT only; `start` must end with the kappa array, below): a pixel whose
  *               FIRST step from the interpolated fixed point has length d1 with kappa d1^2 <= stop_tol / 4 * max(|a|, 1) ends
- *               there - kappa bounds what Newton's step leaves of a distance d1 (from the Hessian and the third derivatives of
+ *               there - kappa bounds what the step leaves of a distance d1 (from the Hessian and the third derivatives of
  *               the likelihood at the tabulated fixed points) - ; every other pixel goes on to its second step and the
- *               tolerance rule.
+ *               tolerance rule.  That first step is of the GAUSS-NEWTON form: the Hessian of matdecomp.py:123 without its
+ *               (g / nu - 1) x second-derivative term (half the sums per energy); the term vanishes with the distance to a
+ *               fixed point that reproduces its counts, what it leaves is second order and must be part of kappa
+ *               (dex-ct-sim_amd/quadrature.py, newton_kappa(gauss_newton=True)).  All further steps are full Newton steps.
  *   blocks_per_cu   > 0: workgroups per CU of the queue kernels (0: what is resident; results do not depend on it). */
 #define DEXCT_GN_DEFAULT_STOP_TOL 1e-12
 #define DEXCT_GN_PASS_COUNT 1
