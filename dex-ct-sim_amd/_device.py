@@ -177,13 +177,15 @@ class LazyPinnedResult:
 
     def _prepare(self):
         for k, (addr, n) in enumerate(self.spans):
-            if n > 0:
-                if self.fresh:
-                    self.lib.dexct_host_touch(addr, n, _TOUCH_THREADS)
-                # (a piece that cannot be locked - a locked-memory limit - is copied through the runtime's staging: same result)
-                if self.lib.dexct_host_pin(addr, n, self.dev) == 0:
-                    self.locked.append(addr)
-            self.ready[k].set()
+            try:
+                if n > 0:
+                    if self.fresh:
+                        self.lib.dexct_host_touch(addr, n, _TOUCH_THREADS)
+                    # (a piece that cannot be locked - a locked-memory limit - is copied through the runtime's staging: same result)
+                    if self.lib.dexct_host_pin(addr, n, self.dev) == 0:
+                        self.locked.append(addr)
+            finally:
+                self.ready[k].set()         # whatever happened: the copy of piece k must not wait for ever
 
     def download(self, k, src_address, stream):
         """piece k of the result from device memory at ``src_address``: one copy per locked span it touches (a copy must stay
@@ -204,9 +206,12 @@ class LazyPinnedResult:
         self.locked = []
 
     def __del__(self):                      # abandoned (an error between construction and finish): the block is still good
-        if getattr(self, 'buf', None) is not None:
-            self._unlock()
-            _give_back(self.buf)
+        if getattr(self, 'buf', None) is not None and getattr(self, 'ready', None):
+            try:
+                self._unlock()
+                _give_back(self.buf)
+            except Exception:               # (interpreter shutdown: nothing left to give back to)
+                pass
 
     def finish(self):
         self._unlock()

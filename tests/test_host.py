@@ -194,6 +194,11 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.dexct_cone_layout_bytes(0, 5, 5) == 0
     assert lib.dexct_cone_layout(one, 8, 8, 0, one, None) == EINVAL
     assert lib.dexct_transpose_batched(one, one, 1, 4, 4, 3, None) == EINVAL            # element size
+    assert lib.dexct_transpose_log(one, one, one, None, 2, 4, 8, 8, None) == EINVAL     # a log sinogram without air values
+    assert lib.dexct_transpose_log(one, one, None, None, 5, 4, 8, 8, None) == ERANGE    # > DEXCT_MAX_SPECTRA
+    assert lib.dexct_transpose_log(one, None, None, None, 1, 4, 8, 8, None) == EINVAL
+    assert lib.dexct_host_pin(None, 4096, 0) == EINVAL and lib.dexct_host_unpin(None, 0) == EINVAL
+    assert lib.dexct_download(None, one, 16, None) == EINVAL
     assert lib.dexct_fbp_filter(one, one, one, 1, 1, 0.01, one, None) == EINVAL
     assert lib.dexct_fbp_backproject(one, one, 10, 16, 1, 60.0, 0.0, 0.1, 32, 20.0, one, None) == EINVAL
     assert lib.dexct_label_moments(None, None, None, 16, 1, one, None) == EINVAL
@@ -381,3 +386,34 @@ def test_ill_posed_pairs_are_told_from_the_calibration():
     assert not q.pair_is_ill_posed(kv) and not q.pair_is_ill_posed({'grid': False}) and not q.pair_is_ill_posed(None)
     assert q.pair_is_ill_posed(mv) and q.pair_is_ill_posed(mvmv)
     assert q.pair_is_ill_posed(dict(kv, open_share=0.70)) and q.pair_is_ill_posed(dict(kv, cond_median=float('inf')))
+
+
+def test_host_pages_are_made_resident_without_a_gpu():
+    """dexct_host_touch (include/dexct.h): the pages of a host range are made resident by 1 .. 64 threads and the bytes stay as
+    they are - pure host code (what a large result block gets before it is page-locked, _device.LazyPinnedResult); bad
+    arguments are refused."""
+    import ctypes as C
+    from dex_ct_sim_amd import _native
+    lib = _native.load()
+    n = 24 << 20
+    for threads in (1, 2, 7):
+        a = np.empty(n + 8192, dtype=np.uint8)
+        a[::4096] = np.arange(a[::4096].size, dtype=np.uint8)             # something to keep in some of the pages
+        a[n // 2 + 5] = 77
+        base = a.ctypes.data + 3                                          # any address, any length
+        assert lib.dexct_host_touch(base, n, threads) == 0
+        assert a[n // 2 + 5] == 77 and np.array_equal(a[::4096], np.arange(a[::4096].size, dtype=np.uint8))
+    assert lib.dexct_host_touch(None, n, 1) == -1 and lib.dexct_host_touch(a.ctypes.data, 0, 1) == -1
+    assert lib.dexct_host_touch(a.ctypes.data, n, 0) == -1 and lib.dexct_host_touch(a.ctypes.data, n, 65) == -1
+
+
+def test_page_spans_of_arrays_that_share_pages():
+    """_device._page_spans: the page-aligned spans that cover byte ranges, merged where two ranges share or touch a page (two
+    halves of one array - sino[0], sino[1] - must be locked as ONE region: a page cannot be registered twice)."""
+    from dex_ct_sim_amd import _device
+    P = 4096
+    assert _device._page_spans([(10 * P + 5, 100)]) == [(10 * P, P)]
+    assert _device._page_spans([(10 * P + 5, P), (11 * P + 5, 8)]) == [(10 * P, 2 * P)]                # overlap in page 11
+    assert _device._page_spans([(10 * P, P), (11 * P, P)]) == [(10 * P, 2 * P)]                        # touching
+    assert _device._page_spans([(20 * P, P), (10 * P, 3)]) == [(10 * P, P), (20 * P, P)]               # apart, sorted
+    assert _device._page_spans([(10 * P, 0)]) == []
