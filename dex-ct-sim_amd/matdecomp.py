@@ -195,6 +195,7 @@ def calibrate_gate(i0_h, mus_h, i0_d, mus_d, dev, cal_tol):
     pieces = quadrature.newton_start_grid(i0_2, mus_h)
     if pieces is None:
         return None, {'grid': False}
+    pieces['device'] = dev                    # (the energy sums of the table assembly run there: quadrature._model_sums)
     lib = _native.load()
     n_e = i0_2.shape[1]
     steps, roots = _walk(lib, dev, i0_d, mus_d, n_e, pieces['corner_g'], cal_tol)

@@ -261,6 +261,22 @@ def _model_sums(pieces, a, third=False):
     slope), and with ``third`` S [n, k, m, p] = sum_e i0_k mu_m mu_p att - one exponential pass and one matrix product."""
     i0, mus = pieces['i0'], pieces['mus']
     a = np.where(np.isfinite(a), a, 0.0)
+    dev = pieces.get('device')
+    if dev is not None:
+        # the same sums on the device the tables are calibrated for (torch float64: one exponential pass of 9e6 values and three
+        # matrix products take 0.2 s per call in NumPy, a few ms there); they feed thresholds and bounds, no bit of a result
+        import torch
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
+        a_t, i0_t, mus_t = t(a), t(i0), t(mus)
+        expo = -(a_t @ mus_t)
+        att = torch.exp(expo.clamp(-700.0, 700.0))
+        nu = att @ i0_t.T
+        live = att * (expo.abs() < 700.0)
+        G = (live @ (i0_t[:, None, :] * mus_t[None, :, :]).reshape(4, -1).T).reshape(-1, 2, 2)
+        if not third:
+            return nu.cpu().numpy(), G.cpu().numpy(), None
+        w2 = (i0_t[:, None, None, :] * mus_t[None, :, None, :] * mus_t[None, None, :, :]).reshape(8, -1)
+        return nu.cpu().numpy(), G.cpu().numpy(), (live @ w2.T).reshape(-1, 2, 2, 2).cpu().numpy()
     expo = -(a @ mus)
     att = np.exp(np.clip(expo, -700.0, 700.0))
     nu = att @ i0.T
@@ -447,15 +463,17 @@ def newton_kappa(pieces, roots, sums=None, gauss_newton=False):
     the kind D3F is made of.  kappa_GN = max_i sum_j |H^-1_ij| sum_pq (1/2 |D3F_jpq| + sum_k S_kjp G_kq / nu_k)."""
     with np.errstate(all='ignore'):
         nu, G, S = sums if sums is not None else _model_sums(pieces, roots, third=True)
-        H = np.einsum('nk,nkm,nkp->nmp', 1.0 / nu, G, G)
-        T = (2.0 * np.einsum('nk,nkm,nkp,nkq->nmpq', 1.0 / nu ** 2, G, G, G)
-             - np.einsum('nk,nkpq,nkm->nmpq', 1.0 / nu, S, G) - np.einsum('nk,nkmq,nkp->nmpq', 1.0 / nu, S, G)
-             - np.einsum('nk,nkmp,nkq->nmpq', 1.0 / nu, S, G))
+        # (broadcast products over [n, k, m, p, q] summed over k: the same sums as the einsum forms in the docstring, 15 x faster)
+        inv = 1.0 / nu
+        Gm, Gp, Gq = G[:, :, :, None, None], G[:, :, None, :, None], G[:, :, None, None, :]
+        H = (inv[:, :, None, None] * G[:, :, :, None] * G[:, :, None, :]).sum(axis=1)
+        T = ((2.0 * inv ** 2)[:, :, None, None, None] * Gm * Gp * Gq
+             - inv[:, :, None, None, None] * (S[:, :, None, :, :] * Gm + S[:, :, :, None, :] * Gp + S[:, :, :, :, None] * Gq)).sum(axis=1)
         det = H[:, 0, 0] * H[:, 1, 1] - H[:, 0, 1] * H[:, 1, 0]
         Hinv = np.stack([np.stack([H[:, 1, 1], -H[:, 0, 1]], -1), np.stack([-H[:, 1, 0], H[:, 0, 0]], -1)], -2) / det[:, None, None]
         per_row = 0.5 * np.abs(T).sum(axis=(2, 3))
         if gauss_newton:
-            per_row = per_row + np.einsum('nk,nkjp,nkq->nj', 1.0 / np.abs(nu), np.abs(S), np.abs(G))
+            per_row = per_row + (np.abs(inv)[:, :, None] * np.abs(S).sum(axis=3) * np.abs(G).sum(axis=2)[:, :, None]).sum(axis=1)
         kap = np.einsum('nij,nj->ni', np.abs(Hinv), per_row).max(axis=1)
     return np.where(np.isfinite(kap) & np.all(np.isfinite(roots), axis=1), kap, np.inf)
 
