@@ -852,6 +852,9 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // holds with orders to spare (kappa |a| is 600 on average, 1e4 at thick rays: profiles/r05_gn_one_step.md).  The one step is of
 // the Gauss-Newton form (newton_step_gn_f64, above: half the accumulations); kappa is tabulated for that form.
 constexpr int kStartHeader = 12;
+#ifndef DEXCT_GN_INTERP_UNROLL
+#define DEXCT_GN_INTERP_UNROLL 2      // rows of the 6 x 6 interpolation per loop trip (A/B: tools/probes/build_variant.sh)
+#endif
 
 // ln(x) for a positive, normal double: the hardware's float32 logarithm as a first guess y0 (|error| < 1e-5), then one
 // Newton step on the table-driven exponential above: ln x = y0 + ln(x e^-y0) = y0 + r - r^2 / 2 with r = x e^-y0 - 1, |r| <
@@ -911,7 +914,7 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const
   const int base = (i0c <= n - 5 ? i0c : n - 5) * (n + 1) + (j0c <= n - 5 ? j0c : n - 5);
   s0 = 0.0;
   s1 = 0.0;
-#pragma unroll 2                      // (twelve loads in flight, not thirty-six: registers at the kernel's tightest spot)
+#pragma unroll DEXCT_GN_INTERP_UNROLL  // (2: twelve loads in flight, not thirty-six: registers at the kernel's tightest spot)
   for (int p = 0; p < 6; ++p) {
     double ra = 0.0, rb = 0.0;
 #pragma unroll

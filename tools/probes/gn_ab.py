@@ -42,9 +42,12 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
 
     modes = [('exact plain', dict(stop_tol=0.0)), ('exact ref-order', dict(stop_tol=0.0, out_rc=(n, chans))),
              ('default ref-order', dict(out_rc=(n, chans)))]
+    reps = 3
+    if os.environ.get('AB_DEFAULT_ONLY'):          # the default (short-cut) launch alone, more repetitions
+        modes, reps = modes[2:], 12
     run(stop_tol=0.0)
     res = {m: [] for m, _ in modes}
-    for rep in range(3):
+    for rep in range(reps):
         for m, kw in modes:
             res[m].append(run(**kw))
     st = md.last_gn_stats()
