@@ -42,7 +42,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=512, help='phantom is n^3')
+    ap.add_argument('--n', '--phantom-n', dest='n', type=int, default=512,
+                    help='phantom is n^3 (--phantom-n: the spelling to use behind torch.distributed.run, whose own parser takes '
+                         '--n for an abbreviation of its options)')
     ap.add_argument('--views', type=int, default=None, help='views of the scan (strong) / per GPU (weak)')
     ap.add_argument('--channels', type=int, default=None)
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'])

@@ -96,3 +96,27 @@ def test_plain_command_three_ranks_config3_labels(hip):
     assert views == [[0, 18], [18, 35], [35, 52]]
     assert out['multi_gpu']['gather_device_allocations_per_call'] == 0
     assert 'value_exact' not in out and out['value'] > 0          # (the exact-mode comparison runs at N = 1 only)
+
+
+def test_under_the_drivers_launcher(hip):
+    """The driver's launch for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` - bench.py then IS a rank (RANK / LOCAL_RANK / WORLD_SIZE from the launcher) and
+    rank 0 prints the one JSON line.  On a one-GPU box the two ranks share the device over gloo (DEXCT_DIST_BACKEND, which the
+    plain command sets by itself)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, DEXCT_DIST_BACKEND='gloo')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), *['--phantom-n' if a == '--n' else a for a in SMALL],
+                        '--gpus', '2'],
+                       capture_output=True, text=True, timeout=900, env=e)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['multi_gpu']['gather'] == 'root' and out['value'] > 0
+    assert len(out['multi_gpu']['per_rank']) == 2
