@@ -25,7 +25,9 @@ extern "C" {
                                  3: struct dexct_gn_options - tolerance stop, results in the reference's order; 256 material ids;
                                  4: dexct_gn_options.pass / .iterations / .start - the Newton short cut (tabulated fixed points);
                                  5: dexct_gn_options.flags / .blocks_per_cu (what the environment used to switch per call), the
-                                    two-launch form of the short cut removed, dexct_sino_gather (peer-to-peer assembly) */
+                                    two-launch form of the short cut removed, DEXCT_GN_FLAG_ONE_STEP, dexct_sino_gather (peer-to-peer
+                                    assembly), dexct_transpose_log (both outputs of get_sino in one pass), dexct_host_touch / _pin /
+                                    _unpin / dexct_download (the NumPy boundary of large arrays) */
 
 #define DEXCT_OK 0
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
