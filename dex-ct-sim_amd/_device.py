@@ -98,10 +98,19 @@ def pool_wanted(n_bytes):
     return n_bytes >= LAZY_MIN_BYTES and os.environ.get('DEXCT_LAZY_PIN', '1') != '0'
 
 
+_pool_age = []                  # sizes of the pooled blocks, oldest first: what leaves when the pool is over its limit
+
+
 def _give_back(buf):
     with _pool_lock:
-        if sum(k * len(v) for k, v in _pool.items()) + buf.nbytes <= POOL_MAX_BYTES:
-            _pool.setdefault(buf.nbytes, []).append(buf)
+        if buf.nbytes > POOL_MAX_BYTES:
+            return
+        _pool.setdefault(buf.nbytes, []).append(buf)
+        _pool_age.append(buf.nbytes)
+        while sum(k * len(v) for k, v in _pool.items()) > POOL_MAX_BYTES and _pool_age:
+            old = _pool_age.pop(0)      # the block that has waited longest (of whatever size: sizes nobody asks for any more go first)
+            if _pool.get(old):
+                _pool[old].pop(0)
 
 
 def empty_pool():
@@ -109,6 +118,7 @@ def empty_pool():
     with _pool_lock:
         n = sum(k * len(v) for k, v in _pool.items())
         _pool.clear()
+        del _pool_age[:]
     return n
 
 
@@ -160,6 +170,8 @@ class LazyPinnedResult:
         with _pool_lock:
             free = _pool.get(n_bytes)
             self.buf = free.pop() if free else None
+            if self.buf is not None:
+                _pool_age.remove(n_bytes)
         self.fresh = self.buf is None
         if self.fresh:
             raw = np.empty(n_bytes + 2 * _PAGE, dtype=np.uint8)

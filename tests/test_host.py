@@ -417,3 +417,21 @@ def test_page_spans_of_arrays_that_share_pages():
     assert _device._page_spans([(10 * P, P), (11 * P, P)]) == [(10 * P, 2 * P)]                        # touching
     assert _device._page_spans([(20 * P, P), (10 * P, 3)]) == [(10 * P, P), (20 * P, P)]               # apart, sorted
     assert _device._page_spans([(10 * P, 0)]) == []
+
+
+def test_host_pool_lets_the_oldest_blocks_go(monkeypatch):
+    """_device's pool of resident result blocks (no GPU needed for its bookkeeping): blocks return when their arrays are garbage,
+    the pool stays within DEXCT_HOST_POOL_GB by dropping the blocks that have waited longest - sizes nobody asks for any more
+    cannot hog it - and a block larger than the limit is not kept at all."""
+    from dex_ct_sim_amd import _device
+    _device.empty_pool()
+    monkeypatch.setattr(_device, 'POOL_MAX_BYTES', 10 << 20)
+    blk = lambda mb: np.empty(mb << 20, dtype=np.uint8)
+    for mb in (4, 4, 3):                       # 11 MB offered: the oldest 4 MB block leaves
+        _device._give_back(blk(mb))
+    assert {k >> 20: len(v) for k, v in _device._pool.items()} == {4: 1, 3: 1} and _device._pool_age == [4 << 20, 3 << 20]
+    _device._give_back(blk(6))                 # 13 MB: the other 4 MB block leaves, 3 + 6 stay
+    assert {k >> 20: len(v) for k, v in _device._pool.items() if v} == {3: 1, 6: 1}
+    _device._give_back(blk(11))                # larger than the pool: not kept, nothing else disturbed
+    assert {k >> 20: len(v) for k, v in _device._pool.items() if v} == {3: 1, 6: 1}
+    assert _device.empty_pool() == 9 << 20 and not _device._pool and not _device._pool_age
