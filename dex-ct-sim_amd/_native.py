@@ -5,7 +5,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libdexct_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every entry point include/dexct.h declares
 SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
@@ -38,6 +38,18 @@ def log_out(sino_log_ptr, air):
     for k in range(4):
         lo.air[k] = float(air[k]) if k < len(air) else 1.0
     return C.byref(lo)
+
+
+class Noise(C.Structure):
+    """dexct_noise (ABI 6): quantum noise drawn by the projection kernel itself"""
+    _fields_ = [('seed', C.c_uint64), ('sample', C.c_int32), ('reserved_', C.c_int32)]
+
+
+def noise(seed, sample=True):
+    """byref-able dexct_noise, or None (``seed`` None): the kernel samples counts = max(signal + sqrt(variance) z, 1e-20)."""
+    if seed is None:
+        return None
+    return C.byref(Noise(int(seed) & (2 ** 64 - 1), 1 if sample else 0, 0))
 
 
 class GnOptions(C.Structure):
@@ -111,13 +123,14 @@ def load():
                                           f64, f64, vp, vp]
     lib.dexct_poisson_detect.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp]
     lib.dexct_cone_project.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, vp, i32, i32, i32, vp, vp,
-                                       vp, vp, vp, vp]
+                                       vp, vp, vp, vp, vp, vp, vp]
     lib.dexct_volume_pack2.argtypes = [vp, i64, vp, vp]
     lib.dexct_volume_groups_pack2.argtypes = [vp, i64, i32, vp, vp]
-    lib.dexct_siddon_project_packed.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
+    lib.dexct_siddon_project_packed.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp,
+                                                vp, vp, vp]
     lib.dexct_cone_layout.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.dexct_cone_project_rows.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, i32, i32, i32, vp, vp, vp,
-                                            vp, vp, vp]
+                                            vp, vp, vp, vp, vp, vp]
     lib.dexct_cone_layout_bytes.argtypes = [i32, i32, i32]
     lib.dexct_cone_layout_bytes.restype = i64
     lib.dexct_siddon_project_grouped.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp,

@@ -8,23 +8,13 @@
 // (written by the projector when asked).  The sum over ~10^2 bins of 10^3..10^6 photons is drawn as
 // mean + sqrt(variance) * z with z standard normal; results are clipped at a tiny positive number so
 // that the log sinogram stays finite.
-// RNG: Philox4x32-10, counter = (global view, row, channel, spectrum), key = seed: every sample depends only
-// on what it belongs to, so any view sharding and either memory layout reproduce the same sinogram.
+// RNG: Philox4x32-10, one block per pixel (noise_sample.h): every sample depends only on what it belongs to, so any view
+// sharding and either memory layout reproduce the same sinogram - and so do the projection kernels that draw the sample
+// themselves (dexct_noise.sample), which share the definition.
 #include "common.h"
+#include "noise_sample.h"
 
 namespace dexct {
-
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
 
 __global__ __launch_bounds__(256) void add_noise_kernel(float* __restrict__ counts, const float* __restrict__ variance,
                                                         int n_spectra, int n_views, int n_rows, int n_channels,
@@ -37,14 +27,10 @@ __global__ __launch_bounds__(256) void add_noise_kernel(float* __restrict__ coun
   uint32_t v, r, c;
   if (layout == 0) { c = ray % n_channels; ray /= n_channels; r = ray % n_rows; v = (uint32_t)(ray / n_rows); }
   else             { r = ray % n_rows; ray /= n_rows; c = ray % n_channels; v = (uint32_t)(ray / n_channels); }
-  uint32_t ctr[4] = {v + (uint32_t)view_offset, r, c, s};
-  philox4x32_10(ctr, seed_lo, seed_hi);
-  // Box-Muller on two 32-bit uniforms in (0, 1]
-  const float u1 = ((float)ctr[0] + 1.0f) * 2.3283064365386963e-10f;
-  const float u2 = (float)ctr[1] * 2.3283064365386963e-10f;
-  const float z = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
-  const float noisy = fmaf(sqrtf(fmaxf(variance[i], 0.0f)), z, counts[i]);
-  counts[i] = fmaxf(noisy, 1.0e-20f);
+  float z[DEXCT_MAX_SPECTRA];
+  pixel_normals<DEXCT_MAX_SPECTRA>(v + (uint32_t)view_offset, r, c, seed_lo, seed_hi, z);
+  const float zs = s == 0u ? z[0] : (s == 1u ? z[1] : (s == 2u ? z[2] : z[3]));      // (selects: a run-time index would put z[] in scratch)
+  counts[i] = noisy_count(counts[i], variance[i], zs);
 }
 
 }  // namespace dexct

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "noise_sample.h"
 #include "siddon_detect.h"
 
 namespace dexct {
@@ -40,11 +41,73 @@ struct ConeArgs {
   float* pathlen;          // optional [ray][M]
   float* sino_log;         // optional [S][view][row][channel]: ln(air[s] / counts)
   float air[DEXCT_MAX_SPECTRA];
+  // quantum noise (ABI 6, struct dexct_noise; the kernels' w2 argument non-null): the variance of the signal is summed in the
+  // detection's own energy loop; `variance` (optional) receives it, `sample` draws the noisy count in registers
+  float* variance;         // optional [S][view][row][channel]
+  int sample;
+  uint32_t seed_lo, seed_hi;
 };
+
+// The tail every cone kernel ends with: per-material lengths (x log2 e) of one ray -> counts of every spectrum (the weighting of
+// the 2-D kernels), stored with the optional log; NOISY: with the variances from the same exponentials, the optional variance
+// output and the sample (noise_sample.h).  Round 5 ran the whole kernel a second time with w2 as weights to get the variance.
+template <int NM, bool NOISY>
+__device__ __forceinline__ void cone_detect_store(const ConeArgs& a, const float (&L2)[NM], const float* __restrict__ mu,
+                                                  const float* __restrict__ w, const float* __restrict__ w2,
+                                                  const BlockMasks& bm, size_t ray, int v, int r, int c) {
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const int n_e = a.n_energies;
+  float accs[DEXCT_MAX_SPECTRA], vars[DEXCT_MAX_SPECTRA];
+#pragma unroll
+  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = vars[sI] = 0.0f;
+  if (a.n_spectra <= 2) {                      // round 3: energies in pairs through v_pk_fma_f32, zero-weight blocks skipped
+    float two[2], twov[2] = {0.0f, 0.0f};
+    if constexpr (NOISY) detect_energy_pairs<NM, true>(L2, mu, w, n_e, a.n_spectra, bm, two, w2, &twov);
+    else detect_energy_pairs<NM>(L2, mu, w, n_e, a.n_spectra, bm, two);
+    accs[0] = two[0];
+    accs[1] = two[1];
+    vars[0] = twov[0];
+    vars[1] = twov[1];
+  } else {
+    int srow[DEXCT_MAX_SPECTRA];
+#pragma unroll
+    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) srow[sI] = (sI < a.n_spectra ? sI : 0) * n_e;
+    for (int e = 0; e < n_e; ++e) {
+      float pe = 0.0f;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
+      const float t = __builtin_amdgcn_exp2f(-pe);
+#pragma unroll
+      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) {
+        accs[sI] = fmaf(w[srow[sI] + e], t, accs[sI]);
+        if constexpr (NOISY) vars[sI] = fmaf(w2[srow[sI] + e], t, vars[sI]);
+      }
+    }
+  }
+  if constexpr (NOISY) {
+    if (a.variance) {
+#pragma unroll
+      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
+        if (sI < a.n_spectra) a.variance[ray + sI * sstride] = vars[sI];
+    }
+    if (a.sample) {
+      float z[DEXCT_MAX_SPECTRA];
+      pixel_normals<DEXCT_MAX_SPECTRA>((uint32_t)(a.view_begin + v), (uint32_t)r, (uint32_t)c, a.seed_lo, a.seed_hi, z);
+#pragma unroll
+      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = noisy_count(accs[sI], vars[sI], z[sI]);
+    }
+  }
+#pragma unroll
+  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
+    if (sI < a.n_spectra) {
+      a.counts[ray + sI * sstride] = accs[sI];
+      if (a.sino_log) a.sino_log[ray + sI * sstride] = log_ratio(a.air[sI], accs[sI]);
+    }
+}
 
 template <int NM, int CB = kConeBlock>   // CB: lanes per workgroup = width of the per-lane LDS columns (NM == 0)
 __global__ __launch_bounds__(CB) void cone_kernel(ConeArgs a, const float* __restrict__ mu,
-                                                          const float* __restrict__ w) {
+                                                          const float* __restrict__ w, const float* __restrict__ w2) {
   extern __shared__ float lds_acc[];     // NM == 0: counts then corrections, [n_materials][CB] each
   const int tid = threadIdx.x;
   const int c = blockIdx.x * CB + tid;
@@ -136,12 +199,6 @@ __global__ __launch_bounds__(CB) void cone_kernel(ConeArgs a, const float* __res
   const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   const int n_e = a.n_energies, n_mat = a.n_materials;
-  float accs[DEXCT_MAX_SPECTRA];
-#pragma unroll
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = 0.0f;
-  int srow[DEXCT_MAX_SPECTRA];
-#pragma unroll
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) srow[s] = (s < a.n_spectra ? s : 0) * n_e;
   if (NM > 0) {
     float L2[NM > 0 ? NM : 1];
 #pragma unroll
@@ -150,33 +207,44 @@ __global__ __launch_bounds__(CB) void cone_kernel(ConeArgs a, const float* __res
       if (a.pathlen) a.pathlen[ray * n_mat + m] = l;
       L2[m] = l * 1.44269504088896340736f;
     }
-    if (a.n_spectra <= 2) {                    // the detection of the row kernels (energies in pairs): identical counts
-      float two[2];
-      detect_energy_pairs<(NM > 0 ? NM : 1)>(L2, mu, w, n_e, a.n_spectra, bm, two);
-      accs[0] = two[0];
-      accs[1] = two[1];
-    } else {
-      for (int e = 0; e < n_e; ++e) {
-        float pe = 0.0f;
+    // (<= 2 spectra: the detection of the row kernels, energies in pairs - identical counts)
+    if (w2) cone_detect_store<(NM > 0 ? NM : 1), true>(a, L2, mu, w, w2, bm, ray, v, r, c);
+    else cone_detect_store<(NM > 0 ? NM : 1), false>(a, L2, mu, w, w2, bm, ray, v, r, c);
+    return;
+  }
+  float accs[DEXCT_MAX_SPECTRA], vars[DEXCT_MAX_SPECTRA];
 #pragma unroll
-        for (int m = 0; m < (NM > 0 ? NM : 1); ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
-        const float t = __builtin_amdgcn_exp2f(-pe);
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = vars[s] = 0.0f;
+  int srow[DEXCT_MAX_SPECTRA];
 #pragma unroll
-        for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = fmaf(w[srow[s] + e], t, accs[s]);
-      }
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) srow[s] = (s < a.n_spectra ? s : 0) * n_e;
+  for (int m = 0; m < n_mat; ++m) {
+    const float l = ((float)lds_cnt[m * CB + tid] + lds_corr[m * CB + tid]) * len3d;
+    if (a.pathlen) a.pathlen[ray * n_mat + m] = l;
+    lds_corr[m * CB + tid] = l * 1.44269504088896340736f;
+  }
+  for (int e = 0; e < n_e; ++e) {
+    float pe = 0.0f;
+    for (int m = 0; m < n_mat; ++m) pe = fmaf(mu[m * n_e + e], lds_corr[m * CB + tid], pe);
+    const float t = __builtin_amdgcn_exp2f(-pe);
+#pragma unroll
+    for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = fmaf(w[srow[s] + e], t, accs[s]);
+    if (w2) {
+#pragma unroll
+      for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) vars[s] = fmaf(w2[srow[s] + e], t, vars[s]);
     }
-  } else {
-    for (int m = 0; m < n_mat; ++m) {
-      const float l = ((float)lds_cnt[m * CB + tid] + lds_corr[m * CB + tid]) * len3d;
-      if (a.pathlen) a.pathlen[ray * n_mat + m] = l;
-      lds_corr[m * CB + tid] = l * 1.44269504088896340736f;
-    }
-    for (int e = 0; e < n_e; ++e) {
-      float pe = 0.0f;
-      for (int m = 0; m < n_mat; ++m) pe = fmaf(mu[m * n_e + e], lds_corr[m * CB + tid], pe);
-      const float t = __builtin_amdgcn_exp2f(-pe);
+  }
+  if (w2) {
+    if (a.variance) {
 #pragma unroll
-      for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = fmaf(w[srow[s] + e], t, accs[s]);
+      for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
+        if (s < a.n_spectra) a.variance[ray + s * sstride] = vars[s];
+    }
+    if (a.sample) {
+      float z[DEXCT_MAX_SPECTRA];
+      pixel_normals<DEXCT_MAX_SPECTRA>((uint32_t)(a.view_begin + v), (uint32_t)r, (uint32_t)c, a.seed_lo, a.seed_hi, z);
+#pragma unroll
+      for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) accs[s] = noisy_count(accs[s], vars[s], z[s]);
     }
   }
 #pragma unroll
@@ -188,19 +256,19 @@ __global__ __launch_bounds__(CB) void cone_kernel(ConeArgs a, const float* __res
 }
 
 template <int NM>
-static int launch_cone(const ConeArgs& a, const float* mu, const float* w, hipStream_t st) {
+static int launch_cone(const ConeArgs& a, const float* mu, const float* w, const float* w2, hipStream_t st) {
   if (NM == 0 && a.n_materials > kManyMaterials) {       // 49..256 materials: LDS columns of 64 lanes (<= 128 KB)
     constexpr int B2 = 64;
     const size_t lds2 = (size_t)2 * a.n_materials * B2 * sizeof(float);
     DEXCT_ALLOW_LDS((cone_kernel<NM, B2>), lds2);
     dim3 grid2((a.g.n_channels + B2 - 1) / B2, a.g.n_rows, a.n_local_views);
-    hipLaunchKernelGGL((cone_kernel<NM, B2>), grid2, dim3(B2), lds2, st, a, mu, w);
+    hipLaunchKernelGGL((cone_kernel<NM, B2>), grid2, dim3(B2), lds2, st, a, mu, w, w2);
     DEXCT_LAUNCH_CHECK();
     return DEXCT_OK;
   }
   dim3 grid((a.g.n_channels + kConeBlock - 1) / kConeBlock, a.g.n_rows, a.n_local_views);
   const size_t lds = NM > 0 ? 0 : (size_t)2 * a.n_materials * kConeBlock * sizeof(float);
-  hipLaunchKernelGGL((cone_kernel<NM, kConeBlock>), grid, dim3(kConeBlock), lds, st, a, mu, w);
+  hipLaunchKernelGGL((cone_kernel<NM, kConeBlock>), grid, dim3(kConeBlock), lds, st, a, mu, w, w2);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }
@@ -245,7 +313,7 @@ constexpr int kConeRows = 256;
 template <int NM, int kB = 4, bool LDSC = true>      // kB: slabs per batch
 __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc,
                                                                const float* __restrict__ mu, const float* __restrict__ w,
-                                                               int n_chunks, int view_tile) {
+                                                               const float* __restrict__ w2, int n_chunks, int view_tile) {
   __shared__ ConeRec rec[kConeRows];
   __shared__ float lds_corr[LDSC ? 4 : 1][kConeRows];     // [id][lane]; id 3 = outside the grid: a cell nobody reads
   const int tid = threadIdx.x;
@@ -434,8 +502,6 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
   if (!live) return;
   // ---- detection (same weighting as the other kernels)
   const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
-  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
-  const int n_e = a.n_energies;
   float L2[NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
@@ -443,33 +509,8 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
     if (a.pathlen) a.pathlen[ray * a.n_materials + m] = l;
     L2[m] = l * 1.44269504088896340736f;
   }
-  float accs[DEXCT_MAX_SPECTRA];
-#pragma unroll
-  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = 0.0f;
-  if (a.n_spectra <= 2) {                      // round 3: energies in pairs through v_pk_fma_f32, zero-weight blocks skipped
-    float two[2];
-    detect_energy_pairs<NM>(L2, mu, w, n_e, a.n_spectra, bm, two);
-    accs[0] = two[0];
-    accs[1] = two[1];
-  } else {
-    int srow[DEXCT_MAX_SPECTRA];
-#pragma unroll
-    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) srow[sI] = (sI < a.n_spectra ? sI : 0) * n_e;
-    for (int e = 0; e < n_e; ++e) {
-      float pe = 0.0f;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
-      const float t = __builtin_amdgcn_exp2f(-pe);
-#pragma unroll
-      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = fmaf(w[srow[sI] + e], t, accs[sI]);
-    }
-  }
-#pragma unroll
-  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
-    if (sI < a.n_spectra) {
-      a.counts[ray + sI * sstride] = accs[sI];
-      if (a.sino_log) a.sino_log[ray + sI * sstride] = log_ratio(a.air[sI], accs[sI]);
-    }
+  if (w2) cone_detect_store<NM, true>(a, L2, mu, w, w2, bm, ray, v, r, c);
+  else cone_detect_store<NM, false>(a, L2, mu, w, w2, bm, ray, v, r, c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -488,7 +529,7 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
 template <int NM, int kB, int CB>
 __global__ __launch_bounds__(kConeRows) __attribute__((amdgpu_waves_per_eu(kB == 4 && CB <= 544 ? 8 : 5, 8)))
 void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const float* __restrict__ mu,
-                      const float* __restrict__ w, int n_chunks, int view_tile) {
+                      const float* __restrict__ w, const float* __restrict__ w2, int n_chunks, int view_tile) {
   constexpr int kBufB = 2 * kB * CB;                       // bytes of one staging buffer: [slab][b column, a column][CB]
   constexpr int kItems = (2 * kB * (CB / 16) + kConeRows - 1) / kConeRows;      // 16-byte pieces per lane and batch
   __shared__ ConeRec rec[kConeRows];
@@ -705,8 +746,6 @@ void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const floa
   if (!live) return;
   // ---- detection (same weighting as the other kernels)
   const size_t ray = ((size_t)v * a.g.n_rows + r) * a.g.n_channels + c;
-  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
-  const int n_e = a.n_energies;
   float L2[NM];
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
@@ -714,33 +753,8 @@ void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const floa
     if (a.pathlen) a.pathlen[ray * a.n_materials + m] = l;
     L2[m] = l * 1.44269504088896340736f;
   }
-  float accs[DEXCT_MAX_SPECTRA];
-#pragma unroll
-  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = 0.0f;
-  if (a.n_spectra <= 2) {                      // round 3: energies in pairs through v_pk_fma_f32, zero-weight blocks skipped
-    float two[2];
-    detect_energy_pairs<NM>(L2, mu, w, n_e, a.n_spectra, bm, two);
-    accs[0] = two[0];
-    accs[1] = two[1];
-  } else {
-    int srow[DEXCT_MAX_SPECTRA];
-#pragma unroll
-    for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) srow[sI] = (sI < a.n_spectra ? sI : 0) * n_e;
-    for (int e = 0; e < n_e; ++e) {
-      float pe = 0.0f;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) pe = fmaf(mu[m * n_e + e], L2[m], pe);
-      const float t = __builtin_amdgcn_exp2f(-pe);
-#pragma unroll
-      for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI) accs[sI] = fmaf(w[srow[sI] + e], t, accs[sI]);
-    }
-  }
-#pragma unroll
-  for (int sI = 0; sI < DEXCT_MAX_SPECTRA; ++sI)
-    if (sI < a.n_spectra) {
-      a.counts[ray + sI * sstride] = accs[sI];
-      if (a.sino_log) a.sino_log[ray + sI * sstride] = log_ratio(a.air[sI], accs[sI]);
-    }
+  if (w2) cone_detect_store<NM, true>(a, L2, mu, w, w2, bm, ray, v, r, c);
+  else cone_detect_store<NM, false>(a, L2, mu, w, w2, bm, ray, v, r, c);
 }
 
 // vol [nz][ny][nx] -> guarded z-fastest layout [(ny*nx + 1)][cone_zs(nz)] of 8 * id (the shift of the packed byte counter the
@@ -758,6 +772,24 @@ __global__ __launch_bounds__(256) void cone_layout_kernel(const uint8_t* __restr
   out[i] = val;
 }
 
+// the noise arguments of the cone entry points (struct dexct_noise): weights2 switches the variance on and needs somewhere for
+// it to go; the log of a noisy sinogram is the log of the SAMPLED counts, so log_out needs the sample
+static int cone_noise_args(const float* weights2, const float* variance, const dexct_noise* noise, const dexct_log_out* log_out) {
+  const bool sample = noise && noise->sample;
+  if (!weights2) return (variance || sample) ? DEXCT_EINVAL : DEXCT_OK;
+  if (!variance && !sample) return DEXCT_EINVAL;
+  if (!sample && log_out && log_out->sino_log) return DEXCT_EINVAL;
+  return DEXCT_OK;
+}
+
+static void set_cone_noise(ConeArgs& a, float* variance, const dexct_noise* noise) {
+  const bool sample = noise && noise->sample;
+  a.variance = variance;
+  a.sample = sample ? 1 : 0;
+  a.seed_lo = sample ? (uint32_t)noise->seed : 0u;
+  a.seed_hi = sample ? (uint32_t)(noise->seed >> 32) : 0u;
+}
+
 }  // namespace dexct
 
 using namespace dexct;
@@ -767,9 +799,10 @@ extern "C" int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_pl
                                   int32_t view_begin, int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
                                   int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
                                   const float* weights, float* counts, float* pathlen, const dexct_log_out* log_out,
-                                  void* stream) {
+                                  const float* weights2, float* variance, const dexct_noise* noise, void* stream) {
   if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_yx || !vol_xy || !mu || !weights || !counts)
     return DEXCT_EINVAL;
+  if (cone_noise_args(weights2, variance, noise, log_out) != DEXCT_OK) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
   if (n_materials > DEXCT_MAX_MATERIALS || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
@@ -798,13 +831,14 @@ extern "C" int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_pl
   a.pathlen = pathlen;
   a.sino_log = log_out ? log_out->sino_log : nullptr;
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = log_out ? log_out->air[s] : 1.0f;
+  set_cone_noise(a, variance, noise);
   hipStream_t st = as_stream(stream);
   switch (n_materials) {
-    case 1: return launch_cone<1>(a, mu, weights, st);
-    case 2: return launch_cone<2>(a, mu, weights, st);
-    case 3: return launch_cone<3>(a, mu, weights, st);
-    case 4: return launch_cone<4>(a, mu, weights, st);
-    default: return launch_cone<0>(a, mu, weights, st);
+    case 1: return launch_cone<1>(a, mu, weights, weights2, st);
+    case 2: return launch_cone<2>(a, mu, weights, weights2, st);
+    case 3: return launch_cone<3>(a, mu, weights, weights2, st);
+    case 4: return launch_cone<4>(a, mu, weights, weights2, st);
+    default: return launch_cone<0>(a, mu, weights, weights2, st);
   }
 }
 
@@ -829,8 +863,10 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
                                        int32_t view_begin, int32_t view_end, const uint8_t* vol_zc,
                                        int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
                                        const float* weights, float* counts, float* pathlen,
-                                       const dexct_log_out* log_out, void* stream) {
+                                       const dexct_log_out* log_out, const float* weights2, float* variance,
+                                       const dexct_noise* noise, void* stream) {
   if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_zc || !mu || !weights || !counts) return DEXCT_EINVAL;
+  if (cone_noise_args(weights2, variance, noise, log_out) != DEXCT_OK) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
   if (n_materials > 3 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;      // code 3 is "outside the grid"
@@ -856,6 +892,7 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
   a.pathlen = pathlen;
   a.sino_log = log_out ? log_out->sino_log : nullptr;
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = log_out ? log_out->air[s] : 1.0f;
+  set_cone_noise(a, variance, noise);
   const int n_chunks = (geom->n_rows + kConeRows - 1) / kConeRows;
   const size_t nblk = (size_t)a.n_local_views * geom->n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
@@ -874,8 +911,8 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
     const bool kb4 = !(ke && atoi(ke) == 8);
 #define DEXCT_CONE_COLS_LAUNCH(NM_, CB_) \
     do { \
-      if (kb4) hipLaunchKernelGGL((cone_cols_kernel<NM_, 4, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); \
-      else hipLaunchKernelGGL((cone_cols_kernel<NM_, 8, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); \
+      if (kb4) hipLaunchKernelGGL((cone_cols_kernel<NM_, 4, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); \
+      else hipLaunchKernelGGL((cone_cols_kernel<NM_, 8, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); \
     } while (0)
     if (zs <= 288u) {
       switch (n_materials) {
@@ -891,9 +928,9 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
       }
     } else {                                   // up to 1024 slices: 4 slabs per batch only (17 KB of LDS per buffer)
       switch (n_materials) {
-        case 1: hipLaunchKernelGGL((cone_cols_kernel<1, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
-        case 2: hipLaunchKernelGGL((cone_cols_kernel<2, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
-        default: hipLaunchKernelGGL((cone_cols_kernel<3, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
+        case 1: hipLaunchKernelGGL((cone_cols_kernel<1, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
+        case 2: hipLaunchKernelGGL((cone_cols_kernel<2, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
+        default: hipLaunchKernelGGL((cone_cols_kernel<3, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
       }
     }
 #undef DEXCT_CONE_COLS_LAUNCH
@@ -901,16 +938,16 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
     return DEXCT_OK;
   }
   switch (n_materials) {
-    case 1: hipLaunchKernelGGL(cone_rows_kernel<1>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
-    case 2: hipLaunchKernelGGL(cone_rows_kernel<2>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile); break;
+    case 1: hipLaunchKernelGGL(cone_rows_kernel<1>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
+    case 2: hipLaunchKernelGGL(cone_rows_kernel<2>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
     default: {
       const char* e = getenv("DEXCT_CONE_BATCH");         // tuning knob
       const int kb = e ? atoi(e) : 4;
       const char* le = getenv("DEXCT_CONE_LDSC");         // 0: corrections in registers (the round-2 form), for A/B
-      if (le && atoi(le) == 0) hipLaunchKernelGGL((cone_rows_kernel<3, 4, false>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
-      else if (kb == 8) hipLaunchKernelGGL((cone_rows_kernel<3, 8>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
-      else if (kb == 2) hipLaunchKernelGGL((cone_rows_kernel<3, 2>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
-      else hipLaunchKernelGGL((cone_rows_kernel<3, 4>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, n_chunks, view_tile);
+      if (le && atoi(le) == 0) hipLaunchKernelGGL((cone_rows_kernel<3, 4, false>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile);
+      else if (kb == 8) hipLaunchKernelGGL((cone_rows_kernel<3, 8>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile);
+      else if (kb == 2) hipLaunchKernelGGL((cone_rows_kernel<3, 2>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile);
+      else hipLaunchKernelGGL((cone_rows_kernel<3, 4>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile);
       break;
     }
   }

@@ -41,7 +41,8 @@ struct ProjArgs {
 };
 
 // log_out of the C ABI -> launch arguments (null: no log sinogram).  With a variance output the log belongs to the noisy
-// counts, which only exist after dexct_add_noise: the caller then uses dexct_sino_log.
+// counts, which only exist after dexct_add_noise: the caller then uses dexct_sino_log (`variance` non-null here = "the counts
+// this launch writes are not the final ones"; a kernel that samples the noise itself passes null).
 inline int set_log_out(ProjArgs& a, const dexct_log_out* lo, const float* variance) {
   a.sino_log = nullptr;
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = 1.0f;
@@ -61,6 +62,11 @@ struct PackedArgs {
   int view_tile;
   int det_masks;           // skip detection FMAs of spectrum slots with zero weights (blocks of four energies)
   int staged_store;        // store the results of a wave through LDS as whole lines (DEXCT_P16_STAGED=0: per-round 16-B stores)
+  // quantum noise (the NOISY instantiations; ABI 6): the kernel detects the variance with the counts and, `sample` != 0, draws
+  // the sample itself (noise_sample.h; the Philox counter needs the GLOBAL view)
+  int view_begin;
+  int sample;
+  uint32_t seed_lo, seed_hi;
 };
 
 // The attenuation and weight tables are passed as DIRECT __restrict__ kernel arguments (not inside
@@ -108,17 +114,27 @@ __device__ __forceinline__ BlockMasks detect_block_masks(const float* __restrict
   return bm;
 }
 
-template <int NM, int R, int SLOTS>
+// VAR (round 6): every slot also accumulates the VARIANCE of its signal, sum_e w2[s][e] 2^(...), from the same exponentials -
+// per energy one more FMA per slot and pair instead of a second pass over exponents and exponentials (the noisy scan: 18
+// instead of 28 vector instructions per energy and four rays of a dual-energy scan).  Per ray exactly the fmaf sequence of
+// the separate variance loop of detect_store, so the two forms give the same bits; a block of four energies a slot does not
+// weight (w = 0, hence w2 = w x gain = 0) is skipped for both sums.
+template <int NM, int R, int SLOTS, bool VAR = false>
 __device__ __forceinline__ void detect_energies(const f32x2 (&Lp)[(R + 1) / 2][NM], const float* __restrict__ mu,
                                                 const float* __restrict__ w, int n_e,
                                                 const int (&srow)[DEXCT_MAX_SPECTRA], const BlockMasks& bm,
-                                                float (&acc)[DEXCT_MAX_SPECTRA][R]) {
+                                                float (&acc)[DEXCT_MAX_SPECTRA][R], const float* __restrict__ w2 = nullptr,
+                                                float (*accv)[DEXCT_MAX_SPECTRA][R] = nullptr) {
   constexpr int P = (R + 1) / 2;                      // pairs; an odd last ray rides alone in a pair's low half
-  f32x2 ap[SLOTS][P];
+  f32x2 ap[SLOTS][P], av[VAR ? SLOTS : 1][P];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
     for (int j = 0; j < P; ++j) ap[s][j] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int s = 0; s < (VAR ? SLOTS : 1); ++s)
+#pragma unroll
+    for (int j = 0; j < P; ++j) av[s][j] = f32x2{0.0f, 0.0f};
   // LIVE: bit s set = slot s accumulates.  A slot whose weights are all +0 over a block of four energies adds exactly
   // nothing (w * finite = 0, acc + 0 = acc), so its FMAs are skipped for the block without changing a bit: the
   // 80 kVp spectrum of a dual-energy scan weights no energy above 80 keV, a single-spectrum scan has no second slot.
@@ -142,6 +158,11 @@ __device__ __forceinline__ void detect_energies(const f32x2 (&Lp)[(R + 1) / 2][N
       const float ws = w[srow[s] + e];
 #pragma unroll
       for (int j = 0; j < P; ++j) ap[s][j] = __builtin_elementwise_fma(f32x2{ws, ws}, te[j], ap[s][j]);
+      if constexpr (VAR) {
+        const float ws2 = w2[srow[s] + e];
+#pragma unroll
+        for (int j = 0; j < P; ++j) av[s][j] = __builtin_elementwise_fma(f32x2{ws2, ws2}, te[j], av[s][j]);
+      }
     }
   };
   constexpr uint32_t kAll = (1u << SLOTS) - 1u;
@@ -186,6 +207,12 @@ __device__ __forceinline__ void detect_energies(const f32x2 (&Lp)[(R + 1) / 2][N
   for (int s = 0; s < SLOTS; ++s)
 #pragma unroll
     for (int q = 0; q < R; ++q) acc[s][q] = (q & 1) ? ap[s][q / 2].y : ap[s][q / 2].x;
+  if constexpr (VAR) {
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+      for (int q = 0; q < R; ++q) (*accv)[s][q] = (q & 1) ? av[s][q / 2].y : av[s][q / 2].x;
+  }
 }
 
 // One ray per lane (the cone-beam kernels, whose lanes are the rows of a pair): the pairs that go through v_pk_fma_f32
@@ -194,11 +221,14 @@ __device__ __forceinline__ void detect_energies(const f32x2 (&Lp)[(R + 1) / 2][N
 // summation order than the one-energy loop's: 1e-7 relative).  3.5 vector instructions per energy instead of 6 and four
 // energies per trip (wide scalar loads); zero-weight blocks of a slot are skipped as in detect_energies.  L2 = path
 // lengths x log2(e).  <= 2 spectrum slots; acc[s] for s >= n_spectra comes back 0.
-template <int NM>
+// VAR: the variances sum_e w2[s][e] 2^(...) from the same exponentials (accv), as detect_energies<VAR>.
+template <int NM, bool VAR = false>
 __device__ __forceinline__ void detect_energy_pairs(const float (&L2)[NM], const float* __restrict__ mu,
                                                     const float* __restrict__ w, int n_e, int n_spectra,
-                                                    const BlockMasks& bm, float (&acc)[2]) {
+                                                    const BlockMasks& bm, float (&acc)[2], const float* __restrict__ w2 = nullptr,
+                                                    float (*accv)[2] = nullptr) {
   f32x2 ap[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+  f32x2 av[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
   const int row1 = (n_spectra > 1 ? 1 : 0) * n_e;
   auto two = [&](int e, auto live_tag) {
     constexpr uint32_t LIVE = decltype(live_tag)::value;
@@ -209,6 +239,10 @@ __device__ __forceinline__ void detect_energy_pairs(const float (&L2)[NM], const
     const f32x2 te = f32x2{__builtin_amdgcn_exp2f(-pe.x), __builtin_amdgcn_exp2f(-pe.y)};
     if (LIVE & 1u) ap[0] = __builtin_elementwise_fma(f32x2{w[e], w[e + 1]}, te, ap[0]);
     if (LIVE & 2u) ap[1] = __builtin_elementwise_fma(f32x2{w[row1 + e], w[row1 + e + 1]}, te, ap[1]);
+    if constexpr (VAR) {
+      if (LIVE & 1u) av[0] = __builtin_elementwise_fma(f32x2{w2[e], w2[e + 1]}, te, av[0]);
+      if (LIVE & 2u) av[1] = __builtin_elementwise_fma(f32x2{w2[row1 + e], w2[row1 + e + 1]}, te, av[1]);
+    }
   };
   auto four = [&](int e, auto live_tag) {
     two(e, live_tag);
@@ -234,7 +268,7 @@ __device__ __forceinline__ void detect_energy_pairs(const float (&L2)[NM], const
     else e = e_end;
     b += run;
   }
-  float tail0 = 0.0f, tail1 = 0.0f;
+  float tail0 = 0.0f, tail1 = 0.0f, tailv0 = 0.0f, tailv1 = 0.0f;
   for (; e < n_e; ++e) {                             // n_e not a multiple of 4: the last energies one at a time
     float pe = 0.0f;
 #pragma unroll
@@ -242,9 +276,17 @@ __device__ __forceinline__ void detect_energy_pairs(const float (&L2)[NM], const
     const float t = __builtin_amdgcn_exp2f(-pe);
     tail0 = fmaf(w[e], t, tail0);
     tail1 = fmaf(w[row1 + e], t, tail1);
+    if constexpr (VAR) {
+      tailv0 = fmaf(w2[e], t, tailv0);
+      tailv1 = fmaf(w2[row1 + e], t, tailv1);
+    }
   }
   acc[0] = (ap[0].x + ap[0].y) + tail0;
   acc[1] = n_spectra > 1 ? (ap[1].x + ap[1].y) + tail1 : 0.0f;
+  if constexpr (VAR) {
+    (*accv)[0] = (av[0].x + av[0].y) + tailv0;
+    (*accv)[1] = n_spectra > 1 ? (av[1].x + av[1].y) + tailv1 : 0.0f;
+  }
 }
 
 // The detected signal of a ray that meets nothing but material 0 (air) depends on its chord only: one value per
@@ -253,18 +295,23 @@ struct AirCache {
   float l0;                 // air length the values belong to
   float v[2];               // per spectrum slot
   bool have;
+  float vv[2];              // the variances (kernels that detect with FVAR)
 };
 
 // counts[s] = sum_e w[s][e] * exp(-sum_m mu[m][e] * L[m]) (v_exp_f32 on the log2(e)-scaled exponent)
 // for R rays at once (R = 4 in rows4_kernel: one scalar table load serves 4 rays and the FMAs pair up
 // into v_pk_fma_f32).  mu and w are wave-uniform (scalar loads); NM materials in registers.
 // EXTRAS = false leaves out the optional path-length and variance outputs (the caller writes them or has none).
-template <int NM, int R, bool EXTRAS = true>
+// FVAR (with res_out and var_out, at most two spectra): the variances sum_e w2[s][e] exp(-...) come out of the same energy
+// loop as the counts (detect_energies<.., VAR>) and are handed to the caller like the counts - the kernels that draw the
+// noise sample themselves.  Same bits as the separate loop below.
+template <int NM, int R, bool EXTRAS = true, bool FVAR = false>
 __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const ProjArgs& a, const float* __restrict__ mu,
                                              const float* __restrict__ w, const float* __restrict__ w2,
                                              const size_t (&ray)[R], const bool (&valid)[R],
                                              const BlockMasks& bm = BlockMasks{{~0ull, ~0ull}, false},
-                                             AirCache* air_cache = nullptr, float (*res_out)[2][R] = nullptr) {
+                                             AirCache* air_cache = nullptr, float (*res_out)[2][R] = nullptr,
+                                             float (*var_out)[2][R] = nullptr) {
   const int n_e = a.n_energies;
   const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
   if (EXTRAS && a.pathlen) {
@@ -281,7 +328,7 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
   for (int q = 0; q < R; ++q)
 #pragma unroll
     for (int m = 0; m < NM; ++m) L2[q][m] = L[q][m] * kLog2e;
-  float acc[DEXCT_MAX_SPECTRA][R];
+  float acc[DEXCT_MAX_SPECTRA][R], accv[FVAR ? DEXCT_MAX_SPECTRA : 1][FVAR ? R : 1];
 #pragma unroll
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s)
 #pragma unroll
@@ -317,25 +364,34 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
     }
   }
   if (wave_air) {
-    float one[DEXCT_MAX_SPECTRA][1];
+    float one[DEXCT_MAX_SPECTRA][1], onev[DEXCT_MAX_SPECTRA][1];
     bool cached = false;
     if (air_cache) cached = __ballot(!(air_cache->have && air_cache->l0 == L[0][0])) == 0ull;
     if (cached) {
       one[0][0] = air_cache->v[0];
       one[1][0] = air_cache->v[1];
+      if constexpr (FVAR) { onev[0][0] = air_cache->vv[0]; onev[1][0] = air_cache->vv[1]; }
     } else {
       f32x2 Lp1[1][NM];
 #pragma unroll
       for (int m = 0; m < NM; ++m) Lp1[0][m] = f32x2{L2[0][m], L2[0][m]};
-      detect_energies<NM, 1, 2>(Lp1, mu, w, n_e, srow, bm, one);
-      if (air_cache) *air_cache = AirCache{L[0][0], {one[0][0], one[1][0]}, true};
+      if constexpr (FVAR) {
+        detect_energies<NM, 1, 2, true>(Lp1, mu, w, n_e, srow, bm, one, w2, &onev);
+        if (air_cache) *air_cache = AirCache{L[0][0], {one[0][0], one[1][0]}, true, {onev[0][0], onev[1][0]}};
+      } else {
+        detect_energies<NM, 1, 2>(Lp1, mu, w, n_e, srow, bm, one);
+        if (air_cache) *air_cache = AirCache{L[0][0], {one[0][0], one[1][0]}, true, {0.0f, 0.0f}};
+      }
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       acc[0][q] = one[0][0];
       acc[1][q] = one[1][0];
+      if constexpr (FVAR) { accv[0][q] = onev[0][0]; accv[1][q] = onev[1][0]; }
     }
-  } else if (a.n_spectra <= 2)
+  } else if constexpr (FVAR)
+    detect_energies<NM, R, 2, true>(Lp, mu, w, n_e, srow, bm, acc, w2, &accv);
+  else if (a.n_spectra <= 2)
     detect_energies<NM, R, 2>(Lp, mu, w, n_e, srow, bm, acc);
   else
     detect_energies<NM, R, DEXCT_MAX_SPECTRA>(Lp, mu, w, n_e, srow, bm, acc);
@@ -377,6 +433,12 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int q = 0; q < R; ++q) (*res_out)[s][q] = acc[s][q];
+    if constexpr (FVAR) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < R; ++q) (*var_out)[s][q] = accv[s][q];
+    }
     return;
   }
   // 4 consecutive rays (layout 1, rows4_kernel): one 16-byte store per spectrum

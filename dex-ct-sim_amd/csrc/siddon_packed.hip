@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "noise_sample.h"
 #include "siddon_detect.h"
 
 namespace dexct {
@@ -117,7 +118,12 @@ struct Sliced {
 // GROUPED: a material-group pass (ids = codes 0..3 of one group of three materials): raw accumulators (units of u) go to
 // acc_out[(mat_base + code) * n_rays + ray], no detection (dexct_siddon_project_grouped_packed).
 // STAGED: results leave through LDS as whole lines (see below); the host picks it whenever it applies.
-template <int NM, int MINW = 4, bool GROUPED = false, bool STAGED = false>      // MINW: waves per SIMD the register allocation must allow
+// NOISY (round 6; at most two spectra): the scan with quantum noise - the reference's live mode, spectra scaled to a dose
+// (main.py:68,101).  The detection rounds accumulate the variance of the signal next to the signal (detect_energies<VAR>:
+// the exponentials are shared) and, pa.sample, draw the sample in the registers that hold both (noise_sample.h: one Philox
+// block per ray serves both spectra): what leaves the kernel is the noisy sinogram - no variance array, no pass over it.
+// a.variance (optional) receives the variances as well (tests; callers that sample with dexct_add_noise).
+template <int NM, int MINW = 4, bool GROUPED = false, bool STAGED = false, bool NOISY = false>      // MINW: waves per SIMD the register allocation must allow
 __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const float* __restrict__ mu, const float* __restrict__ w,
                                                     const float* __restrict__ w2) {
   static_assert(NM >= 2 && NM <= 4, "ids 0..3");
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
   // also stores pieces of other lanes.
   constexpr int kResSlots = 2;               // spectra whose results the stage holds
   static_assert(!(GROUPED && STAGED), "group passes hand over raw accumulators");
+  static_assert(!(GROUPED && NOISY), "group passes hand over raw accumulators");
   constexpr bool staged = STAGED;            // host: layout 1, n_rows % 4 == 0, n_spectra <= kResSlots
   const bool lane_live = pair_live && r0 < a.g.n_rows;
   if (!staged && !lane_live) return;
@@ -328,7 +335,8 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
     }
     return;
   }
-  AirCache air_cache{0.0f, {0.0f, 0.0f}, false};
+  AirCache air_cache{0.0f, {0.0f, 0.0f}, false, {0.0f, 0.0f}};
+  const size_t sstride_n = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
 #pragma unroll 1
   for (int q4 = 0; q4 < 4; ++q4) {
     const bool round_live = lane_live && r0 + 4 * q4 < a.g.n_rows;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
 #pragma unroll
         for (int m = 1; m < NM; ++m) L[rr][m] = corr[m - 1][rr] * p.len_per_u;
       }
-      if constexpr (staged) {
+      if constexpr (staged || NOISY) {
         if (a.pathlen) {             // (test output) written here so that the detection holds no store addresses
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
@@ -360,6 +368,52 @@ __global__ __launch_bounds__(64, MINW) void rows16_kernel(PackedArgs pa, const f
               for (int m = 0; m < NM; ++m) a.pathlen[rays[rr] * NM + m] = L[rr][m];
             }
         }
+      }
+      if constexpr (NOISY) {
+        float var[2][4];
+        detect_store<NM, 4, false, true>(L, a, mu, w, w2, rays, valid, bm, &air_cache, &res, &var);
+        if (a.variance && round_live) {            // (optional output: plain stores)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            if (s < a.n_spectra) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr)
+                if (valid[rr]) a.variance[rays[rr] + s * sstride_n] = var[s][rr];
+            }
+        }
+        if (pa.sample) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float z[2];
+            pixel_normals<2>((uint32_t)(pa.view_begin + v), (uint32_t)(r0 + 4 * q4 + rr), (uint32_t)c, pa.seed_lo, pa.seed_hi, z);
+            res[0][rr] = noisy_count(res[0][rr], var[0][rr], z[0]);
+            res[1][rr] = noisy_count(res[1][rr], var[1][rr], z[1]);
+          }
+        }
+        if constexpr (!staged) {                   // the round's stores (what detect_store does for the noise-free kernel)
+          if (round_live) {
+            const bool vec4 = a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[3];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              if (s < a.n_spectra) {
+                if (vec4) {
+                  *reinterpret_cast<float4*>(a.counts + rays[0] + s * sstride_n) = make_float4(res[s][0], res[s][1], res[s][2], res[s][3]);
+                  if (a.sino_log)
+                    *reinterpret_cast<float4*>(a.sino_log + rays[0] + s * sstride_n) =
+                        make_float4(log_ratio(a.air[s], res[s][0]), log_ratio(a.air[s], res[s][1]),
+                                    log_ratio(a.air[s], res[s][2]), log_ratio(a.air[s], res[s][3]));
+                } else {
+#pragma unroll
+                  for (int rr = 0; rr < 4; ++rr)
+                    if (valid[rr]) {
+                      a.counts[rays[rr] + s * sstride_n] = res[s][rr];
+                      if (a.sino_log) a.sino_log[rays[rr] + s * sstride_n] = log_ratio(a.air[s], res[s][rr]);
+                    }
+                }
+              }
+          }
+        }
+      } else if constexpr (staged) {
         detect_store<NM, 4, false>(L, a, mu, w, w2, rays, valid, bm, &air_cache, &res);
       } else {
         detect_store<NM, 4>(L, a, mu, w, w2, rays, valid, bm, &air_cache);
@@ -500,10 +554,17 @@ int dexct_volume_groups_pack2(const uint8_t* vol_zf, int64_t n_voxels, int32_t n
 int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                                 int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
                                 int32_t n_spectra, const float* mu, const float* weights, float* counts, float* pathlen,
-                                int32_t layout, const dexct_log_out* log_out, void* stream) {
+                                int32_t layout, const dexct_log_out* log_out, const float* weights2, float* variance,
+                                const dexct_noise* noise, void* stream) {
   if (!geom || !plan || !vol_z2 || !mu || !weights || !counts) return DEXCT_EINVAL;
   if (n_energies < 1 || n_spectra < 1) return DEXCT_EINVAL;
   if (n_materials < 2 || n_materials > 4 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;     // ids 0..3
+  // quantum noise: weights2 switches the variance on; it then needs somewhere to go - the optional output, the sample, or both
+  const bool sample = noise && noise->sample;
+  const bool noisy = weights2 != nullptr;
+  if (!noisy && (variance || sample)) return DEXCT_EINVAL;
+  if (noisy && !variance && !sample) return DEXCT_EINVAL;
+  if (noisy && n_spectra > 2) return DEXCT_ERANGE;              // (the fused variance runs in the two-slot detection)
   PackedArgs pa;
   size_t nblk, lds;
   const int rc = packed_shape(geom, view_begin, view_end, layout, pa, nblk, lds);
@@ -520,13 +581,18 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   a.n_spectra = n_spectra;
   a.counts = counts;
   a.pathlen = pathlen;
-  a.variance = nullptr;
+  a.variance = variance;
   a.acc_out = nullptr;
   a.mat_base = 0;
   a.layout = layout;
-  set_log_out(a, log_out, nullptr);
+  // the log of a noisy sinogram is the log of the SAMPLED counts: the kernel writes it only when it draws the sample itself
+  if (set_log_out(a, log_out, (noisy && !sample) ? weights2 : nullptr) != DEXCT_OK) return DEXCT_EINVAL;
   a.view_tile = pa.view_tile;
   pa.vol_z2 = vol_z2;
+  pa.view_begin = view_begin;
+  pa.sample = sample ? 1 : 0;
+  pa.seed_lo = sample ? (uint32_t)noise->seed : 0u;
+  pa.seed_hi = sample ? (uint32_t)(noise->seed >> 32) : 0u;
   hipStream_t st = as_stream(stream);
   int minw = 4;
   if (const char* e = getenv("DEXCT_P16_MINW")) minw = atoi(e);      // tuning knob
@@ -534,6 +600,22 @@ int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan
   // whole-line stores through LDS (STAGED) wherever the output allows them: row-fastest layout, whole groups of 4 rows,
   // one or two spectra (what the stage holds)
   const bool staged = pa.staged_store && layout == 1 && geom->n_rows % 4 == 0 && n_spectra <= 2;
+  if (noisy) {
+    if (n_materials == 2 && staged)
+      hipLaunchKernelGGL((rows16_kernel<2, 4, false, true, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, weights2);
+    else if (n_materials == 2)
+      hipLaunchKernelGGL((rows16_kernel<2, 4, false, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, weights2);
+    else if (n_materials == 4 && staged)
+      hipLaunchKernelGGL((rows16_kernel<4, 3, false, true, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, weights2);
+    else if (n_materials == 4)
+      hipLaunchKernelGGL((rows16_kernel<4, 3, false, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, weights2);
+    else if (staged)
+      hipLaunchKernelGGL((rows16_kernel<3, 4, false, true, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, weights2);
+    else
+      hipLaunchKernelGGL((rows16_kernel<3, 4, false, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, weights2);
+    DEXCT_LAUNCH_CHECK();
+    return DEXCT_OK;
+  }
   if (n_materials == 2 && staged)
     hipLaunchKernelGGL((rows16_kernel<2, 4, false, true>), dim3((unsigned)nblk), dim3(64), lds, st, pa, mu, weights, none);
   else if (n_materials == 2)
@@ -589,6 +671,9 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
   a.layout = layout;
   if (set_log_out(a, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
   a.view_tile = pa.view_tile;
+  pa.view_begin = view_begin;
+  pa.sample = 0;
+  pa.seed_lo = pa.seed_hi = 0u;
   hipStream_t st = as_stream(stream);
   const size_t group_bytes = (size_t)geom->nx * geom->ny * (geom->nz / 4);
   const int n_groups = (n_materials - 1 + 2) / 3;

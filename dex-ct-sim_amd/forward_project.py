@@ -253,7 +253,7 @@ class Projector:
         return 1 if (self.kernel == 0 and self.vol_zf is not None and self.ct.N_rows >= 64) else 0
 
     def project_tables(self, mu_d, w_d, want_pathlen=False, out=None, layout=0, w2_d=None, seed=0, air=None,
-                       log_out=None, views=None):
+                       log_out=None, views=None, want_variance=False):
         """Device-side call: mu_d [M, nE], w_d [S, nE] float32 tensors -> counts.
 
         ``air`` (S unattenuated signals, sum_e w[s][e]) asks for get_sino's second output as well, the log sinogram
@@ -264,12 +264,21 @@ class Projector:
         (what the row-parallel kernels produce natively); ``layout=None`` returns the native one.  When
         the requested layout is not the kernel's own, the kernel writes its own layout and
         dexct_transpose_batched converts (cheaper than scattered 4-byte stores).
-        ``w2_d`` (variance weights, merged_tables(with_variance=True)) switches quantum noise on: the kernel also
-        writes the signal variance and dexct_add_noise draws the sample (Philox, keyed by ``seed`` and by the
-        GLOBAL (view, row, channel, spectrum), so shards reproduce the unsharded sinogram).
+        ``w2_d`` (variance weights, merged_tables(with_variance=True)) switches quantum noise on (Philox, keyed by ``seed``
+        and by the GLOBAL (view, row, channel), so shards reproduce the unsharded sinogram).  The default kernels - the
+        packed stacked fan (<= 2 spectra) and the cone beam - sum the variance in the detection's own energy loop and draw
+        the sample in registers (struct dexct_noise): no variance array, no extra pass, and the log sinogram comes from the
+        same store.  The other kernels write the variance and dexct_add_noise draws the same sample from it.
+        ``want_variance``: the variance of the detected signal as a further result (appended last; tests).
         ``views=(a, b)``: only the local views [a, b) of this projector's range (outputs sized for b - a views): a step that
         hands its sinogram on in chunks projects chunk by chunk (bench.py, the sharded step)."""
+        # the kernels read the tables through raw pointers: dense float32, whatever view the caller built
+        # (torch.tensor(w[:, keep]) keeps NumPy's column-major result of the advanced index)
+        mu_d, w_d = (t.to(dtype=torch.float32).contiguous() for t in (mu_d, w_d))
+        w2_d = None if w2_d is None else w2_d.to(dtype=torch.float32).contiguous()
         S, nE = w_d.shape
+        if mu_d.shape[1] != nE or (w2_d is not None and tuple(w2_d.shape) != (S, nE)):
+            raise ValueError(f'tables disagree: mu {tuple(mu_d.shape)}, w {tuple(w_d.shape)}' + ('' if w2_d is None else f', w2 {tuple(w2_d.shape)}'))
         sl0, sl1 = (0, self.n_local_views) if views is None else (int(views[0]), int(views[1]))
         if not 0 <= sl0 < sl1 <= self.n_local_views:
             raise ValueError(f'views={views}: a non-empty range within the {self.n_local_views} local views')
@@ -296,40 +305,39 @@ class Projector:
         if want_pathlen:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
-        variance = torch.empty_like(counts) if w2_d is not None else None
+        noisy = w2_d is not None
+        # kernels that draw the noise sample themselves (ABI 6): the packed stacked fan and the cone beam
+        in_kernel = noisy and (self.cone or (self.use_packed and S <= 2))
+        variance = torch.empty_like(counts) if (noisy and (want_variance or not in_kernel)) else None
+        nz = _native.noise(seed) if in_kernel else None
         # the log sinogram: written by the detection store when the kernel's layout is the one wanted; else together with the
         # transpose at the end (dexct_transpose_log: the counts are read once for both outputs)
         fuse_log = air is not None and not direct
         log = None
         if air is not None and not fuse_log:
             log = log_out if log_out is not None else torch.empty(shape[run_layout], dtype=torch.float32, device=self.dev)
-        # fused into the detection store, except for noisy sinograms (their counts exist after the sampling)
-        lo = _native.log_out(ptr(log), air) if (log is not None and w2_d is None) else None
+        # fused into the detection store, except where the noisy counts only exist after dexct_add_noise
+        lo = _native.log_out(ptr(log), air) if (log is not None and (not noisy or in_kernel)) else None
         if self.cone:
             max_dz = float(np.max(np.abs(self.ct.row_z() - self.ct.src_z)))
 
-            def cone_call(weights, out_counts, out_pathlen, out_log):
-                if self.cone_rows:
-                    _native.check(self.lib.dexct_cone_project_rows(
-                        C.byref(self.geom), plan_ptr, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
-                        self.ct.src_z, max_dz, vb, ve, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
-                        ptr(weights), ptr(out_counts), ptr(out_pathlen), out_log, stream_ptr()), 'dexct_cone_project_rows')
-                else:
-                    _native.check(self.lib.dexct_cone_project(
-                        C.byref(self.geom), plan_ptr, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
-                        self.ct.src_z, max_dz, vb, ve, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
-                        ptr(mu_d), ptr(weights), ptr(out_counts), ptr(out_pathlen), out_log, stream_ptr()), 'dexct_cone_project')
-
-            cone_call(w_d, counts, pathlen, lo)
-            if w2_d is not None:
-                # quantum noise on a cone-beam scan: the variance of the detected signal, sum_e w2[e] exp(-...), is the same
-                # detection with the weights w2 - a second pass of the same kernel (the cone kernels carry no variance
-                # output of their own); dexct_add_noise then draws the sample below, keyed by the global (view, row, channel)
-                cone_call(w2_d, variance, None, None)
-        elif self.use_packed and w2_d is None:           # (with noise the byte-volume kernel below runs: it carries the variance)
+            # (quantum noise: the variance of the detected signal comes out of the same launch and the kernel draws the sample -
+            # round 5 ran the kernel a second time with w2 as weights)
+            if self.cone_rows:
+                _native.check(self.lib.dexct_cone_project_rows(
+                    C.byref(self.geom), plan_ptr, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                    self.ct.src_z, max_dz, vb, ve, ptr(self.vol_zc), M, nE, S, ptr(mu_d),
+                    ptr(w_d), ptr(counts), ptr(pathlen), lo, ptr(w2_d), ptr(variance), nz, stream_ptr()), 'dexct_cone_project_rows')
+            else:
+                _native.check(self.lib.dexct_cone_project(
+                    C.byref(self.geom), plan_ptr, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                    self.ct.src_z, max_dz, vb, ve, ptr(self.vol_yx), ptr(self.vol_xy), M, nE, S,
+                    ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), lo, ptr(w2_d), ptr(variance), nz, stream_ptr()), 'dexct_cone_project')
+        elif self.use_packed and (not noisy or in_kernel):      # (noise on > 2 spectra: the byte-volume kernel below)
             _native.check(self.lib.dexct_siddon_project_packed(
                 C.byref(self.geom), plan_ptr, vb, ve, ptr(self.vol_z2), M, nE, S,
-                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, lo, stream_ptr()), 'dexct_siddon_project_packed')
+                ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), run_layout, lo, ptr(w2_d), ptr(variance), nz, stream_ptr()),
+                'dexct_siddon_project_packed')
         elif self.grouped_packed or self.grouped:        # noise too: the detection pass carries the variance
             fn, what = ((self.lib.dexct_siddon_project_grouped_packed, 'dexct_siddon_project_grouped_packed') if self.grouped_packed
                         else (self.lib.dexct_siddon_project_grouped, 'dexct_siddon_project_grouped'))
@@ -368,7 +376,7 @@ class Projector:
                 ptr(self.vol_xy), ptr(self.vol_zf), M, nE, S, ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen),
                 3 if self.kernel in (7, 8) else self.kernel, run_layout, ptr(w2_d), ptr(variance), lo, stream_ptr()),
                 'dexct_siddon_project')
-        if variance is not None:
+        if noisy and not in_kernel:
             _native.check(self.lib.dexct_add_noise(ptr(counts), ptr(variance), S, nV, nR, nC, run_layout,
                                                    vb, int(seed) & (2 ** 64 - 1), stream_ptr()),
                           'dexct_add_noise')
@@ -383,9 +391,13 @@ class Projector:
             counts = dst
             if pathlen is not None:
                 pathlen = pathlen.permute(0, 2, 1, 3).contiguous()      # test-only output
+            if variance is not None and want_variance:
+                variance = variance.permute(0, 1, 3, 2).contiguous()    # test-only output
         res = (counts, pathlen) if want_pathlen else (counts,)
         if log is not None:
             res = res + (log,)
+        if want_variance:
+            res = res + (variance,)
         return res if len(res) > 1 else res[0]
 
     def transpose_log(self, src, dst, log_dst, air, rows, cols):
@@ -558,12 +570,19 @@ _SINO_CHUNKS = 8                # view chunks of a large noise-free projection o
                                 # crosses PCIe (3.3 GB of results take 58 ms, their kernels 12)
 
 
-def _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature):
+def _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature, noise=False):
     """get_sinos for a large scan on one process: the views are projected in _SINO_CHUNKS chunks (Projector.project_tables,
     views=) and every chunk's two outputs leave for host memory on a download stream while the next chunk is projected.  The same
-    kernels on the same rays as the single launch: the same bits.  One host block per spectrum and output (_device.LazyPinnedResult:
-    touched and locked chunk by chunk in front of the copies, unlocked before it is returned)."""
-    _, mu_d, w_d, air = pj.upload_tables(specs, quadrature)
+    kernels on the same rays as the single launch: the same bits - with quantum noise too (``noise`` True: the Philox counter is
+    the global view).  One host block per spectrum and output (_device.LazyPinnedResult: touched and locked chunk by chunk in
+    front of the copies, unlocked before it is returned)."""
+    w2_d = None
+    if noise:
+        _, mu, w, w2 = merged_tables(ct, phantom, specs, with_variance=True)
+        mu_d, w_d, w2_d = (to_dev(x, torch.float32, pj.dev) for x in (pj.compact(mu), w, w2))
+        air = w.sum(axis=1)
+    else:
+        _, mu_d, w_d, air = pj.upload_tables(specs, quadrature)
     S, nV, nR, nC = len(specs), pj.n_local_views, ct.N_rows, ct.N_channels
     bounds = [_shard.split(nV, k, _SINO_CHUNKS) for k in range(_SINO_CHUNKS)]
     row = nR * nC * 4
@@ -574,7 +593,7 @@ def _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature):
     keep = []                                  # (the chunks' device tensors live until their copies are done)
     with torch.cuda.stream(main):
         for k, (b, e) in enumerate(bounds):
-            c_k, l_k = pj.project_tables(mu_d, w_d, layout=0, air=air, views=(b, e))
+            c_k, l_k = pj.project_tables(mu_d, w_d, layout=0, air=air, views=(b, e), w2_d=w2_d, seed=seed)
             keep.append((c_k, l_k))
             done = torch.cuda.Event()
             done.record(main)
@@ -589,7 +608,7 @@ def _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature):
     if stale:
         del out
         invalidate()
-        return get_sinos(ct, phantom, specs, noise=False, seed=seed, quadrature=quadrature)
+        return get_sinos(ct, phantom, specs, noise=noise, seed=seed, quadrature=quadrature)
     if nR == 1:
         out = [(r[:, 0, :], l[:, 0, :]) for r, l in out]
     return out
@@ -618,8 +637,8 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0, quadrature=None):
     pj, check = _projector(ct, phantom, (vb, ve))
     sharded = _shard.world()[1] > 1
     per_array = ct.N_proj * ct.N_rows * ct.N_channels * 4
-    if not sharded and not noise and pool_wanted(per_array) and ct.N_proj >= 4 * _SINO_CHUNKS:
-        return _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature)
+    if not sharded and noise != 'poisson' and pool_wanted(per_array) and ct.N_proj >= 4 * _SINO_CHUNKS:
+        return _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature, noise=bool(noise))
     res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded, quadrature=quadrature)
     if sharded:
         counts = _shard.gather_views(res, ct.N_proj, view_dim=1, tag='get_sinos')

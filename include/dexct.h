@@ -21,13 +21,16 @@
 extern "C" {
 #endif
 
-#define DEXCT_ABI_VERSION 5   /* 2: log_out argument of the projection entry points, dexct_sino_log;
+#define DEXCT_ABI_VERSION 6   /* 2: log_out argument of the projection entry points, dexct_sino_log;
                                  3: struct dexct_gn_options - tolerance stop, results in the reference's order; 256 material ids;
                                  4: dexct_gn_options.pass / .iterations / .start - the Newton short cut (tabulated fixed points);
                                  5: dexct_gn_options.flags / .blocks_per_cu (what the environment used to switch per call), the
                                     two-launch form of the short cut removed, DEXCT_GN_FLAG_ONE_STEP, dexct_sino_gather (peer-to-peer
                                     assembly), dexct_transpose_log (both outputs of get_sino in one pass), dexct_host_touch / _pin /
-                                    _unpin / dexct_download (the NumPy boundary of large arrays) */
+                                    _unpin / dexct_download (the NumPy boundary of large arrays);
+                                 6: quantum noise inside the projection kernels - struct dexct_noise; weights2 / variance / noise
+                                    arguments of dexct_siddon_project_packed, dexct_cone_project, dexct_cone_project_rows; one Philox
+                                    block per detector pixel serves all its spectra (dexct_add_noise draws the same sample) */
 
 #define DEXCT_OK 0
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
@@ -82,6 +85,23 @@ typedef struct dexct_log_out {
   float* sino_log;              /* device, n_spectra * n_rays float32 */
   float air[DEXCT_MAX_SPECTRA]; /* host values, copied into the launch arguments */
 } dexct_log_out;
+
+/* Quantum noise drawn by the projection kernel itself (ABI 6).  The reference scales every spectrum to a dose before it
+ * projects (main.py:68, doses at main.py:101) and reads sino_raw as photon counts (matdecomp.py:30,179): the noisy scan is its
+ * live mode.  With `weights2` (weights x detector signal per photon, as for dexct_siddon_project) an entry point that takes
+ * this struct accumulates the variance of the detected signal, sum_e weights2 exp(-...), in the same energy loop as the signal
+ * (the exponentials are shared) and
+ *   sample != 0: writes counts = max(signal + sqrt(variance) z, 1e-20), z standard normal from Philox4x32-10 with counter
+ *                (global view, row, channel, 0) and key `seed` - one block per detector pixel, its four words feed two
+ *                Box-Muller pairs, spectrum s takes normal s - exactly the sample dexct_add_noise draws from the same signal
+ *                and variance (shard-, layout- and kernel-independent).  A log_out then receives the log of the SAMPLED counts.
+ *   variance != NULL (argument of the entry point): also writes the variances, [s*n_rays + ray] like counts.
+ * At least one of the two; at most two spectra.  NULL / weights2 == NULL: the noise-free expectation. */
+typedef struct dexct_noise {
+  uint64_t seed;
+  int32_t sample;
+  int32_t reserved_;
+} dexct_noise;
 
 const char* dexct_strerror(int code);
 int dexct_abi_version(void);
@@ -162,12 +182,15 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
  * dexct_siddon_project_packed: same outputs and layouts as dexct_siddon_project; nz and z_first multiples of 16;
  *   nx, ny <= 2047.  A (view, channel) pair occupies ceil(n_rows/16) lanes of a 16-, 32- or 64-lane group (lanes past
  *   the last row idle: efficient for n_rows near 256, 512 or a multiple of 1024).  Bit-identical per-material path
- *   lengths. */
+ *   lengths.  weights2 / variance / noise (ABI 6): see struct dexct_noise - the noisy scan on this kernel (the variance rides
+ *   in the detection rounds, the sample is drawn in registers: no variance array, no sampling pass; same bits as
+ *   dexct_siddon_project(kernel 3, variance) + dexct_add_noise). */
 int dexct_volume_pack2(const uint8_t* vol_zf, int64_t n_voxels, uint8_t* vol_z2, void* stream);
 int dexct_siddon_project_packed(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                                 int32_t view_end, const uint8_t* vol_z2, int32_t n_materials, int32_t n_energies,
                                 int32_t n_spectra, const float* mu, const float* weights, float* counts,
-                                float* pathlen, int32_t layout, const dexct_log_out* log_out, void* stream);
+                                float* pathlen, int32_t layout, const dexct_log_out* log_out, const float* weights2,
+                                float* variance, const dexct_noise* noise, void* stream);
 
 /* Material groups on the packed volume (5..DEXCT_MAX_MATERIALS materials; the packed form of dexct_volume_groups /
  * dexct_siddon_project_grouped, same arguments and outputs; preconditions of dexct_siddon_project_packed).
@@ -185,12 +208,15 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
  * src_z, detector row r at height row_z[r] (device float64 [n_rows], cm, z = 0 at the centre of the grid;
  * geom->z_first is ignored).  max_abs_dz = max_r |row_z[r] - src_z| (the caller knows it; it bounds the z
  * slope: at most one z-plane may be crossed per dominant-axis slab, else DEXCT_ERANGE).  One thread per ray;
- * counts / pathlen in layout 0 of dexct_siddon_project; every material is accumulated directly. */
+ * counts / pathlen in layout 0 of dexct_siddon_project; every material is accumulated directly.
+ * weights2 / variance / noise (ABI 6, both cone entry points): struct dexct_noise - the noisy scan in the same launch (any
+ * number of spectra); variance [s*n_rays + ray] in the order of counts. */
 int dexct_cone_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
                        const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
                        int32_t view_begin, int32_t view_end, const uint8_t* vol_yx, const uint8_t* vol_xy,
                        int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
-                       const float* weights, float* counts, float* pathlen, const dexct_log_out* log_out, void* stream);
+                       const float* weights, float* counts, float* pathlen, const dexct_log_out* log_out,
+                       const float* weights2, float* variance, const dexct_noise* noise, void* stream);
 
 /* The same projection with the ROWS of one (view, channel) pair as lanes: the in-plane slab records are computed once
  * per pair and shared by all its rows, a lane carries only its z DDA.  <= 3 materials.  Round 3 (cone_cols_kernel): the
@@ -207,7 +233,8 @@ int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* pl
                             const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
                             int32_t view_begin, int32_t view_end, const uint8_t* vol_zc, int32_t n_materials,
                             int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights,
-                            float* counts, float* pathlen, const dexct_log_out* log_out, void* stream);
+                            float* counts, float* pathlen, const dexct_log_out* log_out, const float* weights2,
+                            float* variance, const dexct_noise* noise, void* stream);
 
 /* counts += sqrt(variance) * z, z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
  * channel, spectrum) and key seed: independent of view sharding and of the layout (0 / 1 as above).

@@ -1121,14 +1121,19 @@ def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
     gc.collect()
     r_again, l_again = dx.get_sino(cts, ph, spec)
     assert [u.fresh for u in used[4:]] == [True, True, False, False] and np.array_equal(r_again, r_pin) and np.array_equal(l_again, l_pin)
-    # a noisy projection is one launch, its results copied in pieces (two of them here)
+    # a noisy projection goes through the same view chunks (round 6: the kernel draws the sample itself, keyed by the GLOBAL view:
+    # the chunks reproduce the single launch bit for bit)
     n_lazy = dx.get_sino(cts, ph, spec, noise=True, seed=5)
-    assert len(used) == 10 and len(used[8].pieces) == 2
+    assert len(used) == 10 and len(used[8].pieces) == fp._SINO_CHUNKS
     monkeypatch.setenv('DEXCT_LAZY_PIN', '0')
-    n_pin = dx.get_sino(cts, ph, spec, noise=True, seed=5)
+    n_pin = dx.get_sino(cts, ph, spec, noise=True, seed=5)                                # one launch
     monkeypatch.delenv('DEXCT_LAZY_PIN')
     assert len(used) == 10 and np.array_equal(n_lazy[0], n_pin[0]) and np.array_equal(n_lazy[1], n_pin[1])
-    del third, fourth, r_again, l_again, n_lazy, used
+    assert not np.array_equal(n_lazy[0], r_pin)
+    # per-bin Poisson photon counts are one launch, its results copied in pieces (two of them here)
+    p_lazy = dx.get_sino(cts, ph, spec, noise='poisson', seed=5)
+    assert len(used) == 12 and len(used[10].pieces) == 2 and np.isfinite(p_lazy[1]).all()
+    del third, fourth, r_again, l_again, n_lazy, p_lazy, used
     gc.collect()
     assert _device.empty_pool() > 0 and not _device._pool
 

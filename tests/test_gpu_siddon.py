@@ -5,6 +5,8 @@ bit-exact: plan table, voxel-index sequences, float32 piece lengths, per-materia
            against the float64 textbook Siddon in test_siddon_oracle.py)
 1e-5 rel : sinogram counts vs the float64 textbook Siddon + float64 detection (north-star tolerance)
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,7 @@ from oracle import c_oracle as co
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
+C_byref = ctypes.byref
 
 
 def projector(ct, ph, **kw):
@@ -205,6 +208,8 @@ def test_quantum_noise_statistics_and_reproducibility(hip):
     n1, _ = projector(ct, ph, kernel=3).project(sp, noise=True, seed=7)
     n1b, _ = projector(ct, ph, kernel=1).project(sp, noise=True, seed=7)      # other kernel, other native layout
     n2, _ = projector(ct, ph, kernel=3).project(sp, noise=True, seed=8)
+    n7, _ = projector(ct, ph, kernel=7).project(sp, noise=True, seed=7)       # rows16_kernel draws the sample itself
+    assert torch.equal(n7, n1)
     assert not torch.equal(n1, clean) and not torch.equal(n1, n2)
     assert torch.allclose(n1, n1b, rtol=2e-6, atol=0)
     a, _ = projector(ct, ph, view_range=(0, 17), kernel=3).project(sp, noise=True, seed=7)
@@ -633,9 +638,10 @@ def test_packed_volume_kernel_refuses_what_it_cannot_do(hip):
         projector(cone, ph, kernel=7)                                # not a stacked fan
 
 
-def test_packed_volume_is_the_default_and_noise_falls_back(hip):
-    """kernel=0 picks the packed-volume kernel for <= 3 materials and 256 rows; with quantum noise the byte-volume
-    kernel runs instead (it carries the variance) and gives the sample kernel 3 gives for the same seed."""
+def test_packed_volume_is_the_default_with_and_without_noise(hip):
+    """kernel=0 picks the packed-volume kernel for <= 3 materials and 256 rows; with quantum noise too (round 6: the kernel
+    sums the variance and draws the sample itself) and gives the sample the byte-volume kernel + dexct_add_noise give for the
+    same seed."""
     ct, ph = small_scan(n=40, nz=256, n_views=6, n_channels=40, n_rows=256)
     sp = spectra()
     auto = projector(ct, ph)
@@ -652,6 +658,83 @@ def test_packed_volume_is_the_default_and_noise_falls_back(hip):
     assert not projector(ct3, ph3).use_packed
     ct4, ph4 = small_scan(n=40, nz=768, n_views=6, n_channels=40, n_rows=768)        # 768 rows: 48 of 64 lanes: packed
     assert projector(ct4, ph4).use_packed
+
+
+@pytest.mark.parametrize('n_rows,nz,z_index,n_mat,n_spec,staged', [
+    (256, 256, 0, 3, 2, '1'), (256, 256, 0, 3, 2, '0'), (512, 512, 0, 3, 1, '1'), (66, 70, 2, 3, 2, '1'), (200, 208, 0, 2, 2, '1'),
+    (1024, 1024, 0, 4, 2, '1'), (2048, 2048, 0, 3, 2, '1'), (64, 64, 0, 4, 1, '0')])
+def test_noisy_scan_on_the_packed_kernel_equals_the_byte_volume_path(hip, n_rows, nz, z_index, n_mat, n_spec, staged, monkeypatch):
+    """Round 6: rows16_kernel<NOISY> (the variance summed in the detection rounds, the sample drawn in registers, the log of
+    the sampled counts from the same store) against rows4_kernel's variance output + dexct_add_noise + dexct_sino_log: the
+    noisy counts, the variances and the log sinogram are the same bits - same Philox keys, same detection arithmetic.
+    Staged whole-line stores and the per-round stores, ragged rows (66 of 70 from slice 2: the host pads; 200: idle lanes),
+    4 / 2 / 1 pairs per wave and two z-chunks, 2 - 4 materials, one and two spectra; also in the reference's order
+    (transpose + log in one pass) and without the sample (variance output only)."""
+    from dex_ct_sim_amd import _native, forward_project as fp
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+    from dex_ct_sim_amd.system import AIR, WATER
+    monkeypatch.setenv('DEXCT_P16_STAGED', staged)
+    ct, ph = small_scan(n=40, nz=nz, n_views=7, n_channels=23, n_rows=n_rows, z_index=z_index)
+    if n_mat == 2:
+        ph.volume = np.minimum(ph.volume, 1).astype(np.uint8)
+        ph.materials = [AIR, WATER]
+    elif n_mat == 4:
+        ph = ph_many(ph, 4)
+    sp = spectra()[:n_spec]
+    for s_ in sp:
+        s_.rescale_counts(1e-2)
+    _, mu, w, w2 = fp.merged_tables(ct, ph, sp, with_variance=True)
+    air = w.sum(axis=1)
+    res = {}
+    for k in (7, 3):
+        pj = projector(ct, ph, kernel=k)
+        mu_d, w_d, w2_d = (torch.tensor(x, dtype=torch.float32, device='cuda').contiguous() for x in (pj.compact(mu), w, w2))
+        res[k] = pj.project_tables(mu_d, w_d, layout=None, w2_d=w2_d, seed=9, air=air, want_variance=True)
+        res[k, 'ref'] = pj.project_tables(mu_d, w_d, layout=0, w2_d=w2_d, seed=9, air=air)
+        res[k, 'clean'] = pj.project_tables(mu_d, w_d, layout=None)
+        w_t = w_d.t().contiguous().t()                      # a column-major view of the same table (what torch.tensor(w[:, keep]) is)
+        assert (n_spec == 1 or not w_t.is_contiguous()) and torch.equal(pj.project_tables(mu_d, w_t, layout=None), res[k, 'clean'])
+        if k == 7:
+            assert pj.use_packed
+            # the variance alone (no sample): counts stay the expectation
+            counts = torch.empty_like(res[7][0])
+            var = torch.empty_like(counts)
+            _native.check(pj.lib.dexct_siddon_project_packed(
+                C_byref(pj.geom), pj.plan.data_ptr(), 0, ct.N_proj, ptr(pj.vol_z2), pj.n_mat, w_d.shape[1], n_spec, ptr(mu_d),
+                ptr(w_d), ptr(counts), None, 1, None, ptr(w2_d), ptr(var), None, stream_ptr()), 'packed, variance only')
+            assert torch.equal(counts, res[7, 'clean']) and torch.equal(var, res[7][2])
+    for a, b in zip(res[7], res[3]):
+        assert torch.equal(a, b)                                                 # noisy counts, log, variance
+    for a, b in zip(res[7, 'ref'], res[3, 'ref']):
+        assert torch.equal(a, b)
+    assert torch.equal(res[7, 'ref'][0], res[7][0].permute(0, 1, 3, 2))
+    assert torch.equal(res[7, 'clean'], res[3, 'clean']) and not torch.equal(res[7][0], res[7, 'clean'])
+    assert torch.isfinite(res[7][1]).all() and (res[7][2] > 0).all()
+    assert torch.equal(res[7][1], projector(ct, ph, kernel=7).sino_log(res[7][0], air))
+
+
+def test_packed_noise_arguments_are_checked(hip):
+    """struct dexct_noise: weights2 needs somewhere for the variance to go; a variance or a sample needs weights2; the log of a
+    noisy sinogram needs the sample; at most two spectra."""
+    from dex_ct_sim_amd import _native, forward_project as fp
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+    ct, ph = small_scan(n=32, nz=64, n_views=4, n_channels=16, n_rows=64)
+    pj = projector(ct, ph, kernel=7)
+    sp = spectra()
+    _, mu, w, w2 = fp.merged_tables(ct, ph, sp, with_variance=True)
+    mu_d, w_d, w2_d = (torch.tensor(x, dtype=torch.float32, device='cuda').contiguous() for x in (pj.compact(mu), w, w2))
+    counts = torch.empty((2, 4, 16, 64), dtype=torch.float32, device='cuda')
+    var, log = torch.empty_like(counts), torch.empty_like(counts)
+
+    def call(w2p, varp, nz, lo=None, n_spec=2):
+        return pj.lib.dexct_siddon_project_packed(C_byref(pj.geom), pj.plan.data_ptr(), 0, 4, ptr(pj.vol_z2), pj.n_mat, w_d.shape[1],
+                                                  n_spec, ptr(mu_d), ptr(w_d), ptr(counts), None, 1, lo, w2p, varp, nz, stream_ptr())
+    assert call(ptr(w2_d), None, None) == -1                       # nowhere to go
+    assert call(None, ptr(var), None) == -1 and call(None, None, _native.noise(3)) == -1
+    assert call(ptr(w2_d), ptr(var), None, _native.log_out(ptr(log), [1.0, 1.0])) == -1       # the log needs the sample
+    assert call(ptr(w2_d), None, _native.noise(3, sample=False)) == -1
+    assert call(ptr(w2_d), ptr(var), _native.noise(3), _native.log_out(ptr(log), [1.0, 1.0])) == 0
+    assert call(ptr(w2_d), None, _native.noise(3)) == 0
 
 
 @pytest.mark.parametrize('seed', range(8))
@@ -929,9 +1012,22 @@ def test_log_sinogram_of_noisy_and_cone_beam_scans(hip):
         plain, _ = pjc.project(sp)
         assert torch.equal(counts, plain)
         assert np.allclose(log.cpu().numpy(), _np_log(air, counts.cpu().numpy()), rtol=5e-6, atol=5e-7)
-        # round 4: quantum noise on cone-beam scans (Philox; the variance from a second detection pass with the variance
-        # weights): reproducible, the same sample from both cone kernels and from view shards, moments as predicted
+        # round 4: quantum noise on cone-beam scans (Philox): reproducible, the same sample from both cone kernels and from
+        # view shards, moments as predicted.  Round 6: ONE launch - the variance comes out of the detection's own energy
+        # loop (the same bits as round 5's second launch with the variance weights as weights) and the kernel draws the
+        # sample dexct_add_noise draws from the same signal and variance
         (noisy, nlog), _ = pjc.project(sp, noise=True, seed=11, want_log=True)
+        from dex_ct_sim_amd import _native, forward_project as fp
+        from dex_ct_sim_amd._device import ptr, stream_ptr
+        _, mu, w, w2 = fp.merged_tables(cone, ph, sp, with_variance=True)
+        mu_d, w_d, w2_d = (torch.tensor(x, dtype=torch.float32, device='cuda').contiguous() for x in (pjc.compact(mu), w, w2))
+        second = pjc.project_tables(mu_d, w2_d)
+        n_again, var = pjc.project_tables(mu_d, w_d, w2_d=w2_d, seed=11, want_variance=True)
+        assert torch.equal(var, second) and torch.equal(n_again, noisy)
+        sampled = plain.clone()
+        _native.check(pjc.lib.dexct_add_noise(ptr(sampled), ptr(var), 2, cone.N_proj, cone.N_rows, cone.N_channels, 0, 0, 11,
+                                              stream_ptr()), 'dexct_add_noise')
+        assert torch.equal(sampled, noisy)
         again, _ = pjc.project(sp, noise=True, seed=11)
         other, _ = pjc.project(sp, noise=True, seed=12)
         assert torch.equal(noisy, again) and not torch.equal(noisy, other) and not torch.equal(noisy, plain)

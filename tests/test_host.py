@@ -111,7 +111,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.dexct_abi_version.restype = ctypes.c_int
-    assert lib.dexct_abi_version() == 5 == _native.ABI_VERSION
+    assert lib.dexct_abi_version() == 6 == _native.ABI_VERSION
     lib.dexct_strerror.restype = ctypes.c_char_p
     assert lib.dexct_strerror(-2) == b'size out of supported range'
     # struct layouts the binding mirrors
