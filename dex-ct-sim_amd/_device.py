@@ -1,4 +1,5 @@
 """torch-ROCm as the device container: allocation, streams, pointers.  No compute happens here."""
+import collections
 import os
 import threading
 import weakref
@@ -71,6 +72,16 @@ def side_streams(dev):
     return _side[key]
 
 
+def quiesce():
+    """Wait for everything queued on the side streams and the current stream: the error paths of the pipelined boundary call
+    this before host memory that a queued copy may still read or write is unlocked or let go."""
+    for streams in list(_side.values()):
+        for st in streams:
+            st.synchronize()
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.current_stream().synchronize()
+
+
 # ---- large results and large inputs: host memory made ready for DMA while the GPU works ---------------------------------------
 # Results cross PCIe by DMA into page-locked host memory that the returned arrays own.  A page-locked allocation (torch's, or
 # hipHostMalloc) of memory the process has never touched runs at 11 GB/s - 0.57 s for the 6.5 GB of the benchmark's
@@ -86,7 +97,20 @@ def side_streams(dev):
 # Large INPUT arrays get the same treatment for the time of a call (locked_arrays): resident by nature, locked in milliseconds,
 # uploaded by DMA instead of through the runtime's staging buffers.
 LAZY_MIN_BYTES = 64 << 20       # smaller results: torch's page-locked allocation (milliseconds)
-POOL_MAX_BYTES = int(float(os.environ.get('DEXCT_HOST_POOL_GB', '64')) * (1 << 30))
+
+
+def _default_pool_gb():
+    """A quarter of the memory the machine has free when the module loads, between 8 and 64 GB (round 5 kept up to 64 GB of a
+    process's dropped results resident whatever the machine: advisor finding); DEXCT_HOST_POOL_GB sets it explicitly."""
+    try:
+        with open('/proc/meminfo') as f:
+            kb = next(int(ln.split()[1]) for ln in f if ln.startswith('MemAvailable:'))
+        return min(64.0, max(8.0, kb / 4.0 / (1 << 20)))
+    except (OSError, StopIteration, ValueError):
+        return 16.0
+
+
+POOL_MAX_BYTES = int(float(os.environ.get('DEXCT_HOST_POOL_GB', _default_pool_gb())) * (1 << 30))
 _pool = {}                      # bytes -> [free blocks (np.uint8 arrays, page aligned, resident)]
 _pool_lock = threading.Lock()
 _PAGE = 4096
@@ -99,23 +123,47 @@ def pool_wanted(n_bytes):
 
 
 _pool_age = []                  # sizes of the pooled blocks, oldest first: what leaves when the pool is over its limit
+_returned = collections.deque() # blocks whose arrays became garbage, not yet in the pool (appended without the lock, see _give_back)
 
 
 def _give_back(buf):
-    with _pool_lock:
+    """Runs as a weakref.finalize callback, i.e. wherever the garbage collector happens to run - also INSIDE a ``with
+    _pool_lock:`` block of the same thread (a cyclic collection triggered by an allocation there), where taking the
+    non-reentrant lock would block for ever (advisor finding of round 5).  So the callback only appends to a deque (atomic,
+    no lock); the blocks enter the pool the next time somebody holds the lock anyway (_drain_returned)."""
+    _returned.append(buf)
+
+
+def _drain_returned():
+    """under _pool_lock: the blocks that came back since the last call join the pool; the oldest leave while it is over its limit"""
+    while True:
+        try:
+            buf = _returned.popleft()
+        except IndexError:
+            break
         if buf.nbytes > POOL_MAX_BYTES:
-            return
+            continue
         _pool.setdefault(buf.nbytes, []).append(buf)
         _pool_age.append(buf.nbytes)
-        while sum(k * len(v) for k, v in _pool.items()) > POOL_MAX_BYTES and _pool_age:
-            old = _pool_age.pop(0)      # the block that has waited longest (of whatever size: sizes nobody asks for any more go first)
-            if _pool.get(old):
-                _pool[old].pop(0)
+    total = sum(k * len(v) for k, v in _pool.items())
+    while total > POOL_MAX_BYTES and _pool_age:
+        old = _pool_age.pop(0)          # the block that has waited longest (of whatever size: sizes nobody asks for any more go first)
+        if _pool.get(old):
+            _pool[old].pop(0)
+            total -= old
+
+
+def pooled():
+    """{block bytes: number of free blocks} after the returned blocks have joined the pool (tests, diagnostics)"""
+    with _pool_lock:
+        _drain_returned()
+        return {k: len(v) for k, v in _pool.items() if v}
 
 
 def empty_pool():
     """Drop every pooled block (back to the system).  Returns the bytes let go."""
     with _pool_lock:
+        _drain_returned()
         n = sum(k * len(v) for k, v in _pool.items())
         _pool.clear()
         del _pool_age[:]
@@ -150,6 +198,8 @@ class locked_arrays:
         return self
 
     def __exit__(self, *exc):
+        if exc and exc[0] is not None:
+            quiesce()                       # an error inside the block: uploads from these arrays may still be queued
         for addr, _ in self.locked:
             self.lib.dexct_host_unpin(addr, self.dev)
         self.locked = []
@@ -168,6 +218,7 @@ class LazyPinnedResult:
         cuts = [int(c) for c in cuts]
         assert cuts[0] == 0 and cuts[-1] == n_bytes and all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
         with _pool_lock:
+            _drain_returned()
             free = _pool.get(n_bytes)
             self.buf = free.pop() if free else None
             if self.buf is not None:
@@ -217,13 +268,17 @@ class LazyPinnedResult:
             self.lib.dexct_host_unpin(addr, self.dev)
         self.locked = []
 
-    def __del__(self):                      # abandoned (an error between construction and finish): the block is still good
+    def __del__(self):
+        # abandoned: an error between construction and finish().  Copies into the block may still be queued on the side streams
+        # (gn_device or dexct_download raised in the middle of a pipeline): nothing may be unlocked, let alone handed to the next
+        # result as its DMA target, before they have drained (advisor finding of round 5) - and the block is dropped, not pooled
         if getattr(self, 'buf', None) is not None and getattr(self, 'ready', None):
             try:
+                quiesce()
                 self._unlock()
-                _give_back(self.buf)
-            except Exception:               # (interpreter shutdown: nothing left to give back to)
+            except Exception:               # (interpreter shutdown: nothing left to wait for)
                 pass
+            self.buf = None
 
     def finish(self):
         self._unlock()

@@ -71,6 +71,14 @@ if DEFAULT_GATHER_MODE not in GATHER_MODES:
     raise ValueError(f'DEXCT_GATHER={DEFAULT_GATHER_MODE!r}: one of {GATHER_MODES}')
 
 
+def dropin_mode():
+    """The mode of the drop-in calls (get_sinos, get_basismat_sinos): they return the assembled array to EVERY process, so a
+    DEXCT_GATHER=root default - meant for step loops that assemble on one rank, like bench.py - cannot serve them (the other
+    ranks would hold None and leave rank 0 alone in the next collective: advisor finding of round 5): 'all' when the
+    environment asks for it, else 'direct'."""
+    return 'all' if DEFAULT_GATHER_MODE == 'all' else 'direct'
+
+
 def part_bounds(n_views, world_size, part):
     """[(begin, end) per rank] of piece ``part = (j, n_parts)`` of every rank's shard, in GLOBAL views: each shard is cut into
     n_parts contiguous pieces by the same rule (split), so every rank knows where every peer's piece j belongs."""

@@ -641,7 +641,7 @@ def get_sinos(ct, phantom, specs, noise=False, seed=0, quadrature=None):
         return _get_sinos_pipelined(pj, check, ct, phantom, specs, seed, quadrature, noise=bool(noise))
     res, air = pj.project(specs, noise=noise, seed=seed, want_log=not sharded, quadrature=quadrature)
     if sharded:
-        counts = _shard.gather_views(res, ct.N_proj, view_dim=1, tag='get_sinos')
+        counts = _shard.gather_views(res, ct.N_proj, view_dim=1, tag='get_sinos', mode=_shard.dropin_mode())
         log = pj.sino_log(counts, air)              # of the gathered sinogram: one collective instead of two
     else:
         counts, log = res

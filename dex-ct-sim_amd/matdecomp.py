@@ -727,7 +727,7 @@ def get_basismat_sinos(ct, sino_raw_1, sino_raw_2, spec1, spec2, n_iters=30, mas
             raise SingularHessianError(f'Singular matrix: {n_bad} pixel(s) outside the air mask ended non-finite '
                                        f'after {n_iters} Newton iterations (first flat index on this rank: {first})')
     if full_in:
-        a = _shard.gather_views(a, n_views, view_dim=0, tag='get_basismat_sinos')     # a new tensor: the caller owns it
+        a = _shard.gather_views(a, n_views, view_dim=0, tag='get_basismat_sinos', mode=_shard.dropin_mode())     # a new tensor: the caller owns it
     if isinstance(sino_raw_1, torch.Tensor):
         return a[..., 0], a[..., 1]
     a = to_host(a)          # page-locked: one DMA; the two results are views of this one buffer, like the reference's

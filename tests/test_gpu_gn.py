@@ -1078,7 +1078,7 @@ def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
     monkeypatch.setattr(_device, 'LAZY_MIN_BYTES', 1)
     _device.empty_pool()
     first = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)
-    assert [u.fresh for u in used] == [True] and not _device._pool and not used[0].locked
+    assert [u.fresh for u in used] == [True] and not _device.pooled() and not used[0].locked
     assert len(locks[0].spans) == 1 and not locks[0].locked                               # (locked inside, unlocked again)
     second = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)                        # the first result is alive: a second block
     assert [u.fresh for u in used] == [True, True]
@@ -1091,13 +1091,13 @@ def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
     address = first[0].ctypes.data
     del first
     gc.collect()
-    assert not _device._pool
+    assert not _device.pooled()
     copy_of_keep = keep.copy()
     del keep
     gc.collect()
-    assert [len(v) for v in _device._pool.values()] == [1]
+    assert list(_device.pooled().values()) == [1]
     third = md.get_basismat_sinos(ct, a1, a2, s1, s2, n_iters=30)                         # ... and now it is reused (nothing to touch)
-    assert [u.fresh for u in used] == [True, True, False] and third[0].ctypes.data == address and not any(_device._pool.values())
+    assert [u.fresh for u in used] == [True, True, False] and third[0].ctypes.data == address and not _device.pooled()
     assert np.array_equal(bits(third[1]), bits(second[1])) and np.array_equal(bits(third[1][5:7]), bits(copy_of_keep))
     pinned_in = torch.from_numpy(a1).pin_memory().numpy()                                 # an input that is locked already: left alone
     fourth = md.get_basismat_sinos(ct, pinned_in, a2, s1, s2, n_iters=30)
@@ -1135,7 +1135,7 @@ def test_first_call_locks_its_result_chunk_by_chunk(hip, golden, monkeypatch):
     assert len(used) == 12 and len(used[10].pieces) == 2 and np.isfinite(p_lazy[1]).all()
     del third, fourth, r_again, l_again, n_lazy, p_lazy, used
     gc.collect()
-    assert _device.empty_pool() > 0 and not _device._pool
+    assert _device.empty_pool() > 0 and not _device.pooled()
 
 
 @pytest.mark.parametrize('seed', [319, 525, 468, 1179, 4, 29, 126, 397, 1795])

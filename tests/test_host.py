@@ -429,9 +429,14 @@ def test_host_pool_lets_the_oldest_blocks_go(monkeypatch):
     blk = lambda mb: np.empty(mb << 20, dtype=np.uint8)
     for mb in (4, 4, 3):                       # 11 MB offered: the oldest 4 MB block leaves
         _device._give_back(blk(mb))
-    assert {k >> 20: len(v) for k, v in _device._pool.items()} == {4: 1, 3: 1} and _device._pool_age == [4 << 20, 3 << 20]
+    # (a returned block waits in a lock-free deque - the finalizer may run inside a locked region of the same thread - and joins
+    # the pool the next time somebody holds the lock: pooled() does)
+    assert not _device._pool and len(_device._returned) == 3
+    assert {k >> 20: n for k, n in _device.pooled().items()} == {4: 1, 3: 1} and _device._pool_age == [4 << 20, 3 << 20]
     _device._give_back(blk(6))                 # 13 MB: the other 4 MB block leaves, 3 + 6 stay
-    assert {k >> 20: len(v) for k, v in _device._pool.items() if v} == {3: 1, 6: 1}
+    assert {k >> 20: n for k, n in _device.pooled().items()} == {3: 1, 6: 1}
     _device._give_back(blk(11))                # larger than the pool: not kept, nothing else disturbed
-    assert {k >> 20: len(v) for k, v in _device._pool.items() if v} == {3: 1, 6: 1}
-    assert _device.empty_pool() == 9 << 20 and not _device._pool and not _device._pool_age
+    assert {k >> 20: n for k, n in _device.pooled().items()} == {3: 1, 6: 1}
+    with _device._pool_lock:                   # the finalizer inside a locked region of the same thread: no deadlock
+        _device._give_back(blk(1))
+    assert _device.empty_pool() == 10 << 20 and not _device._pool and not _device._pool_age and not _device._returned

@@ -56,6 +56,14 @@ def _worker(rank, world, port, n_views, q):
     except ValueError:
         pass
     got = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1)               # the default mode holds the result everywhere
+    # the drop-in calls never gather to one rank, whatever DEXCT_GATHER says (advisor finding of round 5)
+    keep = _shard.DEFAULT_GATHER_MODE
+    for env_mode, want in (('root', 'direct'), ('direct', 'direct'), ('all', 'all')):
+        _shard.DEFAULT_GATHER_MODE = env_mode
+        owned = owned and _shard.dropin_mode() == want
+        res = _shard.gather_views(full[:, b:e].clone(), n_views, view_dim=1, mode=_shard.dropin_mode())
+        owned = owned and res is not None and bool(torch.equal(res, full))
+    _shard.DEFAULT_GATHER_MODE = keep
     mx = _shard.global_max(torch.tensor(float(rank + 1), dtype=torch.float64))
     # np.max semantics over ranks (matdecomp.py:195-196): one rank's NaN makes the global maximum NaN on every rank;
     # -inf on a rank (an empty shard) does not disturb the others' values
