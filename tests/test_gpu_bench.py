@@ -33,6 +33,17 @@ def test_plain_command_single_gpu(hip):
     assert out['roofline']['kernel'].startswith('gn_shortcut_kernel') and 'roofline_siddon' in out
     for r in (out['roofline'], out['roofline_siddon']):
         assert r['frac'] is None or 0 < r['frac'] <= 1.0, r
+    # round 6: frac = the FP64 flops the launch ISSUES / time / peak; SURVEY 8d's unit (which counts flops the short cut's
+    # Gauss-Newton step does not issue) is kept beside it; where a PMC file matches, frac cannot exceed the issue share
+    roof = out['roofline']
+    assert roof['frac'] == roof['hardware_fp64_utilisation'] and roof['frac'] <= roof['frac_by_survey_unit']
+    assert abs(roof['frac'] - roof['hardware_fp64_flop_share'] * roof['frac_by_survey_unit']) < 1e-12
+    if 'issue' in roof:
+        assert roof['frac'] <= roof['issue']['frac'] <= 1.0
+    assert 'n_iters = 10 asked' in out['config']['workload'] and 'full-table steps executed per unmasked pixel' in out['config']['workload']
+    ns = out['noisy_step']                       # the step WITH quantum noise (the reference's dose-scaled mode), default kernels
+    assert ns['projection_ms']['gaussian'] > 0 and ns['projection_ms']['poisson'] > 0 and ns['ms_per_step'] > 0
+    assert ns['gn']['default_max_diff_vs_exact'] <= 1e-12 and 0 < ns['relative_noise_of_the_sample'] < 0.1
     q = out['siddon_reduced_quadrature']         # opt-in shorter energy table: measured beside the step, bound checked on every ray
     assert q['applied'] and 3 * q['nodes'] < q['full_grid_bins'] and q['verified_max_rel_err_f64'] <= 1e-6
     assert q['max_rel_deviation_of_counts_all_rays'] <= 2e-6
@@ -43,15 +54,25 @@ def test_plain_command_single_gpu(hip):
         assert case['bytes']['d2h_per_get_sino'] == 8 * case['rays']
 
 
-@pytest.mark.parametrize('scaling,gather', [('strong', None), ('weak', 'direct'), ('strong', 'all')])
+@pytest.mark.parametrize('scaling,gather', [('strong', None), ('weak', 'direct'), ('strong', 'all'), ('strong', 'root')])
 def test_plain_command_two_ranks(hip, scaling, gather):
     """`python bench.py --gpus 2` (no torchrun): on a one-GPU box the two ranks share the device and rehearse over
-    gloo; with two devices the same command runs RCCL.  Every mode of the assembly (default: the gather to rank 0), with the
-    other two measured beside it."""
+    gloo; with two devices the same command runs RCCL.  Every mode of the assembly, with the other two measured beside it; the
+    default (--gather auto) picks the mode of the timed loop from measured warm-up steps and says which and why; the line also
+    carries the step without its fabric part (value_compute_only)."""
     out, err = run_bench('--gpus', '2', '--scaling', scaling, *(('--gather', gather) if gather else ()))
     assert out['n_gpus'] == 2 and out['scaling'] == scaling
     m = out['multi_gpu']
-    assert m['gather'] == (gather or 'root') and m['view_chunks_per_rank'] == (1 if gather == 'all' else 4)
+    assert m['gather_flag'] == (gather or 'auto') and m['gather'] in ('root', 'direct', 'all')
+    if gather:
+        assert m['gather'] == gather and m['gather_choice'] is None
+        assert m['view_chunks_per_rank'] == (1 if gather == 'all' else 4)
+    else:
+        ch = m['gather_choice']
+        assert sorted(ch['step_ms']) == ['all', 'direct', 'root'] and ch['why'].startswith(m['gather'])
+        assert ch['step_ms'][m['gather']] <= 1.02 * min(ch['step_ms'].values())
+    assert m['value_compute_only'] > 0 and m['ms_per_step_compute_only'] > 0 and 0 <= m['fabric_share_of_step'] < 1
+    assert m['implied_GBps_into_root'] == m['by_mode']['root']['GBps_into_a_receiving_rank'] > 0
     assert len(m['per_rank']) == 2 and m['gather_ms'] > 0
     assert sorted(m['by_mode']) == ['all', 'direct', 'root']
     for mode, b in m['by_mode'].items():
@@ -68,7 +89,7 @@ def test_plain_command_two_ranks(hip, scaling, gather):
 
 def test_plain_command_four_ranks_ragged(hip):
     """Four ranks (gloo rehearsal on a one-GPU box) over a scan whose views do not divide evenly: 50 = 13+13+12+12."""
-    out, _ = run_bench('--gpus', '4', '--views', '50', '--gather-chunks', '5')            # chunks of 3, 3, 3, 2, 2 / 3, 3, 2, 2, 2 views
+    out, _ = run_bench('--gpus', '4', '--views', '50', '--gather-chunks', '5', '--gather', 'root')      # chunks of 3, 3, 3, 2, 2 / 3, 3, 2, 2, 2 views
     assert out['n_gpus'] == 4 and out['multi_gpu']['view_chunks_per_rank'] == 5 and out['config']['rays_total'] == 50 * 64 * 96
     views = [r['views'] for r in sorted(out['multi_gpu']['per_rank'], key=lambda r: r['rank'])]
     assert views == [[0, 13], [13, 26], [26, 38], [38, 50]]
@@ -118,5 +139,5 @@ def test_under_the_drivers_launcher(hip):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['multi_gpu']['gather'] == 'root' and out['value'] > 0
+    assert out['n_gpus'] == 2 and out['multi_gpu']['gather_flag'] == 'auto' and out['value'] > 0
     assert len(out['multi_gpu']['per_rank']) == 2

@@ -440,3 +440,40 @@ def test_host_pool_lets_the_oldest_blocks_go(monkeypatch):
     with _device._pool_lock:                   # the finalizer inside a locked region of the same thread: no deadlock
         _device._give_back(blk(1))
     assert _device.empty_pool() == 10 << 20 and not _device._pool and not _device._pool_age and not _device._returned
+
+
+def test_the_timed_region_of_the_bench_imports_no_checker():
+    """bench/step.py is the timed region and nothing else: it imports the product and torch - neither the oracle (the checker)
+    nor NumPy-side solvers; bench/cpu.py is the only part of the bench that touches oracle/ (after the timed loop)."""
+    import ast
+    bdir = os.path.join(ROOT, 'bench')
+    mods = {}
+    for fn in sorted(os.listdir(bdir)):
+        if fn.endswith('.py'):
+            tree = ast.parse(open(os.path.join(bdir, fn)).read())
+            names = set()
+            for node in ast.walk(tree):
+                if isinstance(node, ast.Import):
+                    names.update(a.name.split('.')[0] for a in node.names)
+                elif isinstance(node, ast.ImportFrom) and node.level == 0 and node.module:
+                    names.add(node.module.split('.')[0])
+            mods[fn] = names
+    assert 'oracle' not in mods['step.py'] and 'numpy' not in mods['step.py'] and 'scipy' not in mods['step.py']
+    assert {fn for fn, names in mods.items() if 'oracle' in names} == {'cpu.py'}
+    src = open(os.path.join(bdir, 'step.py')).read()
+    assert 'gn_oracle' not in src and 'c_oracle' not in src
+    main_src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert main_src.index('wl.timed_steps(args.steps, args.warmup)') < main_src.index('from bench import cpu')
+
+
+def test_gather_auto_picks_the_fastest_step_and_prefers_the_north_stars_gather_on_a_tie():
+    """bench/multi.py pick_mode: the mode of the timed loop from measured warm-up steps (the gloo worlds of
+    tests/test_gpu_bench.py exercise the whole selection; this is its rule)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from bench.multi import pick_mode
+    assert pick_mode({'root': 10.0, 'direct': 12.0, 'all': 30.0}) == 'root'
+    assert pick_mode({'root': 14.0, 'direct': 12.0, 'all': 30.0}) == 'direct'
+    assert pick_mode({'root': 12.2, 'direct': 12.0, 'all': 11.99}) == 'root'           # within 2 %: root, direct, all in that order
+    assert pick_mode({'root': 13.0, 'direct': 12.1, 'all': 12.0}) == 'direct'
+    assert pick_mode({'root': 13.0, 'direct': 12.5, 'all': 12.0}) == 'all'

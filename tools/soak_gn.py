@@ -124,7 +124,12 @@ def check_case(seed, stats=None):
             size = np.maximum(np.abs(ref).max(-1), 1.0)
             ok = np.isfinite(ref).all(-1) & (np.abs(ref).max(-1) < 1e6) & np.isfinite(g).all(0) & (g > 0).all(0)
             eps = np.finfo(np.float64).eps
-            ok &= (np.abs(ref - ref_p).max(-1) <= 1e-11 * size) & (eps * sens['walk'] <= 1e-11) & (sens['twin'] <= 1e-11)
+            ok &= (np.abs(ref - ref_p).max(-1) <= 1e-11 * size) & (eps * sens['walk'] <= 1e-11)
+            # what the twin-trajectory rule of screen v3 ALONE takes out of the comparison (advisor finding of round 5: the rule was
+            # added after seed 1795 failed under v2, so how much it hides is counted per case and bounded over the campaign)
+            twin_only = ok & ~(sens['twin'] <= 1e-11)
+            ok &= sens['twin'] <= 1e-11
+        stats['twin_only'] = stats.get('twin_only', 0) + int(twin_only.sum())
         stats['pixels'] = stats.get('pixels', 0) + n_v * n_c
         stats['stable'] = stats.get('stable', 0) + int(ok.sum())
         if ok.any():
@@ -144,6 +149,9 @@ def check_case(seed, stats=None):
     return what, bad
 
 
+TWIN_ONLY_MAX_SHARE = 0.02
+
+
 if __name__ == '__main__':
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -156,6 +164,12 @@ if __name__ == '__main__':
             print(f'FAIL seed {seed0 + case}: {what}: ' + '; '.join(bad), flush=True)
         if case % 100 == 99 or case == n_cases - 1:
             print(f'{case + 1} cases from seed {seed0}, {fails} failed, {stats.get("pixels", 0):.3g} pixels x 15 launches, {stats.get("stable", 0):.3g} stable '
-                  f'pixels compared (screen v3); short-cut launches ended up as '
-                  f'{ {k: v for k, v in stats.items() if k not in ("pixels", "stable")} }; {time.time() - t0:.0f} s', flush=True)
+                  f'pixels compared (screen v3; {stats.get("twin_only", 0)} excluded by the twin rule alone); short-cut launches ended up as '
+                  f'{ {k: v for k, v in stats.items() if k not in ("pixels", "stable", "twin_only")} }; {time.time() - t0:.0f} s', flush=True)
+    # the twin rule may only remove a small share: results on wandering pixels are kernel-dependent, but a rule that
+    # grew to hide a kernel's loss of digits would show here
+    twin_share = stats.get('twin_only', 0) / max(stats.get('pixels', 0), 1)
+    if twin_share > TWIN_ONLY_MAX_SHARE:
+        print(f'FAIL: the twin-trajectory rule alone excluded {twin_share:.2%} of the pixels (bound {TWIN_ONLY_MAX_SHARE:.0%})', flush=True)
+        fails += 1
     sys.exit(1 if fails else 0)
