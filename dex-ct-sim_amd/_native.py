@@ -14,7 +14,8 @@ SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
            'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
            'dexct_siddon_project_grouped_packed', 'dexct_poisson_detect', 'dexct_vmi', 'dexct_label_moments', 'dexct_fdk_backproject', 'dexct_sino_allgather', 'dexct_sino_gather', 'dexct_transpose_log', 'dexct_host_pin', 'dexct_host_touch', 'dexct_host_unpin', 'dexct_download',
-           'dexct_volume_ids', 'dexct_volume_remap', 'dexct_fbp_parker', 'dexct_sino_log', 'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
+           'dexct_volume_ids', 'dexct_volume_remap', 'dexct_fbp_parker', 'dexct_sino_log', 'dexct_cone_layout_groups', 'dexct_cone_project_grouped',
+           'dexct_cone_layout_bytes', 'dexct_gn_workspace_bytes']
 
 
 class FanGeom(C.Structure):
@@ -131,6 +132,9 @@ def load():
     lib.dexct_cone_layout.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.dexct_cone_project_rows.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, i32, i32, i32, vp, vp, vp,
                                             vp, vp, vp, vp, vp, vp]
+    lib.dexct_cone_layout_groups.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.dexct_cone_project_grouped.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, i32, i32, i32, vp, vp, vp,
+                                               vp, vp, vp, vp, vp, vp]
     lib.dexct_cone_layout_bytes.argtypes = [i32, i32, i32]
     lib.dexct_cone_layout_bytes.restype = i64
     lib.dexct_siddon_project_grouped.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp,

@@ -18,35 +18,49 @@ __global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __
   int v, c;
   if (a.layout == 0) { c = q % a.g.n_channels; q /= a.g.n_channels; v = (int)(q / a.g.n_rows); }
   else               { q /= a.g.n_rows; c = q % a.g.n_channels; v = (int)(q / a.g.n_channels); }
-  const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];    // the R rays share (view, channel)
   float L[R][NMAT];
-  float others[R];
-#pragma unroll
-  for (int k = 0; k < R; ++k) others[k] = 0.0f;
-#pragma unroll
-  for (int m = 1; m < NMAT; ++m) {
-    const float* plane = a.acc_out + (size_t)m * n_rays + ray0;
-    if (R == 4) {
-      const float4 x = *reinterpret_cast<const float4*>(plane);
-      L[0][m] = x.x; L[R > 1 ? 1 : 0][m] = x.y; L[R > 2 ? 2 : 0][m] = x.z; L[R > 3 ? 3 : 0][m] = x.w;
-    } else if (R == 2) {
-      const float2 x = *reinterpret_cast<const float2*>(plane);
-      L[0][m] = x.x; L[R > 1 ? 1 : 0][m] = x.y;
-    } else {
-      L[0][m] = plane[0];
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) others[k] += L[k][m];
-  }
   size_t rays[R];
   bool valid[R];
+  if (a.acc_lengths) {        // cone-beam group passes: the planes hold lengths [cm] of ALL materials; no plan, no chord
 #pragma unroll
-  for (int k = 0; k < R; ++k) {
-    L[k][0] = (p.chord_u - others[k]) * p.len_per_u;
+    for (int m = 0; m < NMAT; ++m) {
+      const float* plane = a.acc_out + (size_t)m * n_rays + ray0;
 #pragma unroll
-    for (int m = 1; m < NMAT; ++m) L[k][m] *= p.len_per_u;
-    rays[k] = ray0 + k;
-    valid[k] = true;
+      for (int k = 0; k < R; ++k) L[k][m] = ray0 + k < n_rays ? plane[k] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      rays[k] = ray0 + k;
+      valid[k] = ray0 + k < n_rays;
+    }
+  } else {
+    const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];    // the R rays share (view, channel)
+    float others[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) others[k] = 0.0f;
+#pragma unroll
+    for (int m = 1; m < NMAT; ++m) {
+      const float* plane = a.acc_out + (size_t)m * n_rays + ray0;
+      if (R == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(plane);
+        L[0][m] = x.x; L[R > 1 ? 1 : 0][m] = x.y; L[R > 2 ? 2 : 0][m] = x.z; L[R > 3 ? 3 : 0][m] = x.w;
+      } else if (R == 2) {
+        const float2 x = *reinterpret_cast<const float2*>(plane);
+        L[0][m] = x.x; L[R > 1 ? 1 : 0][m] = x.y;
+      } else {
+        L[0][m] = plane[0];
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) others[k] += L[k][m];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      L[k][0] = (p.chord_u - others[k]) * p.len_per_u;
+#pragma unroll
+      for (int m = 1; m < NMAT; ++m) L[k][m] *= p.len_per_u;
+      rays[k] = ray0 + k;
+      valid[k] = true;
+    }
   }
   detect_store<NMAT, R>(L, a, mu, w, w2, rays, valid);
 }
@@ -67,7 +81,10 @@ __global__ __launch_bounds__(256) void detect_kernel_chunked(ProjArgs a, const f
   int v, c;
   if (a.layout == 0) { c = q % a.g.n_channels; q /= a.g.n_channels; v = (int)(q / a.g.n_rows); }
   else               { q /= a.g.n_rows; c = q % a.g.n_channels; v = (int)(q / a.g.n_channels); }
-  const dexct_ray_plan p = a.plan[(size_t)v * a.g.n_channels + c];
+  const bool lengths = a.acc_lengths != 0;      // (cone-beam group passes: every plane holds lengths [cm]; no plan)
+  dexct_ray_plan p;
+  if (lengths) { p.chord_u = 0.0f; p.len_per_u = 1.0f; }
+  else p = a.plan[(size_t)v * a.g.n_channels + c];
   const int n_e = a.n_energies, n_mat = a.n_materials;
   const size_t sstride = n_rays;
   // material 0 fills what the others leave of the chord (same sum, same order as detect_kernel_lds)
@@ -77,7 +94,7 @@ __global__ __launch_bounds__(256) void detect_kernel_chunked(ProjArgs a, const f
     if (a.pathlen) a.pathlen[ray * n_mat + m] = l * p.len_per_u;
     others += l;
   }
-  const float L0 = (p.chord_u - others) * p.len_per_u;
+  const float L0 = lengths ? a.acc_out[ray] : (p.chord_u - others) * p.len_per_u;
   if (a.pathlen) a.pathlen[ray * n_mat] = L0;
   float acc[DEXCT_MAX_SPECTRA], var[DEXCT_MAX_SPECTRA];
 #pragma unroll

@@ -46,6 +46,11 @@ struct ConeArgs {
   float* variance;         // optional [S][view][row][channel]
   int sample;
   uint32_t seed_lo, seed_hi;
+  // material-group passes of the row kernels (round 6; more than 3 materials): the volume layout holds codes 0..2 of ONE group of
+  // three materials (every other voxel reads as "outside", which belongs to nobody); the pass writes the path lengths [cm] of
+  // its materials to acc_out[(mat_base + code) * n_rays + ray] and leaves the detection to one pass over all planes
+  float* acc_out = nullptr;
+  int mat_base = 0;
 };
 
 // The tail every cone kernel ends with: per-material lengths (x log2 e) of one ray -> counts of every spectrum (the weighting of
@@ -506,9 +511,15 @@ __global__ __launch_bounds__(kConeRows) void cone_rows_kernel(ConeArgs a, const 
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     const float l = ((float)(int32_t)cnt[m] + corr[m]) * len3d;
+    if (a.acc_out) {         // group pass: lengths out, detection later (uniform branch)
+      if (a.mat_base + m < a.n_materials)
+        a.acc_out[(size_t)(a.mat_base + m) * a.n_local_views * a.g.n_rows * a.g.n_channels + ray] = l;
+      continue;
+    }
     if (a.pathlen) a.pathlen[ray * a.n_materials + m] = l;
     L2[m] = l * 1.44269504088896340736f;
   }
+  if (a.acc_out) return;
   if (w2) cone_detect_store<NM, true>(a, L2, mu, w, w2, bm, ray, v, r, c);
   else cone_detect_store<NM, false>(a, L2, mu, w, w2, bm, ray, v, r, c);
 }
@@ -750,9 +761,15 @@ void cone_cols_kernel(ConeArgs a, const uint8_t* __restrict__ vol_zc, const floa
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     const float l = ((float)(int32_t)cnt[m] + lds_corr[m][tid]) * len3d;
+    if (a.acc_out) {         // group pass: lengths out, detection later (uniform branch)
+      if (a.mat_base + m < a.n_materials)
+        a.acc_out[(size_t)(a.mat_base + m) * a.n_local_views * a.g.n_rows * a.g.n_channels + ray] = l;
+      continue;
+    }
     if (a.pathlen) a.pathlen[ray * a.n_materials + m] = l;
     L2[m] = l * 1.44269504088896340736f;
   }
+  if (a.acc_out) return;
   if (w2) cone_detect_store<NM, true>(a, L2, mu, w, w2, bm, ray, v, r, c);
   else cone_detect_store<NM, false>(a, L2, mu, w, w2, bm, ray, v, r, c);
 }
@@ -788,6 +805,25 @@ static void set_cone_noise(ConeArgs& a, float* variance, const dexct_noise* nois
   a.sample = sample ? 1 : 0;
   a.seed_lo = sample ? (uint32_t)noise->seed : 0u;
   a.seed_hi = sample ? (uint32_t)(noise->seed >> 32) : 0u;
+}
+
+// the guarded layout once per group of three materials: layout g holds 8 * (id - 3 g) for ids 3g .. 3g + 2 and 24 ("outside":
+// a voxel that belongs to nobody) for every other id - the row kernels then accumulate exactly the sums of these three
+// materials (the per-material sums of orc_cone_pathlen are independent of each other)
+__global__ __launch_bounds__(256) void cone_layout_groups_kernel(const uint8_t* __restrict__ vol, int nx, int ny, int nz, int n_groups,
+                                                                 uint8_t* __restrict__ out) {
+  const size_t zs = cone_zs(nz);
+  const size_t total = ((size_t)nx * ny + 1) * zs;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t col = i / zs;
+  const int kz = (int)(i - col * zs) - kConeGuard;
+  const bool in = col < (size_t)nx * ny && kz >= 0 && kz < nz;
+  const uint32_t id = in ? vol[(size_t)kz * nx * ny + col] : 0u;
+  for (int g = 0; g < n_groups; ++g) {
+    const uint32_t rel = id - 3u * (uint32_t)g;
+    out[(size_t)g * total + i] = (in && rel < 3u) ? (uint8_t)(rel << 3) : (uint8_t)24;
+  }
 }
 
 }  // namespace dexct
@@ -858,45 +894,26 @@ extern "C" int dexct_cone_layout(const uint8_t* vol, int32_t nx, int32_t ny, int
   return DEXCT_OK;
 }
 
-extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
-                                       const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
-                                       int32_t view_begin, int32_t view_end, const uint8_t* vol_zc,
-                                       int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
-                                       const float* weights, float* counts, float* pathlen,
-                                       const dexct_log_out* log_out, const float* weights2, float* variance,
-                                       const dexct_noise* noise, void* stream) {
-  if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_zc || !mu || !weights || !counts) return DEXCT_EINVAL;
-  if (cone_noise_args(weights2, variance, noise, log_out) != DEXCT_OK) return DEXCT_EINVAL;
+// what both row-kernel entry points check
+static int cone_rows_checks(const dexct_fan_geom* geom, int32_t view_begin, int32_t view_end, int32_t n_energies, int32_t n_spectra,
+                            double max_abs_dz) {
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
-  if (n_materials < 1 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
-  if (n_materials > 3 || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;      // code 3 is "outside the grid"
+  if (n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
+  if (n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
   if (dexct_cone_layout_bytes(geom->nx, geom->ny, geom->nz) > 0xFFFFFFFEll) return DEXCT_ERANGE;
   if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
   const double dmax = geom->dx > geom->dy ? geom->dx : geom->dy;
   if (!(max_abs_dz >= 0) || max_abs_dz / geom->sdd / geom->dz * dmax * 1.4142135623730951 > 1.0) return DEXCT_ERANGE;
-  ConeArgs a;
-  a.g = *geom;
-  a.plan = plan;
-  a.view_cs = view_cs;
-  a.chan_cs = chan_cs;
-  a.row_z = row_z;
-  a.src_z = src_z;
-  a.vol_yx = nullptr;
-  a.vol_xy = nullptr;
-  a.view_begin = view_begin;
-  a.n_local_views = view_end - view_begin;
-  a.n_materials = n_materials;
-  a.n_energies = n_energies;
-  a.n_spectra = n_spectra;
-  a.counts = counts;
-  a.pathlen = pathlen;
-  a.sino_log = log_out ? log_out->sino_log : nullptr;
-  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = log_out ? log_out->air[s] : 1.0f;
-  set_cone_noise(a, variance, noise);
+  return DEXCT_OK;
+}
+
+// one launch of the row kernels on the layout vol_zc; nm = the materials (codes) the layout holds: 1..3
+static int launch_cone_rows(const ConeArgs& a, const uint8_t* vol_zc, int nm, const float* mu, const float* weights,
+                            const float* weights2, hipStream_t st) {
+  const dexct_fan_geom* geom = &a.g;
   const int n_chunks = (geom->n_rows + kConeRows - 1) / kConeRows;
   const size_t nblk = (size_t)a.n_local_views * geom->n_channels * n_chunks;
   if (nblk > 0x7FFFFFFFull) return DEXCT_ERANGE;
-  hipStream_t st = as_stream(stream);
   // views per tile of the block order: 1 = all channels of a view before the next view (round 3: 9.6 -> 9.2 ms on a
   // 100-view scan, whose views 3.6 degrees apart share no columns; no difference at 0.36 degrees)
   int view_tile = 1;
@@ -915,19 +932,19 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
       else hipLaunchKernelGGL((cone_cols_kernel<NM_, 8, CB_>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); \
     } while (0)
     if (zs <= 288u) {
-      switch (n_materials) {
+      switch (nm) {
         case 1: DEXCT_CONE_COLS_LAUNCH(1, 288); break;
         case 2: DEXCT_CONE_COLS_LAUNCH(2, 288); break;
         default: DEXCT_CONE_COLS_LAUNCH(3, 288); break;
       }
     } else if (zs <= 544u) {
-      switch (n_materials) {
+      switch (nm) {
         case 1: DEXCT_CONE_COLS_LAUNCH(1, 544); break;
         case 2: DEXCT_CONE_COLS_LAUNCH(2, 544); break;
         default: DEXCT_CONE_COLS_LAUNCH(3, 544); break;
       }
     } else {                                   // up to 1024 slices: 4 slabs per batch only (17 KB of LDS per buffer)
-      switch (n_materials) {
+      switch (nm) {
         case 1: hipLaunchKernelGGL((cone_cols_kernel<1, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
         case 2: hipLaunchKernelGGL((cone_cols_kernel<2, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
         default: hipLaunchKernelGGL((cone_cols_kernel<3, 4, 1056>), dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
@@ -937,7 +954,7 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
     DEXCT_LAUNCH_CHECK();
     return DEXCT_OK;
   }
-  switch (n_materials) {
+  switch (nm) {
     case 1: hipLaunchKernelGGL(cone_rows_kernel<1>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
     case 2: hipLaunchKernelGGL(cone_rows_kernel<2>, dim3((unsigned)nblk), dim3(kConeRows), 0, st, a, vol_zc, mu, weights, weights2, n_chunks, view_tile); break;
     default: {
@@ -953,4 +970,110 @@ extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_r
   }
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
+}
+
+static void fill_cone_args(ConeArgs& a, const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
+                           const double* chan_cs, const double* row_z, double src_z, int32_t view_begin, int32_t view_end,
+                           int32_t n_materials, int32_t n_energies, int32_t n_spectra, float* counts, float* pathlen,
+                           const dexct_log_out* log_out) {
+  a.g = *geom;
+  a.plan = plan;
+  a.view_cs = view_cs;
+  a.chan_cs = chan_cs;
+  a.row_z = row_z;
+  a.src_z = src_z;
+  a.vol_yx = nullptr;
+  a.vol_xy = nullptr;
+  a.view_begin = view_begin;
+  a.n_local_views = view_end - view_begin;
+  a.n_materials = n_materials;
+  a.n_energies = n_energies;
+  a.n_spectra = n_spectra;
+  a.counts = counts;
+  a.pathlen = pathlen;
+  a.sino_log = log_out ? log_out->sino_log : nullptr;
+  for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = log_out ? log_out->air[s] : 1.0f;
+}
+
+extern "C" int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
+                                       const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
+                                       int32_t view_begin, int32_t view_end, const uint8_t* vol_zc,
+                                       int32_t n_materials, int32_t n_energies, int32_t n_spectra, const float* mu,
+                                       const float* weights, float* counts, float* pathlen,
+                                       const dexct_log_out* log_out, const float* weights2, float* variance,
+                                       const dexct_noise* noise, void* stream) {
+  if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_zc || !mu || !weights || !counts) return DEXCT_EINVAL;
+  if (cone_noise_args(weights2, variance, noise, log_out) != DEXCT_OK) return DEXCT_EINVAL;
+  if (n_materials < 1) return DEXCT_EINVAL;
+  if (n_materials > 3) return DEXCT_ERANGE;      // code 3 is "outside the grid" (more: dexct_cone_project_grouped)
+  const int rc = cone_rows_checks(geom, view_begin, view_end, n_energies, n_spectra, max_abs_dz);
+  if (rc != DEXCT_OK) return rc;
+  ConeArgs a;
+  fill_cone_args(a, geom, plan, view_cs, chan_cs, row_z, src_z, view_begin, view_end, n_materials, n_energies, n_spectra, counts,
+                 pathlen, log_out);
+  set_cone_noise(a, variance, noise);
+  return launch_cone_rows(a, vol_zc, n_materials, mu, weights, weights2, as_stream(stream));
+}
+
+extern "C" int dexct_cone_layout_groups(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, int32_t n_materials,
+                                        uint8_t* vol_zcg, void* stream) {
+  if (!vol || !vol_zcg || nx <= 0 || ny <= 0 || nz <= 0) return DEXCT_EINVAL;
+  if (n_materials < 1 || n_materials > DEXCT_MAX_MATERIALS) return DEXCT_ERANGE;
+  const int64_t total = dexct_cone_layout_bytes(nx, ny, nz);
+  if (total > 0xFFFFFFFEll) return DEXCT_ERANGE;
+  const int n_groups = (n_materials + 2) / 3;
+  const int64_t nblk = (total + 255) / 256;
+  hipLaunchKernelGGL(cone_layout_groups_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), vol, nx, ny, nz, n_groups,
+                     vol_zcg);
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+extern "C" int dexct_cone_project_grouped(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
+                                          const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
+                                          int32_t view_begin, int32_t view_end, const uint8_t* vol_zcg, int32_t n_materials,
+                                          int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights,
+                                          float* counts, float* pathlen, float* acc_scratch, const dexct_log_out* log_out,
+                                          const float* weights2, float* variance, void* stream) {
+  if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_zcg || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
+  if (n_materials < 1) return DEXCT_EINVAL;
+  if (n_materials > DEXCT_MAX_MATERIALS) return DEXCT_ERANGE;
+  if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
+  const int rc = cone_rows_checks(geom, view_begin, view_end, n_energies, n_spectra, max_abs_dz);
+  if (rc != DEXCT_OK) return rc;
+  hipStream_t st = as_stream(stream);
+  // ---- one traversal per group of three materials: lengths [cm] into the planes of acc_scratch
+  ConeArgs a;
+  fill_cone_args(a, geom, plan, view_cs, chan_cs, row_z, src_z, view_begin, view_end, n_materials, n_energies, n_spectra, counts,
+                 nullptr, nullptr);
+  set_cone_noise(a, nullptr, nullptr);
+  a.acc_out = acc_scratch;
+  const size_t layout_bytes = (size_t)dexct_cone_layout_bytes(geom->nx, geom->ny, geom->nz);
+  const int n_groups = (n_materials + 2) / 3;
+  for (int g = 0; g < n_groups; ++g) {
+    a.mat_base = 3 * g;
+    const int left = n_materials - 3 * g;
+    const int lrc = launch_cone_rows(a, vol_zcg + (size_t)g * layout_bytes, left >= 3 ? 3 : left, mu, weights, nullptr, st);
+    if (lrc != DEXCT_OK) return lrc;
+  }
+  // ---- one detection pass over all planes (the pass of the stacked fan's material groups, reading lengths)
+  ProjArgs d;
+  d.g = *geom;
+  d.plan = plan;
+  d.vol_yx = d.vol_xy = d.vol_zf = nullptr;
+  d.n_local_views = view_end - view_begin;
+  d.n_materials = n_materials;
+  d.n_energies = n_energies;
+  d.n_spectra = n_spectra;
+  d.counts = counts;
+  d.pathlen = pathlen;
+  d.variance = variance;
+  d.view_tile = 1;
+  d.layout = 0;
+  d.acc_out = acc_scratch;
+  d.mat_base = 0;
+  d.acc_lengths = 1;
+  if (set_log_out(d, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
+  const Tables t{mu, weights, weights2};
+  return launch_detect_any(d, t, st);
 }

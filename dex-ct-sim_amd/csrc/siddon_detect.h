@@ -34,6 +34,9 @@ struct ProjArgs {
   // three materials; raw accumulators (units of u) go to acc_out[(mat_base + code)*n_rays + ray], no detection
   float* acc_out;
   int mat_base;
+  // 1: the planes of acc_out hold path lengths [cm] of EVERY material, material 0 included (the cone-beam group passes, which
+  // accumulate material 0 like any other: a 3-D ray has no chord trick); the detection pass then reads no plan
+  int acc_lengths = 0;
   // second output of get_sino (main.py:120-122): sino_log[s][ray] = ln(air[s] / counts[s][ray]), same ray order as
   // counts; null = not wanted.  air[s] = sum_e w[s][e] (the unattenuated signal), given by the caller.
   float* sino_log;

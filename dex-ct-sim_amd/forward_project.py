@@ -159,20 +159,25 @@ class Projector:
         self.vol_yx = vol_raw.contiguous()
         self.vol_xy = torch.empty_like(self.vol_yx)
         self.vol_zc = None
+        self.cone_groups = False
         if self.cone:
             # cone beam: kernel 1 = one thread per ray (dexct_cone_project, any number of materials), 2 = the rows of a
-            # (view, channel) pair as lanes (dexct_cone_project_rows, <= 3 materials); 0 picks 2 where it applies
-            rows_ok = M <= 3
-            if kernel == 2 and not rows_ok:
-                raise ValueError('the row-parallel cone kernel takes at most 3 materials')
-            self.cone_rows = kernel == 2 or (kernel == 0 and rows_ok and ct.N_rows >= 32)
+            # (view, channel) pair as lanes (dexct_cone_project_rows for <= 3 materials; round 6: one pass per group of three
+            # materials + one detection pass beyond that, dexct_cone_project_grouped); 0 picks 2 from 32 rows on
+            self.cone_rows = kernel == 2 or (kernel == 0 and ct.N_rows >= 32)
+            self.cone_groups = self.cone_rows and M > 3
             kernel = self.kernel = 1
             self.row_z = to_dev(ct.row_z(), torch.float64, self.dev)
             if self.cone_rows:
                 nb = self.lib.dexct_cone_layout_bytes(phantom.Nx, phantom.Ny, nz)
-                self.vol_zc = torch.empty(nb, dtype=torch.uint8, device=self.dev)
-                _native.check(self.lib.dexct_cone_layout(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz, ptr(self.vol_zc), st),
-                              'dexct_cone_layout')
+                if self.cone_groups:
+                    self.vol_zc = torch.empty(((M + 2) // 3) * nb, dtype=torch.uint8, device=self.dev)
+                    _native.check(self.lib.dexct_cone_layout_groups(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz, M, ptr(self.vol_zc), st),
+                                  'dexct_cone_layout_groups')
+                else:
+                    self.vol_zc = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+                    _native.check(self.lib.dexct_cone_layout(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz, ptr(self.vol_zc), st),
+                                  'dexct_cone_layout')
         want_zf = kernel in (2, 3, 4, 5, 7, 8) or (kernel == 0 and ct.N_rows >= 64)
         self.vol_zf = torch.empty_like(self.vol_yx) if want_zf else None
         _native.check(self.lib.dexct_volume_layouts(ptr(self.vol_yx), phantom.Nx, phantom.Ny, nz,
@@ -306,8 +311,9 @@ class Projector:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
         noisy = w2_d is not None
-        # kernels that draw the noise sample themselves (ABI 6): the packed stacked fan and the cone beam
-        in_kernel = noisy and (self.cone or (self.use_packed and S <= 2))
+        # kernels that draw the noise sample themselves (ABI 6): the packed stacked fan and the cone beam (its material-group
+        # passes hand the variance to dexct_add_noise like the stacked fan's)
+        in_kernel = noisy and ((self.cone and not self.cone_groups) or (self.use_packed and S <= 2))
         variance = torch.empty_like(counts) if (noisy and (want_variance or not in_kernel)) else None
         nz = _native.noise(seed) if in_kernel else None
         # the log sinogram: written by the detection store when the kernel's layout is the one wanted; else together with the
@@ -323,7 +329,33 @@ class Projector:
 
             # (quantum noise: the variance of the detected signal comes out of the same launch and the kernel draws the sample -
             # round 5 ran the kernel a second time with w2 as weights)
-            if self.cone_rows:
+            if self.cone_groups:
+                # more than 3 table rows: one traversal per group of three materials into M planes of path lengths, one detection
+                # pass over them; many materials on a large scan go through in view chunks (the scratch stays bounded)
+                per_view = M * nR * nC * 4
+                n_chunk = max(1, min(nV, _GROUP_SCRATCH_BYTES // max(per_view, 1)))
+                scratch = torch.empty((M, n_chunk * nR * nC), dtype=torch.float32, device=self.dev)
+                for v0 in range(0, nV, n_chunk):
+                    v1 = min(nV, v0 + n_chunk)
+                    whole = v0 == 0 and v1 == nV
+                    c_t = counts if whole else torch.empty((S, v1 - v0, nR, nC), dtype=torch.float32, device=self.dev)
+                    p_t = pathlen if (whole or pathlen is None) else torch.empty((v1 - v0, nR, nC, M), dtype=torch.float32, device=self.dev)
+                    v_t = variance if (whole or variance is None) else torch.empty_like(c_t)
+                    l_t = log if (whole or lo is None) else torch.empty_like(c_t)
+                    lo_t = lo if whole else (_native.log_out(ptr(l_t), air) if lo is not None else None)
+                    _native.check(self.lib.dexct_cone_project_grouped(
+                        C.byref(self.geom), plan_ptr + v0 * nC * _native.PLAN_BYTES, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
+                        self.ct.src_z, max_dz, vb + v0, vb + v1, ptr(self.vol_zc), M, nE, S, ptr(mu_d), ptr(w_d), ptr(c_t), ptr(p_t),
+                        ptr(scratch), lo_t, ptr(w2_d), ptr(v_t), stream_ptr()), 'dexct_cone_project_grouped')
+                    if not whole:
+                        counts[:, v0:v1].copy_(c_t)
+                        if pathlen is not None:
+                            pathlen[v0:v1].copy_(p_t)
+                        if variance is not None:
+                            variance[:, v0:v1].copy_(v_t)
+                        if lo is not None:
+                            log[:, v0:v1].copy_(l_t)
+            elif self.cone_rows:
                 _native.check(self.lib.dexct_cone_project_rows(
                     C.byref(self.geom), plan_ptr, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
                     self.ct.src_z, max_dz, vb, ve, ptr(self.vol_zc), M, nE, S, ptr(mu_d),

@@ -30,7 +30,9 @@ extern "C" {
                                     _unpin / dexct_download (the NumPy boundary of large arrays);
                                  6: quantum noise inside the projection kernels - struct dexct_noise; weights2 / variance / noise
                                     arguments of dexct_siddon_project_packed, dexct_cone_project, dexct_cone_project_rows; one Philox
-                                    block per detector pixel serves all its spectra (dexct_add_noise draws the same sample) */
+                                    block per detector pixel serves all its spectra (dexct_add_noise draws the same sample);
+                                    dexct_cone_layout_groups / dexct_cone_project_grouped (material groups on the row-parallel
+                                    cone kernels) */
 
 #define DEXCT_OK 0
 #define DEXCT_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported combination) */
@@ -236,9 +238,28 @@ int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* pl
                             float* counts, float* pathlen, const dexct_log_out* log_out, const float* weights2,
                             float* variance, const dexct_noise* noise, void* stream);
 
-/* counts += sqrt(variance) * z, z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
- * channel, spectrum) and key seed: independent of view sharding and of the layout (0 / 1 as above).
- * Results are clipped at 1e-20 so that a log sinogram stays finite. */
+/* Material groups for the row-parallel cone kernels (ABI 6; more than 3 materials, up to DEXCT_MAX_MATERIALS; volumes of any
+ * height the row kernels take): what dexct_volume_groups / dexct_siddon_project_grouped are to the stacked fan.
+ * dexct_cone_layout_groups: ceil(n_materials / 3) guarded layouts of dexct_cone_layout_bytes each; layout g holds 8 * (id - 3g)
+ *   for the ids 3g .. 3g + 2 and 24 ("outside": nobody's voxel) for every other id.
+ * dexct_cone_project_grouped: one traversal per group (cone_cols_kernel / cone_rows_kernel) writes the path lengths [cm] of its
+ *   three materials to acc_scratch[m*n_rays + ray] (float32, caller-provided, n_materials*n_rays values), then one detection pass
+ *   applies the tables; outputs as dexct_cone_project.  The per-material sums are independent, so the path lengths are
+ *   bit-identical to dexct_cone_project's.  weights2 / variance (both or neither) as in dexct_siddon_project: the variance for
+ *   dexct_add_noise; no log_out together with a variance. */
+int dexct_cone_layout_groups(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, int32_t n_materials, uint8_t* vol_zcg,
+                             void* stream);
+int dexct_cone_project_grouped(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
+                               const double* chan_cs, const double* row_z, double src_z, double max_abs_dz,
+                               int32_t view_begin, int32_t view_end, const uint8_t* vol_zcg, int32_t n_materials,
+                               int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights, float* counts,
+                               float* pathlen, float* acc_scratch, const dexct_log_out* log_out, const float* weights2,
+                               float* variance, void* stream);
+
+/* counts = max(counts + sqrt(variance) * z, 1e-20), z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
+ * channel, 0) and key seed - one block per detector pixel, spectrum s takes the s-th normal of its two Box-Muller pairs (ABI 6;
+ * struct dexct_noise: the projection kernels that sample by themselves draw exactly this) - : independent of view sharding and
+ * of the layout (0 / 1 as above).  The clip keeps a log sinogram finite. */
 int dexct_add_noise(float* counts, const float* variance, int32_t n_spectra, int32_t n_views, int32_t n_rows,
                     int32_t n_channels, int32_t layout, int32_t view_offset, uint64_t seed, void* stream);
 

@@ -329,14 +329,14 @@ def test_cone_beam_matches_oracle(hip, n_mat):
     cls, _ = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, 20, cone.row_z(), 0.3, ph.volume, mu, w, dda=False,
                              n_threads=8)
     # kernel 1: one thread per ray (any number of materials); kernel 2: the rows of a (view, channel) pair as lanes
-    # with the shared in-plane records and one byte load per slab (<= 3 materials) - the same bits
-    for kernel in ((1, 2) if n_mat <= 3 else (1,)):
-        (counts, pl), _ = projector(cone, ph, kernel=kernel).project(sp, want_pathlen=True)
+    # with the shared in-plane records and one byte load per slab - <= 3 materials in one pass, more in one pass per group of
+    # three + one detection pass (round 6) - the same bits
+    for kernel in (1, 2):
+        pjk = projector(cone, ph, kernel=kernel)
+        assert pjk.cone_groups == (kernel == 2 and n_mat > 3)
+        (counts, pl), _ = pjk.project(sp, want_pathlen=True)
         assert np.array_equal(pl.cpu().numpy(), rpl), kernel
         assert np.max(np.abs(counts.cpu().numpy() - cls) / cls) < REL_TOL
-    if n_mat > 3:
-        with pytest.raises(ValueError):
-            projector(cone, ph, kernel=2)
     # zero cone angle through the centre of slice 7 == the 2-D fan of slice 7
     flat = dx.FanBeamGeometry(N_channels=48, N_proj=20, gamma_fan=0.8230337, SID=60.0, SDD=100.0, h_iso=1.0,
                               eid=True, detector_file=ct.detector_file, N_rows=1, cone=True,
@@ -533,6 +533,67 @@ def test_cone_row_kernels_on_tall_volumes(hip, nz, n_rows, monkeypatch):
         if first is None:
             first = counts.clone()
         assert torch.equal(counts, first), env
+
+
+@pytest.mark.parametrize('n_mat,nz,n_rows', [(4, 40, 36), (6, 300, 64), (12, 96, 257), (50, 64, 40), (5, 1030, 33)])
+def test_cone_beam_material_groups(hip, n_mat, nz, n_rows, monkeypatch):
+    """Round 6: more than 3 table rows on the row-parallel cone kernels - one cone_cols_kernel (cone_rows_kernel beyond 1024
+    slices) pass per group of three materials into planes of path lengths, one detection pass over them
+    (dexct_cone_project_grouped), as the stacked fan has had since round 3.  Path lengths bit-identical to the one-thread-per-ray
+    kernel and to the oracle's mirror (the per-material sums are independent), counts identical for <= 48 table rows (the same
+    detection arithmetic) and within 1e-5 of the float64 3-D Siddon; log sinogram, quantum noise (the same sample as kernel 1
+    draws), view shards, view chunks of the scratch (DEXCT_GROUP_SCRATCH), what kernel 0 picks."""
+    import dex_ct_sim_amd as dx
+    from dex_ct_sim_amd import forward_project as fp
+    from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
+    rng = np.random.default_rng(n_mat * 100 + nz)
+    nx, ny = 22, 19
+    dxv, dyv, dzv = 0.2, 0.25, 0.05
+    vol = rng.integers(0, n_mat, (nz, ny, nx), dtype=np.uint8)
+    vol[rng.random(vol.shape) < 0.4] = 0
+    mats = [AIR, WATER, BONE] + [Material(f'm{i}', 0.8 + 0.03 * i, 'H(11.2)O(88.8)' if i % 2 else 'H(10.2)C(14.3)N(3.4)O(71.0)Na(0.1)') for i in range(3, n_mat)]
+    ph = dx.VoxelPhantom.from_array('groups', vol, mats, dx=dxv, dy=dyv, dz=dzv)
+    sid, sdd = 9.0, 16.0
+    reach = 0.6 * sdd * dzv / (max(dxv, dyv) * np.sqrt(2.0))
+    h_iso = float(reach / (0.5 * (n_rows - 1)) * sid / sdd * 0.9)
+    n_views, n_ch = 6, 13
+    cone = dx.FanBeamGeometry(N_channels=n_ch, N_proj=n_views, gamma_fan=0.9, SID=sid, SDD=sdd, h_iso=h_iso,
+                              N_rows=n_rows, cone=True, src_z=0.1 * reach)
+    g = co.make_geom(n_views, n_ch, n_rows, 0, nx, ny, nz, dxv, dyv, dzv, sid, sdd)
+    sp = spectra()
+    for s_ in sp:
+        s_.rescale_counts(1e2)
+    E, mu, w = fp.merged_tables(cone, ph, sp)
+    pj1, pj2, pj0 = projector(cone, ph, kernel=1), projector(cone, ph, kernel=2), projector(cone, ph)
+    assert pj2.cone_groups and pj0.cone_groups and not pj1.cone_groups          # kernel 0 picks the group passes from 32 rows on
+    M = pj2.n_mat
+    _, rpl = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), 0.1 * reach, vol, pj2.compact(mu), w,
+                             dda=True, n_threads=8) if M == n_mat else (None, None)
+    (c1, p1, l1), air = pj1.project(sp, want_pathlen=True, want_log=True)
+    (c2, p2, l2), _ = pj2.project(sp, want_pathlen=True, want_log=True)
+    assert torch.equal(p1, p2)
+    if rpl is not None:
+        assert np.array_equal(p2.cpu().numpy(), rpl)
+    same_detection = 4 < M <= 48     # (4 rows: kernel 1 sums its energies in pairs; beyond 48 the detection pass forms its exponents
+    if same_detection:               # unscaled: another rounding, the same numbers to 2e-6)
+        assert torch.equal(c1, c2) and torch.equal(l1, l2)
+    else:
+        assert torch.allclose(c1, c2, rtol=2e-6, atol=0)
+    cls, _ = co.project_cone(g, cone.view_cs(), cone.chan_cs(), 0, n_views, cone.row_z(), 0.1 * reach, vol, mu, w, dda=False, n_threads=8)
+    assert np.max(np.abs(c2.cpu().numpy() - cls) / cls) < REL_TOL
+    n1, _ = pj1.project(sp, noise=True, seed=4)
+    (n2, nl2), _ = pj2.project(sp, noise=True, seed=4, want_log=True)
+    if same_detection:
+        assert torch.equal(n1, n2)
+    assert not torch.equal(n2, c2) and np.allclose(nl2.cpu().numpy(), _np_log(air, n2.cpu().numpy()), rtol=5e-6, atol=5e-7)
+    a, _ = projector(cone, ph, kernel=2, view_range=(0, 2)).project(sp)
+    b, _ = projector(cone, ph, kernel=2, view_range=(2, 6)).project(sp)
+    assert torch.equal(torch.cat([a, b], dim=1), c2)
+    monkeypatch.setattr(fp, '_GROUP_SCRATCH_BYTES', 2 * M * n_rows * n_ch * 4)      # two views of scratch: three chunks
+    (c3, p3, l3), _ = pj2.project(sp, want_pathlen=True, want_log=True)
+    assert torch.equal(c3, c2) and torch.equal(p3, p2) and torch.equal(l3, l2)
+    n3, _ = pj2.project(sp, noise=True, seed=4)
+    assert torch.equal(n3, n2)
 
 
 def test_sino_allgather_entry_point_single_rank(hip):
