@@ -112,9 +112,10 @@ def newton(wl, args, gstats, gn_ms, masked, prof, traffic_src, gate_prep_s, md):
     gn_name = ('gn_shortcut_kernel (start values from the table of the reference\'s fixed points + full-table steps)' if two_level
                else 'gn_refill_kernel<false>') if precision == 'f64' else 'gn_kernel<true,false>'
     main_ms = gstats['main_ms'] if gstats else gn_ms      # HIP events around the launch, on its stream, last timed step
-    gn_form = two_level and gstats.get('mode') == 'one'    # the one step of the short cut is of the Gauss-Newton form: 6 of the 12 sums
+    gn_form = two_level and gstats.get('mode') == 'one'    # the one step of the short cut is the CHORD step: 2 of the 12 sums (nu alone)
     if gn_form:
-        hw_share = (17.0 * n_both + 11.0 * n_one) / (29.0 * i0.shape[1])
+        # per energy: exponent 2 FMA = 4 flops, the exponential counted as 1, one accumulation (2 flops) per weighting spectrum
+        hw_share = (9.0 * n_both + 7.0 * n_one) / (29.0 * i0.shape[1])
     roof = {'kernel': gn_name, 'bound': 'valu_fp64' if precision == 'f64' else 'valu_fp32+fp64',
             'unit': 'TFLOP/s', 'peak': FP64_VALU_PEAK_TFLOPS, 'avg_launch_ms': main_ms, 'gn_ms_all_launches': gn_ms,
             'traffic': ((prof.get('gn_fetch_bytes_raw', 0) if prof.get('gn_fetch_counted_in_full') else prof.get('gn_fetch_bytes_x2_corrected', 0))
@@ -146,13 +147,13 @@ def newton(wl, args, gstats, gn_ms, masked, prof, traffic_src, gate_prep_s, md):
                              'Newton iteration of one pixel at the reference\'s 28 flops + 1 exp per energy - counts %.2f x as many flops as '
                              'are issued (hardware_fp64_flop_share = %.2f): frac_by_survey_unit keeps that figure, which rises when work is '
                              'removed and is therefore not the roofline.  The rest of the busy vector pipe is the exponential (14 of the '
-                             '20.5 instructions per energy), integer / move work and the per-pixel gate, interpolation and 2x2 solve: see '
+                             '~16 instructions per energy), integer / move work and the per-pixel gate and interpolations: see '
                              '`issue`.%s  exit_saving = share of the n_iters x pixels full-table iterations the short cut and the exits '
                              'made unnecessary - reported separately, not as throughput'
                              % (i0.shape[1], n_both, n_one, i0.shape[1] - n_both - n_one, 1.0 / hw_share, hw_share,
-                                '  The ONE step per pixel of the default short cut is of the Gauss-Newton form (the Hessian without '
-                                'its (g / nu - 1) x second-derivative term - a second-order effect the tabulated kappa includes): 6 of the 12 '
-                                'accumulations per energy.' if gn_form else '')})
+                                '  The ONE step per pixel of the default short cut is the chord step (round 6): the relative misfit of the counts '
+                                '- the full energy sum of nu, 2 of the 12 accumulations per energy - times the TABULATED inverse log-Jacobian '
+                                '(what it leaves is bounded by the table\'s (kappa, eps) per cell).' if gn_form else '')})
         valu = prof.get('gn_valu_insts')
         if valu:
             rate = valu / (main_ms * 1e-3) / 1e9
@@ -164,7 +165,7 @@ def newton(wl, args, gstats, gn_ms, masked, prof, traffic_src, gate_prep_s, md):
                                      'issue peak (1024 SIMDs x 2.4 GHz / 4 cycles): the kernel sits at the issue ceiling - only fewer '
                                      'instructions make it faster'}
         if gn_form:
-            roof['one_step_form'] = 'gauss-newton (6 of 12 sums per energy; the dropped term is second order and inside the tabulated kappa)'
+            roof['one_step_form'] = 'chord step: misfit of the counts (2 of 12 sums per energy) x tabulated inverse log-Jacobian; |e1| <= eps e0 + kappa e0^2, both tabulated per cell'
         if two_level:
             roof['short_cut'] = {
                 'mode': gstats['mode'], 'launch_ms': main_ms, 'full_energies': int(i0.shape[1]),

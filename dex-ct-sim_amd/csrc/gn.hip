@@ -86,8 +86,9 @@ __device__ __forceinline__ double rcp_f64(double x) {
 // (nB), only spectrum 1 (nC); energies no spectrum weights are dropped.  A zero weight contributes exactly
 // 0 to every sum (the attenuation factor is finite thanks to the clip), so skipping those FMAs changes no
 // term of the reference's sums - only their order.
-template <int KSEL, bool CLIP, bool HESS = true>   // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip;
-                                                   // HESS: also the three second-derivative sums (false: the Gauss-Newton form of the step)
+template <int KSEL, bool CLIP, int SUMS = 2>       // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip;
+                                                   // SUMS 2: all six sums per measurement (a Newton step), 0: the expected counts nu
+                                                   // alone (the chord step of the short cut: 2 of the 12 accumulations per energy)
 __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 int e0, int e1, double a0, double a1, double (&nu)[2], double (&nuo)[2],
                                                 double (&G0)[2], double (&G1)[2], double (&H00)[2], double (&H01)[2],
@@ -107,9 +108,11 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
       if ((KSEL == 1 && k == 1) || (KSEL == 2 && k == 0)) continue;
       const double* __restrict__ tk = t + 2 + 6 * k;
       nuk[k] = fma(tk[0], at, nuk[k]);
-      G0[k] = fma(tk[1], at, G0[k]);
-      G1[k] = fma(tk[2], at, G1[k]);
-      if (HESS) {
+      if (SUMS >= 1) {
+        G0[k] = fma(tk[1], at, G0[k]);
+        G1[k] = fma(tk[2], at, G1[k]);
+      }
+      if (SUMS >= 2) {
         H00[k] = fma(tk[3], at, H00[k]);
         H01[k] = fma(tk[4], at, H01[k]);
         H11[k] = fma(tk[5], at, H11[k]);
@@ -135,7 +138,7 @@ struct EnergyClasses { int nA, nAc, nB, nBc, nC, nCc; double m0_free, m1_free; }
 // split the energy loop of the same 64 pixels.
 struct GnSums { double nu[2], G0[2], G1[2], H00[2], H01[2], H11[2]; };
 
-template <int NPARTS, bool HESS = true>
+template <int NPARTS, int SUMS = 2>
 __device__ __forceinline__ void newton_sums_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
                                                 EnergyClasses ec, int part, double a0, double a1, GnSums& s) {
   double nu[2] = {0, 0}, nuo[2] = {0, 0}, G0[2] = {0, 0}, G1[2] = {0, 0}, H00[2] = {0, 0}, H01[2] = {0, 0}, H11[2] = {0, 0};
@@ -143,21 +146,21 @@ __device__ __forceinline__ void newton_sums_f64(const double* __restrict__ tab, 
   auto lo = [&](int b, int e) { return NPARTS == 1 ? b : b + (e - b) * part / NPARTS; };
   auto hi = [&](int b, int e) { return NPARTS == 1 ? e : b + (e - b) * (part + 1) / NPARTS; };
   // the always-clipped heads of the three classes
-  energy_sums_f64<0, true, HESS>(tab, lds_pow, lo(bA, bA + ec.nAc), hi(bA, bA + ec.nAc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<1, true, HESS>(tab, lds_pow, lo(bB, bB + ec.nBc), hi(bB, bB + ec.nBc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-  energy_sums_f64<2, true, HESS>(tab, lds_pow, lo(bC, bC + ec.nCc), hi(bC, bC + ec.nCc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<0, true, SUMS>(tab, lds_pow, lo(bA, bA + ec.nAc), hi(bA, bA + ec.nAc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<1, true, SUMS>(tab, lds_pow, lo(bB, bB + ec.nBc), hi(bB, bB + ec.nBc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+  energy_sums_f64<2, true, SUMS>(tab, lds_pow, lo(bC, bC + ec.nCc), hi(bC, bC + ec.nCc), a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   // the tails: clip-free when the bound holds for this pixel (NaN compares false -> clipped path)
   const int tA0 = lo(bA + ec.nAc, bA + ec.nA), tA1 = hi(bA + ec.nAc, bA + ec.nA);
   const int tB0 = lo(bB + ec.nBc, bB + ec.nB), tB1 = hi(bB + ec.nBc, bB + ec.nB);
   const int tC0 = lo(bC + ec.nCc, bC + ec.nC), tC1 = hi(bC + ec.nCc, bC + ec.nC);
   if (fma(fabs(a1), ec.m1_free, fabs(a0) * ec.m0_free) <= 699.9) {
-    energy_sums_f64<0, false, HESS>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, false, HESS>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, false, HESS>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, false, SUMS>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, false, SUMS>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, false, SUMS>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   } else {
-    energy_sums_f64<0, true, HESS>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<1, true, HESS>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
-    energy_sums_f64<2, true, HESS>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<0, true, SUMS>(tab, lds_pow, tA0, tA1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<1, true, SUMS>(tab, lds_pow, tB0, tB1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
+    energy_sums_f64<2, true, SUMS>(tab, lds_pow, tC0, tC1, a0, a1, nu, nuo, G0, G1, H00, H01, H11);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -200,35 +203,28 @@ __device__ __forceinline__ void newton_step_f64(const double* __restrict__ tab, 
   newton_solve_f64(s, g0, g1, a0, a1);
 }
 
-// THE GAUSS-NEWTON FORM of the step, for the one step of the short cut (gn_shortcut_kernel<1>): the Hessian without its
-// (g / nu - 1) * hessian(nu) term (matdecomp.py:123, the first term), i.e. without the three second-derivative sums per
-// measurement - 6 of the 12 accumulations per energy.  Both forms have the same fixed points where the counts reproduce, and from
-// a start value at distance e0 of one the Gauss-Newton step leaves a1 - a* = Ht^-1 (X(a0) + 1/2 D3F [e0, .]) e0 with X = sum_k
-// c_k S_k the dropped term: c_k(a0) = (G_k . e0) / nu_k vanishes with e0 (the counts reproduce at a*), so X e0 is a SECOND-ORDER
-// term like Newton's own, with coefficients S_kjp G_kq / nu_k of the kind D3F is made of.  The table's kappa is the constant of
-// THIS step (quadrature.newton_kappa(gauss_newton=True): the third-derivative term plus max_i sum_j |H^-1_ij| sum_pqk S_kjp G_kq /
-// nu_k, from the same energy sums at the tabulated fixed points): |e1| <= kappa |e0|^2 as for the full step, about twice its
-// constant.
-__device__ __forceinline__ void newton_step_gn_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
-                                                   EnergyClasses ec, double g0, double g1, double& a0, double& a1) {
+// THE CHORD STEP of the short cut (gn_shortcut_kernel<1>; round 6 - round 5 took a Gauss-Newton step here: 6 of the 12 sums).
+// From a start value s within 1e-10 of |a| of the fixed point a*, what a step has to get right is the RESIDUAL - the relative
+// misfit of the counts c_k = g_k / nu_k(s) - 1, which needs the full energy sum of nu to its last bits - not the Jacobian it is
+// multiplied with: a relative error eps of the Jacobian leaves eps e0 of the distance.  And the inverse of the model's
+// log-Jacobian, B = (d ln nu / d a)^-1, is already in the table: it is the GRADIENT of the tabulated fixed points with respect to
+// the (logarithms of the) counts - gn_start<DERIV> forms it from the same 36 loads - so the energy loop carries 2 accumulations per energy
+// (nu of both measurements) instead of 6: with c(a) = g / nu(a) - 1, Dc(a*) = -L*, the step m = s + Bt c(s) leaves
+//     m - a* = (I - Bt L*) e0 + 1/2 Bt D2c(xi) [e0, e0],      |e1| <= eps |e0| + kappa |e0|^2,
+// eps >= |I - Bt L*| (what the derivative of the interpolant leaves: measured by the host at every cell's corners - where the
+// derivative of an even-order interpolant is worst - and centre, against the exact Jacobians there; per cell, with a safety factor)
+// and kappa = 1/2 max_i sum_j |B_ij| sum_pq |D2c_jpq| (quadrature.chord_tables; both per cell, as the pair (kappa, eps)).
+// The residuals only:
+__device__ __forceinline__ void chord_residuals_f64(const double* __restrict__ tab, const double* __restrict__ lds_pow,
+                                                    EnergyClasses ec, double g0, double g1, double a0, double a1, double (&c)[2]) {
   GnSums s;
-  newton_sums_f64<1, false>(tab, lds_pow, ec, 0, a0, a1, s);
+  newton_sums_f64<1, 0>(tab, lds_pow, ec, 0, a0, a1, s);
   const double g[2] = {g0, g1};
-  double c[2], q[2];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {                                  // (as newton_solve_f64)
-    const double inv = rcp_f64(s.nu[k]), ratio = g[k] * inv;
-    c[k] = fabs(s.nu[k]) < __builtin_huge_val() ? (g[k] - s.nu[k]) * inv : ratio - 1.0;
-    q[k] = ratio * inv;
+  for (int k = 0; k < 2; ++k) {                                  // (g - nu) / nu as in newton_solve_f64
+    const double inv = rcp_f64(s.nu[k]);
+    c[k] = fabs(s.nu[k]) < __builtin_huge_val() ? (g[k] - s.nu[k]) * inv : g[k] * inv - 1.0;
   }
-  const double dF0 = c[0] * s.G0[0] + c[1] * s.G0[1];
-  const double dF1 = c[0] * s.G1[0] + c[1] * s.G1[1];
-  const double h00 = q[0] * (s.G0[0] * s.G0[0]) + q[1] * (s.G0[1] * s.G0[1]);
-  const double h01 = q[0] * (s.G0[0] * s.G1[0]) + q[1] * (s.G0[1] * s.G1[1]);
-  const double h11 = q[0] * (s.G1[0] * s.G1[0]) + q[1] * (s.G1[1] * s.G1[1]);
-  const double inv_det = rcp_f64(h00 * h11 - h01 * h01);
-  a0 -= (h11 * dF0 - h01 * dF1) * inv_det;
-  a1 -= (h00 * dF1 - h01 * dF0) * inv_det;
 }
 
 // float32 table layout per energy: [mu0*log2e, mu1*log2e, then for c in {1, mu0, mu1, mu0^2, mu0mu1, mu1^2}:
@@ -837,20 +833,23 @@ __device__ __forceinline__ bool gn_exit_or_advance(double n0, double n1, int n_i
 // outside the grid, another fixed point, NaN) is solved the reference's way.
 // Layout: [0],[1] unattenuated signals; [2] 1 / log_range; [3] cells per axis n; [4] ln of the smallest u0 of the grid;
 // [5] cells per unit of ln u0; [6] smallest ratio u1 / u0 of the grid; [7] cells per unit of the ratio; [8],[9] ln of [0],[1];
-// [10] 1 if the array ends with kappa[n^2] (below), else 0; [11] reserved; then the corners' fixed points as pairs
-// (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair (need, radius)[n^2], then - optional - per cell kappa[n^2];
-// the array is 16-byte aligned (pairs are read with one load).
+// [10] 2 if the tables of the one-step acceptance follow the cells (below), else 0; [11] reserved; then the corners' fixed points
+// as pairs (a0, a1)[(n+1)^2] (row = index along ln u0), then per cell the pair (need, radius)[n^2], then - [10] = 2 - per cell the
+// pair (kappa, eps)[n^2]; the array is 16-byte aligned (pairs are read with one load).
 //
-// ONE STEP INSTEAD OF TWO (kappa; DEXCT_GN_FLAG_ONE_STEP).  Newton's iteration on the likelihood F from a start value s at
-// distance e0 of the fixed point a* lands at n with  n - a* = 1/2 H(s)^-1 D3F(xi) [e0, e0]:  e1 <= kappa e0^2 in the max norm with
-// kappa = 1/2 max_i sum_j |H^-1_ij| sum_pq |D3F_jpq|, and the step itself measures e0: d1 = |n - s| >= e0 - e1.  The host tabulates
-// kappa per cell from the Hessian and the third derivatives of the Poisson likelihood at the tabulated fixed points
-// (quadrature.newton_kappa: 2.5 x the largest value at the corners of the cell and of the eight around it; infinity where one
-// does not count).  A pixel whose first step satisfies kappa d1^2 <= stop_tol / 4 * max(|a|, 1) has what the tolerance rule asks
-// of two steps - a bound on the distance it still has to go, below stop_tol / 4 of its size - from one, and ends there; every
-// other pixel takes its second step and the rule, as before.  With the sextic interpolant d1 is 1e-10 of |a| and the bound
-// holds with orders to spare (kappa |a| is 600 on average, 1e4 at thick rays: profiles/r05_gn_one_step.md).  The one step is of
-// the Gauss-Newton form (newton_step_gn_f64, above: half the accumulations); kappa is tabulated for that form.
+// ONE STEP INSTEAD OF TWO (DEXCT_GN_FLAG_ONE_STEP).  A step from a start value s at distance e0 of the fixed point a* that
+// provably leaves  e1 <= eps e0 + kappa e0^2  (the chord step above; round 5: a Gauss-Newton step with eps = 0) measures e0 by its
+// own length, d1 = |m - s| >= e0 - e1.  The host tabulates (kappa, eps) per cell - kappa from the second derivatives of the
+// misfit at the tabulated fixed points (2.5 x the largest value at the corners of the cell and of the eight around it), eps
+// from the table's own gradient against the exact Jacobians at the cell's corners and centre (4 x the largest of the cell and the
+// eight around it); infinity where a corner or centre does not count.  A pixel whose step satisfies
+//     (kappa d1 + eps) d1 <= stop_tol / 4 * max(min(|a0|, |a1|), 1)
+// has what the tolerance rule asks of two steps - a bound on the distance it still has to go, below stop_tol / 4 of its size
+// (here even of its SMALLER component: the one-step results are compared with the exact count per component) -
+// from one, and ends there; every other pixel goes on with full Newton steps and the rule, as before.  With the sextic
+// interpolant d1 is 1e-11 of |a| at the median point of the data plane (5e-10 at the 90th percentile, 1e-8 at the 99th: the thick
+// end at the edges of the physical ratios), kappa |a| is 100 on average, eps 2e-8 at the median point (2e-7 / 1e-5 at the 90th /
+// 99th percentile: it shrinks and grows with d1): ~99 % of the plane passes with orders to spare, the rest takes full Newton steps.
 constexpr int kStartHeader = 12;
 #ifndef DEXCT_GN_INTERP_UNROLL
 #define DEXCT_GN_INTERP_UNROLL 2      // rows of the 6 x 6 interpolation per loop trip (A/B: tools/probes/build_variant.sh)
@@ -871,14 +870,28 @@ __device__ __forceinline__ double log_pos(double x, const double* __restrict__ l
 #endif
 }
 
+// What the chord step needs of the pixel's cell: the one-step pair and the inverse log-Jacobian at the pixel's place, as
+// Bx_p = d a_p / d x * (-1 / (log_range u0)), Bt_p = d a_p / d t * (-1 / (log_range u0)) (x = ln u0, t = u1 / u0 - see gn_start)
+struct GnCell { int idx; double t, Bx[2], Bt[2]; };      // idx: the cell, for its pairs (need, radius) and (kappa, eps) AFTER the energy loop
+
+// DERIV (the chord step, round 6): besides the interpolant also ITS DERIVATIVES along the two coordinates, from the same 36
+// loads - the fixed point as a function of the data-plane coordinates IS the inverse of the forward model, so the gradient of
+// the table is the inverse Jacobian the chord step multiplies its residuals with: d a* / d ln g_k = (d a* / d (x, t)) (d (x, t) /
+// d ln g_k), the first factor from the derivative weights of the Lagrange basis, the second analytic (u_k = (ln air_k - ln g_k) /
+// log_range, x = ln u0, t = u1 / u0:  dx / d ln g0 = -1 / (log_range u0),  dt / d ln g0 = t / (log_range u0),  dt / d ln g1 =
+// -1 / (log_range u0)).  No table of Jacobians, no load; its error shrinks with the interpolant's own (eps ~ e0 / cell x cond):
+// 2e-8 at the median point of the plane, where a float32 table of the inverse stopped at 1e-5 (rounding x cond(L) = 200).
+template <bool DERIV = false>
 __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const double* __restrict__ lds_pow, int n_iters,
-                                         double g0, double g1, double& s0, double& s1, double& radius, double* kappa = nullptr) {
+                                         double g0, double g1, double& s0, double& s1, double& radius, GnCell* cell_out = nullptr) {
 #ifdef DEXCT_GN_LIBM_LOG          // (round 4's arithmetic, kept for one bit-for-bit comparison of the two kernels)
   const double u0 = log(start[0] / g0) * start[2], u1 = log(start[1] / g1) * start[2];
+  const double ru0 = 1.0 / u0;
   const double t = u1 / u0;
 #else
   const double u0 = (start[8] - log_pos(g0, lds_pow)) * start[2], u1 = (start[9] - log_pos(g1, lds_pow)) * start[2];
-  const double t = u1 * rcp_f64(u0);
+  const double ru0 = rcp_f64(u0);
+  const double t = u1 * ru0;
 #endif
   const int n = (int)start[3];
   const double fx = (log_pos(u0, lds_pow) - start[4]) * start[5], fy = (t - start[6]) * start[7];
@@ -891,12 +904,14 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const
   ok = ok && (double)n_iters >= cell.x;
   // 6 x 6 Lagrange interpolation of the corners' fixed points (the corners of the 5 x 5 cells the step table vouches for; cells
   // within two of the border of the grid are closed by the host).  The fixed point is an analytic function of (ln u0, u1 / u0);
-  // at 256 cells per axis the sextic interpolant is within 1e-10 of |a| of the pixel's own fixed point (the Catmull-Rom
-  // interpolant of round 4, third order: 2e-6; tools/probes/gn_interp_cpu.py) - close enough for ONE Newton step to land at
-  // rounding level with a proven bound (kappa, above), and it costs 36 loads and 100 FMAs against a step's 3 000.
+  // at 256 cells per axis the sextic interpolant is within 1e-11 of |a| of the pixel's own fixed point at the median point of the
+  // plane, 5e-10 at the 90th percentile (the Catmull-Rom interpolant of round 4, third order: 2e-6; tools/probes/gn_interp_cpu.py)
+  // - close enough for ONE step to land at rounding level with a proven bound, and it costs 36 loads and 100 - 250 FMAs against a
+  // step's 2 500.
   const double wx = fx - (double)i, wy = fy - (double)j;
-  auto weights = [](double t_, double (&w)[6]) {
-    // nodes -2 .. 3: w_a = prod_(b != a) (t - x_b) / (x_a - x_b), by prefix and suffix products of p_b = t - x_b
+  auto weights = [](double t_, double (&w)[6], double (&dw)[6]) {
+    // nodes -2 .. 3: w_a = prod_(b != a) (t - x_b) / (x_a - x_b), by prefix and suffix products of p_b = t - x_b; DERIV: and
+    // dw_a / dt by the product rule on the same recurrences (l_(a+1) = l_a p_a: l'_(a+1) = l'_a p_a + l_a)
     const double p0 = t_ + 2.0, p1 = t_ + 1.0, p2 = t_, p3 = t_ - 1.0, p4 = t_ - 2.0, p5 = t_ - 3.0;
     const double l1 = p0, l2 = l1 * p1, l3 = l2 * p2, l4 = l3 * p3, l5 = l4 * p4;          // prod_(b < a) p_b
     const double r4 = p5, r3 = r4 * p4, r2 = r3 * p3, r1 = r2 * p2, r0 = r1 * p1;          // prod_(b > a) p_b
@@ -906,29 +921,66 @@ __device__ __forceinline__ bool gn_start(const double* __restrict__ start, const
     w[3] = l3 * r3 * (1.0 / 12.0);
     w[4] = l4 * r4 * (-1.0 / 24.0);
     w[5] = l5 * (1.0 / 120.0);
+    if (DERIV) {
+      const double dl1 = 1.0, dl2 = fma(dl1, p1, l1), dl3 = fma(dl2, p2, l2), dl4 = fma(dl3, p3, l3), dl5 = fma(dl4, p4, l4);
+      const double dr4 = 1.0, dr3 = fma(dr4, p4, r4), dr2 = fma(dr3, p3, r3), dr1 = fma(dr2, p2, r2), dr0 = fma(dr1, p1, r1);
+      dw[0] = dr0 * (-1.0 / 120.0);
+      dw[1] = fma(dl1, r1, l1 * dr1) * (1.0 / 24.0);
+      dw[2] = fma(dl2, r2, l2 * dr2) * (-1.0 / 12.0);
+      dw[3] = fma(dl3, r3, l3 * dr3) * (1.0 / 12.0);
+      dw[4] = fma(dl4, r4, l4 * dr4) * (-1.0 / 24.0);
+      dw[5] = dl5 * (1.0 / 120.0);
+    }
   };
-  double cx[6], cy[6];
-  weights(wx, cx);
-  weights(wy, cy);
+  double cx[6], cy[6], dx[6], dy[6];
+  weights(wx, cx, dx);
+  weights(wy, cy, dy);
   const int i0c = i > 2 ? i - 2 : 0, j0c = j > 2 ? j - 2 : 0;               // (closed border cells never get here with ok)
   const int base = (i0c <= n - 5 ? i0c : n - 5) * (n + 1) + (j0c <= n - 5 ? j0c : n - 5);
   s0 = 0.0;
   s1 = 0.0;
-#pragma unroll DEXCT_GN_INTERP_UNROLL  // (2: twelve loads in flight, not thirty-six: registers at the kernel's tightest spot)
+  double ax0 = 0.0, ax1 = 0.0, at0 = 0.0, at1 = 0.0;                         // DERIV: d s / d fx, d s / d fy (cell units)
+  // (rows per trip: 2 - twelve loads in flight, not thirty-six: registers at the kernel's tightest spot; 1 with the derivatives,
+  // whose four more row sums and twelve more weights spilled 8 registers at 2)
+#pragma unroll DERIV ? 1 : DEXCT_GN_INTERP_UNROLL
   for (int p = 0; p < 6; ++p) {
-    double ra = 0.0, rb = 0.0;
+    double ra = 0.0, rb = 0.0, da = 0.0, db = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const d2 r = roots[base + p * (n + 1) + q];
       ra = fma(cy[q], r.x, ra);
       rb = fma(cy[q], r.y, rb);
+      if (DERIV) {
+        da = fma(dy[q], r.x, da);
+        db = fma(dy[q], r.y, db);
+      }
     }
     s0 = fma(cx[p], ra, s0);
     s1 = fma(cx[p], rb, s1);
+    if (DERIV) {
+      ax0 = fma(dx[p], ra, ax0);
+      ax1 = fma(dx[p], rb, ax1);
+      at0 = fma(cx[p], da, at0);
+      at1 = fma(cx[p], db, at1);
+    }
   }
   radius = cell.y;
-  if (kappa) *kappa = start[10] != 0.0 ? reinterpret_cast<const double*>(cells + n * n)[i * n + j] : __builtin_huge_val();
+  if (DERIV) {
+    const double kx = -(start[5] * start[2]) * ru0, kt = -(start[7] * start[2]) * ru0;     // cells per unit x (t) x d x (t) / d ln g
+    *cell_out = GnCell{i * n + j, t, {ax0 * kx, ax1 * kx}, {at0 * kt, at1 * kt}};
+  }
   return ok;
+}
+
+// (radius, kappa, eps) of cell idx: read AFTER the energy loop of the chord step (registers), not carried through it
+__device__ __forceinline__ void gn_cell_pairs(const double* __restrict__ start, int idx, double& radius, double& kappa, double& eps) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const int n = (int)start[3];
+  const d2* __restrict__ cells = reinterpret_cast<const d2*>(start + kStartHeader) + (n + 1) * (n + 1);
+  const d2 ke = start[10] == 2.0 ? (cells + n * n)[idx] : d2{__builtin_huge_val(), __builtin_huge_val()};
+  radius = cells[idx].y;
+  kappa = ke.x;
+  eps = ke.y;
 }
 
 // float64, one shared spectrum - the single launch from the reference's start value - with lane refill.  The exits end
@@ -1272,16 +1324,24 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
     d2 st_a = d2{1e-6, 1e-6}, st_p = d2{0.0, 0.0};
     double st_rad = 0.0;
     if (__ballot(act) != 0ull) {
-      double s0, s1, rad, kap = __builtin_huge_val();
-      const bool open = gn_start(start, lds_pow, n_iters, gd0, gd1, s0, s1, rad, STEPS == 1 ? &kap : nullptr) && n_iters >= 3;
+      double s0, s1, rad;
+      GnCell cl{0, 0.0, {0.0, 0.0}, {0.0, 0.0}};
+      double kap1 = __builtin_huge_val(), eps1 = __builtin_huge_val();
+      const bool open = gn_start<STEPS == 1>(start, lds_pow, n_iters, gd0, gd1, s0, s1, rad, &cl) && n_iters >= 3;
       const bool fast = act && open;
       to_walk = act && !open;
       const unsigned long long fm = __ballot(fast);
       if (fm != 0ull) {
         n_exec += (unsigned long long)(STEPS * (int)__popcll(fm));
         double n0 = s0, n1 = s1, m0 = s0, m1 = s1;
-        if (STEPS == 1) {                                                    // from s to m, Gauss-Newton form (newton_step_gn_f64)
-          newton_step_gn_f64(tab, lds_pow, ec, gd0, gd1, m0, m1);
+        if (STEPS == 1) {                                                    // from s to m: the chord step (chord_residuals_f64)
+          double c[2];
+          chord_residuals_f64(tab, lds_pow, ec, gd0, gd1, s0, s1, c);
+          // m = s + B c with B_p0 = Bx_p - t Bt_p, B_p1 = Bt_p (gn_start<DERIV>)
+          const double ct = fma(-cl.t, c[0], c[1]);
+          m0 = s0 + fma(cl.Bx[0], c[0], cl.Bt[0] * ct);
+          m1 = s1 + fma(cl.Bx[1], c[0], cl.Bt[1] * ct);
+          gn_cell_pairs(start, cl.idx, rad, kap1, eps1);
         } else {
 #pragma nounroll
           for (int k = 0; k < STEPS; ++k) {                                  // step 1: from s to n, step 2: from n to m
@@ -1292,11 +1352,14 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
         bool ended;
         double f0, f1;
         if (STEPS == 1) {
-          // one step, from s to m: a fixed point, or the cell's kappa vouches that what is left is below the tolerance (gn_start)
+          // one step, from s to m: a fixed point, or the cell's (kappa, eps) vouch that what is left is below the tolerance (gn_start)
           const bool fixed1 = exact_exit && __double_as_longlong(m0) == __double_as_longlong(s0) &&
                               __double_as_longlong(m1) == __double_as_longlong(s1);
-          const double d1 = fmax(fabs(m0 - s0), fabs(m1 - s1)), size = fmax(fmax(fabs(m0), fabs(m1)), 1.0);
-          const bool conv1 = kap * (d1 * d1) <= (0.25 * stop_tol) * size;      // (NaN, inf: no)
+          // (the size that counts is the SMALLER component's, at least 1: what the bound leaves is then below stop_tol / 4 of
+          // every component by itself - a ray through 37 cm of water has a second component of -0.6, and the comparisons
+          // with the exact count hold 1e-12 per component)
+          const double d1 = fmax(fabs(m0 - s0), fabs(m1 - s1)), size = fmax(fmin(fabs(m0), fabs(m1)), 1.0);
+          const bool conv1 = fma(kap1, d1, eps1) * d1 <= (0.25 * stop_tol) * size;      // (NaN, inf: no)
           ended = fixed1 || conv1;
           f0 = fixed1 ? s0 : m0; f1 = fixed1 ? s1 : m1;
         } else {

@@ -317,15 +317,20 @@ int dexct_host_touch(void* host, int64_t n_bytes, int32_t threads) {
   // is what page-locking it costs; memory that is resident locks in microseconds (tools/probes/pin_resident.py)
   if (!host || n_bytes <= 0 || threads < 1 || threads > 64) return DEXCT_EINVAL;
   const uintptr_t page = 4096, huge = (uintptr_t)1 << 21;
-  const uintptr_t lo = reinterpret_cast<uintptr_t>(host) / page * page;
-  const uintptr_t hi = (reinterpret_cast<uintptr_t>(host) + (uintptr_t)n_bytes + page - 1) / page * page;
-  auto part = [](uintptr_t b, uintptr_t e) {
+  const uintptr_t first = reinterpret_cast<uintptr_t>(host), end = first + (uintptr_t)n_bytes;
+  const uintptr_t lo = first / page * page;
+  const uintptr_t hi = (end + page - 1) / page * page;
+  auto part = [first, end](uintptr_t b, uintptr_t e) {
     if (e <= b) return;
 #ifdef MADV_POPULATE_WRITE
     if (madvise(reinterpret_cast<void*>(b), e - b, MADV_POPULATE_WRITE) == 0) return;
 #endif
-    for (uintptr_t a = b; a < e; a += 4096) {          // (kernels before 5.14: a read-modify-write of one byte per page)
-      volatile unsigned char* q = reinterpret_cast<volatile unsigned char*>(a);
+    // (kernels before 5.14: a read-modify-write of one byte per page - of a byte INSIDE the caller's block: the first and the
+    // last page may also hold other objects of the heap, and a byte of theirs rewritten with a stale value is a corrupted heap)
+    for (uintptr_t a = b; a < e; a += 4096) {
+      const uintptr_t at = a < first ? first : a;
+      if (at >= end) break;
+      volatile unsigned char* q = reinterpret_cast<volatile unsigned char*>(at);
       *q = *q;
     }
   };

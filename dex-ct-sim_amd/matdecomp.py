@@ -262,8 +262,8 @@ def _gate_from_disk(path, i0_h, mus_h):
             n = quadrature.GATE_CELLS
             head = None if pieces is None else pieces['head'].copy()
             if head is not None:
-                head[10] = 1.0                # (the kappa table follows the cells)
-            if (head is None or start_h.shape != (quadrature.START_HEADER + 2 * (n + 1) ** 2 + 3 * n * n,)
+                head[10] = 2.0                # (the tables of the one-step acceptance follow the cells)
+            if (head is None or start_h.shape != (quadrature.start_layout(n)[-1],)
                     or not np.array_equal(start_h[:quadrature.START_HEADER], head)):
                 return None
         return start_h, stats

@@ -183,10 +183,14 @@ def max_rel_error(mu, w, cols, w_red, L):
     return float(err.max())
 
 
-GATE_VERSION = 8           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
+GATE_VERSION = 9           # part of the key of the on-disk copy of a gate table (matdecomp._gate_cache_path): bump with any change here
 START_HEADER = 12          # doubles before the tables (csrc/gn.hip, gn_start)
-GATE_CELLS = 256           # cells per axis of the grid over (ln u0, u1 / u0): the kernel's 6 x 6 Lagrange interpolant of the fixed points is then
-                           # within 1e-10 of |a| of a pixel's own (128 cells: 7e-9; Catmull-Rom, round 4: 2e-6; tools/probes/gn_interp_cpu.py)
+GATE_CELLS = 384           # cells per axis of the grid over (ln u0, u1 / u0).  The error of the kernel's 6 x 6 Lagrange interpolant of the fixed
+                           # points goes with the sixth power of the cell size, and it is NOT uniform over the plane: at 256 cells (round 5)
+                           # 2e-11 of |a| at the median point but 1.4e-9 at the median WATER ray - water in a tissue / bone basis sits at the edge
+                           # of the physical ratios (a1 = -0.016 a0), where the fixed points bend - so that 7 % (round 5's Gauss-Newton step) to
+                           # 40 % (round 6's chord step, held to 1e-12 per component) of a water scan's pixels took a second step; at 384 cells:
+                           # 1.0e-10 at the median water ray, no second steps (profiles/r06_gn_chord.md).  7.1 MB instead of 3.2
 GATE_U_MIN = 1.0e-4        # smallest u0 = ln(air_0 / g_0) / log_range of the grid: thinner rays walk from 1e-6 (a handful of steps)
 GATE_U_MAX = 0.75          # largest u0 with open cells: attenuation exp(-12), six counts per million.  Beyond, the long walk from 1e-6 is
                            # fragile - photon-starved counts inside a cell whose corners all arrive have been seen to end at another
@@ -370,8 +374,11 @@ def assemble_start(pieces, steps, roots):
     x_hi = pieces['head'][4] + (np.arange(n) + 1.0) / pieces['head'][5]            # ln u0 at the upper edge of each cell row
     need[x_hi > np.log(GATE_U_MAX), :] = np.inf
     radius = np.where(cell_ok, GATE_RADIUS * spread + 1e-9, 0.0)
-    # kappa of the one-step acceptance: KAPPA_SAFETY x the largest value at the corners of the cell and of the eight around it
-    kc = np.where(good, newton_kappa(pieces, r.reshape(-1, 2), sums, gauss_newton=True).reshape(n + 1, n + 1), np.inf)
+    # the one-step acceptance (csrc/gn.hip: the chord step, whose inverse Jacobian is the gradient of this table): per cell kappa -
+    # KAPPA_SAFETY x the largest value at the corners of the cell and of the eight around it - and eps, which validate_start
+    # measures at the cells' corners and centres (infinity until then: a table that was not validated takes two steps everywhere)
+    _, kc = chord_tables(pieces, r.reshape(-1, 2), sums)
+    kc = np.where(good, kc.reshape(n + 1, n + 1), np.inf)
     kcell = np.maximum.reduce([kc[:-1, :-1], kc[:-1, 1:], kc[1:, :-1], kc[1:, 1:]])
     padk = np.pad(kcell, 1, mode='edge')
     kappa = KAPPA_SAFETY * np.max([padk[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
@@ -379,9 +386,17 @@ def assemble_start(pieces, steps, roots):
     stats['one_step_share'] = float(np.isfinite(kappa).mean())
     r = np.where(good[:, :, None], r, 0.0)
     head = pieces['head'].copy()
-    head[10] = 1.0                        # the kappa table follows the cells
-    out = np.concatenate([head, r.ravel(), np.stack([need, radius], axis=-1).ravel(), kappa.ravel()])     # pairs (a0, a1), pairs (need, radius), kappa
+    head[10] = 2.0                        # the pairs of the one-step acceptance follow the cells
+    # pairs (a0, a1), pairs (need, radius), pairs (kappa, eps)
+    out = np.concatenate([head, r.ravel(), np.stack([need, radius], axis=-1).ravel(),
+                          np.stack([kappa, np.full_like(kappa, np.inf)], axis=-1).ravel()])
     return out, float(np.isfinite(need).mean()), stats
+
+
+def start_layout(n):
+    """Offsets (in doubles) of the parts of a start array with n cells per axis: roots, cells, one-step pairs, end."""
+    c0 = START_HEADER + 2 * (n + 1) ** 2
+    return START_HEADER, c0, c0 + 2 * n * n, c0 + 4 * n * n
 
 
 # A pair of spectra is ILL-POSED when it does not determine two thicknesses - MV against kV: above a few hundred keV both basis
@@ -448,23 +463,85 @@ def centre_interpolant(start, n):
     return s
 
 
+EPS_SAFETY = 4.0           # on the largest |I - Bt L| measured at the corners and the centre of a cell and of the eight around it (the
+                           # derivative of an even-order interpolant is worst at the ends of the middle interval, i.e. at the corners)
+
+
+def chord_tables(pieces, roots, sums=None):
+    """What the chord step of the short cut (csrc/gn.hip, chord_residuals_f64 / gn_binv) needs at the fixed points ``roots`` [n, 2]
+    of the counts they reproduce: B [n, 2, 2] = L^-1, the inverse of the model's log-Jacobian L_kp = d ln nu_k / d a_p = -G_kp /
+    nu_k, and the constant of what the step leaves beyond the Jacobian's own error: with c_k(a) = g_k / nu_k(a) - 1 (root:
+    c = 0, Dc = -L) the step m = s + B c(s) lands at m - a* = (I - B L*) e0 + 1/2 B D2c(xi) [e0, e0], and at a root
+    D2c_k,pq = 2 G_kp G_kq / nu_k^2 - S_kpq / nu_k; kappa = 1/2 max_i sum_k |B_ik| sum_pq (2 G_kp G_kq / nu_k^2 + S_kpq / nu_k)
+    (the two terms bounded separately: they partly cancel at the root, not necessarily next to it).  inf where L is singular."""
+    with np.errstate(all='ignore'):
+        nu, G, S = sums if sums is not None else _model_sums(pieces, roots, third=True)
+        inv = 1.0 / nu
+        L = -G * inv[:, :, None]                                        # [n, k, p]
+        det = L[:, 0, 0] * L[:, 1, 1] - L[:, 0, 1] * L[:, 1, 0]
+        B = np.stack([np.stack([L[:, 1, 1], -L[:, 0, 1]], -1), np.stack([-L[:, 1, 0], L[:, 0, 0]], -1)], -2) / det[:, None, None]   # [n, p, k]
+        d2 = (2.0 * inv ** 2)[:, :, None, None] * np.abs(G[:, :, :, None] * G[:, :, None, :]) + np.abs(inv)[:, :, None, None] * np.abs(S)
+        per_k = 0.5 * d2.sum(axis=(2, 3))                               # [n, k]
+        kap = np.einsum('npk,nk->np', np.abs(B), per_k).max(axis=1)
+    ok = np.isfinite(kap) & np.all(np.isfinite(roots), axis=1) & np.isfinite(B).all(axis=(1, 2))
+    return np.where(ok[:, None, None], B, np.nan), np.where(ok, kap, np.inf)
+
+
+def dlagrange6(t):
+    """d/dt of lagrange6's weights (the derivative weights csrc/gn.hip gn_start<DERIV> forms by the product rule)."""
+    nodes = np.arange(-2.0, 4.0)
+    dw = np.zeros(6)
+    for a in range(6):
+        for c in range(6):
+            if c == a:
+                continue
+            term = 1.0 / (nodes[a] - nodes[c])
+            for b in range(6):
+                if b != a and b != c:
+                    term *= (t - nodes[b]) / (nodes[a] - nodes[b])
+            dw[a] += term
+    return dw
+
+
+def table_gradient(start, pieces, tx, ty):
+    """The inverse log-Jacobian the chord step of the kernel uses at the place (tx, ty) in [0, 1]^2 of every cell that has its two
+    rings of neighbours [n, n, 2 (p), 2 (k)] (nan elsewhere): the gradient of the 6 x 6 Lagrange interpolant of the tabulated fixed
+    points along (x = ln u0, t = u1 / u0), times d (x, t) / d ln g (csrc/gn.hip, gn_start<DERIV>):
+    B_p0 = Bx_p - t Bt_p, B_p1 = Bt_p with Bx = d a / d x * (-1 / (log_range u0)), Bt = d a / d t * (-1 / (log_range u0))."""
+    h = pieces['head']
+    n = int(h[3])
+    r = np.asarray(start)[START_HEADER:START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)
+    wx, wy, dx, dy = lagrange6(tx), lagrange6(ty), dlagrange6(tx), dlagrange6(ty)
+    ax = np.zeros((n - 4, n - 4, 2))
+    at = np.zeros((n - 4, n - 4, 2))
+    for p in range(6):
+        for q_ in range(6):
+            blk = r[p:n - 4 + p, q_:n - 4 + q_]                        # corner (i + p - 2, j + q - 2) of cell (i, j), i, j = 2 .. n - 3
+            ax += dx[p] * wy[q_] * blk
+            at += wx[p] * dy[q_] * blk
+    u0 = np.exp(h[4] + (np.arange(2, n - 2) + tx) / h[5])[:, None, None]
+    t = (h[6] + (np.arange(2, n - 2) + ty) / h[7])[None, :, None]
+    bx = ax * (-(h[5] * h[2]) / u0)
+    bt = at * (-(h[7] * h[2]) / u0)
+    out = np.full((n, n, 2, 2), np.nan)
+    out[2:-2, 2:-2, :, 0] = bx - t * bt
+    out[2:-2, 2:-2, :, 1] = bt
+    return out
+
+
 KAPPA_SAFETY = 2.5         # on the largest kappa at the corners of a cell and of the eight around it: covers its variation across the
                            # cells (a few per cent) and the factor (1 - kappa e0)^-2 <= 1.25 between e0^2 and the measured d1^2
 
 
-def newton_kappa(pieces, roots, sums=None, gauss_newton=False):
+def newton_kappa(pieces, roots, sums=None):
     """The contraction constant of Newton's iteration on the Poisson likelihood F(a) = sum_k nu_k(a) - g_k ln nu_k(a) at the fixed
-    points ``roots`` [n, 2] of the counts they reproduce (g_k = nu_k there; csrc/gn.hip kStartHeader, DEXCT_GN_FLAG_ONE_STEP): a step
-    from a0 lands at a1 with a1 - a* = 1/2 H^-1 D3F [e0, e0], hence |e1| <= kappa |e0|^2 in the max norm with
+    points ``roots`` [n, 2] of the counts they reproduce (g_k = nu_k there): a step from a0 lands at a1 with
+    a1 - a* = 1/2 H^-1 D3F [e0, e0], hence |e1| <= kappa |e0|^2 in the max norm with
     kappa = 1/2 max_i sum_j |H^-1_ij| sum_pq |D3F_jpq|.  With G_km = sum_e i0_k mu_m att, S_kmp = sum_e i0_k mu_m mu_p att:
     H_mp = sum_k G_km G_kp / nu_k and D3F_mpq = sum_k [2 G_km G_kp G_kq / nu_k^2 - (S_kpq G_km + S_kmq G_kp + S_kmp G_kq) / nu_k]
     (the terms with g_k / nu_k - 1 vanish at a root that reproduces its counts).  inf where H is singular or anything overflows.
-
-    ``gauss_newton``: the constant of the step the short cut takes (csrc/gn.hip, newton_step_gn_f64) - the Hessian Ht without its
-    (g / nu - 1) x second-derivative term X = sum_k c_k S_k.  a1 - a* = Ht^-1 (Ht - Hbar) e0 with Hbar the Hessian averaged over
-    the segment: Ht - Hbar = X(a0) + 1/2 D3F [e0, .], and c_k(a0) = (G_k . e0) / nu_k (the counts reproduce at a*), so
-    (X e0)_j = sum_pq [sum_k S_kjp G_kq / nu_k] e0_p e0_q: a second-order term like Newton's own, with non-negative coefficients of
-    the kind D3F is made of.  kappa_GN = max_i sum_j |H^-1_ij| sum_pq (1/2 |D3F_jpq| + sum_k S_kjp G_kq / nu_k)."""
+    (Round 5's one-step acceptance was built on this constant; round 6's chord step carries its own, chord_tables - this one
+    stays as the yardstick: what a FULL Newton step leaves, tests/test_quadrature.py.)"""
     with np.errstate(all='ignore'):
         nu, G, S = sums if sums is not None else _model_sums(pieces, roots, third=True)
         # (broadcast products over [n, k, m, p, q] summed over k: the same sums as the einsum forms in the docstring, 15 x faster)
@@ -476,8 +553,6 @@ def newton_kappa(pieces, roots, sums=None, gauss_newton=False):
         det = H[:, 0, 0] * H[:, 1, 1] - H[:, 0, 1] * H[:, 1, 0]
         Hinv = np.stack([np.stack([H[:, 1, 1], -H[:, 0, 1]], -1), np.stack([-H[:, 1, 0], H[:, 0, 0]], -1)], -2) / det[:, None, None]
         per_row = 0.5 * np.abs(T).sum(axis=(2, 3))
-        if gauss_newton:
-            per_row = per_row + (np.abs(inv)[:, :, None] * np.abs(S).sum(axis=3) * np.abs(G).sum(axis=2)[:, :, None]).sum(axis=1)
         kap = np.einsum('nij,nj->ni', np.abs(Hinv), per_row).max(axis=1)
     return np.where(np.isfinite(kap) & np.all(np.isfinite(roots), axis=1), kap, np.inf)
 
@@ -491,14 +566,35 @@ def validate_start(start, pieces, steps, roots):
     h = pieces['head']
     n = int(h[3])
     out = np.array(start, dtype=np.float64, copy=True)
-    c0 = START_HEADER + 2 * (n + 1) ** 2
-    cells = out[c0:c0 + 2 * n * n].reshape(n, n, 2)
-    kappa = out[c0 + 2 * n * n:].reshape(n, n)
+    _, c0, k0, k1 = start_layout(n)
+    cells = out[c0:k0].reshape(n, n, 2)
+    onestep = out[k0:k1].reshape(n, n, 2)                              # (kappa, eps)
+    kappa = onestep[:, :, 0]
     steps = np.asarray(steps, dtype=np.float64).reshape(n, n)
     rc = np.asarray(roots, dtype=np.float64).reshape(n, n, 2)
     s = centre_interpolant(out, n)
     g = cell_centres(pieces)
-    resid, cond = _counts_and_condition(pieces, rc.reshape(-1, 2), g)
+    with np.errstate(all='ignore'):
+        sums_c = _model_sums(pieces, rc.reshape(-1, 2))
+    resid, cond = _counts_and_condition(pieces, rc.reshape(-1, 2), g, sums_c)
+    # eps of the chord step: the gradient of the table as the kernel forms it, against the exact log-Jacobian L = -G / nu of the
+    # model at the cell's four corners (their tabulated roots) and at its centre (the centre's own root): |I - Bt L| (max row
+    # sum), EPS_SAFETY x the largest of a cell and the eight around it
+    def misfit(B, nu_, G_):
+        with np.errstate(all='ignore'):
+            L = -G_ / nu_[..., None]                                                                 # [.., k, p]
+            m_ = np.abs(np.eye(2) - np.einsum('...pk,...kq->...pq', B, L)).sum(axis=-1).max(axis=-1)
+        return np.where(np.isfinite(m_), m_, np.inf)
+    nu_c, G_c, _ = sums_c
+    eps_c = misfit(table_gradient(out, pieces, 0.5, 0.5), nu_c.reshape(n, n, 2), G_c.reshape(n, n, 2, 2))
+    with np.errstate(all='ignore'):
+        nu_k, G_k, _ = _model_sums(pieces, out[START_HEADER:c0].reshape(-1, 2))
+    nu_k, G_k = nu_k.reshape(n + 1, n + 1, 2), G_k.reshape(n + 1, n + 1, 2, 2)
+    for tx_, ty_ in ((0.0, 0.0), (0.0, 1.0), (1.0, 0.0), (1.0, 1.0)):
+        di, dj = int(tx_), int(ty_)
+        eps_c = np.maximum(eps_c, misfit(table_gradient(out, pieces, tx_, ty_), nu_k[di:n + di, dj:n + dj], G_k[di:n + di, dj:n + dj]))
+    pade = np.pad(eps_c, 1, mode='edge')
+    onestep[:, :, 1] = EPS_SAFETY * np.max([pade[1 + di:n + 1 + di, 1 + dj:n + 1 + dj] for di in (-1, 0, 1) for dj in (-1, 0, 1)], axis=0)
     with np.errstate(all='ignore'):
         off = np.abs(rc - s).max(axis=2)
         fine = ((steps < 255) & np.all(np.isfinite(rc), axis=2) & (resid.reshape(n, n) <= 1.0e-8) & (cond.reshape(n, n) <= GATE_MAX_COND)
@@ -508,4 +604,6 @@ def validate_start(start, pieces, steps, roots):
     near = np.any([pad[2 + di:n + 2 + di, 2 + dj:n + 2 + dj] for di in (-2, -1, 0, 1, 2) for dj in (-2, -1, 0, 1, 2)], axis=0)
     cells[near, 0] = np.inf
     kappa[near] = np.inf
+    onestep[~np.isfinite(kappa), 1] = np.inf
+    kappa[~np.isfinite(onestep[:, :, 1])] = np.inf
     return out, float(np.isfinite(cells[:, :, 0]).mean()), int(bad.sum())

@@ -349,8 +349,8 @@ def test_gate_table_on_disk_is_validated_before_use(tmp_path, monkeypatch):
     n = q.GATE_CELLS
     rng = np.random.default_rng(0)
     head = p['head'].copy()
-    head[10] = 1.0                                                        # (with the kappa table, as the calibration leaves it)
-    start = np.concatenate([head, rng.random(2 * (n + 1) ** 2 + 3 * n * n)])
+    head[10] = 2.0                                                        # (with the one-step pairs, as the calibration leaves it)
+    start = np.concatenate([head, rng.random(q.start_layout(n)[-1] - q.START_HEADER)])
     stats = {'grid': True, 'open_share': 0.9, 'walk_nonfinite_share': 0.0, 'walk_not_by_rule_share': 0.0}
     assert md._gate_from_disk(path, i0, mus) is None                      # nothing there yet
     md._gate_to_disk(path, start, stats)

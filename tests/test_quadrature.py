@@ -120,11 +120,11 @@ def test_gate_grid_and_start_array():
     start, share, stats = q.assemble_start(p, steps, roots)
     assert stats['walk_nonfinite_share'] == 0.0 and 0.0 < stats['walk_not_by_rule_share'] < 1e-3 and not q.pair_is_ill_posed(stats)
     assert np.allclose(start[8:10], np.log(start[0:2]), rtol=0, atol=0)          # ln of the open-beam signals, for the kernel's logarithm
-    assert start.size == q.START_HEADER + 2 * (n + 1) ** 2 + 3 * n * n and start[10] == 1.0
+    assert start.size == q.start_layout(n)[-1] and start[10] == 2.0
     r0 = start[q.START_HEADER:q.START_HEADER + 2 * (n + 1) ** 2].reshape(n + 1, n + 1, 2)[:, :, 0]          # pairs (a0, a1)
     c0 = q.START_HEADER + 2 * (n + 1) ** 2
     cells = start[c0:c0 + 2 * n * n].reshape(n, n, 2)                                                         # pairs (need, radius)
-    kappa = start[c0 + 2 * n * n:].reshape(n, n)                                                              # then kappa per cell
+    kappa = start[c0 + 2 * n * n:c0 + 4 * n * n].reshape(n, n, 2)[:, :, 0]                                    # then pairs (kappa, eps) per cell, then B per corner
     need, radius = cells[:, :, 0], cells[:, :, 1]
     ok = np.ones((n + 1) ** 2, bool)
     ok[[30 * (n + 1) + 30, 45 * (n + 1) + 20, 70 * (n + 1) + 60]] = False
@@ -175,7 +175,7 @@ def test_gate_table_is_validated_at_the_cell_centres():
     finally:
         q.cell_centres = orig
     c0 = q.START_HEADER + 2 * (n + 1) ** 2
-    need, kappa = out[c0:c0 + 2 * n * n].reshape(n, n, 2)[:, :, 0], out[c0 + 2 * n * n:].reshape(n, n)
+    need, kappa = out[c0:c0 + 2 * n * n].reshape(n, n, 2)[:, :, 0], out[c0 + 2 * n * n:c0 + 4 * n * n].reshape(n, n, 2)[:, :, 0]
     assert n_bad == 2 and share_bad < share
     for ci, cj in ((40, 50), (60, 70)):
         assert np.all(np.isinf(need[ci - 2:ci + 3, cj - 2:cj + 3])) and np.isfinite(need[ci - 3, cj]) and np.isfinite(need[ci, cj + 3])
@@ -249,42 +249,103 @@ def _one_step(i0, mus, g, a):
     return a - np.linalg.solve(H, dF)
 
 
-def _gauss_newton_step(i0, mus, g, a):
-    """The step of csrc/gn.hip newton_step_gn_f64 from the state a (NumPy): the Hessian without its (g / nu - 1) x second-derivative
-    term."""
+def _chord_step(i0, mus, g, a, B):
+    """The step of csrc/gn.hip gn_shortcut_kernel<1> from the state a (NumPy): the relative misfit of the counts through a GIVEN
+    inverse log-Jacobian B (the kernel's comes from the table)."""
     att = np.exp(np.clip(-(a @ mus), -700, 700))
     nu = i0 @ att
-    G = np.einsum('ke,me,e->km', i0, mus, att)
-    c, qq = g / nu - 1.0, g / nu ** 2
-    dF = (c[:, None] * G).sum(0)
-    H = (qq[:, None, None] * G[:, :, None] * G[:, None, :]).sum(0)
-    return a - np.linalg.solve(H, dF)
+    return a + B @ ((g - nu) / nu)
 
 
-def test_gauss_newton_step_of_the_short_cut_is_bounded():
-    """The ONE step of the default short cut is of the Gauss-Newton form (csrc/gn.hip, newton_step_gn_f64): from a0 next to a root a*
-    that reproduces its counts it leaves |a1 - a*| <= kappa_GN |a0 - a*|^2 with quadrature.newton_kappa(gauss_newton=True) - the
-    constant the table carries - checked in NumPy in many directions at two distances; the bound is not idle, it is at most a few
-    times the full step's constant, and the Gauss-Newton step and the full step land within second order of each other."""
+def test_chord_step_of_the_short_cut_is_bounded():
+    """The ONE step of the default short cut (round 6) multiplies the relative misfit of the counts with a TABULATED inverse
+    log-Jacobian instead of summing the Jacobian per pixel: from a0 next to a root a* that reproduces its counts, with a Jacobian
+    that is off by eps (|I - B L*| <= eps in the max-row-sum norm), it leaves |a1 - a*| <= eps |e0| + kappa |e0|^2 with
+    quadrature.chord_tables' kappa - checked in NumPy in many directions, at two distances, with the exact inverse and with
+    perturbed ones; the bound is not idle; and with the exact inverse the chord step and the full Newton step land within second
+    order of each other."""
     _, i0, mus = newton_tables()
     p = q.newton_start_grid(i0, mus)
     rng = np.random.default_rng(14)
     roots = np.stack([rng.uniform(0.5, 40.0, 200), rng.uniform(-0.2, 6.0, 200)], 1)
     g = np.exp(-(roots @ p['mus'])) @ p['i0'].T
-    kap = q.newton_kappa(p, roots, gauss_newton=True)
+    B, kap = q.chord_tables(p, roots)
     full = q.newton_kappa(p, roots)
-    assert np.all(kap >= full) and np.all(kap <= 6.0 * full)
+    assert np.all(np.isfinite(kap)) and np.all(kap <= 40.0 * full) and np.all(kap >= 0.01 * full)      # (the square system's constant: a few times SMALLER than the likelihood's)
+    # B is the inverse of the log-Jacobian: a finite difference of ln nu
+    k = 17
+    h = 1e-6 * np.abs(roots[k]).max()
+    lnnu = lambda a: np.log(p['i0'] @ np.exp(-(a @ p['mus'])))
+    L = np.stack([(lnnu(roots[k] + h * e) - lnnu(roots[k] - h * e)) / (2 * h) for e in np.eye(2)], axis=1)      # [k, p]
+    assert np.allclose(B[k] @ L, np.eye(2), atol=1e-6)
     worst = 0.0
     for rel in (1e-4, 1e-6):
-        for _ in range(4):
+        for eps_rel in (0.0, 1e-4):
             e0 = rng.standard_normal((200, 2))
             e0 *= (rel * np.abs(roots).max(1) / np.abs(e0).max(1))[:, None]
             for k in range(200):
-                a1 = _gauss_newton_step(p['i0'], p['mus'], g[k], roots[k] + e0[k])
+                Bk = B[k] * (1.0 + eps_rel * rng.standard_normal((2, 2)))
+                nu_k, G_k, _ = q._model_sums(p, roots[k:k + 1])
+                L_k = -G_k[0] / nu_k[0][:, None]
+                eps = np.abs(np.eye(2) - Bk @ L_k).sum(axis=1).max()
+                a1 = _chord_step(p['i0'], p['mus'], g[k], roots[k] + e0[k], Bk)
                 d0 = np.abs(e0[k]).max()
                 e1 = np.abs(a1 - roots[k]).max()
-                assert e1 <= kap[k] * d0 ** 2 * (1.0 + 1e-3) + 1e-13 * np.abs(roots[k]).max(), (k, e1, kap[k] * d0 ** 2)
-                if rel == 1e-4:
+                assert e1 <= (eps * d0 + kap[k] * d0 ** 2) * (1.0 + 1e-3) + 1e-13 * np.abs(roots[k]).max(), (k, e1, eps * d0, kap[k] * d0 ** 2)
+                if rel == 1e-4 and eps_rel == 0.0:
                     worst = max(worst, e1 / (kap[k] * d0 ** 2))
-                    assert np.abs(a1 - _one_step(p['i0'], p['mus'], g[k], roots[k] + e0[k])).max() <= 2.0 * kap[k] * d0 ** 2
+                    assert np.abs(a1 - _one_step(p['i0'], p['mus'], g[k], roots[k] + e0[k])).max() <= 2.0 * (kap[k] + full[k]) * d0 ** 2
     assert worst > 1e-3                                                    # (within three orders of what directions reach)
+    same = dict(p, mus=np.stack([p['mus'][0], 2.0 * p['mus'][0]]))         # parallel attenuation vectors: no inverse
+    assert not np.isfinite(q.chord_tables(same, roots[:5])[1]).any() or q.chord_tables(same, roots[:5])[1].min() > 1e10
+
+
+def test_the_tables_eps_is_what_the_gradient_of_the_table_leaves():
+    """The chord step's inverse Jacobian is the GRADIENT of the tabulated fixed points (quadrature.table_gradient = csrc/gn.hip
+    gn_start<DERIV>): on a field of roots that are the model's own it agrees with the exact inverse log-Jacobian to the
+    interpolation error x the Jacobian's condition; validate_start measures that misfit per cell (corners and centre) as eps; a
+    disturbed table entry shows up in the cells whose stencil uses it - they lose the one-step acceptance, nothing else."""
+    _, i0, mus = newton_tables()
+    p = q.newton_start_grid(i0, mus)
+    n = int(p['head'][3])
+    # a physical field: the corner counts of a block of the grid, solved for their roots in NumPy (the rest of the grid is closed)
+    from oracle import gn_oracle
+    g = p['corner_g'].reshape(n + 1, n + 1, 2)
+    blk = (slice(96, 128), slice(96, 128))
+    with np.errstate(all='ignore'):
+        rb = gn_oracle.newton_solve(g[blk].reshape(-1, 2).T.reshape(2, 1, -1), p['i0'], p['mus'], 60).reshape(-1, 2)
+    roots = np.zeros(((n + 1), (n + 1), 2))
+    roots[blk] = rb.reshape(32, 32, 2)
+    steps = np.full((n + 1, n + 1), 255)
+    steps[blk] = 17
+    start, share, _ = q.assemble_start(p, steps.ravel(), roots.reshape(-1, 2))
+    _, c0, k0, k1 = q.start_layout(n)
+    assert start.size == k1 and start[10] == 2.0
+    # the derivative weights are the derivative of the weights
+    for t in (0.0, 0.3, 1.0):
+        assert np.allclose(q.dlagrange6(t), (q.lagrange6(t + 1e-6) - q.lagrange6(t - 1e-6)) / 2e-6, atol=1e-8) and abs(q.dlagrange6(t).sum()) < 1e-12
+    # the gradient of the table IS the inverse log-Jacobian of the model at the tabulated roots
+    B = q.table_gradient(start, p, 0.0, 0.0)[105:118, 105:118]                     # at the corners (i, j) of those cells
+    Bx, _ = q.chord_tables(p, roots[105:118, 105:118].reshape(-1, 2))
+    assert np.allclose(B.reshape(-1, 2, 2), Bx, rtol=1e-6, atol=1e-6 * np.abs(Bx).max())
+    # the centres of the block's interior cells: their counts and NumPy roots
+    gc = q.cell_centres(p).reshape(n, n, 2)
+    cb = (slice(96, 127), slice(96, 127))
+    with np.errstate(all='ignore'):
+        rc_b = gn_oracle.newton_solve(gc[cb].reshape(-1, 2).T.reshape(2, 1, -1), p['i0'], p['mus'], 60).reshape(31, 31, 2)
+    rc = np.zeros((n, n, 2))
+    rc[cb] = rc_b
+    sc = np.full((n, n), 255)
+    sc[cb] = 17
+    out, _, _ = q.validate_start(start, p, sc.ravel(), rc.reshape(-1, 2))
+    one = out[k0:k1].reshape(n, n, 2)
+    inner = one[102:120, 102:120]
+    assert np.all(np.isfinite(inner)) and inner[:, :, 1].max() < 1e-5 and inner[:, :, 1].min() > 0.0      # interpolation error x cond(L) x safety
+    # a disturbed root: the gradient around it is off, the cells whose stencil uses it lose the one-step acceptance (eps beyond any
+    # use), the others keep theirs
+    bad = start.copy()
+    bad[q.START_HEADER:c0].reshape(n + 1, n + 1, 2)[110, 110] *= 1.0 + 1e-6
+    out2, _, _ = q.validate_start(bad, p, sc.ravel(), rc.reshape(-1, 2))
+    one2 = out2[k0:k1].reshape(n, n, 2)
+    assert one2[109, 109, 1] > 100 * one[109, 109, 1] and one2[110, 110, 1] > 100 * one[110, 110, 1]
+    assert np.allclose(one2[102:105, 102:105], one[102:105, 102:105])
