@@ -77,35 +77,38 @@ DEFAULT_STOP_TOL = _default_stop_tol()
 # Most of the reference's ~17 Newton steps per pixel are the walk from its start value 1e-6 to the neighbourhood of the
 # solution; what it returns is the fixed point its walk ends at.  That is a function of the pixel's two counts alone, so it is
 # tabulated once per pair of spectra: the library's own single launch (full tables, from 1e-6, counting steps) is run on the
-# counts at the corners of a 128 x 128 cell grid over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / 16, and once more on the cell
-# centres as a check (quadrature.newton_start_grid / assemble_start / validate_start: where does the walk end, after how many
-# steps, is that an isolated root of the two equations, how smoothly does it vary).  A pixel whose counts fall in an open cell
-# - the walk ends by the tolerance rule within n_iters steps at all corners around it, at well-conditioned roots that vary
-# smoothly (no boundary between two basins), the attenuation is not beyond exp(-12) - starts from the Catmull-Rom interpolant
-# of those fixed points (1e-6 of |a| from its own) and takes TWO steps on the full tables: the second is the tolerance rule's
-# evidence that the FULL model has converged to stop_tol.  The result is accepted only within the cell's radius of the
-# interpolant (the reference's branch); a pixel without that evidence or acceptance, or in a closed cell (few steps asked
-# for, counts outside the grid, NaN), is solved from 1e-6 with all n_iters steps in the same launch.  What comes out is, per
-# pixel, a fixed point of the full model verified to stop_tol on the reference's branch, or the reference's own trajectory:
-# the contract of the single launch with the tolerance stop, asserted against the exact count on every pixel of the benchmark
-# (bench.py, tests/test_gpu_full_scale.py), on the reference goldens at 1 / 2 / 5 / 50 iterations and in tools/soak_gn.py.
-# 2.0 full-table steps per pixel instead of ~17.
+# counts at the corners of a 384 x 384 cell grid (quadrature.GATE_CELLS) over (ln u0, u1 / u0), u_k = ln(air_k / g_k) / 16, and
+# once more on the cell centres as a check (quadrature.newton_start_grid / assemble_start / validate_start: where does the walk
+# end, after how many steps, is that an isolated root of the two equations, how smoothly does it vary).  A pixel whose counts
+# fall in an open cell - the walk ends by the tolerance rule within n_iters steps at all corners of the 5 x 5 cells around it, at
+# well-conditioned roots that vary smoothly (no boundary between two basins), the attenuation is not beyond exp(-12) - starts
+# from the 6 x 6 Lagrange interpolant of those fixed points (1e-10 of |a| from its own at the median water ray) and takes ONE step
+# where the table vouches for it, else two - the second being the tolerance rule's evidence that the FULL model has converged to
+# stop_tol.  The result is accepted only within the cell's radius of the interpolant (the reference's branch); a pixel without
+# that evidence or acceptance, or in a closed cell (few steps asked for, counts outside the grid, NaN), is solved from 1e-6 with
+# all n_iters steps in the same launch.  What comes out is, per pixel, a fixed point of the full model verified to stop_tol on
+# the reference's branch, or the reference's own trajectory: the contract of the single launch with the tolerance stop, asserted
+# against the exact count on every pixel of the benchmark (bench.py, tests/test_gpu_full_scale.py), on the reference goldens at
+# 1 / 2 / 5 / 50 iterations and in tools/soak_gn.py.  1.0 steps per pixel instead of ~17.
 #
 # ILL-POSED PAIRS run the reference's fixed count.  Where the calibration itself shows that the pair of spectra does not
-# determine two thicknesses (quadrature.pair_is_ill_posed: the walk ends non-finite or without the rule on a measurable share
-# of the corner grid - the MV / kV pairs, the class of the reference's live pair, main.py:101) the default is stop_tol = 0 for
-# that pair: the tolerance rule on the wandering pixels of such a pair was the only place where the default ever differed from
-# the exact count (profiles/r04_gn_noisy_public.log), and it saved 15 % there.  An explicit stop_tol > 0 is honoured.
+# determine two thicknesses (quadrature.pair_is_ill_posed: the walk comes to rest where it does not reproduce its counts on more
+# than 5 % of the data plane, fewer than 78 % of the cells are open, or the roots are ill-conditioned - the MV / kV pairs, the
+# class of the reference's live pair, main.py:101; every bundled pair's class is pinned in tests/test_gpu_gn.py) the default is
+# stop_tol = 0 for that pair: the tolerance rule on the wandering pixels of such a pair was the only place where the default
+# ever differed from the exact count (profiles/r04_gn_noisy_public.log), and it saved 15 % there.  An explicit stop_tol > 0 is
+# honoured.
 #
-# ONE STEP where the table vouches for it (the default since round 5; quadrature.newton_kappa, csrc/gn.hip kStartHeader).  From a
-# start value at distance e0 of the fixed point Newton's step leaves at most kappa e0^2 - kappa from the Hessian and the third
-# derivatives of the likelihood at the tabulated fixed points - and the step's own length d1 measures e0.  A pixel whose first
-# step has kappa d1^2 <= stop_tol / 4 * size ends there: a bound on the distance it still has to go, which is what the tolerance
-# rule extracts from two steps; every other pixel takes the second step and the rule.  The kernel's sextic interpolant over the
-# 256-cell grid is within 1e-10 of |a| of the pixel's fixed point, so the bound holds with three orders to spare and the step
-# lands at rounding level.  That one step is of the Gauss-Newton form - the Hessian without its (g / nu - 1) x second-derivative
-# term, half the accumulations per energy: the dropped term vanishes with the distance to the fixed point and leaves a second-
-# order remainder like Newton's own, which kappa (tabulated for this form) covers.
+# ONE STEP where the table vouches for it (the default since round 5; round 6: the CHORD step - csrc/gn.hip chord_residuals_f64,
+# gn_start<DERIV>; quadrature.chord_tables).  What a step from 1e-10 of the fixed point has to get right is the residual - the
+# relative misfit of the counts, c_k = g_k / nu_k(s) - 1: the full energy sum of nu, 2 of the 12 accumulations per energy - not
+# the Jacobian: and the inverse Jacobian is already in the table, as the GRADIENT of the tabulated fixed points with respect to
+# the (logarithms of the) counts, formed from the same 36 loads as the start value.  The step m = s + B c leaves at most
+# eps e0 + kappa e0^2 - kappa from the second derivatives of the misfit at the tabulated fixed points, eps from the table's
+# gradient against the exact Jacobians at every cell's corners and centre - and its own length d1 measures e0: a pixel with
+# (kappa d1 + eps) d1 <= stop_tol / 4 * max(min(|a0|, |a1|), 1) ends there (a bound on the distance it still has to go, per
+# component, which is what the tolerance rule extracts from two steps); every other pixel goes on with full Newton steps and the
+# rule.  (Round 5's one step was of the Gauss-Newton form: 6 of the 12 sums.)
 #
 # Modes (``two_level=`` of the calls below; DEXCT_GN_TWO_LEVEL in the environment; DEFAULT_TWO_LEVEL):
 #   None / True / 'one'     the short cut, one step where kappa allows (one launch)

@@ -402,12 +402,12 @@ def start_layout(n):
 # A pair of spectra is ILL-POSED when it does not determine two thicknesses - MV against kV: above a few hundred keV both basis
 # materials attenuate by Compton scattering alone, their curves are parallel.  The calibration sees it in the reference's own
 # iteration, run on noise-free counts of its own forward model over the part of the data plane a detector can deliver
-# (profiles/r05_pair_classes.log - every pair of the bundled spectra, the benchmark's Kramers pair, the three golden cases):
+# (profiles/r06_pair_classes.log - every pair of the bundled spectra, the benchmark's Kramers pair, the three golden cases):
 #                                 kV / kV (6 cases)      kV / MV (7 cases)      6MV / detunedMV
-#   open cells                    0.845 .. 0.944         0.23 .. 0.70           0.42
-#   walk rests where it does not  0.0001 .. 0.0019       0.17 .. 0.55           0.011
+#   open cells                    0.857 .. 0.952         0.24 .. 0.73           0.45
+#   walk rests where it does not  0.00006 .. 0.0016      0.17 .. 0.54           0.011
 #     reproduce its counts
-#   median cond of the log-       22 .. 69               31 .. 78               3674
+#   median cond of the log-       22 .. 69               31 .. 78               3667
 #     Jacobian at the roots
 # (the share of corners where the walk ends non-finite, 0.1 - 26 %, does not tell the classes apart: those are the corners in
 # the margin the grid adds around the physical ratios).  Ill-posed = the walk comes to rest at points that are no solutions on

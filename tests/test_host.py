@@ -377,7 +377,7 @@ def test_gate_table_on_disk_is_validated_before_use(tmp_path, monkeypatch):
 
 def test_ill_posed_pairs_are_told_from_the_calibration():
     """quadrature.pair_is_ill_posed on the statistics the GPU calibration recorded for the bundled pairs
-    (profiles/r05_pair_classes.log): kV / kV pairs keep the short cut, every pair with an MV spectrum runs the fixed count."""
+    (profiles/r06_pair_classes.log): kV / kV pairs keep the short cut, every pair with an MV spectrum runs the fixed count."""
     from dex_ct_sim_amd import quadrature as q
     kv = {'grid': True, 'walk_nonfinite_share': 0.082, 'walk_not_by_rule_share': 0.0019, 'not_a_root_share': 0.0019, 'cond_median': 21.7,
           'open_share': 0.845}                                                      # 140 kV / 80 kV
@@ -386,6 +386,30 @@ def test_ill_posed_pairs_are_told_from_the_calibration():
     assert not q.pair_is_ill_posed(kv) and not q.pair_is_ill_posed({'grid': False}) and not q.pair_is_ill_posed(None)
     assert q.pair_is_ill_posed(mv) and q.pair_is_ill_posed(mvmv)
     assert q.pair_is_ill_posed(dict(kv, open_share=0.70)) and q.pair_is_ill_posed(dict(kv, cond_median=float('inf')))
+
+
+def test_the_committed_pair_class_log_agrees_with_the_rule_line_by_line():
+    """profiles/r06_pair_classes.log (tools/probes/gn_pair_classes.py on an MI355X, every pair of the bundled spectra + the
+    benchmark's Kramers pair + the three goldens): the class printed on each line is what quadrature.pair_is_ill_posed returns
+    for the statistics printed on that line, under the thresholds committed NOW - evidence and rule cannot drift apart again
+    (round 5's log said the opposite of the final rule for two pairs).  The GPU test test_every_bundled_pair_has_its_class
+    re-measures the statistics; this one keeps the documentation honest on CPU."""
+    from dex_ct_sim_amd import quadrature as q
+    lines = [ln for ln in open(os.path.join(ROOT, 'profiles', 'r06_pair_classes.log')) if 'ill_posed=' in ln]
+    assert len(lines) == 14
+    classes = {}
+    for ln in lines:
+        name = ln.split('energies')[0].rsplit(None, 1)[0].strip()
+        logged = 'ill_posed=True' in ln
+        stats = {}
+        for k, v in re.findall(r'(\w+)=([-+.\w]+)', ln.split('calibration')[1]):
+            stats[k] = {'True': True, 'False': False}.get(v, None)
+            if stats[k] is None:
+                stats[k] = float(v)
+        assert q.pair_is_ill_posed(stats) == logged, (name, stats)
+        classes[name] = logged
+    assert [k for k, v in classes.items() if not v] == ['140kV / 120kV', '140kV / 80kV', '120kV / 80kV', 'kramers140 / kramers80',
+                                                        'golden0 / (reference)', 'golden2 / (reference)']
 
 
 def test_host_pages_are_made_resident_without_a_gpu():

@@ -36,9 +36,9 @@ CONFIGS = [
     ('configs[4] 1024^3, 128 bins, 2000 x 1024, forward only, 1/8 of the views', 1024, 2000, 1024, 8, ['grid128'], False),
 ]
 GN_MODES = [('default', {}), ('two steps', dict(two_level='start')), ('single launch', dict(two_level=False)), ('exact', dict(stop_tol=0.0))]
-print('| configuration (per-GPU share) | rows | rays | projection ms | rays/s | ray-energy integrals/s | Newton ms, 50 it: '
+print('| configuration (per-GPU share) | rows | rays | projection ms | WITH quantum noise ms (x noise-free) | rays/s | ray-energy integrals/s | Newton ms, 50 it: '
       + ' / '.join(m for m, _ in GN_MODES) + ' (full-table steps per unmasked pixel) |')
-print('|---|---|---|---|---|---|---|')
+print('|---|---|---|---|---|---|---|---|')
 for name, n, views, chans, gpus, kvs, gn in CONFIGS:
     specs = [synthetic.uniform_grid_spectrum(128) if kv == 'grid128' else synthetic.kramers_spectrum(kv) for kv in kvs]
     ph = synthetic.make_phantom(n, n, extent=51.2, seed=1234)
@@ -52,6 +52,11 @@ for name, n, views, chans, gpus, kvs, gn in CONFIGS:
         n_e = int((w_d != 0).sum().item())
         out = pj.project_tables(mu_d, w_d, layout=None)
         ms = timed(lambda: pj.project_tables(mu_d, w_d, out=out, layout=None))
+        # the same scan WITH quantum noise (round 6: variance and sample inside the default kernels)
+        _, _, _, w2 = fp.merged_tables(ct, ph, specs, with_variance=True)
+        w2_d = torch.from_numpy(w2).to(device=w_d.device, dtype=torch.float32).contiguous()
+        ms_n = timed(lambda: pj.project_tables(mu_d, w_d, out=out, layout=None, w2_d=w2_d, seed=5))
+        pj.project_tables(mu_d, w_d, out=out, layout=None)
         n_rays = out[0].numel()
         gn_ms = ''
         if gn:
@@ -66,7 +71,7 @@ for name, n, views, chans, gpus, kvs, gn in CONFIGS:
                 parts.append('%.2f (%.2f)' % (t, md.last_gn_stats()['pixel_iterations'] / live))
             gn_ms = ' / '.join(parts)
             del a
-        print(f'| {name} | {rows} | {n_rays:.3g} | {ms:.2f} | {n_rays / ms * 1e3:.3g} | {n_rays * n_e / ms * 1e3:.3g} | {gn_ms} |',
+        print(f'| {name} | {rows} | {n_rays:.3g} | {ms:.2f} | {ms_n:.2f} ({ms_n / ms:.2f}) | {n_rays / ms * 1e3:.3g} | {n_rays * n_e / ms * 1e3:.3g} | {gn_ms} |',
               flush=True)
         del pj, out
         torch.cuda.empty_cache()

@@ -1,5 +1,6 @@
 """What the gate calibration sees of every pair of bundled spectra (and of the benchmark's Kramers pair): the statistics
-quadrature.pair_is_ill_posed decides on.  gpurun -- python tools/probes/gn_pair_classes.py  -> profiles/r05_pair_classes.log"""
+quadrature.pair_is_ill_posed decides on.  gpurun -- python tools/probes/gn_pair_classes.py  -> profiles/r06_pair_classes.log
+(the classes themselves are pinned by tests/test_gpu_gn.py::test_every_bundled_pair_has_its_class)"""
 import itertools
 import os
 import sys

@@ -11,7 +11,9 @@ REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 # the PMC passes keep the single-row and cone-beam legs of bench.py (their kernels get rooflines too) and drop the
 # CPU baseline, the public-boundary timing and the extra Newton launches
-LEAN="--steps 1 --warmup 0 --no-cpu-baseline --skip-gn-full-loop --skip-dropin --skip-quadrature"
+# (--skip-noisy: the noisy step runs the traversal kernel with other outputs - path lengths for the per-bin Poisson sampler - and
+# would be averaged into the step kernel's counters; its own passes: tools/profile_config4.sh <tag> noisy=1 ...)
+LEAN="--steps 1 --warmup 0 --no-cpu-baseline --skip-gn-full-loop --skip-dropin --skip-quadrature --skip-noisy"
 run() {  # name, rocprofv3 args...
   local name=$1; shift
   rocprofv3 "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $REPO/bench.py $BENCH_ARGS > $OUT/bench_$name.json 2> $OUT/bench_$name.err

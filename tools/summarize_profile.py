@@ -83,6 +83,18 @@ if tl:
     lines += [f'Newton launch in bench.py (HIP events around it, last timed step; mode {tl["mode"]}): {tl["launch_ms"]:.2f} ms', '']
 cal = [k for k in fetch if 'transpose_xy' in k]
 traffic = {}
+# the traversal kernel of the timed step: the one bench.py names; of rows16_kernel the noise-free instantiation (its NOISY twin -
+# last template argument true - runs in bench.py's noisy_step and is recorded under other_kernels)
+step_kernel = (bench.get('roofline_siddon') or {}).get('kernel', 'rows')
+
+
+def is_step_traversal(k):
+    name = k.split('(')[0]
+    if 'cone_' in name or (step_kernel + '<') not in name:
+        return False
+    return not (step_kernel == 'rows16_kernel' and name.rstrip().endswith(', true>'))
+
+
 if cal:
     # 512^3 = known bytes read by the in-plane transpose
     n = bench['config']['rays_per_gpu']
@@ -98,7 +110,7 @@ if cal:
         if 'dexct' in k:
             lines.append(f'| `{k[:60]}` | {fetch[k] / 1e9:.3f} | {write.get(k, 0) / 1e9:.3f} |')
     for k in fetch:
-        if 'rows' in k and 'kernel' in k and 'cone_' not in k and 'siddon_kernel' not in traffic:
+        if is_step_traversal(k) and 'siddon_kernel' not in traffic:
             traffic['siddon_kernel'] = k
             # 4-B-per-lane dword loads (rows4) are tallied at half, like gn_kernel's float32 input stream
             corr = 2.0 if ('rows4' in k or 'rows16' in k) else 1.0
@@ -123,8 +135,8 @@ if cal:
             traffic['gn_count_fetch_bytes_raw'] = fetch[k]
             traffic['gn_count_write_bytes'] = write.get(k, 0.0)
     for k, d in sq.items():
-        if ('rows' in k and 'kernel' in k and 'cone_' not in k) or 'gn_refill_kernel' in k or 'gn_shortcut_kernel' in k:
-            tag2 = 'siddon' if 'rows' in k else ('gn_count' if 'gn_refill_kernel<true>' in k else 'gn')
+        if is_step_traversal(k) or 'gn_refill_kernel' in k or 'gn_shortcut_kernel' in k:
+            tag2 = 'siddon' if is_step_traversal(k) else ('gn_count' if 'gn_refill_kernel<true>' in k else 'gn')
             traffic[f'{tag2}_valu_insts'] = d.get('SQ_INSTS_VALU')
             if d.get('GRBM_GUI_ACTIVE'):
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's waves; GRBM_GUI_ACTIVE sums the 8 XCDs
@@ -135,9 +147,13 @@ if cal:
     sq2 = pmc_raw('sq2')
     extra = {}
     for key, pat in (('single_row', 'rays_kernel'), ('wave_per_ray', 'wave_ray_kernel'), ('cone_rows', 'cone_rows_kernel'),
-                     ('cone_rows', 'cone_cols_kernel'), ('cone_thread_per_ray', 'cone_kernel')):      # cone_rows = the row-parallel kernel the host picks (round 3: cone_cols_kernel)
+                     ('cone_rows', 'cone_cols_kernel'), ('cone_thread_per_ray', 'cone_kernel'),      # cone_rows = the row-parallel kernel the host picks (round 3: cone_cols_kernel)
+                     ('noisy', 'rows16_kernel'), ('noisy_round5_path', 'rows4_kernel'), ('add_noise', 'add_noise_kernel'),
+                     ('transpose_log', 'transpose_log_kernel')):
         for k in fetch:
-            if pat + '<' in k and 'layout' not in k:
+            if key == 'noisy' and not k.split('(')[0].rstrip().endswith(', true>'):
+                continue                               # (the NOISY instantiation of rows16_kernel only)
+            if (pat + '<' in k or (pat + '(') in k) and 'layout' not in k:
                 d, d2 = sq.get(k, {}), sq2.get(k, {})
                 e = {'kernel': k.split('(')[0].replace('void dexct::', ''), 'fetch_bytes_raw': fetch[k], 'write_bytes': write.get(k, 0.0),
                      'valu_insts': d.get('SQ_INSTS_VALU'), 'vmem_rd_insts': d2.get('SQ_INSTS_VMEM_RD'),
