@@ -110,12 +110,13 @@ def test_plain_command_three_ranks_config3_labels(hip):
     6 processes on the card and the test runner is one of them: the 4-rank test above is as far as a rehearsal here should
     go; the 8-rank launch is the driver's, on an 8-GPU node, and the 8-rank gather itself runs on CPU in
     tests/test_shard_gloo.py.)"""
-    out, _ = run_bench('--gpus', '3', '--views', '52', '--workload', 'config3', '--gather', 'direct')
+    out, _ = run_bench('--gpus', '3', '--views', '52', '--workload', 'config3')          # --gather auto: three ranks agree on one mode
     assert out['n_gpus'] == 3 and out['config']['rays_total'] == 52 * 64 * 96
     assert out['config']['baseline_config'] == 'configs[3]'
     views = [r['views'] for r in sorted(out['multi_gpu']['per_rank'], key=lambda r: r['rank'])]
     assert views == [[0, 18], [18, 35], [35, 52]]
     assert out['multi_gpu']['gather_device_allocations_per_call'] == 0
+    assert out['multi_gpu']['gather_flag'] == 'auto' and out['multi_gpu']['gather'] in out['multi_gpu']['gather_choice']['step_ms']
     assert 'value_exact' not in out and out['value'] > 0          # (the exact-mode comparison runs at N = 1 only)
 
 
