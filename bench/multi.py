@@ -109,9 +109,9 @@ def measure(wl, args, backend, chosen, auto, ms_per_step, t_sid, t_gn, t_exposed
             'fabric_share_of_step': max(0.0, 1.0 - compute_ms / ms_per_step),
             'gather_device_allocations_per_call': gather_allocs,     # buffers are allocated once
             'by_mode': by_mode, 'per_rank': per_rank,
-            'predicted': 'profiles/r05_shard_of.md (one rank\'s share measured alone, 50 GB/s per xGMI link assumed): configs[2] / [3] at 8 '
-                         'GPUs 6.95x for the compute (value_compute_only) and 4.4x with the point-to-point assembly on rank 0 (value); 0.75x '
-                         'if an all-gather rings over one link',
+            'predicted': 'profiles/r06_shard_of.md (one rank\'s share measured alone, 50 GB/s per xGMI link assumed): configs[2] / [3] at 8 '
+                         'GPUs 6.8x / 7.4x for the compute (value_compute_only) and 4.1x with the point-to-point assembly on rank 0 (value); '
+                         '0.7x if an all-gather rings over one link',
             'note': 'value_compute_only: the same step with the sinogram left sharded (no transfer started; the scalar all-reduce kept) - '
                     'what separates compute scaling from fabric time; gather_ms: the assembly alone (whole shard, nothing else running); '
                     'gather_exposed_ms: what the step still waits for after its last kernel (transfers start chunk by chunk during the '

@@ -2,7 +2,7 @@
 (`bench.py --shard-of K`), for K = 1, 2, 4, 8 on BASELINE configs[2] (1000 x 800) and configs[3] (2000 x 1024) - the
 prediction the driver's first N-rank RCCL line is to be compared with.
 
-    python tools/shard_of_table.py > profiles/r05_shard_of.md
+    python tools/shard_of_table.py > profiles/r06_shard_of.md
 """
 import json
 import os
@@ -18,11 +18,11 @@ for workload, views, chans in (('config2', 1000, 800), ('config3', 2000, 1024)):
         for rank in sorted({0, K // 2}):
             cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--shard-of', str(K), '--shard-rank',
                    str(rank), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--skip-single-row', '--skip-quadrature', '--skip-gn-full-loop',
-                   '--skip-dropin']
+                   '--skip-dropin', '--skip-noisy']
             if K == 1:
                 cmd = [c for c in cmd if c not in ('--shard-of', '--shard-rank')][:]
                 cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--steps', '3', '--warmup', '1',
-                       '--no-cpu-baseline', '--skip-single-row', '--skip-quadrature', '--skip-gn-full-loop', '--skip-dropin']
+                       '--no-cpu-baseline', '--skip-single-row', '--skip-quadrature', '--skip-gn-full-loop', '--skip-dropin', '--skip-noisy']
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             if p.returncode != 0:
                 print(p.stderr[-2000:], file=sys.stderr)
@@ -52,7 +52,7 @@ for r in rows:
     exposed = max(0.0, r['ring_ms'] - r['gn_ms'])
     print(f"| {r['workload']} | {r['K']} | {r['rank']} | {r['views']} | {r['step_ms']:.1f} | {r['sid_ms']:.2f} | {r['gn_ms']:.1f} | "
           f"{r['recv_gb']:.2f} | {r['ring_ms']:.1f} | {r['direct_ms']:.1f} | {exposed:.1f} |")
-print('\nWith the Newton share at ~5 ms per rank at K = 8 (one step per pixel, profiles/r05_gn_one_step.md) nothing hides the assembly: the')
+print('\nWith the Newton share at ~5 ms per rank at K = 8 (one chord step per pixel, profiles/r06_gn_chord.md) nothing hides the assembly: the')
 print('step is what the transfers cost - bracketed here by the ring-bound estimate (one link: what an all-gather that RCCL runs as a ring')
 print('would cost; bench.py --gather all) and the direct one (one transfer per peer link in parallel: what bench.py --gather root / direct')
 print('issue, dexct_sino_gather; RCCL bus bandwidths of ~300 GB/s reported for 8-GPU xGMI meshes correspond to it).\n')
