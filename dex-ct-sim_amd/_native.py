@@ -134,11 +134,11 @@ def load():
                                             vp, vp, vp, vp, vp, vp]
     lib.dexct_cone_layout_groups.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.dexct_cone_project_grouped.argtypes = [C.POINTER(FanGeom), vp, vp, vp, vp, f64, f64, i32, i32, vp, i32, i32, i32, vp, vp, vp,
-                                               vp, vp, vp, vp, vp, vp]
+                                               vp, vp, vp, vp, vp, vp, vp]
     lib.dexct_cone_layout_bytes.argtypes = [i32, i32, i32]
     lib.dexct_cone_layout_bytes.restype = i64
     lib.dexct_siddon_project_grouped.argtypes = [C.POINTER(FanGeom), vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp,
-                                                 i32, vp, vp, vp, vp]
+                                                 i32, vp, vp, vp, vp, vp]
     lib.dexct_siddon_project_grouped_packed.argtypes = lib.dexct_siddon_project_grouped.argtypes
     lib.dexct_transpose_batched.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     lib.dexct_transpose_log.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, i64, i32, i32, vp]

@@ -2,6 +2,7 @@
 // the accumulator planes -> counts of every spectrum.  Its own translation unit since round 5: 94 instantiations (one per number
 // of table rows, lengths in registers) that used to make siddon.hip 100 s of the library's 2-minute build.
 #include "common.h"
+#include "noise_sample.h"
 #include "siddon_detect.h"
 
 namespace dexct {
@@ -61,6 +62,36 @@ __global__ __launch_bounds__(256) void detect_kernel(ProjArgs a, const float* __
       rays[k] = ray0 + k;
       valid[k] = true;
     }
+  }
+  if (a.sample) {
+    // quantum noise drawn here (round 6; <= 2 spectra): the variance from the same exponentials as the signal, one Philox block
+    // per ray - the sample dexct_add_noise draws from the same signal and variance; a.variance (optional) receives the variance
+    float res[2][R], var[2][R];
+    if (a.pathlen) {
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if (valid[k]) {
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) a.pathlen[rays[k] * NMAT + m] = L[k][m];
+        }
+    }
+    detect_store<NMAT, R, false, true>(L, a, mu, w, w2, rays, valid, BlockMasks{{~0ull, ~0ull}, false}, nullptr, &res, &var);
+    const int rr0 = a.layout == 0 ? (int)((ray0 / a.g.n_channels) % a.g.n_rows) : (int)(ray0 % a.g.n_rows);     // row of the first ray
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (a.variance && valid[k]) {
+#pragma unroll
+        for (int sI = 0; sI < 2; ++sI)
+          if (sI < a.n_spectra) a.variance[rays[k] + (size_t)sI * n_rays] = var[sI][k];
+      }
+      // the R rays of a thread are consecutive rows of one (view, channel) pair (layout 1) or R = 1
+      float z[2];
+      pixel_normals<2>((uint32_t)(a.view_begin + v), (uint32_t)(rr0 + k), (uint32_t)c, a.seed_lo, a.seed_hi, z);
+      res[0][k] = noisy_count(res[0][k], var[0][k], z[0]);
+      res[1][k] = noisy_count(res[1][k], var[1][k], z[1]);
+    }
+    store_rays<R>(a, rays, valid, res);
+    return;
   }
   detect_store<NMAT, R>(L, a, mu, w, w2, rays, valid);
 }

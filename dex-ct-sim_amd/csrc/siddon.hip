@@ -1240,7 +1240,7 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
                                  int32_t view_end, const uint8_t* codes, int32_t n_materials, int32_t n_energies,
                                  int32_t n_spectra, const float* mu, const float* weights, float* counts, float* pathlen,
                                  float* acc_scratch, int32_t layout, const float* weights2, float* variance,
-                                 const dexct_log_out* log_out, void* stream) {
+                                 const dexct_log_out* log_out, const dexct_noise* noise, void* stream) {
   if (!geom || !plan || !codes || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
   if (view_begin < 0 || view_end > geom->n_views || view_end <= view_begin) return DEXCT_EINVAL;
   if (n_materials < 2 || n_energies < 1 || n_spectra < 1 || geom->n_rows < 1) return DEXCT_EINVAL;
@@ -1249,7 +1249,6 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
   if (geom->nz % 4 != 0 || geom->z_first % 4 != 0) return DEXCT_EINVAL;
   if ((uint64_t)geom->nx * geom->ny * geom->nz > 0xFFFFFFFEull) return DEXCT_ERANGE;
   if (layout != 0 && layout != 1) return DEXCT_EINVAL;
-  if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
   if (geom->n_rows > 65535 || view_end - view_begin > 65535) return DEXCT_ERANGE;
   ProjArgs a;
   a.g = *geom;
@@ -1265,7 +1264,9 @@ int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_pla
   a.variance = variance;
   a.layout = layout;
   a.acc_out = acc_scratch;
-  if (set_log_out(a, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
+  { const int nrc = set_noise(a, view_begin, weights2, variance, noise); if (nrc != DEXCT_OK) return nrc; }
+  // (the log of a noisy sinogram is the log of the SAMPLED counts: written here only when the detection pass draws the sample)
+  if (set_log_out(a, log_out, a.sample ? nullptr : variance) != DEXCT_OK) return DEXCT_EINVAL;
   a.view_tile = kViewTileDefault;
   if (const char* e = getenv("DEXCT_VIEW_TILE")) { const int t = atoi(e); if (t >= 1 && t <= 4096) a.view_tile = t; }
   const Tables t{mu, weights, weights2};

@@ -1034,11 +1034,10 @@ extern "C" int dexct_cone_project_grouped(const dexct_fan_geom* geom, const dexc
                                           int32_t view_begin, int32_t view_end, const uint8_t* vol_zcg, int32_t n_materials,
                                           int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights,
                                           float* counts, float* pathlen, float* acc_scratch, const dexct_log_out* log_out,
-                                          const float* weights2, float* variance, void* stream) {
+                                          const float* weights2, float* variance, const dexct_noise* noise, void* stream) {
   if (!geom || !plan || !view_cs || !chan_cs || !row_z || !vol_zcg || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
   if (n_materials < 1) return DEXCT_EINVAL;
   if (n_materials > DEXCT_MAX_MATERIALS) return DEXCT_ERANGE;
-  if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
   const int rc = cone_rows_checks(geom, view_begin, view_end, n_energies, n_spectra, max_abs_dz);
   if (rc != DEXCT_OK) return rc;
   hipStream_t st = as_stream(stream);
@@ -1073,7 +1072,8 @@ extern "C" int dexct_cone_project_grouped(const dexct_fan_geom* geom, const dexc
   d.acc_out = acc_scratch;
   d.mat_base = 0;
   d.acc_lengths = 1;
-  if (set_log_out(d, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
+  { const int nrc = set_noise(d, view_begin, weights2, variance, noise); if (nrc != DEXCT_OK) return nrc; }
+  if (set_log_out(d, log_out, d.sample ? nullptr : variance) != DEXCT_OK) return DEXCT_EINVAL;
   const Tables t{mu, weights, weights2};
   return launch_detect_any(d, t, st);
 }

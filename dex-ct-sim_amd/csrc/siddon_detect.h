@@ -37,6 +37,11 @@ struct ProjArgs {
   // 1: the planes of acc_out hold path lengths [cm] of EVERY material, material 0 included (the cone-beam group passes, which
   // accumulate material 0 like any other: a 3-D ray has no chord trick); the detection pass then reads no plan
   int acc_lengths = 0;
+  // quantum noise drawn by the detection pass of the material groups (struct dexct_noise, ABI 6): the Philox counter needs the
+  // GLOBAL view of a ray; 0 = the pass writes the expectation (and the variance, if asked)
+  int view_begin = 0;
+  int sample = 0;
+  uint32_t seed_lo = 0, seed_hi = 0;
   // second output of get_sino (main.py:120-122): sino_log[s][ray] = ln(air[s] / counts[s][ray]), same ray order as
   // counts; null = not wanted.  air[s] = sum_e w[s][e] (the unattenuated signal), given by the caller.
   float* sino_log;
@@ -46,6 +51,23 @@ struct ProjArgs {
 // log_out of the C ABI -> launch arguments (null: no log sinogram).  With a variance output the log belongs to the noisy
 // counts, which only exist after dexct_add_noise: the caller then uses dexct_sino_log (`variance` non-null here = "the counts
 // this launch writes are not the final ones"; a kernel that samples the noise itself passes null).
+// the noise arguments of the group entry points -> launch arguments; DEXCT_EINVAL for a combination that makes no sense
+inline int set_noise(ProjArgs& a, int32_t view_begin, const float* weights2, const float* variance, const dexct_noise* noise) {
+  const bool sample = noise && noise->sample;
+  a.view_begin = view_begin;
+  a.sample = 0;
+  a.seed_lo = a.seed_hi = 0u;
+  if (!weights2) return (variance || sample) ? DEXCT_EINVAL : DEXCT_OK;
+  if (!variance && !sample) return DEXCT_EINVAL;
+  if (sample) {
+    if (a.n_spectra > 2 || a.n_materials > 48) return DEXCT_ERANGE;      // (the fused variance: two spectrum slots, register lengths)
+    a.sample = 1;
+    a.seed_lo = (uint32_t)noise->seed;
+    a.seed_hi = (uint32_t)(noise->seed >> 32);
+  }
+  return DEXCT_OK;
+}
+
 inline int set_log_out(ProjArgs& a, const dexct_log_out* lo, const float* variance) {
   a.sino_log = nullptr;
   for (int s = 0; s < DEXCT_MAX_SPECTRA; ++s) a.air[s] = 1.0f;
@@ -462,6 +484,33 @@ __device__ __forceinline__ void detect_store(const float (&L)[R][NM], const Proj
           if (valid[q]) {
             a.counts[ray[q] + s * sstride] = acc[s][q];
             if (a.sino_log) a.sino_log[ray[q] + s * sstride] = log_ratio(a.air[s], acc[s][q]);
+          }
+      }
+    }
+}
+
+// The stores of detect_store for callers that took the results into registers (res_out): counts and, if asked, the log sinogram
+// of up to two spectra; R consecutive rays leave as one 16-byte piece where the layout allows.
+template <int R>
+__device__ __forceinline__ void store_rays(const ProjArgs& a, const size_t (&ray)[R], const bool (&valid)[R], const float (&res)[2][R]) {
+  const size_t sstride = (size_t)a.n_local_views * a.g.n_rows * a.g.n_channels;
+  const bool vec4 = R == 4 && a.layout == 1 && (a.g.n_rows & 3) == 0 && valid[R - 1];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    if (s < a.n_spectra) {
+      if (vec4) {
+        *reinterpret_cast<float4*>(a.counts + ray[0] + s * sstride) =
+            make_float4(res[s][0], res[s][R > 1 ? 1 : 0], res[s][R > 2 ? 2 : 0], res[s][R > 3 ? 3 : 0]);
+        if (a.sino_log)
+          *reinterpret_cast<float4*>(a.sino_log + ray[0] + s * sstride) =
+              make_float4(log_ratio(a.air[s], res[s][0]), log_ratio(a.air[s], res[s][R > 1 ? 1 : 0]),
+                          log_ratio(a.air[s], res[s][R > 2 ? 2 : 0]), log_ratio(a.air[s], res[s][R > 3 ? 3 : 0]));
+      } else {
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+          if (valid[q]) {
+            a.counts[ray[q] + s * sstride] = res[s][q];
+            if (a.sino_log) a.sino_log[ray[q] + s * sstride] = log_ratio(a.air[s], res[s][q]);
           }
       }
     }

@@ -644,11 +644,10 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
                                         int32_t view_end, const uint8_t* codes2, int32_t n_materials, int32_t n_energies,
                                         int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                         float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
-                                        float* variance, const dexct_log_out* log_out, void* stream) {
+                                        float* variance, const dexct_log_out* log_out, const dexct_noise* noise, void* stream) {
   if (!geom || !plan || !codes2 || !mu || !weights || !counts || !acc_scratch) return DEXCT_EINVAL;
   if (n_materials < 2 || n_energies < 1 || n_spectra < 1) return DEXCT_EINVAL;
   if (n_materials > DEXCT_MAX_MATERIALS || n_spectra > DEXCT_MAX_SPECTRA) return DEXCT_ERANGE;
-  if ((variance != nullptr) != (weights2 != nullptr)) return DEXCT_EINVAL;
   PackedArgs pa;
   size_t nblk, lds;
   const int rc = packed_shape(geom, view_begin, view_end, layout, pa, nblk, lds);
@@ -669,7 +668,8 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
   a.acc_out = acc_scratch;
   a.mat_base = 0;
   a.layout = layout;
-  if (set_log_out(a, log_out, variance) != DEXCT_OK) return DEXCT_EINVAL;
+  { const int nrc = set_noise(a, view_begin, weights2, variance, noise); if (nrc != DEXCT_OK) return nrc; }
+  if (set_log_out(a, log_out, a.sample ? nullptr : variance) != DEXCT_OK) return DEXCT_EINVAL;
   a.view_tile = pa.view_tile;
   pa.view_begin = view_begin;
   pa.sample = 0;

@@ -311,9 +311,11 @@ class Projector:
             pl_shape = (nV, nR, nC, M) if run_layout == 0 else (nV, nC, nR, M)
             pathlen = torch.empty(pl_shape, dtype=torch.float32, device=self.dev)
         noisy = w2_d is not None
-        # kernels that draw the noise sample themselves (ABI 6): the packed stacked fan and the cone beam (its material-group
-        # passes hand the variance to dexct_add_noise like the stacked fan's)
-        in_kernel = noisy and ((self.cone and not self.cone_groups) or (self.use_packed and S <= 2))
+        # kernels that draw the noise sample themselves (ABI 6): the packed stacked fan, the cone beam, and the detection pass of
+        # the material groups (<= 2 spectra, <= 48 table rows); everything else writes the variance for dexct_add_noise
+        groups = self.cone_groups or (not self.cone and (self.grouped_packed or self.grouped))
+        in_kernel = noisy and ((self.cone and not self.cone_groups) or (self.use_packed and S <= 2 and not groups)
+                               or (groups and S <= 2 and M <= 48))
         variance = torch.empty_like(counts) if (noisy and (want_variance or not in_kernel)) else None
         nz = _native.noise(seed) if in_kernel else None
         # the log sinogram: written by the detection store when the kernel's layout is the one wanted; else together with the
@@ -346,7 +348,7 @@ class Projector:
                     _native.check(self.lib.dexct_cone_project_grouped(
                         C.byref(self.geom), plan_ptr + v0 * nC * _native.PLAN_BYTES, ptr(self.view_cs), ptr(self.chan_cs), ptr(self.row_z),
                         self.ct.src_z, max_dz, vb + v0, vb + v1, ptr(self.vol_zc), M, nE, S, ptr(mu_d), ptr(w_d), ptr(c_t), ptr(p_t),
-                        ptr(scratch), lo_t, ptr(w2_d), ptr(v_t), stream_ptr()), 'dexct_cone_project_grouped')
+                        ptr(scratch), lo_t, ptr(w2_d), ptr(v_t), nz, stream_ptr()), 'dexct_cone_project_grouped')
                     if not whole:
                         counts[:, v0:v1].copy_(c_t)
                         if pathlen is not None:
@@ -381,7 +383,7 @@ class Projector:
                 scratch = torch.empty((M, nV * nR * nC), dtype=torch.float32, device=self.dev)
                 _native.check(fn(C.byref(self.geom), plan_ptr, vb, ve, ptr(self.codes), M, nE, S,
                                  ptr(mu_d), ptr(w_d), ptr(counts), ptr(pathlen), ptr(scratch), run_layout, ptr(w2_d), ptr(variance),
-                                 lo, stream_ptr()), what)
+                                 lo, nz, stream_ptr()), what)
             else:
                 scratch = torch.empty((M, n_chunk * nR * nC), dtype=torch.float32, device=self.dev)
                 for v0 in range(0, nV, n_chunk):
@@ -394,7 +396,7 @@ class Projector:
                     lo_t = _native.log_out(ptr(l_t), air) if lo is not None else None
                     _native.check(fn(C.byref(self.geom), plan_ptr + v0 * nC * _native.PLAN_BYTES, vb + v0,
                                      vb + v1, ptr(self.codes), M, nE, S, ptr(mu_d), ptr(w_d), ptr(c_t), ptr(p_t),
-                                     ptr(scratch), run_layout, ptr(w2_d), ptr(v_t), lo_t, stream_ptr()), what)
+                                     ptr(scratch), run_layout, ptr(w2_d), ptr(v_t), lo_t, nz, stream_ptr()), what)
                     counts[:, v0:v1].copy_(c_t)
                     if pathlen is not None:
                         pathlen[v0:v1].copy_(p_t)

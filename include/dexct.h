@@ -169,13 +169,17 @@ int dexct_siddon_project(const dexct_fan_geom* geom, const dexct_ray_plan* plan,
  * dexct_siddon_project_grouped: one packed-count traversal per group writes raw per-material accumulators
  *   to acc_scratch[m*n_rays + ray] (float32, caller-provided, n_materials*n_rays values), then one
  *   detection pass forms material 0 from the chord and applies the tables; outputs as dexct_siddon_project.
- *   Bit-identical path lengths to the single-pass kernels (per-material sums are independent). */
+ *   Bit-identical path lengths to the single-pass kernels (per-material sums are independent).
+ *   noise (ABI 6, the three group entry points; struct dexct_noise): with weights2 and noise->sample the detection pass sums the
+ *   variance with the signal and draws the sample itself (<= 2 spectra, <= 48 materials, else DEXCT_ERANGE: use the variance
+ *   output + dexct_add_noise, which draws the same sample); variance is then optional and log_out receives the log of the sampled
+ *   counts.  weights2 without a sample needs the variance output (and admits no log_out). */
 int dexct_volume_groups(const uint8_t* vol_zf, int64_t n_voxels, int32_t n_materials, uint8_t* codes, void* stream);
 int dexct_siddon_project_grouped(const dexct_fan_geom* geom, const dexct_ray_plan* plan, int32_t view_begin,
                                  int32_t view_end, const uint8_t* codes, int32_t n_materials, int32_t n_energies,
                                  int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                  float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
-                                 float* variance, const dexct_log_out* log_out, void* stream);
+                                 float* variance, const dexct_log_out* log_out, const dexct_noise* noise, void* stream);
 
 /* The stacked-fan projection on a 2-BIT PACKED volume (rows16_kernel; <= 4 materials, i.e. ids 0..3): a voxel is 2
  * bits, one dword load serves 16 detector rows, the per-row material counts are kept bit-sliced (carry-save adders).
@@ -204,7 +208,7 @@ int dexct_siddon_project_grouped_packed(const dexct_fan_geom* geom, const dexct_
                                         int32_t view_end, const uint8_t* codes2, int32_t n_materials, int32_t n_energies,
                                         int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                         float* pathlen, float* acc_scratch, int32_t layout, const float* weights2,
-                                        float* variance, const dexct_log_out* log_out, void* stream);
+                                        float* variance, const dexct_log_out* log_out, const dexct_noise* noise, void* stream);
 
 /* Cone-beam (3-D) projection, SURVEY 8f.4: the fan of dexct_fan_plan in the (x, y) plane, source at height
  * src_z, detector row r at height row_z[r] (device float64 [n_rows], cm, z = 0 at the centre of the grid;
@@ -245,8 +249,7 @@ int dexct_cone_project_rows(const dexct_fan_geom* geom, const dexct_ray_plan* pl
  * dexct_cone_project_grouped: one traversal per group (cone_cols_kernel / cone_rows_kernel) writes the path lengths [cm] of its
  *   three materials to acc_scratch[m*n_rays + ray] (float32, caller-provided, n_materials*n_rays values), then one detection pass
  *   applies the tables; outputs as dexct_cone_project.  The per-material sums are independent, so the path lengths are
- *   bit-identical to dexct_cone_project's.  weights2 / variance (both or neither) as in dexct_siddon_project: the variance for
- *   dexct_add_noise; no log_out together with a variance. */
+ *   bit-identical to dexct_cone_project's.  weights2 / variance / noise: as dexct_siddon_project_grouped. */
 int dexct_cone_layout_groups(const uint8_t* vol, int32_t nx, int32_t ny, int32_t nz, int32_t n_materials, uint8_t* vol_zcg,
                              void* stream);
 int dexct_cone_project_grouped(const dexct_fan_geom* geom, const dexct_ray_plan* plan, const double* view_cs,
@@ -254,7 +257,7 @@ int dexct_cone_project_grouped(const dexct_fan_geom* geom, const dexct_ray_plan*
                                int32_t view_begin, int32_t view_end, const uint8_t* vol_zcg, int32_t n_materials,
                                int32_t n_energies, int32_t n_spectra, const float* mu, const float* weights, float* counts,
                                float* pathlen, float* acc_scratch, const dexct_log_out* log_out, const float* weights2,
-                               float* variance, void* stream);
+                               float* variance, const dexct_noise* noise, void* stream);
 
 /* counts = max(counts + sqrt(variance) * z, 1e-20), z ~ N(0, 1) from Philox4x32-10 with counter (view_offset + view, row,
  * channel, 0) and key seed - one block per detector pixel, spectrum s takes the s-th normal of its two Box-Muller pairs (ABI 6;

@@ -583,6 +583,15 @@ def test_cone_beam_material_groups(hip, n_mat, nz, n_rows, monkeypatch):
     assert np.max(np.abs(c2.cpu().numpy() - cls) / cls) < REL_TOL
     n1, _ = pj1.project(sp, noise=True, seed=4)
     (n2, nl2), _ = pj2.project(sp, noise=True, seed=4, want_log=True)
+    if M <= 48:                   # the detection pass of the groups draws the sample itself: what dexct_add_noise draws from its variance
+        from dex_ct_sim_amd import _native
+        from dex_ct_sim_amd._device import ptr, stream_ptr
+        _, mu_v, w_v, w2_v = fp.merged_tables(cone, ph, sp, with_variance=True)
+        tabs = [torch.tensor(x, dtype=torch.float32, device='cuda').contiguous() for x in (pj2.compact(mu_v), w_v, w2_v)]
+        nv, var = pj2.project_tables(tabs[0], tabs[1], w2_d=tabs[2], seed=4, want_variance=True)
+        sampled = c2.clone()
+        _native.check(pj2.lib.dexct_add_noise(ptr(sampled), ptr(var), 2, n_views, n_rows, n_ch, 0, 0, 4, stream_ptr()), 'dexct_add_noise')
+        assert torch.equal(nv, n2) and torch.equal(sampled, n2)
     if same_detection:
         assert torch.equal(n1, n2)
     assert not torch.equal(n2, c2) and np.allclose(nl2.cpu().numpy(), _np_log(air, n2.cpu().numpy()), rtol=5e-6, atol=5e-7)
@@ -897,6 +906,22 @@ def test_material_groups_on_the_packed_volume(hip, n_rows, n_mat):
     n8, _ = pj8.project(sp, noise=True, seed=3)
     n4, _ = projector(ct, ph, kernel=4).project(sp, noise=True, seed=3)
     assert torch.equal(n8, n4) and not torch.equal(n8, c8)
+    # round 6: the detection pass of the groups draws the sample itself (variance from the same exponentials, one Philox block per
+    # ray) - the sample dexct_add_noise draws from the pass's own signal and variance, and the log of the sampled counts
+    from dex_ct_sim_amd import _native, forward_project as fp
+    from dex_ct_sim_amd._device import ptr, stream_ptr
+    _, mu, w, w2 = fp.merged_tables(ct, ph, sp, with_variance=True)
+    mu_d, w_d, w2_d = (torch.tensor(x, dtype=torch.float32, device='cuda').contiguous() for x in (pj8.compact(mu), w, w2))
+    air = w.sum(axis=1)
+    noisy, log, var = pj8.project_tables(mu_d, w_d, layout=None, w2_d=w2_d, seed=3, air=air, want_variance=True)
+    assert pj8.native_layout == 1 and torch.equal(noisy.permute(0, 1, 3, 2), n8)        # (n8: the reference's order)
+    sampled = pj8.project_tables(mu_d, w_d, layout=None).clone()
+    _native.check(pj8.lib.dexct_add_noise(ptr(sampled), ptr(var), 2, ct.N_proj, ct.N_rows, ct.N_channels, pj8.native_layout, 0, 3,
+                                          stream_ptr()), 'dexct_add_noise')
+    assert torch.equal(sampled, noisy) and torch.equal(log, pj8.sino_log(noisy, air))
+    # four spectra: beyond the fused form - the variance output + dexct_add_noise, as before; the same sample for the same spectra
+    four, _ = pj8.project(sp + sp, noise=True, seed=3)
+    assert torch.equal(four[0], n8[0]) and torch.equal(four[1], n8[1]) and not torch.equal(four[2], four[0])
 
 
 # ---- round 4: the full uint8 id range

@@ -45,7 +45,7 @@ def run(name, ct, ph, specs, views=None, kernel=0):
     print(f'    per-bin Poisson (native)  {poisson:8.3f} ms', flush=True)
 
 
-which = sys.argv[1:] or ['c2', 'c4', 'cone']
+which = sys.argv[1:] or ['c2', 'c4', 'cone', 'groups']
 if 'c2' in which:
     ph = synthetic.make_phantom(512, 512, extent=51.2, seed=1234)
     ct = dx.FanBeamGeometry(N_channels=800, N_proj=1000, gamma_fan=0.8230337, SID=60.0, SDD=100.0, eid=True, detector_file=det, N_rows=512)
@@ -61,3 +61,19 @@ if 'cone' in which:
     ph = synthetic.make_phantom(512, 512, extent=51.2, seed=1234)
     cone = dx.FanBeamGeometry(800, 100, detector_file=det, N_rows=512, cone=True, h_iso=0.1)
     run('cone beam 100 x 800 x 512', cone, ph, [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)])
+if 'groups' in which:
+    # an XCAT-like case: 12 table rows on the benchmark's stacked fan (4 group passes of rows16_kernel + the detection pass, which
+    # since round 6 sums the variance with the signal and draws the sample itself) and on the cone beam (4 group passes of
+    # cone_cols_kernel + the same detection pass)
+    import numpy as np
+    from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
+    ph = synthetic.make_phantom(512, 512, extent=51.2, seed=1234)
+    v = ph.volume
+    z = np.arange(v.shape[0])[:, None, None]
+    ph.volume = np.where(v == 2, 2 + (z // 8) % 10, v).astype(np.uint8)
+    ph.materials = [AIR, WATER, BONE] + [Material(f'm{i}', 1.0 + 0.05 * i, 'H(11.2)O(88.8)') for i in range(3, 12)]
+    specs = [synthetic.kramers_spectrum(140), synthetic.kramers_spectrum(80)]
+    ct = dx.FanBeamGeometry(N_channels=800, N_proj=250, gamma_fan=0.8230337, SID=60.0, SDD=100.0, eid=True, detector_file=det, N_rows=512)
+    run('12 table rows, stacked fan 250 x 800 x 512 (material groups)', ct, ph, specs)
+    cone = dx.FanBeamGeometry(800, 100, detector_file=det, N_rows=512, cone=True, h_iso=0.1)
+    run('12 table rows, cone beam 100 x 800 x 512 (material groups)', cone, ph, specs)
