@@ -50,10 +50,20 @@ __device__ __forceinline__ T load_g(const void* p, int is_f64, int64_t i) {
 // exp(x) = 2^k * 2^(j/2048) * e^(f ln2/2048), a cubic in f for e^r - 1 (truncation r^4/24 < 4e-17, r = f ln2/2048).
 // n comes out of the low mantissa bits of y + 1.5 * 2^52 (round to nearest even, like rint); f = y - n is exact.
 // About 1 ulp.
+// 2^k without an instruction of its own (round 6): the table entry j holds 2^(j/2048) with j << 9 SUBTRACTED from its high word
+// (pow_entry), so that adding n << 9 = (k << 20) + (j << 9) to the high word of what was loaded - one v_lshl_add_u32, no mask -
+// gives 2^k 2^(j/2048) before the last FMA; scaling by a power of two is exact, so the bits are those of ldexp(fma(tj, p, tj), k)
+// (rounds 3-5: a shift and v_ldexp_f64) wherever that is a normal number - and it is for |x| <= 700 (e^-700 = 1e-304), which every
+// caller guarantees: the clip of matdecomp.py:116, the clip-free bound of newton_sums_f64, float32-normal arguments of log_pos.
+// NaN stays NaN (f is NaN then, whatever the table entry became).
 constexpr int kPowBits = 11;
 constexpr int kPowN = 1 << kPowBits;
 constexpr double kExpScale = 0x1.71547652b82fep+11;          // 2048 / ln 2
 constexpr double kExpClip = 700.0 * kExpScale;               // the reference's clip of the exponent (matdecomp.py:116)
+__device__ __forceinline__ double pow_entry(int j) {
+  const double v = exp2((double)j * (1.0 / kPowN));
+  return __hiloint2double(__double2hiint(v) - (j << (20 - kPowBits)), __double2loint(v));
+}
 __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ lds_pow) {
   const double kMagic = 6755399441055744.0;   // 1.5 * 2^52
   constexpr double c1 = 0x1.62e42fefa39efp-12;               // ln2 / 2048
@@ -64,9 +74,9 @@ __device__ __forceinline__ double exp_tab(double y, const double* __restrict__ l
   double q = fma(f, c3, c2);
   q = fma(f, q, c1);
   const double p = f * q;
-  const double tj = lds_pow[ni & (kPowN - 1)];
-  const double t = fma(tj, p, tj);
-  return ldexp(t, ni >> kPowBits);     // (2^k by integer adds on the exponent field was measured equal: profiles/r03_gn_isa.md)
+  const double tr = lds_pow[ni & (kPowN - 1)];
+  const double tj = __hiloint2double((int)((unsigned)__double2hiint(tr) + ((unsigned)ni << (20 - kPowBits))), __double2loint(tr));
+  return fma(tj, p, tj);
 }
 
 // 1 / x by v_rcp_f64 and two Newton refinements (what a float64 division starts with, without its scaling and
@@ -527,8 +537,8 @@ __global__ __launch_bounds__(kGnBlock) void gn_kernel(const void* __restrict__ g
                                                       const double* __restrict__ mask_max, double mask_frac,
                                                       int exact_exit, double stop_tol, GnTiling tl,
                                                       double* __restrict__ out_a) {
-  __shared__ double lds_pow[kPowN];     // 2^(j/2048), 16 KB
-  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
+  __shared__ double lds_pow[kPowN];     // 2^(j/2048) in pow_entry's form, 16 KB
+  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = pow_entry(j);
   __syncthreads();
   const float* __restrict__ tab32 = reinterpret_cast<const float*>(ws + kWsHeader + (size_t)n_bins * n_e * kTab);
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
@@ -1012,7 +1022,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_refill_kernel(const void* __re
   __shared__ d2 lds_out[kGnBlock / kWave][kSlots * kTilePix];            // 12 KB: with the table 28 KB = 5 workgroups per CU
   __shared__ unsigned char lds_it[COUNT ? kGnBlock / kWave : 1][COUNT ? kSlots * kTilePix : 1];
   unsigned char* __restrict__ my_it = lds_it[COUNT ? (threadIdx.x >> 6) : 0];
-  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
+  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = pow_entry(j);
   __syncthreads();                        // the only barrier: waves leave the loop below independently
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
   const double* __restrict__ tab = ws + kWsHeader;
@@ -1205,7 +1215,7 @@ __global__ __launch_bounds__(kGnBlock, 4) void gn_shortcut_kernel(const void* __
   __shared__ d2 lds_sa[kGnBlock / kWave][kStashCap];                     // 6 KB: its state,
   __shared__ d2 lds_sp[kGnBlock / kWave][kStashCap];                     // 6 KB: the state before,
   __shared__ double lds_srad[kGnBlock / kWave][kStashCap];               // 3 KB: its acceptance radius  (38 KB: 4 workgroups per CU)
-  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
+  for (int j = threadIdx.x; j < kPowN; j += kGnBlock) lds_pow[j] = pow_entry(j);
   __syncthreads();                        // the only barrier: waves work independently from here on
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
   const double* __restrict__ tab = ws + kWsHeader;
@@ -1450,7 +1460,7 @@ __global__ __launch_bounds__(kCoopWaves * kWave, 3) void gn_coop_kernel(const vo
   __shared__ double lds_pow[kPowN];                                      // 16 KB
   __shared__ double lds_part[kCoopWaves][12][kWave];                     // 24 KB: the partial sums of one step
   __shared__ long long lds_tile[2];
-  for (int j = threadIdx.x; j < kPowN; j += kCoopWaves * kWave) lds_pow[j] = exp2((double)j * (1.0 / kPowN));
+  for (int j = threadIdx.x; j < kPowN; j += kCoopWaves * kWave) lds_pow[j] = pow_entry(j);
   __syncthreads();
   const EnergyClasses ec{(int)ws[1], (int)ws[4], (int)ws[2], (int)ws[5], (int)ws[3], (int)ws[6], ws[7], ws[8]};
   const double* __restrict__ tab = ws + kWsHeader;
