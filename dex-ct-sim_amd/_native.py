@@ -9,7 +9,7 @@ ABI_VERSION = 6
 
 # every entry point include/dexct.h declares
 SYMBOLS = ['dexct_strerror', 'dexct_abi_version', 'dexct_last_hip_error', 'dexct_volume_layouts', 'dexct_fan_plan',
-           'dexct_siddon_project', 'dexct_siddon_trace', 'dexct_gn_decompose', 'dexct_gn_apply_mask',
+           'dexct_siddon_project', 'dexct_siddon_trace', 'dexct_gn_decompose', 'dexct_gn_apply_mask', 'dexct_gn_model_sums',
            'dexct_reduce_max', 'dexct_transpose_batched', 'dexct_fbp_filter', 'dexct_fbp_backproject',
            'dexct_add_noise', 'dexct_volume_groups', 'dexct_siddon_project_grouped', 'dexct_cone_project',
            'dexct_cone_layout', 'dexct_cone_project_rows', 'dexct_volume_pack2', 'dexct_siddon_project_packed', 'dexct_volume_groups_pack2',
@@ -150,6 +150,7 @@ def load():
     lib.dexct_gn_workspace_bytes.argtypes = [i32, i32]
     lib.dexct_gn_workspace_bytes.restype = i64
     lib.dexct_gn_apply_mask.argtypes = [vp, i32, i64, f64, vp, vp]
+    lib.dexct_gn_model_sums.argtypes = [vp, i64, vp, vp, i32, vp, vp, vp, vp]
     lib.dexct_reduce_max.argtypes = [vp, i32, i64, vp, vp]
     for name in SYMBOLS[3:-2]:
         getattr(lib, name).restype = C.c_int

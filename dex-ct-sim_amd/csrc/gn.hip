@@ -96,6 +96,9 @@ __device__ __forceinline__ double rcp_f64(double x) {
 // (nB), only spectrum 1 (nC); energies no spectrum weights are dropped.  A zero weight contributes exactly
 // 0 to every sum (the attenuation factor is finite thanks to the clip), so skipping those FMAs changes no
 // term of the reference's sums - only their order.
+#ifndef DEXCT_GN_ENERGY_UNROLL
+#define DEXCT_GN_ENERGY_UNROLL 4
+#endif
 template <int KSEL, bool CLIP, int SUMS = 2>       // KSEL 0: both measurements, 1: only k = 0, 2: only k = 1; CLIP: apply the +-700 clip;
                                                    // SUMS 2: all six sums per measurement (a Newton step), 0: the expected counts nu
                                                    // alone (the chord step of the short cut: 2 of the 12 accumulations per energy)
@@ -130,6 +133,9 @@ __device__ __forceinline__ void energy_sums_f64(const double* __restrict__ tab, 
     }
   };
   int e = e0;
+  // (4 pairs per trip: eight table rows' scalar loads and eight LDS reads in flight - 27.2 -> 26.4 ms for the chord launch of the
+  // benchmark, 756 -> 747 ms for the exact count; 8 pairs: no further gain.  tools/probes/gn_ab.py, build_variant.sh)
+#pragma unroll DEXCT_GN_ENERGY_UNROLL
   for (; e + 2 <= e1; e += 2) {
     one(e, nu);
     one(e + 1, nuo);
@@ -1642,6 +1648,51 @@ static const GnEnv& gn_env() {
 
 using namespace dexct;
 
+// The energy sums of the forward model at n states (the table assembly of the short cut: quadrature._model_sums - thresholds and
+// bounds, no bit of a result): per state nu[k] = sum_e i0[k][e] att_e, G[k][m] = sum_e i0[k][e] mu[m][e] live_e and, when asked,
+// S[k][m][p] = sum_e i0[k][e] mu[m][e] mu[p][e] live_e, with att_e = exp(clip(-(a0 mu0[e] + a1 mu1[e]), +-700)) (matdecomp.py:116)
+// and live_e = att_e where the clip is not active, else 0 (the clipped exponent has no slope).  One lane per state, the tables by
+// scalar loads, the library exponential.  (Round 6: these ran as torch float64 kernels on the tables' device; the calibration of
+// the soak's 1 - 3 energy tables then aborted the process once in a few runs of the GPU suite, from a thread of the runtime,
+// with the host in exactly these passes - the product's own arithmetic does not go through another library any more.)
+__global__ __launch_bounds__(256) void gn_model_sums_kernel(const double* __restrict__ a, long long n, const double* __restrict__ i0,
+                                                             const double* __restrict__ mus, int n_e, double* __restrict__ nu_out,
+                                                             double* __restrict__ g_out, double* __restrict__ s_out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const double a0 = a[2 * p], a1 = a[2 * p + 1];
+  double nu[2] = {0.0, 0.0}, G[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, S[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  for (int e = 0; e < n_e; ++e) {
+    const double m0 = mus[e], m1 = mus[n_e + e];
+    const double x = -(a0 * m0 + a1 * m1);
+    const double att = exp(fmin(fmax(x, -700.0), 700.0));
+    const double live = fabs(x) < 700.0 ? att : 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double w = i0[k * n_e + e];
+      nu[k] = fma(w, att, nu[k]);
+      const double wl = w * live;
+      G[k][0] = fma(wl, m0, G[k][0]);
+      G[k][1] = fma(wl, m1, G[k][1]);
+      if (s_out) {
+        S[k][0] = fma(wl * m0, m0, S[k][0]);
+        S[k][1] = fma(wl * m0, m1, S[k][1]);
+        S[k][2] = fma(wl * m1, m1, S[k][2]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    nu_out[2 * p + k] = nu[k];
+    g_out[4 * p + 2 * k] = G[k][0];
+    g_out[4 * p + 2 * k + 1] = G[k][1];
+    if (s_out) {
+      double* sp = s_out + 8 * p + 4 * k;          // [k][m][p], symmetric in (m, p)
+      sp[0] = S[k][0]; sp[1] = S[k][1]; sp[2] = S[k][1]; sp[3] = S[k][2];
+    }
+  }
+}
+
 extern "C" {
 
 int64_t dexct_gn_workspace_bytes(int32_t n_energies, int32_t n_bins) {
@@ -1781,6 +1832,17 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
     hipLaunchKernelGGL((gn_kernel<true, false>), grid, block, 0, st, g1, g2, g_is_f64, n_pix, (const double*)ws,
                        n_energies, n_iters, n_polish, 1, 1, mask_max, mask_frac, exact_exit, 0.0, tl, out_a);
   }
+  DEXCT_LAUNCH_CHECK();
+  return DEXCT_OK;
+}
+
+int dexct_gn_model_sums(const double* a, int64_t n_states, const double* i0, const double* mus, int32_t n_energies,
+                        double* nu_out, double* g_out, double* s_out, void* stream) {
+  if (!a || !i0 || !mus || !nu_out || !g_out || n_states <= 0 || n_energies <= 0) return DEXCT_EINVAL;
+  const int64_t nblk = (n_states + 255) / 256;
+  if (nblk > 0x7FFFFFFFll) return DEXCT_ERANGE;
+  hipLaunchKernelGGL(gn_model_sums_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), a, (long long)n_states, i0, mus,
+                     n_energies, nu_out, g_out, s_out);
   DEXCT_LAUNCH_CHECK();
   return DEXCT_OK;
 }

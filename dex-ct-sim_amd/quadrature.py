@@ -267,24 +267,24 @@ def _model_sums(pieces, a, third=False):
     a = np.where(np.isfinite(a), a, 0.0)
     dev = pieces.get('device')
     if dev is not None:
-        # the same sums on the device the tables are calibrated for (torch float64: one exponential pass of 9e6 values and the
-        # weighted sums take 0.2 s per call in NumPy, a few ms there); they feed thresholds and bounds, no bit of a result.
-        # Written as multiply-and-sum passes, NOT matrix products: a float64 GEMM with an inner dimension of 2 - 3 (the soak's
-        # short tables) aborted inside the BLAS library once in three runs of the GPU suite (round 6, gpurun_out/r6b_tests.log:
-        # SIGABRT in `live @ w.T`, no message) - the host side keeps to elementwise kernels and reductions.
+        # the same sums on the device the tables are calibrated for, by the library's own kernel (dexct_gn_model_sums: 0.2 s per
+        # call in NumPy for the 1.5e5 states x 140 energies of a calibration, a millisecond there); they feed thresholds and
+        # bounds, no bit of a result.  torch only carries the arrays (round 6 first ran these sums as torch float64 kernels: the
+        # GPU suite then aborted once in a few runs, from a thread of the runtime, inside exactly these passes).
         import torch
-        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev)
+        from . import _native
+        from ._device import ptr, stream_ptr
+        lib = _native.load()
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=dev)
         a_t, i0_t, mus_t = t(a), t(i0), t(mus)
-        wsum = lambda x, rows: torch.stack([(x * r).sum(dim=-1) for r in rows], dim=-1)      # [n, len(rows)]
-        expo = -(a_t[:, 0:1] * mus_t[0] + a_t[:, 1:2] * mus_t[1])
-        att = torch.exp(expo.clamp(-700.0, 700.0))
-        nu = wsum(att, i0_t)
-        live = att * (expo.abs() < 700.0)
-        G = wsum(live, (i0_t[:, None, :] * mus_t[None, :, :]).reshape(4, -1)).reshape(-1, 2, 2)
-        if not third:
-            return nu.cpu().numpy(), G.cpu().numpy(), None
-        w2 = (i0_t[:, None, None, :] * mus_t[None, :, None, :] * mus_t[None, None, :, :]).reshape(8, -1)
-        return nu.cpu().numpy(), G.cpu().numpy(), wsum(live, w2).reshape(-1, 2, 2, 2).cpu().numpy()
+        n = a_t.shape[0]
+        nu = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        G = torch.empty((n, 2, 2), dtype=torch.float64, device=dev)
+        S = torch.empty((n, 2, 2, 2), dtype=torch.float64, device=dev) if third else None
+        if n:
+            _native.check(lib.dexct_gn_model_sums(ptr(a_t), n, ptr(i0_t), ptr(mus_t), i0.shape[1], ptr(nu), ptr(G),
+                                                  ptr(S) if third else None, stream_ptr()), 'dexct_gn_model_sums')
+        return nu.cpu().numpy(), G.cpu().numpy(), (S.cpu().numpy() if third else None)
     expo = -(a @ mus)
     att = np.exp(np.clip(expo, -700.0, 700.0))
     nu = att @ i0.T

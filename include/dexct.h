@@ -460,6 +460,14 @@ int dexct_gn_decompose(const void* g1, const void* g2, int32_t g_is_f64, int64_t
                        int32_t precision, int32_t n_polish, const double* mask_max, double mask_frac, double* out_a,
                        const dexct_gn_options* options, void* workspace, void* stream);
 
+/* The energy sums of the decomposition's forward model (matdecomp.py:116-121) at n_states states a [n][2] (device float64), for the
+ * table assembly of the short cut (quadrature.py, assemble_start / validate_start; no counterpart in the reference): nu_out
+ * [n][2] = sum_e i0[k][e] exp(clip(-(a0 mu0[e] + a1 mu1[e]), +-700)); g_out [n][2][2] = sum_e i0[k][e] mu[m][e] x the same
+ * exponential over the energies whose exponent is not clipped; s_out [n][2][2][2] (may be NULL) = sum_e i0[k][e] mu[m][e]
+ * mu[p][e] likewise.  i0 [2][n_energies], mus [2][n_energies] device float64 (one shared spectrum per measurement). */
+int dexct_gn_model_sums(const double* a, int64_t n_states, const double* i0, const double* mus, int32_t n_energies,
+                        double* nu_out, double* g_out, double* s_out, void* stream);
+
 /* Air mask of get_basismat_sinos (matdecomp.py:194-205): out_a[2p], out_a[2p+1] = 0 wherever
  * g1[p] >= thresh_value (thresh_value = mask_thresh * global max, computed by the caller so that a
  * sharded run can all-reduce the max first). */

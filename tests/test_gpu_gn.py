@@ -1197,3 +1197,34 @@ def test_soak_cases_that_were_flagged(hip, seed):
     from soak_gn import check_case
     what, bad = check_case(seed)
     assert not bad, (what, bad)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_e', [1, 3, 140])
+def test_model_sums_of_the_table_assembly(hip, n_e):
+    """dexct_gn_model_sums (the energy sums of the short cut's table assembly, quadrature._model_sums on a device) against the
+    NumPy form of the same function: expected counts, first and second moments of the attenuation, the clip of matdecomp.py:116
+    (a clipped exponent counts in nu and has no slope), non-finite states read as 0.  Tolerance 5e-12 relative: the exponent
+    itself, up to 700, is rounded differently by a dot product and by a multiply-add (one ulp of 700 = 1e-13 of the exponential)."""
+    from dex_ct_sim_amd import quadrature as q
+    rng = np.random.default_rng(n_e)
+    E = np.linspace(15.0, 150.0, n_e) if n_e > 1 else np.array([60.0])
+    mus = np.stack([0.3 * (E / 60.0) ** -0.6 + 0.15, 0.2 * (E / 60.0) ** -2.8 + 0.12])
+    if n_e > 4:
+        mus[:, :n_e // 8] *= 30.0                       # exponents beyond the clip
+    i0 = rng.uniform(0.2, 1.0, (2, n_e)) * 1e5
+    a = np.stack([rng.uniform(-5.0, 45.0, 5003), rng.uniform(-3.0, 8.0, 5003)], 1)
+    a[::97] = [np.inf, 1.0]
+    a[5::101] = [2.0, np.nan]
+    a[7::211] *= 100.0                                  # every exponent clipped
+    host = dict(i0=i0, mus=mus)
+    for third in (False, True):
+        want = q._model_sums(host, a, third=third)
+        got = q._model_sums(dict(host, device=torch.device('cuda:0')), a, third=third)
+        for w, g in zip(want, got):
+            if w is None:
+                assert g is None
+                continue
+            assert g.shape == w.shape
+            np.testing.assert_allclose(g, w, rtol=5e-12, atol=0.0)
+    assert q._model_sums(dict(host, device=torch.device('cuda:0')), np.zeros((0, 2)))[0].shape == (0, 2)
+
