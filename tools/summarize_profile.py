@@ -15,6 +15,9 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dex_ct_sim_amd.quadrature import GATE_CELLS      # (the size of the short cut's table: what the step-counting launches ran on)
+
 tag = sys.argv[1]
 src = os.path.join('gpurun_out', f'prof_{tag}')
 os.makedirs('profiles', exist_ok=True)
@@ -75,7 +78,8 @@ if tl:
     for pat, v in big.items():
         if pat.endswith('<true>'):
             lines.append(f'`{pat}` (the step-counting instantiation): {len(v)} dispatches averaging {sum(v) / len(v):.2f} ms - the reference\'s walk on '
-                         f'the gate\'s 66 049 cell corners and 65 536 cell centres, once per pair of spectra (then from DEXCT_CACHE_DIR)')
+                         f'the gate\'s {(GATE_CELLS + 1) ** 2} cell corners and {GATE_CELLS ** 2} cell centres, once per pair of spectra '
+                         f'(then from DEXCT_CACHE_DIR)')
             continue
         step = [x for x in v if x > 0.25 * max(v)]
         lines.append(f'`{pat}`: {len(v)} dispatches, of which {len(step)} are step launches averaging {sum(step) / len(step):.2f} ms'
