@@ -4,7 +4,9 @@ materials, dense random volumes or small objects in air.  Demanded in every case
 
   * per-material path lengths of cone_kernel (one thread per ray) bit-identical to the oracle's mirror (CPU);
   * with <= 3 materials, path lengths AND counts of cone_rows_kernel (rows of a (view, channel) pair as lanes, shared
-    in-plane records, guarded volume layout) bit-identical to cone_kernel's.
+    in-plane records, guarded volume layout) bit-identical to cone_kernel's;
+  * (round 6) with more, the group passes of the row-parallel kernels: path lengths bit-identical, counts identical for 5 - 48
+    table rows; the noisy sample of the host's choice = dexct_add_noise on the same call's signal and variance.
 
     python tools/soak_cone.py [n_cases] [first_seed]
 """
@@ -18,7 +20,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dex_ct_sim_amd as dx
-from dex_ct_sim_amd import forward_project as fp
+from dex_ct_sim_amd import _native, forward_project as fp
+from dex_ct_sim_amd._device import ptr, stream_ptr
 from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
 from oracle import c_oracle as co
 
@@ -26,7 +29,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device('cuda:0')
 t0 = time.time()
-fails, rays, n_rows_kernel = 0, 0, 0
+fails, rays, n_rows_kernel, n_groups = 0, 0, 0, 0
 for case in range(n_cases):
     seed = seed0 + case
     rng = np.random.default_rng(330000 + seed)
@@ -42,7 +45,7 @@ for case in range(n_cases):
     src_z = float(rng.uniform(-0.3, 0.3) * reach)
     half_rows = max(0.5 * (n_rows - 1), 0.5)
     h_iso = float((reach - abs(src_z)) / half_rows * sid / sdd * rng.uniform(0.05, 1.0))
-    n_mat = int(rng.choice([2, 3, 3, 3, 4, 6]))
+    n_mat = int(rng.choice([2, 3, 3, 3, 4, 6, 9, 13]))
     vol = np.zeros((nz, ny, nx), dtype=np.uint8)
     style = rng.choice(['dense', 'blob', 'empty'])
     if style == 'dense':
@@ -81,6 +84,31 @@ for case in range(n_cases):
                 bad.append(f'cone_rows_kernel: path lengths differ ({int((p2 != p1).sum())} values)')
             if not torch.equal(c2, c1):
                 bad.append(f'cone_rows_kernel: counts differ ({int((c2 != c1).sum())} values)')
+        # round 6: more than 3 table rows in group passes of the row-parallel kernels (kernel=2 asks for them whatever the row
+        # count): path lengths bit-identical to cone_kernel, counts identical where the detection arithmetic is the same (5 - 48
+        # table rows), else to 2e-6
+        if pj1.n_mat > 3:
+            pjg = fp.Projector(cone, ph, kernel=2)
+            if pjg.cone_groups:
+                cg, pg = pjg.project_tables(mu_d, w_d, want_pathlen=True)
+                n_groups += 1
+                if not torch.equal(pg, p1):
+                    bad.append(f'cone group passes: path lengths differ ({int((pg != p1).sum())} values)')
+                if pj1.n_mat > 4 and not torch.equal(cg, c1):
+                    bad.append(f'cone group passes: counts differ ({int((cg != c1).sum())} values)')
+                if not torch.allclose(cg, c1, rtol=2e-6, atol=0):
+                    bad.append(f'cone group passes: counts off by {float(((cg - c1).abs() / c1.abs().clamp_min(1e-30)).max()):.2e}')
+        # round 6: quantum noise - what the host picks (variance + sample inside the cone kernels / the group passes' detection
+        # pass, or variance output + dexct_add_noise) draws the sample dexct_add_noise draws from the same call's signal and variance
+        auto = fp.Projector(cone, ph)
+        w2_d = torch.from_numpy((w * rng.uniform(0.5, 3.0, w.shape)).astype(np.float32)).to(dev)
+        nseed = int(rng.integers(0, 2 ** 31))
+        noisy, var = auto.project_tables(mu_d, w_d, layout=None, w2_d=w2_d, seed=nseed, want_variance=True)
+        sampled = auto.project_tables(mu_d, w_d, layout=None).clone()
+        _native.check(auto.lib.dexct_add_noise(ptr(sampled), ptr(var), n_s, n_views, n_rows, n_ch, auto.native_layout, 0, nseed,
+                                               stream_ptr()), 'dexct_add_noise')
+        if not torch.equal(noisy, sampled):
+            bad.append(f'noise: the host-choice sample differs from dexct_add_noise on its own variance ({int((noisy != sampled).sum())} values)')
     except Exception as exc:
         bad = [f'{type(exc).__name__}: {exc}']
     rays += n_views * n_rows * n_ch
@@ -89,6 +117,6 @@ for case in range(n_cases):
         print(f'FAIL seed {seed}: grid {nx}x{ny}x{nz}, {n_rows} rows, {n_views} views x {n_ch} ch, {n_mat} materials, {style}: '
               + '; '.join(bad), flush=True)
     if case % 500 == 499 or case == n_cases - 1:
-        print(f'{case + 1} cases, {fails} failed, {rays:.3g} rays, {n_rows_kernel} cases through both kernels, {time.time() - t0:.0f} s',
+        print(f'{case + 1} cases, {fails} failed, {rays:.3g} rays, {n_rows_kernel} cases through both kernels, {n_groups} through the group passes, every case with the noise leg (round 6), {time.time() - t0:.0f} s',
               flush=True)
 sys.exit(1 if fails else 0)

@@ -22,7 +22,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dex_ct_sim_amd as dx
-from dex_ct_sim_amd import forward_project as fp
+from dex_ct_sim_amd import _native, forward_project as fp
+from dex_ct_sim_amd._device import ptr, stream_ptr
 from dex_ct_sim_amd.system import AIR, BONE, WATER, Material
 from oracle import c_oracle as co
 
@@ -123,6 +124,24 @@ for case in range(n_cases):
             same0 = rel(got0, ref) <= 1e-5
         if not same0:
             bad.append('kernel 0 (host choice): counts differ')
+        # round 6: quantum noise.  Whatever the host picks (variance + sample inside rows16_kernel<NOISY> / the group passes'
+        # detection kernel, or a variance output + dexct_add_noise) must draw the sample dexct_add_noise draws from the same
+        # call's signal and variance, deliver that variance, and - up to 4 table rows - agree bit for bit with the byte-volume
+        # path (kernel 3: separate variance loop + dexct_add_noise)
+        w2_d = torch.from_numpy((w * rng.uniform(0.5, 3.0, w.shape)).astype(np.float32)).to(dev)
+        nseed = int(rng.integers(0, 2 ** 31))
+        noisy, var = auto.project_tables(mu_d, w_d, layout=None, w2_d=w2_d, seed=nseed, want_variance=True)
+        clean = auto.project_tables(mu_d, w_d, layout=None)
+        sampled = clean.clone()
+        _native.check(auto.lib.dexct_add_noise(ptr(sampled), ptr(var), n_s, n_views, n_rows, n_ch, auto.native_layout, 0, nseed,
+                                               stream_ptr()), 'dexct_add_noise')
+        if not torch.equal(noisy, sampled):
+            bad.append(f'noise: the host-choice sample differs from dexct_add_noise on its own variance ({int((noisy != sampled).sum())} values)')
+        if n_mat <= 4:
+            n3, v3 = fp.Projector(ct, ph, kernel=3).project_tables(mu_d, w_d, layout=auto.native_layout, w2_d=w2_d, seed=nseed, want_variance=True)
+            if not (torch.equal(n3, noisy) and torch.equal(v3, var)):
+                bad.append(f'noise: sample / variance differ from the byte-volume path ({int((n3 != noisy).sum())} / {int((v3 != var).sum())} values)')
+        stats['noisy'] = stats.get('noisy', 0) + 1
         nsub = min(8, n_rows)
         r0 = int(rng.integers(0, n_rows - nsub + 1))
         sub = co.make_geom(n_views, n_ch, nsub, z_index + r0, nx, ny, nz, dxv, dyv, dzv, sid, sdd)
@@ -140,5 +159,5 @@ for case in range(n_cases):
     if case % 500 == 499 or case == n_cases - 1:
         print(f'{case + 1} cases, {fails} failed, {stats["rays"]:.3g} rays ({stats["hit"] / max(stats["rays"], 1):.2f} of them through the '
               f'object, sum of all counts {stats["counts_sum"]:.6g}), host picked the packed kernel in {stats["packed_auto"]}, '
-              f'{stats["air_cases"]} small-object cases, {time.time() - t0:.0f} s', flush=True)
+              f'{stats["air_cases"]} small-object cases, {stats.get("noisy", 0)} with the noise leg (round 6), {time.time() - t0:.0f} s', flush=True)
 sys.exit(1 if fails else 0)
