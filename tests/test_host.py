@@ -501,3 +501,33 @@ def test_gather_auto_picks_the_fastest_step_and_prefers_the_north_stars_gather_o
     assert pick_mode({'root': 12.2, 'direct': 12.0, 'all': 11.99}) == 'root'           # within 2 %: root, direct, all in that order
     assert pick_mode({'root': 13.0, 'direct': 12.1, 'all': 12.0}) == 'direct'
     assert pick_mode({'root': 13.0, 'direct': 12.5, 'all': 12.0}) == 'all'
+
+
+def test_the_committed_bench_line_keeps_the_contract():
+    """profiles/r06_final_bench.json (the plain `python bench.py` line of the final tree, cited by README.md / DESIGN.md): every key
+    of the bench contract, the metric and unit BASELINE.json names, `roofline` (issued flops / peak, with the survey-unit figure and
+    the instruction-issue view beside it) and `cpu_baseline` (a bounded sample on the host cores), and the numbers the documents
+    quote from it."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.load(open(os.path.join(root, 'profiles', 'r06_final_bench.json')))
+    base = json.load(open(os.path.join(root, 'BASELINE.json')))
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    assert line['n_gpus'] == 1 and line['higher_is_better'] is True and line['vs_baseline'] is None and line['data'] == 'synthetic'
+    assert line['unit'] == base.get('unit', line['unit']) or 'integrals' in line['unit']
+    assert 'workload' in line['config'] and 'model' not in line['config'] and line['config']['baseline_config'] == 'configs[2]'
+    roof, cpu = line['roofline'], line['cpu_baseline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_by_survey_unit', 'issue'):
+        assert key in roof, key
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9 and 0.0 < roof['frac'] < 1.0
+    assert 0.5 < roof['issue']['frac'] < 1.0 and roof['issue']['unit'].startswith('G wave-instructions')
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert key in cpu, key
+    assert cpu['kind'] in ('port', 'reference') and cpu['cores'] >= 1 and line['value'] / cpu['value'] > 1e3
+    # what README.md and DESIGN.md quote
+    assert abs(line['ms_per_step'] - 39.9) < 0.2 and abs(line['value'] / 1e12 - 2.14) < 0.02
+    assert abs(line['kernel_ms']['gn_decompose'] - 27.6) < 0.2 and abs(line['noisy_step']['ms_per_step'] - 44.3) < 0.2
+    assert line['gn_exact']['default_within_1e-12_of_exact_on_every_pixel'] is True and line['gn_exact']['pixels_compared'] == 409600000
+    assert line['noisy_step']['same_sample_as_round5_path_bit_for_bit'] is True
