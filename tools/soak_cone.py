@@ -101,11 +101,15 @@ for case in range(n_cases):
         # round 6: quantum noise - what the host picks (variance + sample inside the cone kernels / the group passes' detection
         # pass, or variance output + dexct_add_noise) draws the sample dexct_add_noise draws from the same call's signal and variance
         auto = fp.Projector(cone, ph)
-        w2_d = torch.from_numpy((w * rng.uniform(0.5, 3.0, w.shape)).astype(np.float32)).to(dev)
+        w_n, w_nd = w, w_d
+        if rng.random() < 0.3:                   # three or four spectra: beyond what the fused forms of the stacked fan hold (fallback)
+            w_n = np.concatenate([w, (0.7 * w[::-1]).astype(np.float32), (1.3 * w).astype(np.float32)])[:int(rng.integers(3, 5))]
+            w_nd = torch.from_numpy(np.ascontiguousarray(w_n)).to(dev)
+        w2_d = torch.from_numpy((w_n * rng.uniform(0.5, 3.0, w_n.shape)).astype(np.float32)).to(dev)
         nseed = int(rng.integers(0, 2 ** 31))
-        noisy, var = auto.project_tables(mu_d, w_d, layout=None, w2_d=w2_d, seed=nseed, want_variance=True)
-        sampled = auto.project_tables(mu_d, w_d, layout=None).clone()
-        _native.check(auto.lib.dexct_add_noise(ptr(sampled), ptr(var), n_s, n_views, n_rows, n_ch, auto.native_layout, 0, nseed,
+        noisy, var = auto.project_tables(mu_d, w_nd, layout=None, w2_d=w2_d, seed=nseed, want_variance=True)
+        sampled = auto.project_tables(mu_d, w_nd, layout=None).clone()
+        _native.check(auto.lib.dexct_add_noise(ptr(sampled), ptr(var), w_n.shape[0], n_views, n_rows, n_ch, auto.native_layout, 0, nseed,
                                                stream_ptr()), 'dexct_add_noise')
         if not torch.equal(noisy, sampled):
             bad.append(f'noise: the host-choice sample differs from dexct_add_noise on its own variance ({int((noisy != sampled).sum())} values)')

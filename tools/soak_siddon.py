@@ -128,17 +128,21 @@ for case in range(n_cases):
         # detection kernel, or a variance output + dexct_add_noise) must draw the sample dexct_add_noise draws from the same
         # call's signal and variance, deliver that variance, and - up to 4 table rows - agree bit for bit with the byte-volume
         # path (kernel 3: separate variance loop + dexct_add_noise)
-        w2_d = torch.from_numpy((w * rng.uniform(0.5, 3.0, w.shape)).astype(np.float32)).to(dev)
+        w_n, w_nd = w, w_d
+        if rng.random() < 0.3:                   # three or four spectra: beyond what the fused forms of the stacked fan hold (fallback)
+            w_n = np.concatenate([w, (0.7 * w[::-1]).astype(np.float32), (1.3 * w).astype(np.float32)])[:int(rng.integers(3, 5))]
+            w_nd = torch.from_numpy(np.ascontiguousarray(w_n)).to(dev)
+        w2_d = torch.from_numpy((w_n * rng.uniform(0.5, 3.0, w_n.shape)).astype(np.float32)).to(dev)
         nseed = int(rng.integers(0, 2 ** 31))
-        noisy, var = auto.project_tables(mu_d, w_d, layout=None, w2_d=w2_d, seed=nseed, want_variance=True)
-        clean = auto.project_tables(mu_d, w_d, layout=None)
+        noisy, var = auto.project_tables(mu_d, w_nd, layout=None, w2_d=w2_d, seed=nseed, want_variance=True)
+        clean = auto.project_tables(mu_d, w_nd, layout=None)
         sampled = clean.clone()
-        _native.check(auto.lib.dexct_add_noise(ptr(sampled), ptr(var), n_s, n_views, n_rows, n_ch, auto.native_layout, 0, nseed,
+        _native.check(auto.lib.dexct_add_noise(ptr(sampled), ptr(var), w_n.shape[0], n_views, n_rows, n_ch, auto.native_layout, 0, nseed,
                                                stream_ptr()), 'dexct_add_noise')
         if not torch.equal(noisy, sampled):
             bad.append(f'noise: the host-choice sample differs from dexct_add_noise on its own variance ({int((noisy != sampled).sum())} values)')
         if n_mat <= 4:
-            n3, v3 = fp.Projector(ct, ph, kernel=3).project_tables(mu_d, w_d, layout=auto.native_layout, w2_d=w2_d, seed=nseed, want_variance=True)
+            n3, v3 = fp.Projector(ct, ph, kernel=3).project_tables(mu_d, w_nd, layout=auto.native_layout, w2_d=w2_d, seed=nseed, want_variance=True)
             if not (torch.equal(n3, noisy) and torch.equal(v3, var)):
                 bad.append(f'noise: sample / variance differ from the byte-volume path ({int((n3 != noisy).sum())} / {int((v3 != var).sum())} values)')
         stats['noisy'] = stats.get('noisy', 0) + 1
